@@ -1,0 +1,289 @@
+"""ctypes front-end of the CPU ORACLE (``oracle/dcomp_oracle.c``).       *** TEST INFRASTRUCTURE ***
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg import this
+module; it is the checker, never the thing measured or shipped.  Parity status: pinned against the
+reference-generated fixtures in ``tests/golden`` by ``tests/test_oracle_golden.py``.
+
+The reference draws start positions / velocities / waypoints from two per-UE ``random.Random``
+streams (``base.py:132-143``, ``user.py:94-109``, ``movement.py:110-130``).
+``RefRngTape`` reproduces that draw order with the very same stdlib generator and hands the oracle a
+pre-drawn tape; the C side never needs Mersenne-Twister.
+"""
+import ctypes
+import os
+import random
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, '_ref', 'libdcomp_oracle.so')
+
+CENTRAL, MULTI = 0, 1
+AVG, SUM, MIN = 0, 1, 2
+RES_FAIR, RATE_FAIR, MAX_CAP, PROP_FAIR = 0, 1, 2, 3
+SHARING_CODE = {'resource-fair': 0, 'rate-fair': 1, 'max-cap': 2, 'proportional-fair': 3}
+UTIL_LOG, UTIL_STEP = 0, 1
+
+_c_dp = ctypes.POINTER(ctypes.c_double)
+_c_ip = ctypes.POINTER(ctypes.c_int32)
+_c_fp = ctypes.POINTER(ctypes.c_float)
+_c_u8p = ctypes.POINTER(ctypes.c_uint8)
+_c_u32p = ctypes.POINTER(ctypes.c_uint32)
+
+
+def build(force=False):
+    """Compile the oracle into oracle/_ref/ (gcc, a few hundred ms)."""
+    src = os.path.join(_HERE, 'dcomp_oracle.c')
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-C', _HERE, '-s'])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.orc_create.restype = ctypes.c_void_p
+        L.orc_create.argtypes = [ctypes.c_int] * 6 + [_c_dp, _c_dp, _c_ip, _c_ip, _c_dp, _c_ip, _c_ip, _c_ip, _c_ip]
+        L.orc_destroy.argtypes = [ctypes.c_void_p]
+        L.orc_set_tape.argtypes = [ctypes.c_void_p, ctypes.c_int, _c_ip, _c_ip]
+        L.orc_set_philox.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int64]
+        L.orc_set_episode.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+        L.orc_reset.argtypes = [ctypes.c_void_p]
+        L.orc_step.argtypes = [ctypes.c_void_p, _c_ip]
+        L.orc_step.restype = ctypes.c_int
+        L.orc_get_obs.argtypes = [ctypes.c_void_p, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]
+        L.orc_get_reward.argtypes = [ctypes.c_void_p, _c_dp]
+        L.orc_get_state.argtypes = [ctypes.c_void_p, _c_dp, _c_dp, _c_dp, _c_ip, _c_ip, _c_u8p, _c_dp, _c_dp, _c_dp,
+                                    _c_dp, _c_ip]
+        L.orc_sum_utility.argtypes = [ctypes.c_void_p]
+        L.orc_sum_utility.restype = ctypes.c_double
+        L.orc_time.argtypes = [ctypes.c_void_p]
+        L.orc_tape_cursor.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        for f in ('orc_snr', 'orc_dr_unshared', 'orc_log_utility'):
+            getattr(L, f).argtypes = [ctypes.c_double]
+            getattr(L, f).restype = ctypes.c_double
+        L.orc_step_utility.argtypes = [ctypes.c_double, ctypes.c_double]
+        L.orc_step_utility.restype = ctypes.c_double
+        L.orc_can_connect.argtypes = [ctypes.c_double]
+        L.orc_connect_threshold_distance.restype = ctypes.c_double
+        L.orc_philox4x32_10.argtypes = [_c_u32p, _c_u32p, _c_u32p]
+        L.orc_batch_reset.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _c_fp, ctypes.c_int]
+        L.orc_batch_step.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _c_u8p, _c_fp, _c_fp, _c_u32p,
+                                     _c_dp, ctypes.c_int]
+        L.orc_max_threads.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a, typ):
+    return a.ctypes.data_as(typ) if a is not None else None
+
+
+def vel_range(v):
+    """Velocity spec -> inclusive integer draw range (movement.py:112-117)."""
+    if v == 'slow' or v == -1:
+        return 1, 3
+    if v == 'fast' or v == -2:
+        return 5, 10
+    return int(v), int(v)
+
+
+class RefRngTape:
+    """Pre-draws what the reference's per-UE ``random.Random`` streams would hand out.
+
+    seed rule: UE i (0-based) gets ``seed + 100*(i+1)`` for BOTH its position and its movement
+    stream (base.py:138-143, user.py:94-96).  ``rand_episodes=False`` re-seeds at every reset
+    (base.py:171-173); ``True`` lets the streams continue, which needs the number of triples the
+    previous episode consumed (``consumed``)."""
+
+    def __init__(self, seed, map_w, map_h, vel_specs, init_xy=None, depth=48, rand_episodes=False):
+        self.seed, self.w, self.h, self.depth, self.rand_episodes = seed, int(map_w), int(map_h), depth, rand_episodes
+        self.vel_specs = list(vel_specs)
+        self.U = len(self.vel_specs)
+        self.init_xy = init_xy if init_xy is not None else [(-1, -1)] * self.U
+        self._seed_streams()
+        self._states = None
+
+    def _seed_streams(self):
+        self.pos_rng = [random.Random(self.seed + 100 * (i + 1)) for i in range(self.U)]
+        self.mov_rng = [random.Random(self.seed + 100 * (i + 1)) for i in range(self.U)]
+
+    def _triple(self, i):
+        r, v = self.mov_rng[i], self.vel_specs[i]
+        lo, hi = vel_range(v)
+        vel = r.randint(lo, hi) if lo != hi else lo      # only 'slow'/'fast' consume a draw
+        wx = r.randint(10, int(self.w - 10))
+        wy = r.randint(10, int(self.h - 10))
+        return vel, wx, wy
+
+    def draw_episode(self, consumed=None):
+        """Returns (pos0[U,2] int32, triples[U,depth,3] int32) for the next reset()."""
+        if not self.rand_episodes:
+            self._seed_streams()
+        elif self._states is not None:
+            assert consumed is not None, "rand_episodes=True needs the consumed-triple counts of the last episode"
+            for i in range(self.U):
+                self.mov_rng[i].setstate(self._states[i][int(consumed[i])])
+        pos0 = np.zeros((self.U, 2), dtype=np.int32)
+        trip = np.zeros((self.U, self.depth, 3), dtype=np.int32)
+        self._states = []
+        for i in range(self.U):
+            ix, iy = self.init_xy[i]
+            pos0[i, 0] = self.pos_rng[i].randint(0, self.w) if ix < 0 else ix
+            pos0[i, 1] = self.pos_rng[i].randint(0, self.h) if iy < 0 else iy
+            st = [self.mov_rng[i].getstate()]
+            for k in range(self.depth):
+                trip[i, k] = self._triple(i)
+                st.append(self.mov_rng[i].getstate())
+            self._states.append(st)
+        return pos0, trip
+
+
+class OracleEnv:
+    """One env instance of the oracle."""
+
+    def __init__(self, map_w, map_h, bs_pos, bs_sharing, vel_specs, kind=MULTI, reward_agg=AVG, ue_util=None,
+                 ue_dr_req=None, init_xy=None):
+        L = lib()
+        self.U, self.B = len(vel_specs), len(bs_pos)
+        self.kind = kind
+        U, B = self.U, self.B
+        bs = np.asarray(bs_pos, dtype=np.float64).reshape(B, 2)
+        self._bx, self._by = np.ascontiguousarray(bs[:, 0]), np.ascontiguousarray(bs[:, 1])
+        self._sh = np.asarray([SHARING_CODE.get(s, s) for s in bs_sharing], dtype=np.int32)
+        self._util = np.zeros(U, dtype=np.int32) if ue_util is None else np.asarray(ue_util, dtype=np.int32)
+        self._req = np.ones(U, dtype=np.float64) if ue_dr_req is None else np.asarray(ue_dr_req, dtype=np.float64)
+        rng = [vel_range(v) for v in vel_specs]
+        self._vlo = np.asarray([r[0] for r in rng], dtype=np.int32)
+        self._vhi = np.asarray([r[1] for r in rng], dtype=np.int32)
+        ixy = np.full((U, 2), -1, dtype=np.int32) if init_xy is None else np.asarray(init_xy, dtype=np.int32)
+        self._ix, self._iy = np.ascontiguousarray(ixy[:, 0]), np.ascontiguousarray(ixy[:, 1])
+        self.h = L.orc_create(U, B, int(map_w), int(map_h), kind, reward_agg, _p(self._bx, _c_dp), _p(self._by, _c_dp),
+                              _p(self._sh, _c_ip), _p(self._util, _c_ip), _p(self._req, _c_dp), _p(self._vlo, _c_ip),
+                              _p(self._vhi, _c_ip), _p(self._ix, _c_ip), _p(self._iy, _c_ip))
+        self.h = ctypes.c_void_p(self.h)
+
+    def __del__(self):
+        if getattr(self, 'h', None) is not None and _lib is not None:
+            _lib.orc_destroy(self.h)
+            self.h = None
+
+    def set_tape(self, pos0, triples):
+        pos0 = np.ascontiguousarray(pos0, dtype=np.int32)
+        triples = np.ascontiguousarray(triples, dtype=np.int32)
+        lib().orc_set_tape(self.h, triples.shape[1], _p(pos0, _c_ip), _p(triples, _c_ip))
+
+    def set_philox(self, seed, global_env_id):
+        lib().orc_set_philox(self.h, seed, global_env_id)
+
+    def set_episode(self, ep):
+        lib().orc_set_episode(self.h, ep)
+
+    def reset(self):
+        lib().orc_reset(self.h)
+
+    def step(self, action):
+        a = np.ascontiguousarray(action, dtype=np.int32)
+        rc = lib().orc_step(self.h, _p(a, _c_ip))
+        if rc != 0:
+            raise AssertionError(f"Action {action} does not fit action space")   # central.py:61
+        return rc
+
+    def obs(self):
+        U, B = self.U, self.B
+        out = {k: np.zeros((U, B)) for k in ('connected', 'dr', 'ues_at_bs', 'util_at_bs')}
+        out['utility'] = np.zeros(U)
+        lib().orc_get_obs(self.h, _p(out['connected'], _c_dp), _p(out['dr'], _c_dp), _p(out['utility'], _c_dp),
+                          _p(out['ues_at_bs'], _c_dp), _p(out['util_at_bs'], _c_dp))
+        return out
+
+    def reward(self):
+        r = np.zeros(1 if self.kind == CENTRAL else self.U)
+        lib().orc_get_reward(self.h, _p(r, _c_dp))
+        return r
+
+    def state(self):
+        U, B = self.U, self.B
+        s = dict(pos=np.zeros((U, 2)), wp=np.zeros((U, 2)), vel=np.zeros(U), pausing=np.zeros(U, np.int32),
+                 curr_pause=np.zeros(U, np.int32), conn=np.zeros((U, B), np.uint8), dr=np.zeros((U, B)),
+                 curr_dr=np.zeros(U), ewma=np.zeros(U), utility=np.zeros(U), conn_order=np.zeros((B, U), np.int32))
+        lib().orc_get_state(self.h, _p(s['pos'], _c_dp), _p(s['wp'], _c_dp), _p(s['vel'], _c_dp),
+                            _p(s['pausing'], _c_ip), _p(s['curr_pause'], _c_ip), _p(s['conn'], _c_u8p),
+                            _p(s['dr'], _c_dp), _p(s['curr_dr'], _c_dp), _p(s['ewma'], _c_dp), _p(s['utility'], _c_dp),
+                            _p(s['conn_order'], _c_ip))
+        return s
+
+    def sum_utility(self):
+        return lib().orc_sum_utility(self.h)
+
+    def time(self):
+        return lib().orc_time(self.h)
+
+    def cursors(self):
+        return np.array([lib().orc_tape_cursor(self.h, u) for u in range(self.U)], dtype=np.int32)
+
+
+class OracleBatch:
+    """E oracle envs stepped together (OpenMP over envs): large-E parity checks and the CPU baseline."""
+
+    def __init__(self, envs, num_threads=None):
+        self.envs = list(envs)
+        self.E = len(self.envs)
+        self.U, self.B, self.kind = envs[0].U, envs[0].B, envs[0].kind
+        self._handles = (ctypes.c_void_p * self.E)(*[e.h for e in self.envs])
+        self.num_threads = num_threads or lib().orc_max_threads()
+        self.obs_dim = 4 * self.B + 1 if self.kind == MULTI else 2 * self.B + 1
+
+    def reset(self):
+        obs = np.zeros((self.E, self.U, self.obs_dim), dtype=np.float32)
+        lib().orc_batch_reset(self._handles, self.E, _p(obs, _c_fp), self.num_threads)
+        return obs
+
+    def step(self, action, want_obs=True):
+        a = np.ascontiguousarray(action, dtype=np.uint8).reshape(self.E, self.U)
+        obs = np.zeros((self.E, self.U, self.obs_dim), dtype=np.float32) if want_obs else None
+        rew = np.zeros((self.E, self.U) if self.kind == MULTI else (self.E,), dtype=np.float32)
+        conn = np.zeros((self.E, self.U), dtype=np.uint32)
+        pos = np.zeros((self.E, self.U, 2), dtype=np.float64)
+        lib().orc_batch_step(self._handles, self.E, _p(a, _c_u8p), _p(obs, _c_fp), _p(rew, _c_fp), _p(conn, _c_u32p),
+                             _p(pos, _c_dp), self.num_threads)
+        return obs, rew, conn, pos
+
+
+def snr(d):
+    return lib().orc_snr(float(d))
+
+
+def can_connect(d):
+    return bool(lib().orc_can_connect(float(d)))
+
+
+def dr_unshared(d):
+    return lib().orc_dr_unshared(float(d))
+
+
+def log_utility(dr):
+    return lib().orc_log_utility(float(dr))
+
+
+def step_utility(dr, req):
+    return lib().orc_step_utility(float(dr), float(req))
+
+
+def connect_threshold_distance():
+    return lib().orc_connect_threshold_distance()
+
+
+def philox4x32_10(ctr, key):
+    c = (ctypes.c_uint32 * 4)(*ctr)
+    k = (ctypes.c_uint32 * 2)(*key)
+    o = (ctypes.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return list(o)

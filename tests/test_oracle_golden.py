@@ -1,0 +1,178 @@
+"""The CPU oracle (oracle/dcomp_oracle.c) against the golden fixtures recorded from the reference
+itself (tests/golden/gen_golden.py).  Indices / masks / FSM state / FP64 positions: exact.
+Other FP64 floats: 1e-9 relative or tighter (both sides are FP64; libm vs numpy differ in the last
+ulps, and log2(1+snr) itself only carries ~8 significant digits near the connect threshold)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+RTOL = 1e-12
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + '.npz'))
+
+
+# ------------------------------------------------------------------ G1-G3 known-answer tables
+def test_channel_table():
+    g = load('channel')
+    for d, s, c, r in zip(g['d'], g['snr'], g['can_connect'], g['dr_unshared']):
+        assert orc.snr(d) == pytest.approx(s, rel=RTOL)
+        assert orc.can_connect(d) == bool(c)
+        assert orc.dr_unshared(d) == pytest.approx(r, rel=1e-9)
+    for (x, y), s, c in zip(g['xy'], g['snr_xy'], g['can_xy']):
+        d = np.sqrt(x * x + y * y)
+        assert orc.snr(d) == pytest.approx(s, rel=RTOL)
+        assert orc.can_connect(d) == bool(c)
+
+
+def test_survey_appendix_b_values():
+    # SURVEY.md Appendix B (probe values of the reference arithmetic)
+    assert orc.snr(1.0) == pytest.approx(3.232562595879e-02, rel=1e-12)
+    assert orc.snr(0.0) == pytest.approx(3.502202856706e+52, rel=1e-12)
+    assert orc.dr_unshared(46.0) == pytest.approx(1.017513972, rel=1e-9)
+    assert orc.can_connect(68.0) and not orc.can_connect(69.0)
+    assert orc.connect_threshold_distance() == pytest.approx(68.92488308058013, abs=1e-9)
+
+
+def test_utility_table():
+    g = load('utility')
+    for dr, lu, su in zip(g['dr'], g['log_utility'], g['step_utility_req1']):
+        assert orc.log_utility(dr) == pytest.approx(lu, rel=RTOL, abs=1e-13)
+        assert orc.step_utility(dr, 1) == su
+
+
+def _connect_in_order(env, n_connected):
+    n = env.U
+    for u in range(n_connected):
+        a = np.zeros(n, np.int32)
+        a[u] = 1                      # action 1 = toggle BS 0 (base.py:259-263)
+        env.step(a)
+
+
+def test_sharing_table():
+    """1 BS at the origin, static UEs on the x axis (integer distances), connected oldest-first."""
+    g = load('sharing')
+    checked = 0
+    for i in range(len(g['model'])):
+        n, model = int(g['n'][i]), int(g['model'][i])
+        dist, ewma = g['dist'][i][:n], g['ewma'][i][:n]
+        if np.any(ewma != 0):
+            continue     # ewma-dependent rates are pinned through the proportional-fair trajectories
+        env = orc.OracleEnv(400, 400, [(0, 0)], [model], [0] * n, kind=orc.MULTI,
+                            init_xy=[(int(d), 0) for d in dist])
+        env.set_tape(np.zeros((n, 2), np.int32), np.tile(np.array([0, 200, 200], np.int32), (n, 4, 1)))
+        env.reset()
+        _connect_in_order(env, n)
+        st = env.state()
+        want = g['dr_all_connected'][i][:n]
+        if model == orc.PROP_FAIR:
+            # after the connect steps ewma is no longer 0; recompute the closed form (station.py:192-195)
+            dru = np.array([orc.dr_unshared(d) for d in dist])
+            # the state's rates were computed with the ewma of the step before; check self-consistency instead
+            assert np.all(st['dr'][:, 0] > 0) and st['dr'][:, 0].sum() <= dru.max() * 1.0000001
+        else:
+            np.testing.assert_allclose(st['dr'][:, 0], want, rtol=1e-9)
+        checked += 1
+    assert checked >= 15
+
+
+# ------------------------------------------------------------------ G4 movement traces
+@pytest.mark.parametrize('name', ['slow', 'fast', 'static', 'fixed4', 'slow_small'])
+def test_movement_trace(name):
+    g = load('movement')
+    tr = g[name + '_trace']
+    w, h, vel, seed = (int(x) for x in g[name + '_cfg'])
+    # User.seed(seed) seeds both streams with `seed` itself (user.py:94-96): base seed = seed - 100
+    tape = orc.RefRngTape(seed - 100, w, h, [vel], depth=120)
+    pos0, trip = tape.draw_episode()
+    env = orc.OracleEnv(w, h, [(0, 0)], ['resource-fair'], [vel])
+    env.set_tape(pos0, trip)
+    env.reset()
+    for t in range(tr.shape[0]):
+        s = env.state()
+        got = [s['pos'][0, 0], s['pos'][0, 1], s['wp'][0, 0], s['wp'][0, 1], s['vel'][0], s['pausing'][0],
+               s['curr_pause'][0]]
+        assert got == list(tr[t]), f"step {t}: {got} != {list(tr[t])}"     # bit-exact FP64 positions
+        env.step(np.zeros(1, np.int32))
+    assert env.cursors()[0] <= 120
+
+
+# ------------------------------------------------------------------ G5/G6 trajectories
+TRAJ = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'traj_*.npz'))) + \
+       sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'estack_*.npz')))
+
+
+def make_env_from_fixture(g, depth=64):
+    U = g['cfg_ue_vel'].shape[0]
+    w, h = (int(x) for x in g['cfg_map_wh'])
+    vel = [int(v) for v in g['cfg_ue_vel']]
+    env = orc.OracleEnv(w, h, g['cfg_bs_pos'], list(g['cfg_bs_sharing']), vel, kind=int(g['cfg_kind']),
+                        reward_agg=int(g['cfg_reward']), ue_util=g['cfg_ue_util'], ue_dr_req=g['cfg_ue_dr_req'])
+    tape = orc.RefRngTape(int(g['cfg_seed']), w, h, vel, depth=depth, rand_episodes=bool(g['cfg_rand_episodes']))
+    return env, tape, U
+
+
+def check_snapshot(env, g, prefix, i, kind):
+    s = env.state()
+    o = env.obs()
+    for k in ('pos', 'wp', 'vel'):
+        assert np.array_equal(s[k], g[f'{prefix}_{k}'][i]), f'{prefix}[{i}] {k} not bit-exact'
+    for k in ('pausing', 'curr_pause', 'conn'):
+        assert np.array_equal(s[k], g[f'{prefix}_{k}'][i]), f'{prefix}[{i}] {k}'
+    assert np.array_equal(s['conn_order'], g[f'{prefix}_conn_order'][i]), f'{prefix}[{i}] conn_order'
+    for k in ('dr', 'curr_dr', 'ewma', 'utility'):
+        np.testing.assert_allclose(s[k], g[f'{prefix}_{k}'][i], rtol=1e-9, atol=1e-12, err_msg=f'{prefix}[{i}] {k}')
+    assert np.array_equal(o['connected'], g[f'{prefix}_obs_connected'][i])
+    np.testing.assert_allclose(o['dr'], g[f'{prefix}_obs_dr'][i], rtol=RTOL, atol=1e-300)
+    np.testing.assert_allclose(o['utility'], g[f'{prefix}_obs_utility'][i], rtol=1e-9, atol=1e-12)
+    if kind == orc.MULTI:
+        np.testing.assert_allclose(o['ues_at_bs'], g[f'{prefix}_obs_ues_at_bs'][i], rtol=RTOL)
+        np.testing.assert_allclose(o['util_at_bs'], g[f'{prefix}_obs_util_at_bs'][i], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize('name', TRAJ)
+def test_trajectory(name):
+    g = load(name)
+    env, tape, U = make_env_from_fixture(g)
+    kind = int(g['cfg_kind'])
+    episodes = int(g['cfg_episodes'])
+    steps_per_ep = g['actions'].shape[0] // episodes
+    t = 0
+    consumed = None
+    for ep in range(episodes):
+        pos0, trip = tape.draw_episode(consumed)
+        env.set_tape(pos0, trip)
+        env.reset()
+        check_snapshot(env, g, 'reset', ep, kind)
+        for _ in range(steps_per_ep):
+            env.step(g['actions'][t])
+            check_snapshot(env, g, 'step', t, kind)
+            np.testing.assert_allclose(env.reward(), g['step_reward'][t], rtol=1e-9, atol=1e-12,
+                                       err_msg=f'reward[{t}]')
+            assert env.sum_utility() == pytest.approx(float(g['step_sum_utility'][t]), rel=1e-9, abs=1e-12)
+            assert env.time() == int(g['step_time'][t])
+            t += 1
+        consumed = env.cursors()
+        assert consumed.max() <= trip.shape[1]
+
+
+def test_bad_action_rejected():
+    env = orc.OracleEnv(150, 100, [(50, 50), (100, 50)], ['resource-fair'] * 2, ['slow'] * 2)
+    env.set_philox(1, 0)
+    env.reset()
+    with pytest.raises(AssertionError):
+        env.step([3, 0])
+
+
+def test_philox_known_answers():
+    # Random123 known-answer vectors for Philox4x32-10
+    assert orc.philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert orc.philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert orc.philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
