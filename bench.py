@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the fused HIP env step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 1000 --warmup 100
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one MobileEnv.step() of every env of the batch (E envs per GPU).  Workload at N=1: BASELINE
+config 3 -- 65 536 parallel envs, 32 UE x 10 BS, multi-agent (DD-CoMP) per-UE observations, mixed sharing,
+log utility, reward 'avg', episode length 100 (reset kernel every 100 steps, inside the timed region), uniform
+random actions pre-generated on the device.  N>1: the env axis is sharded, 65 536 envs per GPU (weak scaling),
+global env ids keep the draws independent of the GPU count; no collective on the data path.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def bytes_per_env_step(U, B, kind, log_metrics=True):
+    """Compulsory HBM bytes of one env-step in this implementation's layout:
+    read pos 16 + mv 8 + conn 4 + ewma 4 + action 1; write pos 16 + mv 8 + conn 4 + ewma 4; obs; reward; info."""
+    per_ue = 33 + 32 + (8 if log_metrics else 0)
+    if kind == 'multi':
+        return U * (per_ue + 4 * (4 * B + 1) + 4) + (4 if log_metrics else 0)
+    return U * (per_ue + 4 * (2 * B + 1)) + 4 + (4 if log_metrics else 0)
+
+
+def survey_bytes_per_env_step(U, B, kind):
+    """SURVEY.md 8(d) figure incl. the FP64-position surcharge (+24 U)."""
+    return U * (55 + 16 * B + 24) + 4 if kind == 'multi' else U * (51 + 8 * B + 24) + 8
+
+
+def cpu_baseline(scn, kind, U, B, budget_s=15.0):
+    """The CPU oracle (oracle/dcomp_oracle.c, OpenMP over envs) on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    threads = orc.lib().orc_max_threads()
+
+    def make(E):
+        envs = []
+        for e in range(E):
+            o = orc.OracleEnv(int(scn.width), int(scn.height), scn.bs_pos, scn.bs_sharing,
+                              [s['velocity'] for s in scn.ue_specs], kind=orc.MULTI if kind == 'multi' else orc.CENTRAL)
+            o.set_philox(42, e)
+            envs.append(o)
+        return orc.OracleBatch(envs, num_threads=threads)
+
+    rng = np.random.default_rng(7)
+    probe = make(threads * 2)
+    probe.reset()
+    a = rng.integers(0, B + 1, size=(probe.E, U)).astype(np.uint8)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        probe.step(a)
+    rate = probe.E * 5 / (time.perf_counter() - t0)
+    steps = 100
+    E = int(max(threads, min(4096, rate * budget_s / steps)))
+    E = (E // threads) * threads
+    batch = make(E)
+    batch.reset()
+    acts = rng.integers(0, B + 1, size=(steps, E, U)).astype(np.uint8)
+    t0 = time.perf_counter()
+    for t in range(steps):
+        batch.step(acts[t])
+    dt = time.perf_counter() - t0
+    return {'value': E * steps / dt, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{E} envs x {steps} steps ({U} UE x {B} BS, {kind}), oracle/dcomp_oracle.c with OpenMP over envs, {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=1000)
+    ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--envs', type=int, default=65536, help='envs per GPU')
+    ap.add_argument('--ues', type=int, default=32)
+    ap.add_argument('--bs', type=int, default=10)
+    ap.add_argument('--kind', default='multi', choices=['multi', 'central'])
+    ap.add_argument('--sharing', default='mixed')
+    ap.add_argument('--eps-length', type=int, default=100)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--traffic-bytes', type=float, default=None, help='HBM bytes per launch from a rocprofv3 --pmc pass')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    E, U, B, K, W, L = args.envs, args.ues, args.bs, args.steps, args.warmup, args.eps_length
+    scn = scenarios.grid_map(B, args.sharing).with_ues(num_slow=U)
+    m, bs, ues = build_from_scenario(scn)
+    env = BatchedMobileEnv(m, bs, ues, args.kind, num_envs=E, seed=42, episode_length=L, rng='philox', rand_episodes=True,
+                           device=dev, env_id_base=rank * E, log_metrics=True)
+    # uniform random actions, Philox-seeded on device, outside the timed region; a pool of 16 tensors is cycled
+    g = torch.Generator(device=dev).manual_seed(7 + rank)
+    pool = torch.randint(0, B + 1, (16, E, U), generator=g, device=dev, dtype=torch.uint8)
+
+    def run(nsteps, t_start, events=None):
+        t = t_start
+        for i in range(nsteps):
+            if t % L == 0:
+                env.reset()
+            if events is not None:
+                events[i][0].record()
+            env.step(pool[t & 15])
+            if events is not None:
+                events[i][1].record()
+            t += 1
+        return t
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    t_env = run(W, 0)
+    fence()
+    t0 = time.perf_counter()
+    t_env = run(K, t_env)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    env.check()
+
+    # per-launch duration of the step kernel: HIP events on the launch stream (torch's current stream is the
+    # stream dcomp_step enqueues on), over a second pass of the same K steps
+    n_ev = min(K, 400)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+    run(n_ev, t_env, ev)
+    torch.cuda.synchronize(dev)
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    if rank == 0:
+        bpe = bytes_per_env_step(U, B, args.kind)
+        achieved = bpe * E / (kern_ms * 1e-3) / 1e9
+        out = {
+            'metric': 'env steps/sec', 'value': world * E * K / elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K,
+            'warmup': W, 'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64 positions / f32 rates', 'data': 'synthetic',
+            'config': {'workload': f'{E} envs/GPU x {U} UE x {B} BS, {args.kind}-agent obs, sharing={args.sharing}, '
+                                   f'log utility, reward avg, episode {L} (reset inside timed region), random actions',
+                       'envs_per_gpu': E, 'num_ue': U, 'num_bs': B, 'pair_steps_per_s': world * E * K / elapsed * U * B,
+                       'parallelism': f'env-shard x{world}'},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': args.traffic_bytes, 'kernel': 'dcomp::step_kernel', 'kernel_ms': kern_ms,
+                         'bytes_per_env_step': bpe, 'survey_bytes_per_env_step': survey_bytes_per_env_step(U, B, args.kind)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(scn, args.kind, U, B)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,105 @@
+"""ctypes binding of libdcomp_hip.so (include/dcomp.h).  Fails loudly when the HIP extension is missing:
+there is no CPU fallback in the product path."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libdcomp_hip.so')
+
+OK, EINVAL, EHIP, EACTION, ETAPE, EPOS, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+CENTRAL, MULTI = 0, 1
+REWARD = {'avg': 0, 'sum': 1, 'min': 2}
+SHARING = {'resource-fair': 0, 'rate-fair': 1, 'max-cap': 2, 'proportional-fair': 3}
+UTILITY = {'log': 0, 'step': 1}
+RNG_TAPE, RNG_PHILOX = 0, 1
+MAX_BS, MAX_UE = 32, 256
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int32)
+_fp = ctypes.POINTER(ctypes.c_float)
+
+
+class DcompCfg(ctypes.Structure):
+    _fields_ = [('num_envs', ctypes.c_int32), ('num_ue', ctypes.c_int32), ('num_bs', ctypes.c_int32),
+                ('map_w', ctypes.c_int32), ('map_h', ctypes.c_int32), ('env_kind', ctypes.c_int32),
+                ('reward_agg', ctypes.c_int32), ('rng_mode', ctypes.c_int32), ('tape_depth', ctypes.c_int32),
+                ('device', ctypes.c_int32), ('reserved', ctypes.c_int32), ('seed', ctypes.c_uint64),
+                ('env_id_base', ctypes.c_int64), ('bs_x', _dp), ('bs_y', _dp), ('bs_sharing', _ip),
+                ('ue_util', _ip), ('ue_dr_req', _fp), ('ue_vel_lo', _ip), ('ue_vel_hi', _ip),
+                ('ue_init_x', _ip), ('ue_init_y', _ip)]
+
+
+class DcompState(ctypes.Structure):
+    _fields_ = [('pos', ctypes.c_void_p), ('mv', ctypes.c_void_p), ('conn', ctypes.c_void_p),
+                ('ewma', ctypes.c_void_p), ('flags', ctypes.c_void_p)]
+
+
+class DcompOut(ctypes.Structure):
+    _fields_ = [('obs', ctypes.c_void_p), ('reward', ctypes.c_void_p), ('sum_utility', ctypes.c_void_p),
+                ('ue_dr', ctypes.c_void_p), ('ue_utility', ctypes.c_void_p)]
+
+
+class DcompTape(ctypes.Structure):
+    _fields_ = [('pos0', ctypes.c_void_p), ('triples', ctypes.c_void_p)]
+
+
+EXPORTS = ['dcomp_create', 'dcomp_destroy', 'dcomp_state_sizes', 'dcomp_obs_dim', 'dcomp_reset', 'dcomp_step',
+           'dcomp_rollout', 'dcomp_check', 'dcomp_time', 'dcomp_episode', 'dcomp_set_episode', 'dcomp_mt_draw_tape',
+           'dcomp_connect_threshold', 'dcomp_last_error', 'dcomp_version', 'dcomp_selftest']
+
+_lib = None
+
+
+class DcompError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP extension; raise (never fall back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build the HIP extension first (python -m deepcomp_amd.build). "
+                          "deepcomp_amd has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    L.dcomp_create.argtypes = [ctypes.POINTER(DcompCfg), ctypes.POINTER(vp)]
+    L.dcomp_destroy.argtypes = [vp]
+    L.dcomp_state_sizes.argtypes = [vp] + [ctypes.POINTER(ctypes.c_size_t)] * 5
+    L.dcomp_obs_dim.argtypes = [vp, _ip, _ip]
+    L.dcomp_reset.argtypes = [vp, ctypes.POINTER(DcompState), ctypes.POINTER(DcompTape), ctypes.POINTER(DcompOut), vp]
+    L.dcomp_step.argtypes = [vp, ctypes.POINTER(DcompState), vp, ctypes.POINTER(DcompOut), vp]
+    L.dcomp_rollout.argtypes = [vp, ctypes.POINTER(DcompState), vp, i32, ctypes.POINTER(DcompOut), vp]
+    L.dcomp_check.argtypes = [vp, ctypes.POINTER(DcompState), vp]
+    L.dcomp_time.argtypes = [vp]
+    L.dcomp_episode.argtypes = [vp]
+    L.dcomp_episode.restype = i64
+    L.dcomp_set_episode.argtypes = [vp, i64]
+    L.dcomp_mt_draw_tape.argtypes = [ctypes.POINTER(DcompCfg), ctypes.POINTER(i64), i32, i32, vp, vp]
+    L.dcomp_connect_threshold.restype = ctypes.c_double
+    L.dcomp_last_error.restype = ctypes.c_char_p
+    L.dcomp_version.restype = ctypes.c_char_p
+    L.dcomp_selftest.argtypes = [i32, i32, vp, vp, vp, i64, vp]
+    for name in EXPORTS:
+        getattr(L, name)
+    _lib = L
+    return L
+
+
+def last_error():
+    return load().dcomp_last_error().decode()
+
+
+def check(rc):
+    """Map a negative return code to the exception the reference raises in the same situation."""
+    if rc == OK:
+        return
+    msg = last_error()
+    if rc in (EACTION, EPOS):
+        raise AssertionError(msg)          # base.py:238, central.py:61, movement.py:165
+    if rc == EUNSUPPORTED:
+        raise NotImplementedError(msg)     # user.py:92, central.py:73
+    if rc == EINVAL:
+        raise ValueError(msg)
+    raise DcompError(f"dcomp error {rc}: {msg}")

@@ -1,0 +1,78 @@
+"""Builds libdcomp_hip.so (hand-written gfx950 kernels + C ABI) in-tree with hipcc.
+
+    python -m deepcomp_amd.build [--force] [--jobs N]
+
+One object per base-station count listed in csrc/dcomp_blist.h (all UE-group widths inside), compiled
+in parallel, plus the API object; linked into deepcomp_amd/csrc/libdcomp_hip.so.  hipcc cross-compiles
+for gfx950 without a GPU present.
+"""
+import argparse
+import concurrent.futures
+import os
+import re
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(CSRC, 'build')
+LIB = os.path.join(CSRC, 'libdcomp_hip.so')
+ARCH = 'gfx950'
+# fast-honor-pragmas: `#pragma clang fp contract(off)` in the FP64 movement code must win (bit-exact positions)
+CXXFLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast-honor-pragmas',
+            '-Wall', '-Wno-unused-function']
+
+
+def b_list():
+    txt = open(os.path.join(CSRC, 'dcomp_blist.h')).read()
+    line = re.search(r'#define DCOMP_B_LIST\(X\)(.*)', txt).group(1)
+    return [int(x) for x in re.findall(r'X\((\d+)\)', line)]
+
+
+def _sources():
+    return [os.path.join(CSRC, f) for f in ('dcomp_device.h', 'dcomp_blist.h', 'dcomp_inst.hip', 'dcomp_api.hip')] + \
+        [os.path.join(os.path.dirname(HERE), 'include', 'dcomp.h')]
+
+
+def up_to_date():
+    if not os.path.exists(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    return all(os.path.getmtime(s) <= t for s in _sources())
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('command failed: ' + ' '.join(cmd) + '\n' + r.stdout)
+    return r.stdout
+
+
+def build(force=False, jobs=None, extra_flags=()):
+    if not force and up_to_date():
+        return LIB
+    hipcc = os.environ.get('HIPCC', 'hipcc')
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = jobs or os.cpu_count() or 4
+    tasks = []
+    for b in b_list():
+        o = os.path.join(OBJ, f'dcomp_inst_b{b}.o')
+        tasks.append((o, [hipcc] + CXXFLAGS + list(extra_flags) + [f'-DDCOMP_B={b}', '-c', os.path.join(CSRC, 'dcomp_inst.hip'),
+                                                                   '-o', o]))
+    o_api = os.path.join(OBJ, 'dcomp_api.o')
+    tasks.append((o_api, [hipcc] + CXXFLAGS + list(extra_flags) + ['-c', os.path.join(CSRC, 'dcomp_api.hip'), '-o', o_api]))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
+        for out in ex.map(lambda t: _run(t[1]), tasks):
+            if out.strip():
+                sys.stderr.write(out)
+    _run([hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + [t[0] for t in tasks] + ['-lpthread'])
+    return LIB
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--force', action='store_true')
+    ap.add_argument('--jobs', type=int, default=None)
+    ap.add_argument('--no-dpp', action='store_true', help='build the __shfl_xor fallback reductions (debug)')
+    a = ap.parse_args()
+    print(build(force=a.force, jobs=a.jobs, extra_flags=['-DDCOMP_NO_DPP'] if a.no_dpp else []))

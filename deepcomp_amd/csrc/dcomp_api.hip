@@ -1,0 +1,423 @@
+// dcomp_api.hip -- C ABI (include/dcomp.h) of libdcomp_hip.so: handle management, kernel dispatch,
+// the CPython-compatible Mersenne-Twister tape generator, device self-tests.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "dcomp_blist.h"
+#include "dcomp_device.h"
+
+namespace dcomp {
+#define DCOMP_DECL(n) KernelPair kernels_b##n(int upad);
+DCOMP_B_LIST(DCOMP_DECL)
+#undef DCOMP_DECL
+
+static KernelPair lookup_kernels(int B, int upad)
+{
+    switch (B) {
+#define DCOMP_CASE(n) case n: return kernels_b##n(upad);
+        DCOMP_B_LIST(DCOMP_CASE)
+#undef DCOMP_CASE
+    default: return KernelPair{nullptr, nullptr};
+    }
+}
+}  // namespace dcomp
+
+using dcomp::KParams;
+using dcomp::UeCfg;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(DCOMP_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct dcomp_env {
+    dcomp_cfg cfg;
+    KParams kp;                 // constant part pre-filled
+    dcomp::KernelPair kern;
+    UeCfg *d_ue_cfg;
+    int upad, grid;
+    int time;
+    int64_t episode;            // index of the current episode (-1 before the first reset)
+};
+
+// ---- channel constants from the reference's own formula (station.py:26-30,110-127), FP64 on the host ----
+static double ref_snr(double d)
+{
+    const double f = 2500.0, hb = 50.0, hu = 1.5, tx = 30.0, noise = 1e-9;
+    double ch = 0.8 + (1.1 * std::log10(f) - 0.7) * hu - 1.56 * std::log10(f);
+    double c1 = 69.55 + 26.16 * std::log10(f) - 13.82 * std::log10(hb) - ch;
+    double c2 = 44.9 - 6.55 * std::log10(hb);
+    double pl = c1 + c2 * std::log10(d + 1e-16);
+    return std::pow(10.0, (tx - pl) / 10.0) / noise;
+}
+extern "C" double dcomp_connect_threshold(void)
+{
+    double lo = 60.0, hi = 80.0;    // snr(lo) > 2e-8 >= snr(hi)
+    for (int i = 0; i < 200; i++) {
+        double mid = 0.5 * (lo + hi);
+        if (mid == lo || mid == hi) break;
+        if (ref_snr(mid) > 2e-8) lo = mid; else hi = mid;
+    }
+    return hi;
+}
+
+static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+extern "C" const char *dcomp_last_error(void) { return g_err; }
+extern "C" const char *dcomp_version(void) { return "deepcomp_amd 0.1 (gfx950)"; }
+
+extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
+{
+    if (!cfg || !out) return fail(DCOMP_EINVAL, "null argument");
+    *out = nullptr;
+    const int E = cfg->num_envs, U = cfg->num_ue, B = cfg->num_bs;
+    if (E < 1 || U < 1 || U > DCOMP_MAX_UE || B < 1 || B > DCOMP_MAX_BS)
+        return fail(DCOMP_EINVAL, "need num_envs>=1, 1<=num_ue<=%d, 1<=num_bs<=%d (got %d, %d, %d)", DCOMP_MAX_UE, DCOMP_MAX_BS, E, U, B);
+    if ((int64_t)E * U > (int64_t)1 << 30) return fail(DCOMP_EINVAL, "num_envs*num_ue too large");
+    if (cfg->map_w < 21 || cfg->map_h < 21 || cfg->map_w > 65535 || cfg->map_h > 65535)
+        return fail(DCOMP_EINVAL, "map must be 21..65535 in both dimensions (waypoints live in [10, size-10])");
+    if (cfg->env_kind != DCOMP_CENTRAL && cfg->env_kind != DCOMP_MULTI) return fail(DCOMP_EINVAL, "bad env_kind");
+    if (cfg->reward_agg < 0 || cfg->reward_agg > 2) return fail(DCOMP_EINVAL, "bad reward_agg");
+    if (cfg->rng_mode != DCOMP_RNG_TAPE && cfg->rng_mode != DCOMP_RNG_PHILOX) return fail(DCOMP_EINVAL, "bad rng_mode");
+    if (cfg->rng_mode == DCOMP_RNG_TAPE && cfg->tape_depth < 1) return fail(DCOMP_EINVAL, "tape mode needs tape_depth >= 1");
+    if (!cfg->bs_x || !cfg->bs_y || !cfg->bs_sharing || !cfg->ue_vel_lo || !cfg->ue_vel_hi)
+        return fail(DCOMP_EINVAL, "bs_x, bs_y, bs_sharing, ue_vel_lo, ue_vel_hi are required");
+
+    dcomp_env *env = new dcomp_env();
+    env->cfg = *cfg;
+    env->cfg.bs_x = env->cfg.bs_y = nullptr;   // host arrays are not retained
+    env->upad = next_pow2(U) < 4 ? 4 : next_pow2(U);
+    env->kern = dcomp::lookup_kernels(B, env->upad);
+    if (!env->kern.step) { delete env; return fail(DCOMP_EUNSUPPORTED, "no kernel built for num_bs=%d (built: " DCOMP_B_LIST_STR ")", B); }
+    env->grid = (E + (256 / env->upad) - 1) / (256 / env->upad);
+    env->time = 0;
+    env->episode = -1;
+
+    KParams &kp = env->kp;
+    std::memset(&kp, 0, sizeof(kp));
+    kp.E = E; kp.U = U;
+    kp.map_w = cfg->map_w; kp.map_h = cfg->map_h;
+    kp.kind = cfg->env_kind; kp.reward_agg = cfg->reward_agg; kp.rng_mode = cfg->rng_mode;
+    kp.tape_depth = cfg->tape_depth;
+    kp.seed_lo = (uint32_t)cfg->seed; kp.seed_hi = (uint32_t)(cfg->seed >> 32);
+    kp.env_base = (uint32_t)cfg->env_id_base;
+    {   // snr = K * (d + eps)^(-gamma): gamma = c2/10, K = snr(1 m)   (station.py:110-127)
+        double c2 = 44.9 - 6.55 * std::log10(50.0);
+        kp.gamma = (float)(c2 / 10.0);
+        kp.log2k = (float)std::log2(ref_snr(1.0));
+        double dt = dcomp_connect_threshold();
+        kp.dt2 = dt * dt;
+    }
+    kp.any_maxcap = 0;
+    for (int b = 0; b < B; b++) {
+        kp.bs_x[b] = cfg->bs_x[b]; kp.bs_y[b] = cfg->bs_y[b];
+        int m = cfg->bs_sharing[b];
+        if (m < 0 || m > 3) { delete env; return fail(DCOMP_EINVAL, "bs_sharing[%d]=%d not supported", b, m); }   // station.py:22
+        kp.bs_mode[b] = m;
+        if (m == DCOMP_MAX_CAP) kp.any_maxcap = 1;
+    }
+    std::vector<UeCfg> uc(U);
+    kp.all_log_util = 1;
+    for (int u = 0; u < U; u++) {
+        UeCfg c;
+        std::memset(&c, 0, sizeof(c));
+        int lo = cfg->ue_vel_lo[u], hi = cfg->ue_vel_hi[u];
+        if (lo < 0 || hi < lo || hi > 255) { delete env; return fail(DCOMP_EINVAL, "ue %d: velocity range [%d,%d] invalid", u, lo, hi); }
+        c.vel_lo = (uint8_t)lo; c.vel_hi = (uint8_t)hi;
+        c.init_x = cfg->ue_init_x ? (int16_t)cfg->ue_init_x[u] : (int16_t)-1;
+        c.init_y = cfg->ue_init_y ? (int16_t)cfg->ue_init_y[u] : (int16_t)-1;
+        c.util = cfg->ue_util ? (uint8_t)cfg->ue_util[u] : (uint8_t)DCOMP_UTIL_LOG;
+        if (c.util > DCOMP_UTIL_STEP) { delete env; return fail(DCOMP_EUNSUPPORTED, "ue %d: utility %d not implemented", u, (int)c.util); }   // user.py:92
+        if (c.util != DCOMP_UTIL_LOG) kp.all_log_util = 0;
+        c.dr_req = cfg->ue_dr_req ? cfg->ue_dr_req[u] : 1.0f;
+        uc[u] = c;
+    }
+    hipError_t e = hipSetDevice(cfg->device);
+    if (e == hipSuccess) e = hipMalloc((void **)&env->d_ue_cfg, sizeof(UeCfg) * U);
+    if (e == hipSuccess) e = hipMemcpy(env->d_ue_cfg, uc.data(), sizeof(UeCfg) * U, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { delete env; return fail(DCOMP_EHIP, "device setup failed: %s", hipGetErrorString(e)); }
+    kp.ue_cfg = env->d_ue_cfg;
+    *out = env;
+    return DCOMP_OK;
+}
+
+extern "C" int dcomp_destroy(dcomp_env *env)
+{
+    if (!env) return DCOMP_OK;
+    if (env->d_ue_cfg) (void)hipFree(env->d_ue_cfg);
+    delete env;
+    return DCOMP_OK;
+}
+
+extern "C" int dcomp_state_sizes(const dcomp_env *env, size_t *pos_bytes, size_t *mv_bytes, size_t *conn_bytes, size_t *ewma_bytes,
+                                 size_t *flags_bytes)
+{
+    if (!env) return fail(DCOMP_EINVAL, "null env");
+    size_t n = (size_t)env->cfg.num_envs * env->cfg.num_ue;
+    if (pos_bytes) *pos_bytes = n * 16;
+    if (mv_bytes) *mv_bytes = n * 8;
+    if (conn_bytes) *conn_bytes = n * 4;
+    if (ewma_bytes) *ewma_bytes = n * 4;
+    if (flags_bytes) *flags_bytes = 16;
+    return DCOMP_OK;
+}
+
+extern "C" int dcomp_obs_dim(const dcomp_env *env, int32_t *floats_per_env, int32_t *reward_per_env)
+{
+    if (!env) return fail(DCOMP_EINVAL, "null env");
+    const int U = env->cfg.num_ue, B = env->cfg.num_bs;
+    if (floats_per_env) *floats_per_env = env->cfg.env_kind == DCOMP_MULTI ? U * (4 * B + 1) : U * (2 * B + 1);
+    if (reward_per_env) *reward_per_env = env->cfg.env_kind == DCOMP_MULTI ? U : 1;
+    return DCOMP_OK;
+}
+
+static int fill_params(dcomp_env *env, const dcomp_state *st, const dcomp_out *out, KParams &kp)
+{
+    if (!env || !st || !out) return fail(DCOMP_EINVAL, "null argument");
+    if (!st->pos || !st->mv || !st->conn || !st->ewma || !st->flags) return fail(DCOMP_EINVAL, "state pointers must all be set");
+    if (!out->obs) return fail(DCOMP_EINVAL, "out->obs is required");
+    kp = env->kp;
+    kp.pos = (double2 *)st->pos; kp.mv = (unsigned long long *)st->mv; kp.conn = st->conn; kp.ewma = st->ewma; kp.flags = st->flags;
+    kp.obs = out->obs; kp.reward = out->reward; kp.sum_util = out->sum_utility; kp.ue_dr = out->ue_dr; kp.ue_util = out->ue_utility;
+    kp.episode = (uint32_t)(env->episode < 0 ? 0 : env->episode);
+    return DCOMP_OK;
+}
+
+extern "C" int dcomp_reset(dcomp_env *env, const dcomp_state *st, const dcomp_tape *tape, const dcomp_out *out, void *stream)
+{
+    KParams kp;
+    int rc = fill_params(env, st, out, kp);
+    if (rc) return rc;
+    if (env->cfg.rng_mode == DCOMP_RNG_TAPE) {
+        if (!tape || !tape->pos0 || !tape->triples) return fail(DCOMP_EINVAL, "tape mode: reset needs the episode's draw tape");
+        env->kp.tape_pos0 = tape->pos0;                     // borrowed until the next reset
+        env->kp.tape_triples = (const ushort4 *)tape->triples;
+        kp.tape_pos0 = env->kp.tape_pos0; kp.tape_triples = env->kp.tape_triples;
+    }
+    env->episode += 1;
+    env->time = 0;
+    kp.episode = (uint32_t)env->episode;
+    hipLaunchKernelGGL(env->kern.reset, dim3(env->grid), dim3(256), 0, (hipStream_t)stream, kp);
+    HIP_TRY(hipGetLastError());
+    return DCOMP_OK;
+}
+
+extern "C" int dcomp_step(dcomp_env *env, const dcomp_state *st, const uint8_t *action, const dcomp_out *out, void *stream)
+{
+    KParams kp;
+    int rc = fill_params(env, st, out, kp);
+    if (rc) return rc;
+    if (!action) return fail(DCOMP_EINVAL, "null action");
+    if (env->episode < 0) return fail(DCOMP_EINVAL, "step() before reset()");
+    kp.action = action;
+    hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(256), 0, (hipStream_t)stream, kp);
+    HIP_TRY(hipGetLastError());
+    env->time += 1;
+    return DCOMP_OK;
+}
+
+extern "C" int dcomp_rollout(dcomp_env *env, const dcomp_state *st, const uint8_t *actions, int32_t num_steps, const dcomp_out *out,
+                             void *stream)
+{
+    KParams kp;
+    int rc = fill_params(env, st, out, kp);
+    if (rc) return rc;
+    if (!actions || num_steps < 1) return fail(DCOMP_EINVAL, "bad action tape");
+    if (env->episode < 0) return fail(DCOMP_EINVAL, "rollout() before reset()");
+    const size_t stride = (size_t)env->cfg.num_envs * env->cfg.num_ue;
+    for (int t = 0; t < num_steps; t++) {
+        kp.action = actions + stride * t;
+        hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(256), 0, (hipStream_t)stream, kp);
+    }
+    HIP_TRY(hipGetLastError());
+    env->time += num_steps;
+    return DCOMP_OK;
+}
+
+extern "C" int dcomp_check(dcomp_env *env, const dcomp_state *st, void *stream)
+{
+    if (!env || !st || !st->flags) return fail(DCOMP_EINVAL, "null argument");
+    uint32_t h[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h, st->flags, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (h[0]) HIP_TRY(hipMemsetAsync(st->flags, 0, sizeof(h), (hipStream_t)stream));
+    if (h[0] & DCOMP_FLAG_BAD_ACTION) return fail(DCOMP_EACTION, "an action does not fit the action space [0, %d]", env->cfg.num_bs);
+    if (h[0] & DCOMP_FLAG_TAPE_EMPTY) return fail(DCOMP_ETAPE, "waypoint draw tape exhausted (depth %d)", env->cfg.tape_depth);
+    if (h[0] & DCOMP_FLAG_OUTSIDE_MAP) return fail(DCOMP_EPOS, "a UE position is outside the map");
+    return DCOMP_OK;
+}
+
+extern "C" int dcomp_time(const dcomp_env *env) { return env ? env->time : -1; }
+extern "C" int64_t dcomp_episode(const dcomp_env *env) { return env ? env->episode : -1; }
+extern "C" int dcomp_set_episode(dcomp_env *env, int64_t episode)
+{
+    if (!env) return fail(DCOMP_EINVAL, "null env");
+    env->episode = episode - 1;     // the next reset() starts `episode`
+    return DCOMP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// CPython-compatible MT19937: random.Random(int).randint(a, b)   (stdlib: Modules/_randommodule.c, Lib/random.py)
+namespace {
+struct PyMT {
+    uint32_t mt[624];
+    int idx;
+    void init_genrand(uint32_t s)
+    {
+        mt[0] = s;
+        for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        idx = 624;
+    }
+    void init_by_array(const uint32_t *key, int len)
+    {
+        init_genrand(19650218u);
+        int i = 1, j = 0;
+        for (int k = (624 > len ? 624 : len); k; k--) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+            i++; j++;
+            if (i >= 624) { mt[0] = mt[623]; i = 1; }
+            if (j >= len) j = 0;
+        }
+        for (int k = 623; k; k--) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+            i++;
+            if (i >= 624) { mt[0] = mt[623]; i = 1; }
+        }
+        mt[0] = 0x80000000u;
+    }
+    void seed(int64_t s)
+    {   // random.seed(int): key = 32-bit little-endian digits of abs(s)
+        uint64_t a = (uint64_t)(s < 0 ? -s : s);
+        uint32_t key[2] = {(uint32_t)a, (uint32_t)(a >> 32)};
+        init_by_array(key, key[1] ? 2 : 1);
+    }
+    uint32_t next()
+    {
+        if (idx >= 624) {
+            int kk;
+            for (kk = 0; kk < 624 - 397; kk++) { uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu); mt[kk] = mt[kk + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+            for (; kk < 623; kk++) { uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu); mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+            uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+            mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
+        return y;
+    }
+    uint32_t randbelow(uint32_t n)
+    {   // Random._randbelow_with_getrandbits: k = n.bit_length(); r = getrandbits(k) until r < n
+        int k = 32 - __builtin_clz(n);
+        uint32_t r = next() >> (32 - k);
+        while (r >= n) r = next() >> (32 - k);
+        return r;
+    }
+    int randint(int a, int b) { return a + (int)randbelow((uint32_t)(b - a + 1)); }
+};
+}  // namespace
+
+extern "C" int dcomp_mt_draw_tape(const dcomp_cfg *cfg, const int64_t *seeds, int32_t num_envs, int32_t depth, int32_t *pos0,
+                                  uint16_t *triples)
+{
+    if (!cfg || !seeds || !pos0 || !triples || depth < 1 || num_envs < 1) return fail(DCOMP_EINVAL, "bad argument");
+    const int U = cfg->num_ue, W = cfg->map_w, H = cfg->map_h;
+    if (!cfg->ue_vel_lo || !cfg->ue_vel_hi) return fail(DCOMP_EINVAL, "velocity ranges required");
+    auto work = [&](int e0, int e1) {
+    for (int e = e0; e < e1; e++) {
+        PyMT pos_rng, mov_rng;
+        for (int u = 0; u < U; u++) {
+            const int64_t s = seeds[e] + 100 * (int64_t)(u + 1);     // base.py:138-143
+            pos_rng.seed(s); mov_rng.seed(s);                        // user.py:94-96 (same seed for both streams)
+            const size_t idx = (size_t)e * U + u;
+            const int ix = cfg->ue_init_x ? cfg->ue_init_x[u] : -1, iy = cfg->ue_init_y ? cfg->ue_init_y[u] : -1;
+            pos0[2 * idx] = ix < 0 ? pos_rng.randint(0, W) : ix;                 // user.py:102-103
+            pos0[2 * idx + 1] = iy < 0 ? pos_rng.randint(0, H) : iy;             // user.py:106-107
+            for (int k = 0; k < depth; k++) {
+                const int lo = cfg->ue_vel_lo[u], hi = cfg->ue_vel_hi[u];
+                uint16_t *t = triples + (idx * depth + k) * 4;
+                t[0] = (uint16_t)(lo != hi ? mov_rng.randint(lo, hi) : lo);      // movement.py:112-117
+                t[1] = (uint16_t)mov_rng.randint(10, W - 10);                    // movement.py:126
+                t[2] = (uint16_t)mov_rng.randint(10, H - 10);                    // movement.py:127
+                t[3] = 0;
+            }
+        }
+    }
+    };
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > 32) nt = 32;
+    if ((int64_t)num_envs * U < 4096) nt = 1;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) {
+        int e0 = (int)((int64_t)num_envs * t / nt), e1 = (int)((int64_t)num_envs * (t + 1) / nt);
+        if (e1 > e0) th.emplace_back(work, e0, e1);
+    }
+    for (auto &t : th) t.join();
+    return DCOMP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// device self-tests
+namespace {
+__global__ void selftest_fp64(int op, const double *x, const double *y, double *out, int64_t n)
+{
+#pragma clang fp contract(off)
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a = x[i], b = y[i], r;
+    if (op == 0) r = __builtin_sqrt(a);
+    else if (op == 1) r = a / b;
+    else r = __builtin_fma(b, b, a * a);
+    out[i] = r;
+}
+template <int W>
+__global__ void selftest_reduce(const double *x, double *out, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float v = i < n ? (float)x[i] : 0.f;
+    float s = dcomp::group_reduce<W, dcomp::OpSum>(v);
+    float m = dcomp::group_reduce<W, dcomp::OpMin>(v);
+    int lane = threadIdx.x & 63;
+    int c = dcomp::group_count<W>(v > 0.f, lane & ~(W - 1));
+    if (i < n) out[i] = (double)s + 1024.0 * (double)c + 1048576.0 * (double)m;
+}
+}  // namespace
+
+extern "C" int dcomp_selftest(int op, int width, const double *x, const double *y, double *out, int64_t n, void *stream)
+{
+    if (!x || !out || n < 1) return fail(DCOMP_EINVAL, "bad argument");
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (op >= 0 && op <= 2) {
+        if (!y) return fail(DCOMP_EINVAL, "y required");
+        hipLaunchKernelGGL(selftest_fp64, grid, block, 0, s, op, x, y, out, n);
+    } else if (op == 3) {
+        switch (width) {
+        case 2: hipLaunchKernelGGL(selftest_reduce<2>, grid, block, 0, s, x, out, n); break;
+        case 4: hipLaunchKernelGGL(selftest_reduce<4>, grid, block, 0, s, x, out, n); break;
+        case 8: hipLaunchKernelGGL(selftest_reduce<8>, grid, block, 0, s, x, out, n); break;
+        case 16: hipLaunchKernelGGL(selftest_reduce<16>, grid, block, 0, s, x, out, n); break;
+        case 32: hipLaunchKernelGGL(selftest_reduce<32>, grid, block, 0, s, x, out, n); break;
+        case 64: hipLaunchKernelGGL(selftest_reduce<64>, grid, block, 0, s, x, out, n); break;
+        default: return fail(DCOMP_EINVAL, "width must be 2..64 (power of two)");
+        }
+    } else return fail(DCOMP_EINVAL, "unknown op");
+    HIP_TRY(hipGetLastError());
+    return DCOMP_OK;
+}

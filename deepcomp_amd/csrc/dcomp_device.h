@@ -1,0 +1,607 @@
+// dcomp_device.h -- CDNA4 (gfx950) device code of the DeepCoMP env step.
+//
+// Mapping: one lane = one (env, UE).  An env occupies UPAD consecutive lanes (UPAD = next power of two
+// >= U, <= 256); a 256-lane workgroup holds 256/UPAD envs.  The per-BS reductions over an env's UEs
+// (connected-UE count, sum 1/rate, sum priority, sum/min utility) are DPP / ds_swizzle all-reduces inside
+// a wavefront and one LDS exchange across wavefronts when U > 64.  The BS table (x, y, sharing mode) is
+// wave-uniform: it lives in the kernel-argument segment and is read with scalar loads into SGPRs, the B
+// loop is fully unrolled (B is a template parameter).  No [U,B] intermediate ever reaches HBM: one read
+// and one write of the UE state, one write of the observation row.
+//
+// Numerics: position / movement / connect-drop decisions in FP64 with the reference's operation order
+// (bit-exact masks); SNR, rates, utility, observation in FP32 in the log2 domain (no overflow at d -> 0).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dcomp.h"
+
+namespace dcomp {
+
+// ---- channel constants (station.py:26-30, 110-127): snr = K * (d + 1e-16)^(-GAMMA) -------------------------
+// K and GAMMA are computed on the host from the reference's formula and passed in KParams.
+constexpr float BW = 9e6f;                 // station.py:26
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float TEN_LOG10_2 = 3.0102999566398120f;   // 10*log10(x) = TEN_LOG10_2 * log2(x)   (utility.py:54)
+constexpr float EPS = 1e-16f;              // constants.py:28
+constexpr float MIN_UTIL = -20.f, MAX_UTIL = 20.f;   // constants.py:40-41
+
+struct UeCfg {          // per-UE immutable config (same in every env), 16 B
+    int16_t init_x, init_y;   // -1 = random
+    uint8_t vel_lo, vel_hi;   // inclusive draw range
+    uint8_t util;             // DCOMP_UTIL_*
+    uint8_t pad;
+    float dr_req;
+    uint32_t pad2;
+};
+
+struct KParams {
+    // state (device)
+    double2 *pos;
+    unsigned long long *mv;
+    uint32_t *conn;
+    float *ewma;
+    uint32_t *flags;
+    // io (device)
+    const uint8_t *action;
+    float *obs, *reward, *sum_util, *ue_dr, *ue_util;
+    // tape (device)
+    const int32_t *tape_pos0;
+    const ushort4 *tape_triples;
+    const UeCfg *ue_cfg;
+    int32_t tape_depth;
+    int32_t E, U;
+    int32_t map_w, map_h;
+    int32_t kind, reward_agg, rng_mode;
+    uint32_t all_log_util;     // 1: every UE uses the log utility (skip the per-UE config load)
+    uint32_t any_maxcap;
+    uint32_t seed_lo, seed_hi, episode;
+    uint32_t env_base;         // global id of env 0
+    float gamma;               // path-loss exponent c2/10
+    float log2k;               // log2(K)
+    double dt2;                // squared connect-threshold distance
+    double bs_x[DCOMP_MAX_BS], bs_y[DCOMP_MAX_BS];
+    int32_t bs_mode[DCOMP_MAX_BS];
+};
+
+// ---------------------------------------------------------------------------------------------- cross-lane
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float swz_xor16(float v)
+{   // ds_swizzle bit mode: and=0x1f, or=0, xor=0x10 -> lane i <-> i^16 inside each 32-lane half
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));
+}
+#define DCOMP_DPP_QUAD_X1 0xB1      // quad_perm [1,0,3,2]
+#define DCOMP_DPP_QUAD_X2 0x4E      // quad_perm [2,3,0,1]
+#define DCOMP_DPP_HALF_MIRROR 0x141 // i <-> 7-i in each 8
+#define DCOMP_DPP_ROW_MIRROR 0x140  // i <-> 15-i in each 16
+
+struct OpSum { __device__ __forceinline__ static float f(float a, float b) { return a + b; } };
+struct OpMin { __device__ __forceinline__ static float f(float a, float b) { return fminf(a, b); } };
+struct OpMax { __device__ __forceinline__ static float f(float a, float b) { return fmaxf(a, b); } };
+
+// All-reduce over aligned groups of W lanes (W = 1,2,4,...,64).  Every lane of a group ends with the
+// bit-identical result (each butterfly stage combines the same two partial results in both partners).
+template <int W, class Op>
+__device__ __forceinline__ float group_reduce(float v)
+{
+#ifdef DCOMP_NO_DPP
+#pragma unroll
+    for (int m = 1; m < W; m <<= 1) v = Op::f(v, __shfl_xor(v, m, 64));
+#else
+    if (W >= 2) v = Op::f(v, dpp_f32<DCOMP_DPP_QUAD_X1>(v));
+    if (W >= 4) v = Op::f(v, dpp_f32<DCOMP_DPP_QUAD_X2>(v));
+    if (W >= 8) v = Op::f(v, dpp_f32<DCOMP_DPP_HALF_MIRROR>(v));
+    if (W >= 16) v = Op::f(v, dpp_f32<DCOMP_DPP_ROW_MIRROR>(v));
+    if (W >= 32) v = Op::f(v, swz_xor16(v));
+    if (W >= 64) v = Op::f(v, __shfl_xor(v, 32, 64));
+#endif
+    return v;
+}
+// Number of lanes of my W-group whose predicate holds (ballot + popcount: scalar mask, 3 VALU).
+template <int W>
+__device__ __forceinline__ int group_count(bool pred, int gbase)
+{
+    unsigned long long m = __ballot(pred);
+    if (W < 64) m = (m >> gbase) & ((1ull << W) - 1ull);
+    return __popcll(m);
+}
+
+// ---------------------------------------------------------------------------------------------- channel
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32 (1 ulp)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32 (1 ulp)
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32 (1 ulp)
+// log2(snr) and in-range test of one (UE, BS) pair.  station.py:110-127, 222-226.
+__device__ __forceinline__ void pair_eval(double px, double py, double bx, double by, const KParams &p, bool &in_range,
+                                          float &l2snr)
+{
+    double dx = bx - px, dy = by - py;
+    double dsq = __builtin_fma(dy, dy, dx * dx);
+    in_range = dsq < p.dt2;                      // snr > 2e-8  <=>  d < d_T, decided in FP64
+    float q = (float)dsq;
+    float h = 0.5f * fast_log2(fmaxf(q, 1e-20f));  // log2(d); the +1e-16 of station.py:116 is below FP32 resolution ...
+    if (q < 1e-20f) h = fast_log2(__builtin_sqrtf(q) + EPS);   // ... except at d ~ 0 (waypoints and BS sit on the integer grid)
+    l2snr = __builtin_fmaf(-p.gamma, h, p.log2k);
+}
+// bw * log2(1 + snr) from log2(snr).  station.py:129-138.  Never forms 1+snr (exactly 1.0f for snr < 6e-8).
+__device__ __forceinline__ float rate_unshared(float l2snr)
+{
+    float r;
+    if (l2snr > 20.f) {
+        r = l2snr + LOG2E * fast_exp2(-l2snr);      // log2(s) + log2(1 + 1/s)
+    } else {
+        float s = fast_exp2(l2snr);
+        if (s < 0.03125f) {
+            // log1p(s) = s - s^2/2 + s^3/3 - s^4/4 + s^5/5 (+ s^6/6 < 5e-9 relative)
+            float t = __builtin_fmaf(s, 0.2f, -0.25f);
+            t = __builtin_fmaf(s, t, 0.33333334f);
+            t = __builtin_fmaf(s, t, -0.5f);
+            t = __builtin_fmaf(s, t, 1.0f);
+            r = s * t * LOG2E;
+        } else {
+            r = log1pf(s) * LOG2E;
+        }
+    }
+    return BW * r;
+}
+// user.py:76-92 -> utility.py:23-54
+__device__ __forceinline__ float ue_utility(float dr, bool step_util, float dr_req)
+{
+    if (step_util) return dr >= dr_req ? MAX_UTIL : MIN_UTIL;
+    if (dr == 0.f) return MIN_UTIL;
+    float u = TEN_LOG10_2 * fast_log2(dr);
+    return fminf(fmaxf(u, MIN_UTIL), MAX_UTIL);
+}
+
+// ---------------------------------------------------------------------------------------------- RNG
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&out)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// packed movement word: wx:16 | wy:16 | vel:8 | pause:8 (bit2 pausing, bits0-1 curr_pause) | cursor:16
+__device__ __forceinline__ unsigned long long mv_pack(uint32_t wx, uint32_t wy, uint32_t vel, uint32_t pausing, uint32_t cp,
+                                                      uint32_t cursor)
+{
+    return (unsigned long long)(wx & 0xFFFF) | ((unsigned long long)(wy & 0xFFFF) << 16) | ((unsigned long long)(vel & 0xFF) << 32) |
+           ((unsigned long long)((pausing << 2) | (cp & 3)) << 40) | ((unsigned long long)(cursor & 0xFFFF) << 48);
+}
+
+// movement.py:110-130 (RandomWaypoint.reset): k-th movement triple of this UE in this episode.
+__device__ __forceinline__ void draw_triple(const KParams &p, int env, int u, int idx, uint32_t k, uint32_t &vel, uint32_t &wx,
+                                            uint32_t &wy)
+{
+    if (p.rng_mode == DCOMP_RNG_TAPE) {
+        if (k >= (uint32_t)p.tape_depth) { atomicOr(p.flags, DCOMP_FLAG_TAPE_EMPTY); k = p.tape_depth - 1; }
+        ushort4 t = p.tape_triples[(size_t)idx * p.tape_depth + k];
+        vel = t.x; wx = t.y; wy = t.z;
+    } else {
+        uint32_t r[4];
+        philox4x32_10(p.env_base + (uint32_t)env, (uint32_t)u, p.episode, k + 1, p.seed_lo, p.seed_hi, r);
+        UeCfg c = p.ue_cfg[u];
+        vel = c.vel_lo + __umulhi(r[0], (uint32_t)(c.vel_hi - c.vel_lo + 1));
+        wx = 10u + __umulhi(r[1], (uint32_t)(p.map_w - 20 + 1));
+        wy = 10u + __umulhi(r[2], (uint32_t)(p.map_h - 20 + 1));
+    }
+}
+
+// One RandomWaypoint step in FP64, in the reference's operation order.  movement.py:132-181.
+// Contraction is off: the only fused op is the explicit fma of the 2-element dot product (numpy).
+__device__ __forceinline__ void move_ue(const KParams &p, int env, int u, int idx, double &px, double &py, unsigned long long &mv)
+{
+#pragma clang fp contract(off)
+    uint32_t wxi = (uint32_t)(mv & 0xFFFF), wyi = (uint32_t)((mv >> 16) & 0xFFFF), vel = (uint32_t)((mv >> 32) & 0xFF);
+    uint32_t pz = (uint32_t)((mv >> 40) & 0xFF), cursor = (uint32_t)(mv >> 48);
+    uint32_t pausing = (pz >> 2) & 1, cp = pz & 3;
+    double wx = (double)wxi, wy = (double)wyi;
+    if (px == wx && py == wy) pausing = 1;                          // movement.py:169-170
+    bool stay = false;
+    if (pausing) {
+        if (cp < 2) { cp += 1; stay = true; }                       // movement.py:172-175 (pause_duration = 2)
+        else {                                                      // movement.py:176 -> reset()
+            draw_triple(p, env, u, idx, cursor, vel, wxi, wyi);
+            cursor += 1; pausing = 0; cp = 0;
+            wx = (double)wxi; wy = (double)wyi;
+        }
+    }
+    if (!stay) {
+        double dx = px - wx, dy = py - wy;
+        double dist = __builtin_sqrt(dx * dx + dy * dy);            // shapely distance (movement.py:142)
+        if (dist <= (double)vel) { px = wx; py = wy; }              // snap onto the waypoint
+        else {
+            double vx = wx - px, vy = wy - py;
+            double nrm = __builtin_sqrt(__builtin_fma(vy, vy, vx * vx));   // np.linalg.norm (movement.py:151)
+            double nx = vx / nrm, ny = vy / nrm;
+            px = px + (double)vel * nx;
+            py = py + (double)vel * ny;
+        }
+    }
+    mv = mv_pack(wxi, wyi, vel, pausing, cp, cursor);
+}
+
+// ---------------------------------------------------------------------------------------------- kernels
+// LDS scratch shared by the cross-wave exchange, max-cap arg-min and the 'sum' neighbourhood reward.
+template <int B, int UPAD>
+struct Geo {
+    static constexpr int WG = UPAD < 64 ? UPAD : 64;        // in-wave group width
+    static constexpr int NW = UPAD > 64 ? UPAD / 64 : 1;    // waves per env
+    static constexpr int GPB = 256 / UPAD;                  // envs per block
+    static constexpr int ROW_MULTI = 4 * B + 1;
+};
+
+template <int B, int UPAD>
+struct alignas(16) BlockSharedT {
+    float xw[4][B + 4];                                     // per-wave partials of the cross-wave exchange
+    unsigned long long mc_key[Geo<B, UPAD>::GPB * B];       // max-cap: min squared-distance bits per (env-in-block, bs)
+    uint32_t mc_win[Geo<B, UPAD>::GPB * B];
+    uint32_t nb_conn[256];                                  // 'sum' reward: conn' and reward_before of the block's UEs
+    float nb_rb[256];
+};
+
+// Sum `N` per-wave values across the NW waves of an env (values are wave-uniform when WG == 64).
+template <int N, int NW, class Op, class SH>
+__device__ __forceinline__ void xwave_reduce_(float (&v)[N], SH &sh, int wave, int lane)
+{
+    if (NW == 1) return;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; i++) sh.xw[wave][i] = v[i];
+    }
+    __syncthreads();
+    int w0 = (wave / NW) * NW;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        float a = sh.xw[w0][i];
+#pragma unroll
+        for (int k = 1; k < NW; k++) a = Op::f(a, sh.xw[w0 + k][i]);
+        v[i] = a;
+    }
+    __syncthreads();
+}
+
+// Shared data rates of this UE at every BS.  station.py:152-220 with S_b = {u : conn[u,b]}.
+//   in : conn mask, l2snr[b], ewma, (px,py) for the max-cap arg-min
+//   out: dr[b] (0 where not connected), cnt[b] = |S_b|
+template <int B, int UPAD>
+__device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, UPAD> &sh, uint32_t conn, const float (&l2)[B], float ewma,
+                                             double px, double py, int u, int env_local, int wave, int lane, int gbase,
+                                             float (&dr)[B], float (&cnt)[B])
+{
+    using G = Geo<B, UPAD>;
+    float agg[B];
+    const float inv_ewma = fast_rcp(ewma + EPS);          // station.py:150 priority denominator (beta = 1)
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        const bool c = (conn >> b) & 1u;
+        const int mode = p.bs_mode[b];
+        float dru = 0.f;
+        if (c) dru = rate_unshared(l2[b]);
+        dr[b] = dru;
+        cnt[b] = (float)group_count<G::WG>(c, gbase);
+        float a = 0.f;
+        if (mode == DCOMP_RATE_FAIR) a = group_reduce<G::WG, OpSum>(c ? fast_rcp(dru) : 0.f);          // station.py:177-180
+        else if (mode == DCOMP_PROP_FAIR) a = group_reduce<G::WG, OpSum>(c ? dru * inv_ewma : 0.f);      // station.py:192-195
+        agg[b] = a;
+    }
+    if (G::NW > 1) {
+        xwave_reduce_<B, G::NW, OpSum>(cnt, sh, wave, lane);
+        xwave_reduce_<B, G::NW, OpSum>(agg, sh, wave, lane);
+    }
+    uint32_t mc_winner = 0;
+    if (p.any_maxcap) {
+        // max-cap (station.py:183-187): only the UE with the highest unshared rate is served = the one with the
+        // smallest FP64 squared distance; exact ties -> lowest UE index (the reference: oldest connection).
+        const int tid = threadIdx.x;
+        for (int i = tid; i < G::GPB * B; i += 256) { sh.mc_key[i] = ~0ull; sh.mc_win[i] = ~0u; }
+        __syncthreads();
+        unsigned long long key[B];
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            key[b] = ~0ull;
+            if (p.bs_mode[b] == DCOMP_MAX_CAP && ((conn >> b) & 1u)) {
+                double dx = p.bs_x[b] - px, dy = p.bs_y[b] - py;
+                key[b] = (unsigned long long)__double_as_longlong(__builtin_fma(dy, dy, dx * dx));
+                atomicMin(&sh.mc_key[env_local * B + b], key[b]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < B; b++)
+            if (key[b] != ~0ull && key[b] == sh.mc_key[env_local * B + b]) atomicMin(&sh.mc_win[env_local * B + b], (uint32_t)u);
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < B; b++)
+            if (key[b] != ~0ull && sh.mc_win[env_local * B + b] == (uint32_t)u) mc_winner |= 1u << b;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        const bool c = (conn >> b) & 1u;
+        const int mode = p.bs_mode[b];
+        float dru = dr[b], out = 0.f;
+        if (mode == DCOMP_RES_FAIR) out = dru * fast_rcp(fmaxf(cnt[b], 1.f));                                  // station.py:171-173
+        else if (mode == DCOMP_RATE_FAIR) out = fast_rcp(agg[b]);                                   // station.py:180
+        else if (mode == DCOMP_PROP_FAIR) out = (dru * inv_ewma) * fast_rcp(agg[b] + EPS) * dru;             // station.py:194-195
+        else out = ((mc_winner >> b) & 1u) ? dru : 0.f;
+        dr[b] = c ? out : 0.f;
+    }
+}
+
+// Observation row + reward of one UE, written straight from registers.  variants.py:271-305,
+// central.py:31-73, multi_agent.py:32-95.
+template <int B, int UPAD, bool RESET>
+__device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, UPAD> &sh, bool active, int env, int env_local, int u, int idx,
+                                              int wave, int lane, int gbase, uint32_t conn, uint32_t in_range,
+                                              const float (&l2)[B], const float (&cnt)[B], float util, float curr_dr,
+                                              float reward_before)
+{
+    using G = Geo<B, UPAD>;
+    const int U = p.U;
+    // per-BS utility aggregates over connected UEs (station.py:63-83)
+    float tsum[B], tmin[B];
+    const bool need_min = (p.kind == DCOMP_MULTI && p.reward_agg == DCOMP_REWARD_MIN);
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        const bool c = (conn >> b) & 1u;
+        tsum[b] = RESET ? 0.f : group_reduce<G::WG, OpSum>(c ? util : 0.f);
+        tmin[b] = MAX_UTIL;
+        if (!RESET && need_min) tmin[b] = group_reduce<G::WG, OpMin>(c ? util : MAX_UTIL);
+    }
+    if (!RESET && G::NW > 1) {
+        xwave_reduce_<B, G::NW, OpSum>(tsum, sh, wave, lane);
+        if (need_min) xwave_reduce_<B, G::NW, OpMin>(tmin, sh, wave, lane);
+    }
+    float l2max = l2[0];
+#pragma unroll
+    for (int b = 1; b < B; b++) l2max = fmaxf(l2max, l2[b]);
+
+    // ---- reward
+    float reward = 0.f;
+    if (p.kind == DCOMP_CENTRAL) {
+        float r[1];
+        if (p.reward_agg == DCOMP_REWARD_MIN) {
+            r[0] = group_reduce<G::WG, OpMin>(active ? reward_before : 1.f);
+            xwave_reduce_<1, G::NW, OpMin>(r, sh, wave, lane);
+        } else {
+            r[0] = group_reduce<G::WG, OpSum>(active ? reward_before : 0.f);
+            xwave_reduce_<1, G::NW, OpSum>(r, sh, wave, lane);
+            if (p.reward_agg == DCOMP_REWARD_AVG) r[0] = r[0] / (float)U;
+        }
+        reward = r[0];
+    } else if (!RESET) {
+        reward = util;                                              // multi_agent.py:52 (own utility, NOT normalised)
+        if (p.reward_agg == DCOMP_REWARD_SUM) {
+            // multi_agent.py:73-79: sum of rewards_before over UEs sharing any BS with this UE
+            sh.nb_conn[threadIdx.x] = active ? conn : 0u;
+            sh.nb_rb[threadIdx.x] = reward_before;
+            __syncthreads();
+            if (in_range != 0) {
+                float s = 0.f;
+                const int base = env_local * UPAD;
+                for (int v = 0; v < U; v++) if (sh.nb_conn[base + v] & conn) s += sh.nb_rb[base + v];
+                reward = s;
+            }
+            __syncthreads();
+        } else if (in_range != 0) {
+            if (p.reward_agg == DCOMP_REWARD_AVG) {                 // multi_agent.py:60-71
+                float n = 0.f, t = 0.f;
+#pragma unroll
+                for (int b = 0; b < B; b++) if ((in_range >> b) & 1u) { n += cnt[b]; t += tsum[b]; }
+                if (n > 0.f) reward = (conn == 0u) ? (t + util) / (n + 1.f) : t / n;
+            } else {                                                // multi_agent.py:81-85
+                float m = util;
+#pragma unroll
+                for (int b = 0; b < B; b++) if ((in_range >> b) & 1u) m = fminf(m, cnt[b] > 0.f ? tmin[b] : MAX_UTIL);
+                reward = m;
+            }
+        }
+    }
+
+    // ---- info (base.py:383-411)
+    if (p.sum_util) {
+        float s[1];
+        s[0] = group_reduce<G::WG, OpSum>(active ? util : 0.f);
+        xwave_reduce_<1, G::NW, OpSum>(s, sh, wave, lane);
+        if (active && u == 0) p.sum_util[env] = s[0];
+    }
+    if (!active) return;
+    if (p.ue_dr) p.ue_dr[idx] = curr_dr;
+    if (p.ue_util) p.ue_util[idx] = util;
+
+    const float inv_u = 1.0f / (float)U;
+    const float util_n = util * (1.0f / MAX_UTIL);
+    if (p.kind == DCOMP_MULTI) {
+        if (p.reward) p.reward[idx] = reward;
+        float *row = p.obs + (size_t)idx * G::ROW_MULTI;
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            row[b] = (float)((conn >> b) & 1u);
+            row[B + b] = fast_exp2(l2[b] - l2max);                    // snr_b / max snr (variants.py:276-284)
+            row[2 * B + b] = cnt[b] * inv_u;                        // variants.py:296
+            row[3 * B + b] = cnt[b] > 0.f ? tsum[b] * fast_rcp(cnt[b]) * (1.0f / MAX_UTIL) : 0.f;   // variants.py:299, station.py:71-76
+        }
+        row[4 * B] = util_n;
+    } else {
+        if (p.reward && u == 0) p.reward[env] = reward;
+        float *base = p.obs + (size_t)env * U * (2 * B + 1);
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            base[u * B + b] = (float)((conn >> b) & 1u);
+            base[U * B + u * B + b] = fast_exp2(l2[b] - l2max);
+        }
+        base[2 * U * B + u] = util_n;
+    }
+}
+
+template <int B, int UPAD>
+__global__ __launch_bounds__(256) void step_kernel(const KParams p)
+{
+    using G = Geo<B, UPAD>;
+    __shared__ BlockSharedT<B, UPAD> sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int env_local = tid / UPAD, u = tid % UPAD;
+    const int env = blockIdx.x * G::GPB + env_local;
+    const bool active = (env < p.E) && (u < p.U);
+    const int idx = env * p.U + u;
+    const int gbase = lane & ~(G::WG - 1);
+
+    double px = 0.0, py = 0.0;
+    unsigned long long mv = 0;
+    uint32_t conn = 0, act = 0;
+    float ewma = 0.f;
+    bool step_util = false;
+    float dr_req = 1.f;
+    if (active) {
+        double2 q = p.pos[idx];
+        px = q.x; py = q.y;
+        mv = p.mv[idx];
+        conn = p.conn[idx];
+        ewma = p.ewma[idx];
+        act = p.action[idx];
+        if (!p.all_log_util) { UeCfg c = p.ue_cfg[u]; step_util = c.util == DCOMP_UTIL_STEP; dr_req = c.dr_req; }
+    }
+
+    // 1. pairs at the pre-move position
+    float l2[B];
+    uint32_t in_range = 0;
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        bool ir;
+        pair_eval(px, py, p.bs_x[b], p.bs_y[b], p, ir, l2[b]);
+        in_range |= (uint32_t)ir << b;
+    }
+    // 2. toggle (base.py:247-263 -> user.py:190-222)
+    if (act > (uint32_t)B) { atomicOr(p.flags, DCOMP_FLAG_BAD_ACTION); act = 0; }
+    if (act > 0) {
+        const uint32_t bit = 1u << (act - 1);
+        if (conn & bit) conn &= ~bit;
+        else if (in_range & bit) conn |= bit;
+    }
+    // 3. rates before the move (base.py:446) -> reward_before (base.py:158-167)
+    float dr[B], cnt[B];
+    shared_rates<B, UPAD>(p, sh, conn, l2, ewma, px, py, u, env_local, wave, lane, gbase, dr, cnt);
+    float curr = 0.f;
+#pragma unroll
+    for (int b = 0; b < B; b++) curr += dr[b];
+    const float util_pre = ue_utility(curr, step_util, dr_req);
+    const float reward_before = fminf(fmaxf(util_pre, MIN_UTIL), MAX_UTIL) * (1.0f / MAX_UTIL);
+    // 4. move (base.py:447 -> user.py:159-173)
+    if (active) {
+        move_ue(p, env, u, idx, px, py, mv);
+        if (px < 0.0 || py < 0.0 || px > (double)p.map_w || py > (double)p.map_h) atomicOr(p.flags, DCOMP_FLAG_OUTSIDE_MAP);
+    }
+    // 5. pairs at the new position; drop lost connections (user.py:175-188); EWMA from the stale rates (user.py:148-157)
+    in_range = 0;
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        bool ir;
+        pair_eval(px, py, p.bs_x[b], p.bs_y[b], p, ir, l2[b]);
+        in_range |= (uint32_t)ir << b;
+    }
+    conn &= in_range;
+    float stale = 0.f;
+#pragma unroll
+    for (int b = 0; b < B; b++) stale += ((conn >> b) & 1u) ? dr[b] : 0.f;
+    ewma = 0.9f * stale + 0.1f * ewma;
+    // 6. rates after the move (base.py:451)
+    shared_rates<B, UPAD>(p, sh, conn, l2, ewma, px, py, u, env_local, wave, lane, gbase, dr, cnt);
+    curr = 0.f;
+#pragma unroll
+    for (int b = 0; b < B; b++) curr += dr[b];
+    const float util = ue_utility(curr, step_util, dr_req);
+    // 7. state write-back
+    if (active) {
+        p.pos[idx] = make_double2(px, py);
+        p.mv[idx] = mv;
+        p.conn[idx] = conn;
+        p.ewma[idx] = ewma;
+    }
+    // 8. observation, reward, info
+    write_outputs<B, UPAD, false>(p, sh, active, env, env_local, u, idx, wave, lane, gbase, conn, in_range, l2, cnt, util, curr,
+                                  reward_before);
+}
+
+// MobileEnv.reset (base.py:169-189): user.py:98-116 + movement.py:110-122 + first observation.
+template <int B, int UPAD>
+__global__ __launch_bounds__(256) void reset_kernel(const KParams p)
+{
+    using G = Geo<B, UPAD>;
+    __shared__ BlockSharedT<B, UPAD> sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int env_local = tid / UPAD, u = tid % UPAD;
+    const int env = blockIdx.x * G::GPB + env_local;
+    const bool active = (env < p.E) && (u < p.U);
+    const int idx = env * p.U + u;
+    const int gbase = lane & ~(G::WG - 1);
+
+    double px = 0.0, py = 0.0;
+    bool step_util = false;
+    float dr_req = 1.f;
+    if (active) {
+        UeCfg c = p.ue_cfg[u];
+        step_util = c.util == DCOMP_UTIL_STEP; dr_req = c.dr_req;
+        int x, y;
+        if (p.rng_mode == DCOMP_RNG_TAPE) { x = p.tape_pos0[2 * idx]; y = p.tape_pos0[2 * idx + 1]; }
+        else {
+            uint32_t r[4];
+            philox4x32_10(p.env_base + (uint32_t)env, (uint32_t)u, p.episode, 0u, p.seed_lo, p.seed_hi, r);
+            x = (int)__umulhi(r[0], (uint32_t)p.map_w + 1u);
+            y = (int)__umulhi(r[1], (uint32_t)p.map_h + 1u);
+        }
+        if (c.init_x >= 0) x = c.init_x;
+        if (c.init_y >= 0) y = c.init_y;
+        px = (double)x; py = (double)y;
+        uint32_t vel, wx, wy;
+        draw_triple(p, env, u, idx, 0u, vel, wx, wy);
+        p.pos[idx] = make_double2(px, py);
+        p.mv[idx] = mv_pack(wx, wy, vel, 0u, 0u, 1u);
+        p.conn[idx] = 0u;
+        p.ewma[idx] = 0.f;
+    }
+    float l2[B], cnt[B];
+    uint32_t in_range = 0;
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        bool ir;
+        pair_eval(px, py, p.bs_x[b], p.bs_y[b], p, ir, l2[b]);
+        in_range |= (uint32_t)ir << b;
+        cnt[b] = 0.f;
+    }
+    const float util = ue_utility(0.f, step_util, dr_req);
+    write_outputs<B, UPAD, true>(p, sh, active, env, env_local, u, idx, wave, lane, gbase, 0u, in_range, l2, cnt, util, 0.f, 0.f);
+}
+
+using KernelFn = void (*)(const KParams);
+struct KernelPair { KernelFn step, reset; };
+
+template <int B, int UPAD>
+inline KernelPair make_pair_() { return KernelPair{step_kernel<B, UPAD>, reset_kernel<B, UPAD>}; }
+
+// One translation unit per B instantiates all UPAD widths (dcomp_inst_bXX.hip).
+template <int B>
+inline KernelPair kernels_for_upad(int upad)
+{
+    switch (upad) {
+    case 1: case 2: case 4: return make_pair_<B, 4>();
+    case 8: return make_pair_<B, 8>();
+    case 16: return make_pair_<B, 16>();
+    case 32: return make_pair_<B, 32>();
+    case 64: return make_pair_<B, 64>();
+    case 128: return make_pair_<B, 128>();
+    case 256: return make_pair_<B, 256>();
+    default: return KernelPair{nullptr, nullptr};
+    }
+}
+
+}  // namespace dcomp

@@ -1,0 +1,443 @@
+"""MI355X-native DeepCoMP environments behind the reference's gym / RLlib surface.
+
+``BatchedMobileEnv`` is the engine: E independent envs stepped by one fused HIP kernel launch, state and
+observations living in device tensors (``pos[E*U,2] f64``, ``mv[E*U] i64``, ``conn[E*U] i32``, ``ewma[E*U] f32``).
+
+``CentralRelNormEnv`` and ``MultiAgentMobileEnv`` keep the reference's class names, constructor
+(``env_config`` dict, env_setup.py:247-256), ``reset()``, ``step(action)``, ``seed()`` and attribute surface
+(deepcomp/env/multi_ue/central.py:143-152, multi_ue/multi_agent.py:6-107, single_ue/base.py:20-466):
+* ``num_envs == 1`` (default): return values have the reference's exact Python shapes (dict observations, float /
+  dict rewards, ``done=None``, ``info`` dict), so RLlib's rollout worker or ``Simulation.run_episode`` can drive
+  it unchanged;
+* ``num_envs > 1`` (extra ``env_config['num_envs']`` key): ``step`` takes an ``[E, U]`` action tensor and returns
+  device tensors (zero-copy for a learner on the same GPU).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, rng as _rng, spaces
+
+SNR_THRESHOLD = 2e-8          # station.py:10
+MIN_UTILITY, MAX_UTILITY = -20, 20   # constants.py:40-41
+
+
+def _coord(v):
+    return -1 if v == 'random' else int(v)
+
+
+class BatchedMobileEnv:
+    """E lock-stepped envs on one GPU.  All heavy lifting is in libdcomp_hip.so (include/dcomp.h)."""
+
+    def __init__(self, map, bs_list, ue_list, kind, num_envs=1, seed=42, episode_length=100, reward='avg',
+                 rand_episodes=False, rng='philox', device='cuda', env_id_base=0, env_seeds=None, log_metrics=True,
+                 tape_depth=None):
+        L = _lib.load()
+        self._L = L
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError("deepcomp_amd runs on an AMD GPU (torch device 'cuda'); there is no CPU path")
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self.kind = _lib.MULTI if kind in ('multi', _lib.MULTI) else _lib.CENTRAL
+        self.E, self.U, self.B = int(num_envs), len(ue_list), len(bs_list)
+        self.map_w, self.map_h = int(map.width), int(map.height)
+        self.episode_length = int(episode_length)
+        self.rand_episodes = bool(rand_episodes)
+        self.log_metrics = bool(log_metrics)
+        if reward not in _lib.REWARD:
+            raise NotImplementedError(f"Unexpected reward aggregation: {reward}")       # central.py:73
+        self.reward_agg = reward
+        self.rng_mode = _lib.RNG_PHILOX if rng == 'philox' else _lib.RNG_TAPE
+        if rng not in ('philox', 'reference'):
+            raise ValueError("rng must be 'philox' (counter-based, in-kernel) or 'reference' (stdlib-random draw tape)")
+        self.tape_depth = int(tape_depth or (self.episode_length // 3 + 4))
+        self.seed_value = seed if seed is not None else int(np.random.SeedSequence().generate_state(1)[0])
+        self.env_id_base = int(env_id_base)
+        # env e of a batch gets base seed `seed + 20000*e` (UE i adds 100*(i+1), base.py:138-143)
+        self.env_seeds = (np.asarray(env_seeds, dtype=np.int64) if env_seeds is not None
+                          else self.seed_value + 20000 * (self.env_id_base + np.arange(self.E, dtype=np.int64)))
+
+        U, B = self.U, self.B
+        self._bs_x = np.array([float(bs.pos.x) for bs in bs_list], dtype=np.float64)
+        self._bs_y = np.array([float(bs.pos.y) for bs in bs_list], dtype=np.float64)
+        for bs in bs_list:
+            assert bs.sharing_model in _lib.SHARING, f"{bs.sharing_model=} not supported."       # station.py:22
+        self._bs_sh = np.array([_lib.SHARING[bs.sharing_model] for bs in bs_list], dtype=np.int32)
+        for ue in ue_list:
+            if ue.util_func not in _lib.UTILITY:
+                raise NotImplementedError(f"Utility function {ue.util_func} not implemented!")   # user.py:92
+        self._ue_util = np.array([_lib.UTILITY[ue.util_func] for ue in ue_list], dtype=np.int32)
+        self._ue_req = np.array([float(ue.dr_req) for ue in ue_list], dtype=np.float32)
+        self.vel_specs = [ue.movement.init_velocity for ue in ue_list]
+        vr = [_rng.vel_range(v) for v in self.vel_specs]
+        self._vlo = np.array([r[0] for r in vr], dtype=np.int32)
+        self._vhi = np.array([r[1] for r in vr], dtype=np.int32)
+        self.init_xy = [(_coord(ue.init_pos_x), _coord(ue.init_pos_y)) for ue in ue_list]
+        self._ix = np.array([p[0] for p in self.init_xy], dtype=np.int32)
+        self._iy = np.array([p[1] for p in self.init_xy], dtype=np.int32)
+
+        c = _lib.DcompCfg()
+        c.num_envs, c.num_ue, c.num_bs = self.E, U, B
+        c.map_w, c.map_h = self.map_w, self.map_h
+        c.env_kind, c.reward_agg = self.kind, _lib.REWARD[reward]
+        c.rng_mode, c.tape_depth = self.rng_mode, self.tape_depth
+        c.device = self.device.index
+        c.seed = int(self.seed_value) & 0xFFFFFFFFFFFFFFFF
+        c.env_id_base = self.env_id_base
+        dp, ip, fp = _lib._dp, _lib._ip, _lib._fp
+        c.bs_x, c.bs_y = self._bs_x.ctypes.data_as(dp), self._bs_y.ctypes.data_as(dp)
+        c.bs_sharing = self._bs_sh.ctypes.data_as(ip)
+        c.ue_util, c.ue_dr_req = self._ue_util.ctypes.data_as(ip), self._ue_req.ctypes.data_as(fp)
+        c.ue_vel_lo, c.ue_vel_hi = self._vlo.ctypes.data_as(ip), self._vhi.ctypes.data_as(ip)
+        c.ue_init_x, c.ue_init_y = self._ix.ctypes.data_as(ip), self._iy.ctypes.data_as(ip)
+        self._cfg = c
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(L.dcomp_create(ctypes.byref(c), ctypes.byref(self._h)))
+
+        n, dev = self.E * U, self.device
+        self.pos = torch.zeros((n, 2), dtype=torch.float64, device=dev)
+        self.mv = torch.zeros(n, dtype=torch.int64, device=dev)
+        self.conn = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.ewma = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flags = torch.zeros(4, dtype=torch.int32, device=dev)
+        if self.kind == _lib.MULTI:
+            self.obs_dim = 4 * B + 1
+            self.obs = torch.zeros((self.E, U, self.obs_dim), dtype=torch.float32, device=dev)
+            self.reward = torch.zeros((self.E, U), dtype=torch.float32, device=dev)
+        else:
+            self.obs_dim = U * (2 * B + 1)
+            self.obs = torch.zeros((self.E, self.obs_dim), dtype=torch.float32, device=dev)
+            self.reward = torch.zeros(self.E, dtype=torch.float32, device=dev)
+        self.sum_utility = torch.zeros(self.E, dtype=torch.float32, device=dev)
+        self.ue_dr = torch.zeros((self.E, U), dtype=torch.float32, device=dev)
+        self.ue_utility = torch.zeros((self.E, U), dtype=torch.float32, device=dev)
+        self._st = _lib.DcompState(self.pos.data_ptr(), self.mv.data_ptr(), self.conn.data_ptr(), self.ewma.data_ptr(),
+                                   self.flags.data_ptr())
+        self._out = self._make_out(self.obs, self.reward)
+        self._tape_dev = None
+        self._streams = None
+        self._fixed_tape = None
+
+    # ------------------------------------------------------------------ helpers
+    def _make_out(self, obs, reward):
+        m = self.log_metrics
+        return _lib.DcompOut(obs.data_ptr(), reward.data_ptr(), self.sum_utility.data_ptr() if m else None,
+                             self.ue_dr.data_ptr() if m else None, self.ue_utility.data_ptr() if m else None)
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h is not None and h.value:
+            self._L.dcomp_destroy(h)
+            self._h = None
+
+    @property
+    def time(self):
+        return self._L.dcomp_time(self._h)
+
+    @property
+    def episode(self):
+        return self._L.dcomp_episode(self._h)
+
+    def seed(self, seed=None):
+        """base.py:132-143 (None leaves the generator state alone)."""
+        if seed is None:
+            return
+        self.seed_value = int(seed)
+        self.env_seeds = self.seed_value + 20000 * (self.env_id_base + np.arange(self.E, dtype=np.int64))
+        self._streams, self._fixed_tape = None, None
+        if self.rng_mode == _lib.RNG_PHILOX:
+            raise NotImplementedError("re-seeding a Philox env: create a new env with the new seed")
+
+    def _draw_tape(self):
+        if self.rand_episodes:
+            if self._streams is None:
+                self._streams = _rng.StdlibStreams(self.env_seeds, self.map_w, self.map_h, self.vel_specs, self.init_xy,
+                                                   self.tape_depth)
+                consumed = None
+            else:
+                consumed = ((self.mv >> 48) & 0xFFFF).cpu().numpy()
+            return self._streams.draw_episode(reseed=False, consumed=consumed)
+        if self._fixed_tape is None:          # re-seeded at every reset (base.py:171-173): same tape every episode
+            self._fixed_tape = _rng.mt_tape(self._cfg, self.env_seeds, self.tape_depth)
+        return self._fixed_tape
+
+    # ------------------------------------------------------------------ gym-like batched API
+    def reset(self):
+        """MobileEnv.reset (base.py:169-189) for all envs -> first observation tensor."""
+        with torch.cuda.device(self.device):
+            tape = None
+            if self.rng_mode == _lib.RNG_TAPE:
+                pos0, trip = self._draw_tape()
+                self._tape_dev = (torch.from_numpy(pos0).to(self.device), torch.from_numpy(trip.view(np.int16)).to(self.device))
+                tape = _lib.DcompTape(self._tape_dev[0].data_ptr(), self._tape_dev[1].data_ptr())
+            elif not self.rand_episodes:
+                self._L.dcomp_set_episode(self._h, 0)     # fixed episodes: same Philox counter word every reset
+            _lib.check(self._L.dcomp_reset(self._h, ctypes.byref(self._st), ctypes.byref(tape) if tape else None,
+                                           ctypes.byref(self._out), self._stream()))
+        return self.obs
+
+    def step(self, action):
+        """MobileEnv.step (base.py:413-466).  action: uint8 tensor [E, U] on this device, values in [0, B]."""
+        if action.dtype != torch.uint8 or action.device != self.device or not action.is_contiguous() or \
+                action.numel() != self.E * self.U:
+            raise ValueError(f"action must be a contiguous uint8 tensor with {self.E}x{self.U} entries on {self.device}")
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.dcomp_step(self._h, ctypes.byref(self._st), ctypes.c_void_p(action.data_ptr()),
+                                          ctypes.byref(self._out), self._stream()))
+        return self.obs, self.reward, None, self.info()
+
+    def step_into(self, action, obs, reward):
+        """Like step() but writes observation / reward into caller-provided tensors (rollout buffers)."""
+        out = self._make_out(obs, reward)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.dcomp_step(self._h, ctypes.byref(self._st), ctypes.c_void_p(action.data_ptr()),
+                                          ctypes.byref(out), self._stream()))
+
+    def rollout(self, actions):
+        """T steps from an action tape [T, E, U] (uint8); outputs of the last step."""
+        T = actions.shape[0]
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.dcomp_rollout(self._h, ctypes.byref(self._st), ctypes.c_void_p(actions.data_ptr()), T,
+                                             ctypes.byref(self._out), self._stream()))
+        return self.obs, self.reward
+
+    def info(self):
+        """base.py:383-411 as tensors."""
+        if not self.log_metrics:
+            return {'time': self.time}
+        return {'time': self.time, 'scalar_metrics': {'sum_utility': self.sum_utility},
+                'vector_metrics': {'dr': self.ue_dr, 'utility': self.ue_utility}}
+
+    def check(self):
+        """Synchronise and raise what the reference would have asserted (bad action, UE outside the map)."""
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.dcomp_check(self._h, ctypes.byref(self._st), self._stream()))
+
+    # ------------------------------------------------------------------ views
+    def obs_views(self, obs=None):
+        """Named slices of the packed observation (keys of variants.py:255-269 / central.py:147-151)."""
+        o = self.obs if obs is None else obs
+        B, U = self.B, self.U
+        if self.kind == _lib.MULTI:
+            return {'connected': o[..., 0:B], 'dr': o[..., B:2 * B], 'ues_at_bs': o[..., 2 * B:3 * B],
+                    'util_at_bs': o[..., 3 * B:4 * B], 'utility': o[..., 4 * B:4 * B + 1]}
+        return {'connected': o[..., 0:U * B], 'dr': o[..., U * B:2 * U * B], 'utility': o[..., 2 * U * B:]}
+
+    def state_host(self):
+        """Host copy of the raw state (parity dumps)."""
+        mv = self.mv.cpu().numpy().astype(np.uint64)
+        E, U = self.E, self.U
+        return {
+            'pos': self.pos.cpu().numpy().reshape(E, U, 2),
+            'wp': np.stack([(mv & 0xFFFF).astype(np.float64), ((mv >> 16) & 0xFFFF).astype(np.float64)], -1).reshape(E, U, 2),
+            'vel': ((mv >> 32) & 0xFF).astype(np.float64).reshape(E, U),
+            'pausing': ((mv >> 42) & 1).astype(np.int32).reshape(E, U),
+            'curr_pause': ((mv >> 40) & 3).astype(np.int32).reshape(E, U),
+            'cursor': ((mv >> 48) & 0xFFFF).astype(np.int32).reshape(E, U),
+            'conn': self.conn.cpu().numpy().astype(np.uint32).reshape(E, U),
+            'ewma': self.ewma.cpu().numpy().reshape(E, U),
+        }
+
+
+# ====================================================================================================
+class _RefSurfaceEnv:
+    """Shared implementation of the reference-named classes (MobileEnv surface, base.py:20-466)."""
+    KIND = None
+    metadata = {'render.modes': ['human']}
+
+    def __init__(self, env_config):
+        self.episode_length = env_config['episode_length']
+        self.map = env_config['map']
+        self.bs_list = env_config['bs_list']
+        self.ue_list = env_config['ue_list']
+        self.original_ue_list = list(self.ue_list)
+        self.new_ue_interval = env_config.get('new_ue_interval')
+        self.ue_arrival = env_config.get('ue_arrival')
+        if self.new_ue_interval is not None or self.ue_arrival is not None:
+            raise NotImplementedError("dynamic UE arrival/departure (base.py:433-443) is not part of the device path")
+        self.env_seed = env_config['seed']
+        self.rand_episodes = env_config['rand_episodes']
+        self.log_metrics = env_config.get('log_metrics', True)
+        self.dashboard = env_config.get('dashboard', False)
+        self.ue_details = env_config.get('ue_details', False)
+        self.reward_agg = env_config['reward']
+        self.max_ues = env_config.get('max_ues') or len(self.ue_list)
+        assert self.max_ues >= self.num_ue                                            # base.py:84
+        self.num_envs = int(env_config.get('num_envs', 1))
+        self.batched = bool(env_config.get('batched', self.num_envs > 1))
+        self.total_utility = 0
+        self.obs = None
+        self.core = BatchedMobileEnv(self.map, self.bs_list, self.ue_list, self.KIND, num_envs=self.num_envs,
+                                     seed=self.env_seed, episode_length=self.episode_length, reward=self.reward_agg,
+                                     rand_episodes=self.rand_episodes, rng=env_config.get('rng', 'reference' if not self.batched else 'philox'),
+                                     device=env_config.get('device', 'cuda'), env_id_base=env_config.get('env_id_base', 0),
+                                     env_seeds=env_config.get('env_seeds'),
+                                     log_metrics=True)
+        for i, ue in enumerate(self.ue_list):
+            if hasattr(ue, '_env'):
+                ue._env, ue._idx = self, i
+        for i, bs in enumerate(self.bs_list):
+            if hasattr(bs, '_env'):
+                bs._env, bs._idx = self, i
+        self._view_cache = None
+        self._define_spaces()
+
+    # ---- attribute surface used by callers (env_setup.py:291-309, callbacks.py:21, simulation.py:111,499)
+    @property
+    def num_bs(self):
+        return len(self.bs_list)
+
+    @property
+    def num_ue(self):
+        return len(self.ue_list)
+
+    @property
+    def time(self):
+        return self.core.time
+
+    @property
+    def current_total_utility(self):
+        return float(self.core.sum_utility[0].item())
+
+    def seed(self, seed=None):
+        self.core.seed(seed)
+
+    def _host_view(self):
+        if self._view_cache is None:
+            c = self.core
+            conn = c.conn[:c.U].cpu().numpy().astype(np.uint32)
+            self._view_cache = {
+                'pos': c.pos[:c.U].cpu().numpy(), 'ewma': c.ewma[:c.U].cpu().numpy().tolist(),
+                'curr_dr': c.ue_dr[0].cpu().numpy().tolist(), 'utility': c.ue_utility[0].cpu().numpy().tolist(),
+                'num_conn': [int(((conn >> b) & 1).sum()) for b in range(c.B)],
+            }
+        return self._view_cache
+
+    def done(self):
+        return None                                                                   # base.py:371-381
+
+    # ---- reset / step
+    def reset(self):
+        self.total_utility = 0
+        self._view_cache = None
+        obs = self.core.reset()
+        if self.batched:
+            return obs
+        self.obs = self._format_obs(obs)
+        return self.obs
+
+    def step(self, action):
+        self._view_cache = None
+        if self.batched:
+            return self.core.step(action)
+        a = self._action_tensor(action)
+        obs, reward, _, info = self.core.step(a)
+        self.core.check()
+        self.total_utility += float(info['scalar_metrics']['sum_utility'][0].item())
+        self.obs = self._format_obs(obs)
+        return self.obs, self._format_reward(reward), self.done(), self.info()
+
+    def _info_dict(self):
+        """base.py:383-411"""
+        if not self.log_metrics:
+            return {'time': self.time}
+        dr = self.core.ue_dr[0].cpu().numpy()
+        ut = self.core.ue_utility[0].cpu().numpy()
+        return {'time': self.time,
+                'scalar_metrics': {'sum_utility': float(self.core.sum_utility[0].item())},
+                'vector_metrics': {'dr': {f'UE {ue}': float(dr[i]) for i, ue in enumerate(self.ue_list)},
+                                   'utility': {f'UE {ue}': float(ut[i]) for i, ue in enumerate(self.ue_list)}}}
+
+
+class CentralRelNormEnv(_RefSurfaceEnv):
+    """Central single-agent env (DeepCoMP): multi_ue/central.py:9-73,143-152."""
+    KIND = 'central'
+
+    def _define_spaces(self):
+        B, M = self.num_bs, self.max_ues
+        self.action_space = spaces.MultiDiscrete([B + 1 for _ in range(M)])            # central.py:28
+        self.observation_space = spaces.Dict({                                         # central.py:147-151
+            'connected': spaces.MultiBinary(M * B),
+            'dr': spaces.Box(low=0, high=1, shape=(M * B,)),
+            'utility': spaces.Box(low=-1, high=1, shape=(M,)),
+        })
+
+    def _action_tensor(self, action):
+        assert self.action_space.contains(action), f"Action {action} does not fit action space {self.action_space}"   # central.py:61
+        a = np.asarray(action, dtype=np.uint8)[:self.num_ue].reshape(1, -1)
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.core.device)
+
+    def _format_obs(self, obs):
+        v = {k: t[0].cpu().numpy() for k, t in self.core.obs_views(obs).items()}
+        pad = self.max_ues - self.num_ue                                               # central.py:46-55
+        out = {'connected': [int(x) for x in v['connected']] + [0] * (pad * self.num_bs),
+               'dr': [float(x) for x in v['dr']] + [0] * (pad * self.num_bs),
+               'utility': [float(x) for x in v['utility']] + [0] * pad}
+        return out
+
+    def _format_reward(self, reward):
+        return float(reward[0].item())
+
+    def info(self):
+        return self._info_dict()
+
+
+class MultiAgentMobileEnv(_RefSurfaceEnv):
+    """Multi-agent env (DD-CoMP / D3-CoMP): multi_ue/multi_agent.py:6-107 on top of variants.py:244-305."""
+    KIND = 'multi'
+
+    def _define_spaces(self):
+        B = self.num_bs
+        self.action_space = spaces.Discrete(B + 1)                                     # variants.py:17
+        self.obs_space_dict = {                                                        # variants.py:255-268
+            'connected': spaces.MultiBinary(B),
+            'dr': spaces.Box(low=0, high=1, shape=(B,)),
+            'utility': spaces.Box(low=-1, high=1, shape=(1,)),
+            'ues_at_bs': spaces.Box(low=0, high=1, shape=(B,)),
+            'util_at_bs': spaces.Box(low=-1, high=1, shape=(B,)),
+        }
+        self.observation_space = spaces.Dict(self.obs_space_dict)
+
+    def _action_tensor(self, action):
+        a = np.zeros((1, self.num_ue), dtype=np.uint8)
+        for i, ue in enumerate(self.ue_list):                                          # multi_agent.py:30 (missing ids: no-op)
+            if ue.id in action:
+                v = int(action[ue.id])
+                if not 0 <= v <= self.num_bs:
+                    raise IndexError(f"action {v} of UE {ue.id} is outside [0, {self.num_bs}]")
+                a[0, i] = v
+        return torch.from_numpy(a).to(self.core.device)
+
+    def _format_obs(self, obs):
+        v = {k: t[0].cpu().numpy() for k, t in self.core.obs_views(obs).items()}
+        out = {}
+        for i, ue in enumerate(self.ue_list):                                          # multi_agent.py:32-37, variants.py:302-303
+            out[ue.id] = {'connected': [int(x) for x in v['connected'][i]], 'dr': [float(x) for x in v['dr'][i]],
+                          'utility': [float(v['utility'][i][0])], 'ues_at_bs': [float(x) for x in v['ues_at_bs'][i]],
+                          'util_at_bs': [float(x) for x in v['util_at_bs'][i]]}
+        return out
+
+    def _format_reward(self, reward):
+        r = reward[0].cpu().numpy()
+        return {ue.id: float(r[i]) for i, ue in enumerate(self.ue_list)}
+
+    def done(self):
+        d = {ue.id: None for ue in self.ue_list}                                       # multi_agent.py:97-102
+        d['__all__'] = None
+        return d
+
+    def info(self):
+        info = self._info_dict()                                                       # multi_agent.py:104-107
+        return {ue.id: info for ue in self.ue_list}
+
+
+def get_env_class(env_type):
+    """env_setup.py:23-37"""
+    assert env_type in ('central', 'multi'), f"Environment type was {env_type} but has to be 'central' or 'multi'."
+    return CentralRelNormEnv if env_type == 'central' else MultiAgentMobileEnv

@@ -1,0 +1,157 @@
+/*
+ * dcomp.h -- C ABI of the MI355X-native DeepCoMP environment step (libdcomp_hip.so).
+ *
+ * The reference (CN-UPB/DeepCoMP) has no FFI: its boundary is the Python class protocol
+ * gym.Env / ray.rllib MultiAgentEnv  --  __init__(env_config), reset(), step(action), seed()
+ * (deepcomp/env/single_ue/base.py:27,132,169,413; multi_ue/central.py:9-73; multi_ue/multi_agent.py:6-107).
+ * This header is the native layer *underneath* that protocol; deepcomp_amd/env.py keeps the Python
+ * surface and calls these entry points through ctypes (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - Every array named "device" is a HIP device pointer allocated by the caller (PyTorch);
+ *     the library borrows it for the duration of one call and never allocates per step.
+ *   - `stream` is the caller's hipStream_t passed as void* (NULL = default stream). Calls only
+ *     enqueue work; nothing synchronises except dcomp_check().
+ *   - Return value: DCOMP_OK (0) or a negative DCOMP_E* code; dcomp_last_error() gives the text.
+ *     Nothing throws across the ABI.
+ *   - One handle <-> one stream at a time; handles are independent; no global mutable state.
+ *
+ * Lane/data layout (E envs, U UEs, B base stations; idx = env*U + ue):
+ *   pos   double[E*U][2]   UE position x,y (FP64: connect/drop decisions are bit-exact vs the reference)
+ *   mv    uint64[E*U]      waypoint x:16 | y:16 | velocity:8 | pausing:1+curr_pause:2 (8 bits) | draw cursor:16
+ *   conn  uint32[E*U]      bit b set <=> UE connected to BS b                  (user.py:34 bs_dr keys)
+ *   ewma  float [E*U]      exponentially weighted average rate                 (user.py:148-157)
+ *   flags uint32[4]        sticky device-side error bits, read by dcomp_check()
+ */
+#ifndef DCOMP_H
+#define DCOMP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCOMP_MAX_BS 32          /* connection set is one 32-bit mask per UE */
+#define DCOMP_MAX_UE 256         /* one env never spans more than one 256-lane workgroup */
+
+enum { DCOMP_OK = 0, DCOMP_EINVAL = -1, DCOMP_EHIP = -2, DCOMP_EACTION = -3, DCOMP_ETAPE = -4, DCOMP_EPOS = -5,
+       DCOMP_EUNSUPPORTED = -6 };
+
+enum { DCOMP_CENTRAL = 0, DCOMP_MULTI = 1 };                    /* central.py:143-152 | multi_agent.py:6 */
+enum { DCOMP_REWARD_AVG = 0, DCOMP_REWARD_SUM = 1, DCOMP_REWARD_MIN = 2 };   /* constants.py:24 */
+enum { DCOMP_RES_FAIR = 0, DCOMP_RATE_FAIR = 1, DCOMP_MAX_CAP = 2, DCOMP_PROP_FAIR = 3 };  /* station.py:152-202 */
+enum { DCOMP_UTIL_LOG = 0, DCOMP_UTIL_STEP = 1 };                /* utility.py:23-54 */
+enum { DCOMP_RNG_TAPE = 0, DCOMP_RNG_PHILOX = 1 };
+
+/* device-side sticky flag bits (flags[0]) */
+#define DCOMP_FLAG_BAD_ACTION   1u   /* action outside [0, B]        (base.py:238, central.py:61 assert) */
+#define DCOMP_FLAG_TAPE_EMPTY   2u   /* waypoint tape exhausted                                           */
+#define DCOMP_FLAG_OUTSIDE_MAP  4u   /* UE left the map              (movement.py:165-166 assert)         */
+
+typedef struct dcomp_env dcomp_env;
+
+/* Immutable per-handle configuration.  Replaces the objects inside the reference's env_config dict
+ * (env_setup.py:247-256): Map -> map_w/map_h (int()-truncated, map.py:20-21); bs_list -> bs_x/bs_y/
+ * bs_sharing; ue_list -> ue_*; 'reward' -> reward_agg; 'seed' -> seed; 'episode_length'. */
+typedef struct dcomp_cfg {
+    int32_t num_envs;            /* E: envs owned by this handle (one GPU's shard) */
+    int32_t num_ue;              /* U <= DCOMP_MAX_UE */
+    int32_t num_bs;              /* B <= DCOMP_MAX_BS */
+    int32_t map_w, map_h;
+    int32_t env_kind;            /* DCOMP_CENTRAL | DCOMP_MULTI */
+    int32_t reward_agg;          /* DCOMP_REWARD_* */
+    int32_t rng_mode;            /* DCOMP_RNG_TAPE (reference-exact draws supplied by the host) | DCOMP_RNG_PHILOX */
+    int32_t tape_depth;          /* movement triples per UE per episode in tape mode */
+    int32_t device;              /* HIP device ordinal */
+    int32_t reserved;
+    uint64_t seed;               /* Philox key */
+    int64_t env_id_base;         /* global id of this shard's env 0 (results do not depend on the GPU count) */
+    const double *bs_x, *bs_y;   /* host [B] */
+    const int32_t *bs_sharing;   /* host [B] DCOMP_*_FAIR / MAX_CAP */
+    const int32_t *ue_util;      /* host [U] DCOMP_UTIL_* or NULL (= log) */
+    const float *ue_dr_req;      /* host [U] or NULL (= 1) -- step utility only (user.py:33) */
+    const int32_t *ue_vel_lo, *ue_vel_hi;  /* host [U] inclusive velocity draw range; lo==hi: fixed (movement.py:112-117) */
+    const int32_t *ue_init_x, *ue_init_y;  /* host [U] fixed start coordinate or -1 = 'random' (user.py:98-109); NULL = random */
+} dcomp_cfg;
+
+typedef struct dcomp_state {     /* device, caller-allocated; sizes via dcomp_state_sizes() */
+    double *pos;
+    uint64_t *mv;
+    uint32_t *conn;
+    float *ewma;
+    uint32_t *flags;
+} dcomp_state;
+
+/* Outputs of reset()/step().  obs layout = RLlib's flatten order of the reference's Dict spaces
+ * (sorted keys; variants.py:255-269, central.py:147-151):
+ *   MULTI   obs[E][U][4B+1] = connected[B] | dr[B] | ues_at_bs[B] | util_at_bs[B] | utility[1]
+ *   CENTRAL obs[E][U*(2B+1)] = connected[U*B] | dr[U*B] | utility[U]
+ * reward: MULTI [E][U] (multi_agent.py:39-95), CENTRAL [E] (central.py:65-73).
+ * Optional info tensors (base.py:383-411): sum_utility[E], ue_dr[E][U], ue_utility[E][U]; NULL to skip. */
+typedef struct dcomp_out {
+    float *obs;
+    float *reward;
+    float *sum_utility;
+    float *ue_dr;
+    float *ue_utility;
+} dcomp_out;
+
+/* Tape-mode draws for one episode (device): pos0[E*U][2] int32 start positions and
+ * triples[E*U][depth] of {velocity, wx, wy, 0} uint16 -- the values the reference's per-UE
+ * random.Random streams hand out. */
+typedef struct dcomp_tape {
+    const int32_t *pos0;
+    const uint16_t *triples;
+} dcomp_tape;
+
+int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out);                 /* MobileEnv.__init__  base.py:27-84 */
+int dcomp_destroy(dcomp_env *env);
+int dcomp_state_sizes(const dcomp_env *env, size_t *pos_bytes, size_t *mv_bytes, size_t *conn_bytes,
+                      size_t *ewma_bytes, size_t *flags_bytes);
+int dcomp_obs_dim(const dcomp_env *env, int32_t *floats_per_env, int32_t *reward_per_env);
+
+/* MobileEnv.reset (base.py:169-189): draw start positions + first waypoint, clear connections and
+ * EWMA, time = 0, write the first observation.  `tape` may be NULL in Philox mode. */
+int dcomp_reset(dcomp_env *env, const dcomp_state *st, const dcomp_tape *tape, const dcomp_out *out, void *stream);
+
+/* MobileEnv.step (base.py:413-466) for all E envs: action[E][U] uint8 in [0, B] (0 = no-op,
+ * k = toggle BS k-1; base.py:259-263).  One fused kernel: toggle -> rates -> move -> drop -> EWMA ->
+ * rates -> obs/reward. */
+int dcomp_step(dcomp_env *env, const dcomp_state *st, const uint8_t *action, const dcomp_out *out, void *stream);
+
+/* T consecutive steps from an action tape actions[T][E][U] (one launch per step, no host work in
+ * between); outputs of the last step only.  Used for launch-overhead-free measurement. */
+int dcomp_rollout(dcomp_env *env, const dcomp_state *st, const uint8_t *actions, int32_t num_steps,
+                  const dcomp_out *out, void *stream);
+
+/* Synchronises `stream`, reads the sticky flags and maps them to DCOMP_EACTION / DCOMP_ETAPE /
+ * DCOMP_EPOS (the reference raises AssertionError in these cases).  Clears the flags. */
+int dcomp_check(dcomp_env *env, const dcomp_state *st, void *stream);
+
+int dcomp_time(const dcomp_env *env);                 /* env.time (base.py:39) -- lock-step over the batch */
+int64_t dcomp_episode(const dcomp_env *env);          /* resets so far - 1 (Philox counter word) */
+int dcomp_set_episode(dcomp_env *env, int64_t episode);
+
+/* Host-side helper for tape mode: CPython-compatible Mersenne Twister draws
+ * (random.Random(seed).randint, user.py:94-109 / movement.py:110-130) for UEs
+ * [0,U) of `num_envs` envs whose base seeds are seeds[e]; UE i uses seeds[e] + 100*(i+1)
+ * (base.py:138-143).  Writes host arrays pos0[E*U][2], triples[E*U][depth][4]. */
+int dcomp_mt_draw_tape(const dcomp_cfg *cfg, const int64_t *seeds, int32_t num_envs, int32_t depth,
+                       int32_t *pos0, uint16_t *triples);
+
+double dcomp_connect_threshold(void);                 /* smallest double d with snr(d) <= 2e-8 (station.py:10,222-226) */
+const char *dcomp_last_error(void);
+const char *dcomp_version(void);
+
+/* Device self-test of the cross-lane reductions and the FP64 sqrt/div/fma used by the movement
+ * step: fills out[n] (device) from x[n], y[n] (device doubles).  op: 0 sqrt(x) 1 x/y 2 fma(y,y,x*x)
+ * 3 segmented all-reduce sums of (float)x over groups of `width` lanes. */
+int dcomp_selftest(int op, int width, const double *x, const double *y, double *out, int64_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCOMP_H */

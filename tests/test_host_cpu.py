@@ -1,0 +1,141 @@
+"""CPU-side checks of the product's host logic: the C-ABI library loads and exports every symbol of
+include/dcomp.h, the in-library MT19937 reproduces stdlib ``random`` (the reference's generator), scenario
+tables, spaces, config validation.  No GPU compute is called here."""
+import ctypes
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from deepcomp_amd import build, _lib
+    build.build()                      # hipcc cross-compiles gfx950 on a GPU-less host
+    return _lib.load()
+
+
+def test_abi_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(REPO, 'include', 'dcomp.h')).read()
+    declared = sorted(set(re.findall(r'\b(dcomp_[a-z0-9_]+)\s*\(', hdr)))
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/dcomp.h but not exported by libdcomp_hip.so'
+    assert b'gfx950' in lib.dcomp_version()
+
+
+def test_connect_threshold_matches_reference_constant(lib):
+    # d_T(snr = 2e-8) = 68.92488308058013 m; "roughly 69 m" (station.py:9)
+    assert lib.dcomp_connect_threshold() == pytest.approx(68.92488308058013, abs=1e-9)
+
+
+def _cfg(U, w, h, vlo, vhi, ix=None, iy=None):
+    from deepcomp_amd import _lib
+    c = _lib.DcompCfg()
+    c.num_envs, c.num_ue, c.num_bs, c.map_w, c.map_h = 1, U, 1, w, h
+    keep = [np.asarray(vlo, np.int32), np.asarray(vhi, np.int32)]
+    c.ue_vel_lo, c.ue_vel_hi = keep[0].ctypes.data_as(_lib._ip), keep[1].ctypes.data_as(_lib._ip)
+    if ix is not None:
+        keep += [np.asarray(ix, np.int32), np.asarray(iy, np.int32)]
+        c.ue_init_x, c.ue_init_y = keep[2].ctypes.data_as(_lib._ip), keep[3].ctypes.data_as(_lib._ip)
+    return c, keep
+
+
+@pytest.mark.parametrize('seeds', [[42, 43, 20042], [0, 1, 2 ** 31 - 1, 2 ** 40 + 17, -5]])
+def test_mt_tape_equals_stdlib_random(lib, seeds):
+    """dcomp_mt_draw_tape == random.Random(seed + 100*(i+1)).randint(...) in the reference's draw order
+    (base.py:138-143, user.py:94-109, movement.py:110-130)."""
+    from deepcomp_amd import rng
+    U, w, h, depth = 5, 194, 120, 9
+    vel = ['slow', 'fast', 0, 4, 'slow']
+    vr = [rng.vel_range(v) for v in vel]
+    c, keep = _cfg(U, w, h, [r[0] for r in vr], [r[1] for r in vr])
+    pos0, trip = rng.mt_tape(c, seeds, depth)
+    for e, s in enumerate(seeds):
+        for i in range(U):
+            pr, mr = random.Random(s + 100 * (i + 1)), random.Random(s + 100 * (i + 1))
+            assert list(pos0[e * U + i]) == [pr.randint(0, w), pr.randint(0, h)]
+            for k in range(depth):
+                lo, hi = vr[i]
+                want = [mr.randint(lo, hi) if lo != hi else lo, mr.randint(10, w - 10), mr.randint(10, h - 10), 0]
+                assert list(trip[e * U + i, k]) == want
+    # the stdlib-stream producer (rand_episodes=True path) hands out the same first episode
+    st = rng.StdlibStreams(seeds, w, h, vel, [(-1, -1)] * U, depth)
+    p2, t2 = st.draw_episode(reseed=False)
+    assert np.array_equal(p2, pos0) and np.array_equal(t2, trip)
+
+
+def test_mt_tape_fixed_start_positions(lib):
+    from deepcomp_amd import rng
+    c, keep = _cfg(2, 150, 100, [1, 0], [3, 0], ix=[-1, 77], iy=[-1, 5])
+    pos0, trip = rng.mt_tape(c, [42], 3)
+    pr = random.Random(142)
+    assert list(pos0[0]) == [pr.randint(0, 150), pr.randint(0, 100)]
+    assert list(pos0[1]) == [77, 5]
+    assert trip[1, 0, 0] == 0
+
+
+def test_stdlib_streams_continue_across_episodes():
+    """rand_episodes=True: the next episode continues the movement stream after the triples actually consumed."""
+    from deepcomp_amd import rng
+    st = rng.StdlibStreams([42], 194, 120, ['slow'], [(-1, -1)], 6)
+    p0, t0 = st.draw_episode(reseed=False)
+    p1, t1 = st.draw_episode(reseed=False, consumed=np.array([2]))
+    ref = random.Random(142)
+    seq = [[ref.randint(1, 3), ref.randint(10, 184), ref.randint(10, 110)] for _ in range(8)]
+    assert t0[0, :, :3].tolist() == seq[:6]
+    assert t1[0, :, :3].tolist() == seq[2:8]
+    pr = random.Random(142)
+    first = [pr.randint(0, 194), pr.randint(0, 120)]
+    second = [pr.randint(0, 194), pr.randint(0, 120)]
+    assert p0[0].tolist() == first and p1[0].tolist() == second
+
+
+def test_create_rejects_bad_config_without_gpu(lib):
+    from deepcomp_amd import _lib
+    c, keep = _cfg(3, 10, 10, [1, 1, 1], [3, 3, 3])          # map too small for the 10 m waypoint border
+    h = ctypes.c_void_p()
+    assert lib.dcomp_create(ctypes.byref(c), ctypes.byref(h)) == _lib.EINVAL
+    assert b'map' in lib.dcomp_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(_lib.EINVAL)
+    with pytest.raises(AssertionError):
+        _lib.check(_lib.EACTION)
+
+
+def test_scenario_tables_match_reference_geometry():
+    """Numbers of env_setup.py:52-176 (also recorded in the golden fixtures by the reference run)."""
+    from deepcomp_amd import scenarios as S
+    g = np.load(os.path.join(REPO, 'tests', 'golden', 'traj_custom4x4_multi_s42.npz'))
+    scn = S.custom_map('mixed')
+    assert np.array_equal(np.array(scn.bs_pos, float), g['cfg_bs_pos'])
+    assert [S.SHARING_MODELS.index(s) for s in scn.bs_sharing] == [0, 1, 3, 0] == list(g['cfg_bs_sharing'])
+    med = S.medium_map('resource-fair')
+    assert (int(med.width), int(med.height)) == (120, 106)                    # map.py:20-21 int() truncation
+    assert med.bs_pos[2] == (60.0, 10 + np.sqrt(100 ** 2 - 50 ** 2))
+    assert S.large_map('mixed').num_bs == 7 and S.large_map('mixed', num_bs=3).width == 125
+    grid = S.grid_map(10)
+    assert (grid.width, grid.height, grid.num_bs) == (400, 300, 10) and grid.bs_pos[4] == (50, 150)
+    assert S.grid_map(32).width == 600 and S.grid_map(5).height == 200
+    ues = S.small_map().with_ues(num_static=1, num_slow=2, num_fast=1).ue_specs
+    assert [u['id'] for u in ues] == ['1', '2', '3', '4'] and [u['velocity'] for u in ues] == [0, 'slow', 'slow', 'fast']
+    with pytest.raises(AssertionError):
+        S.sharing_for_bs('best-effort', 0)
+
+
+def test_spaces_and_entities():
+    from deepcomp_amd import spaces
+    from deepcomp_amd.entities import Basestation, Map, Point, RandomWaypoint, User
+    md = spaces.MultiDiscrete([4, 4, 4])
+    assert md.contains([0, 3, 1]) and not md.contains([4, 0, 0]) and not md.contains([0, 0])
+    assert list(spaces.Dict({'b': spaces.Discrete(2), 'a': spaces.Discrete(3)}).spaces.keys()) == ['a', 'b']
+    m = Map(120.0, 106.6)
+    assert (m.width, m.height) == (120, 106)
+    with pytest.raises(AssertionError):
+        Basestation('A', Point(0, 0), 'nope')
+    with pytest.raises(AssertionError):
+        User('1', m, 0, 0, RandomWaypoint(m, 1), util_func='quadratic')

@@ -1,0 +1,326 @@
+"""GPU parity tests: the HIP path (through the C ABI) against (1) the golden fixtures recorded from the
+reference and (2) the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): connection masks / cell indices, FSM state and FP64 positions BIT-EXACT;
+SNR / data-rate floats within 1e-5 relative.  Utility is 10*log10(rate), so a 1e-5 relative rate error is a
+4.3e-5 absolute utility error: utilities and rewards on the [-20, 20] scale use ATOL_UTIL = 1e-4, observation
+entries (normalised to [-1, 1]) use 1e-5.
+"""
+import ctypes
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL_RATE = 1e-5
+ATOL_UTIL = 1e-4
+ATOL_OBS = 1e-5
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+@pytest.fixture(scope='module')
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def _entities_from_fixture(g):
+    from deepcomp_amd.entities import Basestation, Map, Point, RandomWaypoint, User
+    inv_sh = {0: 'resource-fair', 1: 'rate-fair', 2: 'max-cap', 3: 'proportional-fair'}
+    w, h = (float(x) for x in g['cfg_map_wh_raw'])
+    m = Map(w, h)
+    bs = [Basestation(chr(65 + i), Point(x, y), inv_sh[int(s)]) for i, ((x, y), s) in enumerate(zip(g['cfg_bs_pos'], g['cfg_bs_sharing']))]
+    vel = {-1: 'slow', -2: 'fast'}
+    ues = [User(str(i + 1), m, 'random', 'random', RandomWaypoint(m, vel.get(int(v), int(v))),
+                util_func='log' if int(u) == 0 else 'step', dr_req=float(r))
+           for i, (v, u, r) in enumerate(zip(g['cfg_ue_vel'], g['cfg_ue_util'], g['cfg_ue_dr_req']))]
+    return m, bs, ues
+
+
+def _core_from_fixture(g, env_seeds=None, num_envs=1):
+    from deepcomp_amd.env import BatchedMobileEnv
+    m, bs, ues = _entities_from_fixture(g)
+    kind = 'central' if int(g['cfg_kind']) == 0 else 'multi'
+    reward = {0: 'avg', 1: 'sum', 2: 'min'}[int(g['cfg_reward'])]
+    return BatchedMobileEnv(m, bs, ues, kind, num_envs=num_envs, seed=int(g['cfg_seed']), episode_length=int(g['cfg_eps_len']),
+                            reward=reward, rand_episodes=bool(g['cfg_rand_episodes']), rng='reference', env_seeds=env_seeds,
+                            tape_depth=64)
+
+
+def _compare(core, g, prefix, i, e=0, with_reward=False):
+    st = core.state_host()
+    U, B = core.U, core.B
+    for k in ('pos', 'wp', 'vel'):
+        assert np.array_equal(st[k][e], g[f'{prefix}_{k}'][i]), f'{prefix}[{i}] {k} not bit-exact'
+    assert np.array_equal(st['pausing'][e], g[f'{prefix}_pausing'][i]), f'{prefix}[{i}] pausing'
+    assert np.array_equal(st['curr_pause'][e], g[f'{prefix}_curr_pause'][i]), f'{prefix}[{i}] curr_pause'
+    conn = ((st['conn'][e][:, None] >> np.arange(B)[None, :]) & 1).astype(np.uint8)
+    assert np.array_equal(conn, g[f'{prefix}_conn'][i]), f'{prefix}[{i}] connection mask'
+    np.testing.assert_allclose(st['ewma'][e], g[f'{prefix}_ewma'][i], rtol=RTOL_RATE, atol=1e-30, err_msg=f'{prefix}[{i}] ewma')
+    v = {k: t.cpu().numpy()[e] for k, t in core.obs_views().items()}
+    assert np.array_equal(v['connected'].reshape(U, B), g[f'{prefix}_obs_connected'][i])
+    np.testing.assert_allclose(v['dr'].reshape(U, B), g[f'{prefix}_obs_dr'][i], rtol=RTOL_RATE, atol=1e-30, err_msg=f'{prefix}[{i}] obs dr')
+    np.testing.assert_allclose(v['utility'].reshape(U), g[f'{prefix}_obs_utility'][i], atol=ATOL_OBS, rtol=0)
+    if core.kind == 1:
+        np.testing.assert_allclose(v['ues_at_bs'], g[f'{prefix}_obs_ues_at_bs'][i], atol=1e-6, rtol=0)
+        np.testing.assert_allclose(v['util_at_bs'], g[f'{prefix}_obs_util_at_bs'][i], atol=ATOL_OBS, rtol=0)
+    if with_reward:
+        np.testing.assert_allclose(core.ue_dr.cpu().numpy()[e], g['step_curr_dr'][i], rtol=RTOL_RATE, atol=1e-30, err_msg=f'curr_dr[{i}]')
+        np.testing.assert_allclose(core.ue_utility.cpu().numpy()[e], g['step_utility'][i], atol=ATOL_UTIL, rtol=0)
+        r = core.reward.cpu().numpy()[e]
+        tol = ATOL_UTIL if core.kind == 1 else ATOL_OBS * (U if core.reward_agg == 'sum' else 1)
+        if core.kind == 1 and core.reward_agg == 'sum':
+            tol = ATOL_OBS * U
+        np.testing.assert_allclose(np.atleast_1d(r), g['step_reward'][i], atol=tol, rtol=0, err_msg=f'reward[{i}]')
+        assert float(core.sum_utility.cpu().numpy()[e]) == pytest.approx(float(g['step_sum_utility'][i]), abs=ATOL_UTIL * U)
+
+
+# ------------------------------------------------------------------------------------ device primitives
+def test_fp64_sqrt_div_fma_bit_exact(torch_cuda):
+    """The movement step needs IEEE-correct FP64 sqrt / divide / fma on the device (bit-exact positions)."""
+    torch = torch_cuda
+    from deepcomp_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(0)
+    n = 1 << 20
+    x = np.concatenate([rng.uniform(0, 1e5, n // 2), rng.uniform(0, 400, n // 2) ** 2])
+    y = rng.uniform(1e-3, 500, n)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    out = torch.zeros(n, dtype=torch.float64, device='cuda')
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for op, want in ((0, np.sqrt(x)), (1, x / y)):
+        _lib.check(L.dcomp_selftest(op, 0, xd.data_ptr(), yd.data_ptr(), out.data_ptr(), n, s))
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want), f'op {op} not correctly rounded'
+    _lib.check(L.dcomp_selftest(2, 0, xd.data_ptr(), yd.data_ptr(), out.data_ptr(), n, s))
+    torch.cuda.synchronize()
+    import math
+    got = out.cpu().numpy()
+    idx = rng.integers(0, n, 2000)
+    from fractions import Fraction
+    for i in idx:
+        want = float(Fraction(float(y[i])) * Fraction(float(y[i])) + Fraction(float(x[i] * x[i])))
+        assert got[i] == want
+    assert math.isfinite(got.sum())
+
+
+@pytest.mark.parametrize('width', [2, 4, 8, 16, 32, 64])
+def test_group_reductions(torch_cuda, width):
+    """DPP / ds_swizzle segmented all-reduce against numpy."""
+    torch = torch_cuda
+    from deepcomp_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(width)
+    n = 4096
+    x = np.round(rng.uniform(-8, 8, n) * 4) / 4          # exactly representable, sums are exact in FP32
+    xd = torch.from_numpy(x).cuda()
+    out = torch.zeros(n, dtype=torch.float64, device='cuda')
+    _lib.check(L.dcomp_selftest(3, width, xd.data_ptr(), None, out.data_ptr(), n, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    g = x.reshape(-1, width)
+    want = (g.sum(1, keepdims=True) + 1024.0 * (g > 0).sum(1, keepdims=True) + 1048576.0 * g.min(1, keepdims=True)) * np.ones_like(g)
+    assert np.array_equal(out.cpu().numpy().reshape(-1, width), want)
+
+
+# ------------------------------------------------------------------------------------ golden trajectories
+TRAJ = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'traj_*.npz')))
+
+
+@pytest.mark.parametrize('name', TRAJ)
+def test_golden_trajectory(torch_cuda, name):
+    torch = torch_cuda
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    core = _core_from_fixture(g)
+    episodes = int(g['cfg_episodes'])
+    steps = g['actions'].shape[0] // episodes
+    t = 0
+    for ep in range(episodes):
+        core.reset()
+        torch.cuda.synchronize()
+        _compare(core, g, 'reset', ep)
+        for _ in range(steps):
+            a = torch.from_numpy(g['actions'][t].astype(np.uint8).reshape(1, -1)).cuda()
+            core.step(a)
+            _compare(core, g, 'step', t, with_reward=True)
+            t += 1
+        core.check()
+
+
+@pytest.mark.parametrize('stack', ['estack_grid32x10_multi', 'estack_grid10x5_central'])
+def test_golden_env_stack(torch_cuda, stack):
+    """E-axis parity: 8 envs seeded 42 + 20000*e in ONE batch vs 8 reference runs."""
+    torch = torch_cuda
+    gs = [np.load(os.path.join(GOLDEN, f'{stack}_e{e}.npz')) for e in range(8)]
+    core = _core_from_fixture(gs[0], num_envs=8)
+    assert list(core.env_seeds) == [int(g['cfg_seed']) for g in gs]
+    core.reset()
+    for e in range(8):
+        _compare(core, gs[e], 'reset', 0, e=e)
+    for t in range(gs[0]['actions'].shape[0]):
+        a = torch.from_numpy(np.stack([g['actions'][t] for g in gs]).astype(np.uint8)).cuda()
+        core.step(a)
+        for e in range(8):
+            _compare(core, gs[e], 'step', t, e=e, with_reward=True)
+    core.check()
+
+
+# ------------------------------------------------------------------------------------ oracle at scale (Philox)
+def _oracle_batch(scn, kind, reward, E, seed, env_id_base=0):
+    from oracle import oracle as orc
+    vel = [s['velocity'] for s in scn.ue_specs]
+    envs = []
+    for e in range(E):
+        o = orc.OracleEnv(int(scn.width), int(scn.height), scn.bs_pos, scn.bs_sharing, vel,
+                          kind=orc.MULTI if kind == 'multi' else orc.CENTRAL, reward_agg={'avg': 0, 'sum': 1, 'min': 2}[reward])
+        o.set_philox(seed, env_id_base + e)
+        envs.append(o)
+    return orc.OracleBatch(envs)
+
+
+@pytest.mark.parametrize('shape', [('multi', 32, 10, 512, 'avg'), ('central', 10, 5, 1024, 'avg'), ('multi', 3, 3, 700, 'min'),
+                                   ('multi', 20, 7, 300, 'sum'), ('multi', 100, 12, 64, 'avg'), ('central', 130, 6, 40, 'min')])
+def test_oracle_parity_philox(torch_cuda, shape):
+    """HIP path vs CPU oracle, same Philox draws, random actions, 60 steps incl. one mid-run reset."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    kind, U, B, E, reward = shape
+    scn = scenarios.grid_map(B, 'mixed').with_ues(num_static=U // 8, num_slow=U - U // 8 - U // 4, num_fast=U // 4)
+    m, bs, ues = build_from_scenario(scn)
+    core = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=1234, reward=reward, rng='philox', rand_episodes=True, env_id_base=5)
+    ob = _oracle_batch(scn, kind, reward, E, 1234, env_id_base=5)
+    rng = np.random.default_rng(7)
+
+    def cmp(obs_o, rew_o, conn_o, pos_o):
+        st = core.state_host()
+        if pos_o is not None:
+            assert np.array_equal(st['pos'], pos_o), 'positions not bit-exact'
+            assert np.array_equal(st['conn'], conn_o), 'connection masks differ'
+        got = core.obs.cpu().numpy()
+        if kind == 'multi':
+            want = obs_o
+        else:   # oracle packs central as [U][2B+1]; device layout is connected | dr | utility blocks
+            want = np.concatenate([obs_o[:, :, :B].reshape(E, -1), obs_o[:, :, B:2 * B].reshape(E, -1), obs_o[:, :, 2 * B]], axis=1)
+        np.testing.assert_allclose(got, want, rtol=RTOL_RATE, atol=ATOL_OBS)
+        if rew_o is not None:
+            tol = ATOL_UTIL if kind == 'multi' else ATOL_OBS
+            if reward == 'sum':
+                tol *= U
+            np.testing.assert_allclose(core.reward.cpu().numpy(), rew_o, atol=tol, rtol=0)
+
+    core.reset()
+    cmp(ob.reset(), None, None, None)
+    for t in range(60):
+        if t == 35:
+            for i, o in enumerate(ob.envs):
+                o.set_episode(1)
+            core.reset()
+            cmp(ob.reset(), None, None, None)
+        a = rng.integers(0, B + 1, size=(E, U)).astype(np.uint8)
+        a[rng.random((E, U)) < 0.5] = 0
+        core.step(torch.from_numpy(a).cuda())
+        cmp(*ob.step(a))
+    core.check()
+
+
+# ------------------------------------------------------------------------------------ full-size properties
+def test_full_size_properties(torch_cuda):
+    """BASELINE config 3 (65 536 envs x 32 UE x 10 BS, multi-agent): size-independent invariants."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    E, U, B = 65536, 32, 10
+    scn = scenarios.grid_map(B, 'mixed').with_ues(num_slow=U)
+    m, bs, ues = build_from_scenario(scn)
+
+    def run(E_, base, steps, seed=42):
+        core = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=E_, seed=seed, rng='philox', env_id_base=base)
+        g = torch.Generator(device='cuda').manual_seed(3)
+        acts = torch.randint(0, B + 1, (steps, E, U), generator=g, device='cuda', dtype=torch.uint8)
+        core.reset()
+        for t in range(steps):
+            core.step(acts[t, base:base + E_].contiguous())
+        core.check()
+        return core
+
+    full = run(E, 0, 25)
+    obs = full.obs_views()
+    conn_bits = full.conn.view(E, U)
+    # (1) observation ranges of the reference's Box spaces (variants.py:255-268)
+    assert float(obs['dr'].min()) >= 0 and float(obs['dr'].max()) <= 1.0
+    assert float(obs['dr'].max(dim=-1).values.min()) == 1.0            # every row is normalised by its own max
+    assert float(obs['utility'].min()) >= -1 and float(obs['utility'].max()) <= 1
+    assert float(obs['util_at_bs'].min()) >= -1 and float(obs['util_at_bs'].max()) <= 1
+    # (2) connected flags == connection bit mask; ues_at_bs == per-BS popcount / U
+    bits = ((conn_bits.unsqueeze(-1) >> torch.arange(B, device='cuda')) & 1).float()
+    assert torch.equal(bits, obs['connected'])
+    assert torch.allclose(obs['ues_at_bs'], (bits.sum(1, keepdim=True) / U).expand(-1, U, -1), atol=1e-6)
+    # (3) a connection implies in range: distance to that BS below the connect threshold (station.py:222-226)
+    pos = full.pos.view(E, U, 2)
+    bsxy = torch.tensor(scn.bs_pos, dtype=torch.float64, device='cuda')
+    d = torch.linalg.norm(pos.unsqueeze(2) - bsxy.view(1, 1, B, 2), dim=-1)
+    assert bool(((bits == 0) | (d < 68.92488308058013 + 1e-9)).all())
+    # (4) UEs never leave the map (movement.py:165-166)
+    assert float(pos.min()) >= 0 and float(pos[..., 0].max()) <= int(scn.width) and float(pos[..., 1].max()) <= int(scn.height)
+    # (5) determinism + shard invariance: envs [4096, 4096+512) recomputed alone (env_id_base) are bit-identical
+    part = run(512, 4096, 25)
+    sl = slice(4096 * U, (4096 + 512) * U)
+    assert torch.equal(part.pos, full.pos[sl]) and torch.equal(part.conn, full.conn[sl]) and torch.equal(part.mv, full.mv[sl])
+    assert torch.equal(part.obs, full.obs[4096:4096 + 512])
+    assert torch.equal(part.reward, full.reward[4096:4096 + 512])
+    # (6) sum_utility == sum over UEs of utility; checksum of per-env sums == total
+    assert torch.allclose(full.sum_utility, full.ue_utility.sum(1), atol=1e-3)
+
+
+def test_bad_action_flag(torch_cuda):
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    scn = scenarios.custom_map('mixed').with_ues(num_slow=4)
+    m, bs, ues = build_from_scenario(scn)
+    core = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=16, rng='philox')
+    core.reset()
+    a = torch.zeros((16, 4), dtype=torch.uint8, device='cuda')
+    a[3, 2] = 9                                      # B = 4: outside the action space
+    core.step(a)
+    with pytest.raises(AssertionError):              # base.py:238 / central.py:61
+        core.check()
+    core.step(torch.zeros((16, 4), dtype=torch.uint8, device='cuda'))
+    core.check()                                     # flag was cleared
+
+
+def test_reference_surface_single_env(torch_cuda):
+    """The drop-in classes (E = 1) return the reference's Python structures and match a golden trajectory."""
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import make_env_config
+    from deepcomp_amd.env import CentralRelNormEnv, MultiAgentMobileEnv
+    g = np.load(os.path.join(GOLDEN, 'traj_custom4x4_multi_s42.npz'))
+    env = MultiAgentMobileEnv(make_env_config(scenarios.custom_map('mixed').with_ues(num_slow=4), seed=42))
+    obs = env.reset()
+    assert sorted(obs.keys()) == ['1', '2', '3', '4'] and sorted(obs['1'].keys()) == ['connected', 'dr', 'ues_at_bs', 'util_at_bs', 'utility']
+    for t in range(30):
+        obs, rew, done, info = env.step({ue.id: int(g['actions'][t][i]) for i, ue in enumerate(env.ue_list)})
+        assert done == {'1': None, '2': None, '3': None, '4': None, '__all__': None}
+        np.testing.assert_allclose([rew[str(i + 1)] for i in range(4)], g['step_reward'][t], atol=ATOL_UTIL)
+        assert [obs[str(i + 1)]['connected'] for i in range(4)] == g['step_obs_connected'][t].astype(int).tolist()
+        assert info['1']['time'] == t + 1
+        assert info['1']['scalar_metrics']['sum_utility'] == pytest.approx(float(g['step_sum_utility'][t]), abs=4e-4)
+    assert env.ue_list[0].pos.x == g['step_pos'][29][0][0]
+    g = np.load(os.path.join(GOLDEN, 'traj_medium3x3_central_s42.npz'))
+    env = CentralRelNormEnv(make_env_config(scenarios.medium_map('mixed').with_ues(num_slow=3), seed=42))
+    obs = env.reset()
+    assert len(obs['connected']) == 9 and len(obs['dr']) == 9 and len(obs['utility']) == 3
+    for t in range(30):
+        obs, rew, done, info = env.step([int(x) for x in g['actions'][t]])
+        assert done is None and isinstance(rew, float)
+        assert rew == pytest.approx(float(g['step_reward'][t][0]), abs=ATOL_OBS)
+        assert obs['connected'] == g['step_obs_connected'][t].astype(int).reshape(-1).tolist()
+    with pytest.raises(AssertionError):
+        env.step([4, 0, 0])                          # central.py:61
