@@ -62,6 +62,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build the HIP extension first (python -m deepcomp_amd.build). "
                           "deepcomp_amd has no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7: import it first so that this library binds to the SAME HIP
+    # runtime (device pointers and streams are shared with torch); loading ours first would pull in /opt/rocm's copy.
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     L.dcomp_create.argtypes = [ctypes.POINTER(DcompCfg), ctypes.POINTER(vp)]
