@@ -124,6 +124,17 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
         double dt = dcomp_connect_threshold();
         kp.dt2 = dt * dt;
     }
+    for (unsigned v = 0; v < 256; v++) {
+        // the kernel's closed form of qmax(v) = max{q : sqrt_rn(q) <= v} (move_ue) against brute force
+        double q = (double)(v * v);
+        while (std::sqrt(std::nextafter(q, INFINITY)) <= (double)v) q = std::nextafter(q, INFINITY);
+        double cf = (double)(v * v);
+        if (v > 1) {
+            int e2 = 2 * (31 - __builtin_clz(v));
+            if ((v & (v - 1)) != 0 && v * v < (2u << e2)) cf += std::ldexp(1.0, e2 - 52);
+        }
+        if (cf != q) { delete env; return fail(DCOMP_EUNSUPPORTED, "host sqrt is not IEEE-correct: qmax(%u) mismatch", v); }
+    }
     kp.any_maxcap = 0;
     for (int b = 0; b < B; b++) {
         kp.bs_x[b] = cfg->bs_x[b]; kp.bs_y[b] = cfg->bs_y[b];
@@ -131,6 +142,7 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
         if (m < 0 || m > 3) { delete env; return fail(DCOMP_EINVAL, "bs_sharing[%d]=%d not supported", b, m); }   // station.py:22
         kp.bs_mode[b] = m;
         if (m == DCOMP_MAX_CAP) kp.any_maxcap = 1;
+        if (m == DCOMP_RATE_FAIR || m == DCOMP_PROP_FAIR) kp.any_sum_mode = 1;
     }
     std::vector<UeCfg> uc(U);
     kp.all_log_util = 1;

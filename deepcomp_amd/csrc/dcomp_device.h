@@ -55,6 +55,7 @@ struct KParams {
     int32_t kind, reward_agg, rng_mode;
     uint32_t all_log_util;     // 1: every UE uses the log utility (skip the per-UE config load)
     uint32_t any_maxcap;
+    uint32_t any_sum_mode;     // some BS is rate-fair or proportional-fair (needs a sum over its UEs)
     uint32_t seed_lo, seed_hi, episode;
     uint32_t env_base;         // global id of env 0
     float gamma;               // path-loss exponent c2/10
@@ -110,6 +111,32 @@ __device__ __forceinline__ int group_count(bool pred, int gbase)
     return __popcll(m);
 }
 
+// N independent all-reduces, stage by stage: the N butterflies interleave, so no DPP read-after-write stalls.
+template <int W, class Op, int N>
+__device__ __forceinline__ void group_reduce_vec(float (&v)[N])
+{
+#ifdef DCOMP_NO_DPP
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = group_reduce<W, Op>(v[i]);
+#else
+#define DCOMP_STAGE(EXPR)                          \
+    _Pragma("unroll") for (int i = 0; i < N; i++) v[i] = Op::f(v[i], EXPR);
+    if (W >= 2) { DCOMP_STAGE(dpp_f32<DCOMP_DPP_QUAD_X1>(v[i])) }
+    if (W >= 4) { DCOMP_STAGE(dpp_f32<DCOMP_DPP_QUAD_X2>(v[i])) }
+    if (W >= 8) { DCOMP_STAGE(dpp_f32<DCOMP_DPP_HALF_MIRROR>(v[i])) }
+    if (W >= 16) { DCOMP_STAGE(dpp_f32<DCOMP_DPP_ROW_MIRROR>(v[i])) }
+    if (W >= 32) { DCOMP_STAGE(swz_xor16(v[i])) }
+    if (W >= 64) { DCOMP_STAGE(__shfl_xor(v[i], 32, 64)) }
+#undef DCOMP_STAGE
+#endif
+}
+// LDS ops of one wave execute in order; this only stops the compiler from moving LDS accesses across it.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ---------------------------------------------------------------------------------------------- channel
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32 (1 ulp)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32 (1 ulp)
@@ -126,26 +153,23 @@ __device__ __forceinline__ void pair_eval(double px, double py, double bx, doubl
     if (q < 1e-20f) h = fast_log2(__builtin_sqrtf(q) + EPS);   // ... except at d ~ 0 (waypoints and BS sit on the integer grid)
     l2snr = __builtin_fmaf(-p.gamma, h, p.log2k);
 }
-// bw * log2(1 + snr) from log2(snr).  station.py:129-138.  Never forms 1+snr (exactly 1.0f for snr < 6e-8).
+// bw * log2(1 + snr) from log2(snr).  station.py:129-138.  Branch-free; never forms 1+snr for small snr
+// (1.0f + snr is exactly 1.0f below 6e-8 while the connect threshold is 2e-8).
 __device__ __forceinline__ float rate_unshared(float l2snr)
 {
-    float r;
-    if (l2snr > 20.f) {
-        r = l2snr + LOG2E * fast_exp2(-l2snr);      // log2(s) + log2(1 + 1/s)
-    } else {
-        float s = fast_exp2(l2snr);
-        if (s < 0.03125f) {
-            // log1p(s) = s - s^2/2 + s^3/3 - s^4/4 + s^5/5 (+ s^6/6 < 5e-9 relative)
-            float t = __builtin_fmaf(s, 0.2f, -0.25f);
-            t = __builtin_fmaf(s, t, 0.33333334f);
-            t = __builtin_fmaf(s, t, -0.5f);
-            t = __builtin_fmaf(s, t, 1.0f);
-            r = s * t * LOG2E;
-        } else {
-            r = log1pf(s) * LOG2E;
-        }
-    }
-    return BW * r;
+    const float s = fast_exp2(fminf(l2snr, 100.f));
+    // snr < 1/16 (d > ~0.9 m, i.e. practically always): log1p series, relative error < 3e-8 at 8 terms
+    float t = __builtin_fmaf(s, -0.125f, 0.14285715f);
+    t = __builtin_fmaf(s, t, -0.16666667f);
+    t = __builtin_fmaf(s, t, 0.2f);
+    t = __builtin_fmaf(s, t, -0.25f);
+    t = __builtin_fmaf(s, t, 0.33333334f);
+    t = __builtin_fmaf(s, t, -0.5f);
+    t = __builtin_fmaf(s, t, 1.0f);
+    const float small = s * t * LOG2E;
+    // larger snr: 1+s is accurate enough (log2 >= 0.087, relative error < 2e-6); huge snr (d -> 0): log2(1+s) = log2(s)
+    const float big = l2snr > 100.f ? l2snr : fast_log2(1.0f + s);
+    return BW * (s < 0.0625f ? small : big);
 }
 // user.py:76-92 -> utility.py:23-54
 __device__ __forceinline__ float ue_utility(float dr, bool step_util, float dr_req)
@@ -216,9 +240,19 @@ __device__ __forceinline__ void move_ue(const KParams &p, int env, int u, int id
         }
     }
     if (!stay) {
+        // movement.py:142: `curr_pos.distance(waypoint) <= velocity` with distance = sqrt(dx*dx + dy*dy).
+        // sqrt is monotone and correctly rounded, so the test is `q <= qmax(vel)`, qmax = largest double whose
+        // rounded sqrt is <= vel: vel^2, plus one ulp when the mantissa m of vel has 1 < m < sqrt(2)
+        // (dcomp_create verifies this closed form against a brute-force sqrt table for vel = 0..255).
         double dx = px - wx, dy = py - wy;
-        double dist = __builtin_sqrt(dx * dx + dy * dy);            // shapely distance (movement.py:142)
-        if (dist <= (double)vel) { px = wx; py = wy; }              // snap onto the waypoint
+        double q = dx * dx + dy * dy;
+        const uint32_t v2 = vel * vel;
+        double qmax = (double)v2;
+        if (vel > 1u) {
+            const int e2 = 2 * (31 - __clz((int)vel));
+            if ((vel & (vel - 1u)) != 0u && v2 < (2u << e2)) qmax += __builtin_ldexp(1.0, e2 - 52);
+        }
+        if (q <= qmax) { px = wx; py = wy; }                        // snap onto the waypoint
         else {
             double vx = wx - px, vy = wy - py;
             double nrm = __builtin_sqrt(__builtin_fma(vy, vy, vx * vx));   // np.linalg.norm (movement.py:151)
@@ -240,8 +274,19 @@ struct Geo {
     static constexpr int ROW_MULTI = 4 * B + 1;
 };
 
+// Observation staging: rows are written lane-per-row into LDS and copied out linearly, so every global store
+// instruction covers 64 x 16 contiguous bytes (1 KiB) instead of 64 scattered 16-byte pieces.
+template <int B>
+struct StageGeo {
+    static constexpr int ROW = 4 * B + 1;
+    static constexpr int NPASS = (64 * ROW * 4 <= 6144) ? 1 : (32 * ROW * 4 <= 6144) ? 2 : (16 * ROW * 4 <= 6144) ? 4 : 8;
+    static constexpr int RPP = 64 / NPASS;                  // rows per pass
+    static constexpr int WORDS = RPP * ROW + 4;             // + alignment phase
+};
+
 template <int B, int UPAD>
 struct alignas(16) BlockSharedT {
+    alignas(16) float stage[4][(StageGeo<B>::WORDS + 3) / 4 * 4];   // per-wave observation staging (multi-agent layout)
     float xw[4][B + 4];                                     // per-wave partials of the cross-wave exchange
     unsigned long long mc_key[Geo<B, UPAD>::GPB * B];       // max-cap: min squared-distance bits per (env-in-block, bs)
     uint32_t mc_win[Geo<B, UPAD>::GPB * B];
@@ -285,18 +330,24 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
     for (int b = 0; b < B; b++) {
         const bool c = (conn >> b) & 1u;
         const int mode = p.bs_mode[b];
+        unsigned long long m = __ballot(c);
         float dru = 0.f;
-        if (c) dru = rate_unshared(l2[b]);
+        if (m != 0ull) {                                   // wave-uniform: skip BSs nobody in this wave is connected to
+            const float t = rate_unshared(l2[b]);
+            dru = c ? t : 0.f;
+        }
         dr[b] = dru;
-        cnt[b] = (float)group_count<G::WG>(c, gbase);
+        if (G::WG < 64) m = (m >> gbase) & ((1ull << G::WG) - 1ull);
+        cnt[b] = (float)__popcll(m);
         float a = 0.f;
-        if (mode == DCOMP_RATE_FAIR) a = group_reduce<G::WG, OpSum>(c ? fast_rcp(dru) : 0.f);          // station.py:177-180
-        else if (mode == DCOMP_PROP_FAIR) a = group_reduce<G::WG, OpSum>(c ? dru * inv_ewma : 0.f);      // station.py:192-195
+        if (mode == DCOMP_RATE_FAIR) a = c ? fast_rcp(dru) : 0.f;         // station.py:177-180
+        else if (mode == DCOMP_PROP_FAIR) a = dru * inv_ewma;             // station.py:192-195 (0 when not connected)
         agg[b] = a;
     }
+    if (p.any_sum_mode) group_reduce_vec<G::WG, OpSum, B>(agg);
     if (G::NW > 1) {
         xwave_reduce_<B, G::NW, OpSum>(cnt, sh, wave, lane);
-        xwave_reduce_<B, G::NW, OpSum>(agg, sh, wave, lane);
+        if (p.any_sum_mode) xwave_reduce_<B, G::NW, OpSum>(agg, sh, wave, lane);
     }
     uint32_t mc_winner = 0;
     if (p.any_maxcap) {
@@ -330,23 +381,24 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
         const bool c = (conn >> b) & 1u;
         const int mode = p.bs_mode[b];
         float dru = dr[b], out = 0.f;
-        if (mode == DCOMP_RES_FAIR) out = dru * fast_rcp(fmaxf(cnt[b], 1.f));                                  // station.py:171-173
-        else if (mode == DCOMP_RATE_FAIR) out = fast_rcp(agg[b]);                                   // station.py:180
-        else if (mode == DCOMP_PROP_FAIR) out = (dru * inv_ewma) * fast_rcp(agg[b] + EPS) * dru;             // station.py:194-195
+        if (mode == DCOMP_RES_FAIR) out = dru * fast_rcp(fmaxf(cnt[b], 1.f));                        // station.py:171-173
+        else if (mode == DCOMP_RATE_FAIR) out = fast_rcp(agg[b]);                                    // station.py:180
+        else if (mode == DCOMP_PROP_FAIR) out = (dru * inv_ewma) * fast_rcp(agg[b] + EPS) * dru;     // station.py:194-195
         else out = ((mc_winner >> b) & 1u) ? dru : 0.f;
         dr[b] = c ? out : 0.f;
     }
 }
 
-// Observation row + reward of one UE, written straight from registers.  variants.py:271-305,
-// central.py:31-73, multi_agent.py:32-95.
+// Observation row + reward of one UE.  variants.py:271-305, central.py:31-73, multi_agent.py:32-95.
+// l2 / cnt are consumed (overwritten with the observation entries).
 template <int B, int UPAD, bool RESET>
 __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, UPAD> &sh, bool active, int env, int env_local, int u, int idx,
                                               int wave, int lane, int gbase, uint32_t conn, uint32_t in_range,
-                                              const float (&l2)[B], const float (&cnt)[B], float util, float curr_dr,
+                                              float (&l2)[B], float (&cnt)[B], float util, float curr_dr,
                                               float reward_before)
 {
     using G = Geo<B, UPAD>;
+    using SG = StageGeo<B>;
     const int U = p.U;
     // per-BS utility aggregates over connected UEs (station.py:63-83)
     float tsum[B], tmin[B];
@@ -354,13 +406,16 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
 #pragma unroll
     for (int b = 0; b < B; b++) {
         const bool c = (conn >> b) & 1u;
-        tsum[b] = RESET ? 0.f : group_reduce<G::WG, OpSum>(c ? util : 0.f);
-        tmin[b] = MAX_UTIL;
-        if (!RESET && need_min) tmin[b] = group_reduce<G::WG, OpMin>(c ? util : MAX_UTIL);
+        tsum[b] = c ? util : 0.f;
+        tmin[b] = c ? util : MAX_UTIL;
     }
-    if (!RESET && G::NW > 1) {
-        xwave_reduce_<B, G::NW, OpSum>(tsum, sh, wave, lane);
-        if (need_min) xwave_reduce_<B, G::NW, OpMin>(tmin, sh, wave, lane);
+    if (!RESET) {
+        group_reduce_vec<G::WG, OpSum, B>(tsum);
+        if (need_min) group_reduce_vec<G::WG, OpMin, B>(tmin);
+        if (G::NW > 1) {
+            xwave_reduce_<B, G::NW, OpSum>(tsum, sh, wave, lane);
+            if (need_min) xwave_reduce_<B, G::NW, OpMin>(tmin, sh, wave, lane);
+        }
     }
     float l2max = l2[0];
 #pragma unroll
@@ -415,30 +470,65 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
         xwave_reduce_<1, G::NW, OpSum>(s, sh, wave, lane);
         if (active && u == 0) p.sum_util[env] = s[0];
     }
-    if (!active) return;
-    if (p.ue_dr) p.ue_dr[idx] = curr_dr;
-    if (p.ue_util) p.ue_util[idx] = util;
+    if (active) {
+        if (p.ue_dr) p.ue_dr[idx] = curr_dr;
+        if (p.ue_util) p.ue_util[idx] = util;
+    }
 
+    // ---- observation entries (in place): l2 -> snr_b / max snr, tsum -> avg utility at BS, cnt -> UEs at BS / U
     const float inv_u = 1.0f / (float)U;
     const float util_n = util * (1.0f / MAX_UTIL);
-    if (p.kind == DCOMP_MULTI) {
-        if (p.reward) p.reward[idx] = reward;
-        float *row = p.obs + (size_t)idx * G::ROW_MULTI;
 #pragma unroll
-        for (int b = 0; b < B; b++) {
-            row[b] = (float)((conn >> b) & 1u);
-            row[B + b] = fast_exp2(l2[b] - l2max);                    // snr_b / max snr (variants.py:276-284)
-            row[2 * B + b] = cnt[b] * inv_u;                        // variants.py:296
-            row[3 * B + b] = cnt[b] > 0.f ? tsum[b] * fast_rcp(cnt[b]) * (1.0f / MAX_UTIL) : 0.f;   // variants.py:299, station.py:71-76
+    for (int b = 0; b < B; b++) {
+        l2[b] = fast_exp2(l2[b] - l2max);                                                       // variants.py:276-284
+        tsum[b] = cnt[b] > 0.f ? tsum[b] * fast_rcp(cnt[b]) * (1.0f / MAX_UTIL) : 0.f;          // variants.py:299, station.py:71-76
+        cnt[b] = cnt[b] * inv_u;                                                                // variants.py:296
+    }
+    if (p.kind == DCOMP_MULTI) {
+        if (active && p.reward) p.reward[idx] = reward;
+        // rows of this wave are contiguous in memory: [row0, row0 + nrows)
+        const unsigned long long am = __ballot(active);
+        const int nrows = __popcll(am);
+        const int row0 = __shfl(idx, am ? __ffsll((long long)am) - 1 : 0, 64);
+        const int r = idx - row0;
+        float *st = sh.stage[wave];
+#pragma unroll 1
+        for (int pass = 0; pass < SG::NPASS; pass++) {
+            const int rbase = pass * SG::RPP;
+            if (rbase >= nrows) break;
+            const int rows = min(SG::RPP, nrows - rbase);
+            const size_t g0 = (size_t)(row0 + rbase) * SG::ROW;            // first float of this pass in obs
+            const int ph = (int)((((size_t)p.obs >> 2) + g0) & 3);         // 16-byte phase of that address
+            if (active && r >= rbase && r < rbase + rows) {
+                float *row = st + ph + (r - rbase) * SG::ROW;              // word stride 4B+1 is odd: conflict-free
+#pragma unroll
+                for (int b = 0; b < B; b++) {
+                    row[b] = (float)((conn >> b) & 1u);
+                    row[B + b] = l2[b];
+                    row[2 * B + b] = cnt[b];
+                    row[3 * B + b] = tsum[b];
+                }
+                row[4 * B] = util_n;
+            }
+            wave_lds_fence();
+            const int n_end = ph + rows * SG::ROW;                         // staged floats live in st[ph, n_end)
+            float *gbase_ptr = p.obs + g0 - ph;                            // 16-byte aligned
+            for (int j = lane * 4; j < n_end; j += 256) {
+                if (j >= ph && j + 4 <= n_end) {
+                    *reinterpret_cast<float4 *>(gbase_ptr + j) = *reinterpret_cast<const float4 *>(st + j);
+                } else {
+                    for (int k = max(j, ph); k < min(j + 4, n_end); k++) gbase_ptr[k] = st[k];
+                }
+            }
+            wave_lds_fence();
         }
-        row[4 * B] = util_n;
-    } else {
+    } else if (active) {
         if (p.reward && u == 0) p.reward[env] = reward;
         float *base = p.obs + (size_t)env * U * (2 * B + 1);
 #pragma unroll
         for (int b = 0; b < B; b++) {
             base[u * B + b] = (float)((conn >> b) & 1u);
-            base[U * B + u * B + b] = fast_exp2(l2[b] - l2max);
+            base[U * B + u * B + b] = l2[b];
         }
         base[2 * U * B + u] = util_n;
     }
