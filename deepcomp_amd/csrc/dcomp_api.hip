@@ -129,9 +129,9 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
         double q = (double)(v * v);
         while (std::sqrt(std::nextafter(q, INFINITY)) <= (double)v) q = std::nextafter(q, INFINITY);
         double cf = (double)(v * v);
-        if (v > 1) {
+        if (v > 0) {
             int e2 = 2 * (31 - __builtin_clz(v));
-            if ((v & (v - 1)) != 0 && v * v < (2u << e2)) cf += std::ldexp(1.0, e2 - 52);
+            if (v * v < (2u << e2)) cf += std::ldexp(1.0, e2 - 52);
         }
         if (cf != q) { delete env; return fail(DCOMP_EUNSUPPORTED, "host sqrt is not IEEE-correct: qmax(%u) mismatch", v); }
     }

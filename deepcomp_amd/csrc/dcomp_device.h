@@ -242,15 +242,15 @@ __device__ __forceinline__ void move_ue(const KParams &p, int env, int u, int id
     if (!stay) {
         // movement.py:142: `curr_pos.distance(waypoint) <= velocity` with distance = sqrt(dx*dx + dy*dy).
         // sqrt is monotone and correctly rounded, so the test is `q <= qmax(vel)`, qmax = largest double whose
-        // rounded sqrt is <= vel: vel^2, plus one ulp when the mantissa m of vel has 1 < m < sqrt(2)
+        // rounded sqrt is <= vel: vel^2, plus one ulp when the mantissa m of vel has m < sqrt(2)
         // (dcomp_create verifies this closed form against a brute-force sqrt table for vel = 0..255).
         double dx = px - wx, dy = py - wy;
         double q = dx * dx + dy * dy;
         const uint32_t v2 = vel * vel;
         double qmax = (double)v2;
-        if (vel > 1u) {
+        if (vel > 0u) {
             const int e2 = 2 * (31 - __clz((int)vel));
-            if ((vel & (vel - 1u)) != 0u && v2 < (2u << e2)) qmax += __builtin_ldexp(1.0, e2 - 52);
+            if (v2 < (2u << e2)) qmax += __builtin_ldexp(1.0, e2 - 52);
         }
         if (q <= qmax) { px = wx; py = wy; }                        // snap onto the waypoint
         else {
