@@ -1,0 +1,118 @@
+"""Env-axis sharding over the GPUs of one node and the rollout hand-off to the learner.
+
+The reference scales out with N independent Ray rollout workers, each holding its own env copy, and ships
+sample batches to the trainer through Ray's object store (env_setup.py:266, simulation.py:143).  Here env
+instances are rows of one batch: rank g owns the contiguous slice [g*E/N, (g+1)*E/N) of the global env axis, the
+BS table is replicated (tiny), and RNG draws are keyed by the *global* env id so results do not depend on N.
+There is no collective inside ``step``.  The only exchange is handing a rollout fragment (T steps of
+observations / rewards / actions) to the learner: ONE all-gather per fragment -- RCCL over xGMI when the tensors
+live on GPUs (torch backend "nccl"), gloo in the CPU tests -- issued asynchronously so it overlaps with the next
+fragment's stepping.
+"""
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total_envs, world_size):
+    """Contiguous partition of the env axis: list of (start, count) per rank; counts differ by at most one."""
+    assert total_envs >= world_size >= 1
+    base, rem = divmod(total_envs, world_size)
+    out, start = [], 0
+    for r in range(world_size):
+        n = base + (1 if r < rem else 0)
+        out.append((start, n))
+        start += n
+    return out
+
+
+def make_sharded_env(scenario, kind, total_envs, rank, world_size, device=None, **kw):
+    """This rank's BatchedMobileEnv over its slice of the global env axis (``env_id_base`` = slice start)."""
+    from .entities import build_from_scenario
+    from .env import BatchedMobileEnv
+    start, count = shard_bounds(total_envs, world_size)[rank]
+    m, bs, ues = build_from_scenario(scenario)
+    dev = device if device is not None else torch.device('cuda', rank % max(torch.cuda.device_count(), 1))
+    return BatchedMobileEnv(m, bs, ues, kind, num_envs=count, env_id_base=start, device=dev, **kw)
+
+
+@dataclass
+class GatherHandle:
+    out: dict
+    works: list
+    stream: object = None
+
+    def wait(self):
+        """Block until the gathered fragment is usable; returns {name: tensor[world, ...fragment shape]}."""
+        for w in self.works:
+            w.wait()
+        if self.stream is not None:
+            torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
+        return self.out
+
+
+class RolloutGather:
+    """All-gathers rollout fragments along a new leading rank axis.
+
+    ``fragment`` is a dict of equally-shaped-per-rank tensors, e.g. ``{'obs': [T, E_local, U, 4B+1],
+    'reward': [T, E_local, U], 'action': [T, E_local, U]}``.  Global env id of ``out[name][r, t, e]`` is
+    ``shard_bounds(...)[r][0] + e``.  One flat collective per tensor (large messages: on the fully connected
+    xGMI mesh every GPU pushes its shard to its 7 peers concurrently)."""
+
+    def __init__(self, group=None, use_side_stream=True):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.use_side_stream = use_side_stream
+        self._stream = None
+
+    def all_gather_async(self, fragment):
+        out, works = {}, []
+        some = next(iter(fragment.values()))
+        stream = None
+        if some.is_cuda and self.use_side_stream:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=some.device)
+            stream = self._stream
+            stream.wait_stream(torch.cuda.current_stream(some.device))    # fragment fully written before it is sent
+        ctx = torch.cuda.stream(stream) if stream is not None else _NullCtx()
+        with ctx:
+            for name, t in fragment.items():
+                t = t.contiguous()
+                o = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+                works.append(dist.all_gather_into_tensor(o.view(-1), t.view(-1), group=self.group, async_op=True))
+                out[name] = o
+        return GatherHandle(out, works, stream)
+
+    def all_gather(self, fragment):
+        return self.all_gather_async(fragment).wait()
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class RolloutBuffer:
+    """Pre-allocated fragment storage [T, E_local, ...] that ``BatchedMobileEnv.step_into`` writes in place."""
+
+    def __init__(self, env, horizon):
+        self.env, self.T = env, horizon
+        dev = env.device
+        self.obs = torch.zeros((horizon,) + tuple(env.obs.shape), dtype=torch.float32, device=dev)
+        self.reward = torch.zeros((horizon,) + tuple(env.reward.shape), dtype=torch.float32, device=dev)
+        self.action = torch.zeros((horizon, env.E, env.U), dtype=torch.uint8, device=dev)
+
+    def collect(self, policy):
+        """T steps: ``policy(obs_tensor) -> uint8 actions [E, U]`` runs on the device; nothing per env on the host."""
+        obs = self.env.obs
+        for t in range(self.T):
+            a = policy(obs)
+            self.action[t].copy_(a)
+            self.env.step_into(self.action[t], self.obs[t], self.reward[t])
+            obs = self.obs[t]
+        return {'obs': self.obs, 'reward': self.reward, 'action': self.action}
