@@ -119,7 +119,7 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
     kp.env_base = (uint32_t)cfg->env_id_base;
     {   // snr = K * (d + eps)^(-gamma): gamma = c2/10, K = snr(1 m)   (station.py:110-127)
         double c2 = 44.9 - 6.55 * std::log10(50.0);
-        kp.gamma = (float)(c2 / 10.0);
+        kp.half_gamma = (float)(c2 / 20.0);
         kp.log2k = (float)std::log2(ref_snr(1.0));
         double dt = dcomp_connect_threshold();
         kp.dt2 = dt * dt;

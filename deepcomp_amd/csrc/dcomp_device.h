@@ -16,6 +16,11 @@
 
 #include "../../include/dcomp.h"
 
+// Ablation builds (tools/ablate.py) compile timing-only variants with stages removed; the product build has 0.
+#ifndef DCOMP_ABLATE
+#define DCOMP_ABLATE 0
+#endif
+
 namespace dcomp {
 
 // ---- channel constants (station.py:26-30, 110-127): snr = K * (d + 1e-16)^(-GAMMA) -------------------------
@@ -58,7 +63,7 @@ struct KParams {
     uint32_t any_sum_mode;     // some BS is rate-fair or proportional-fair (needs a sum over its UEs)
     uint32_t seed_lo, seed_hi, episode;
     uint32_t env_base;         // global id of env 0
-    float gamma;               // path-loss exponent c2/10
+    float half_gamma;          // path-loss exponent c2/10, halved (applied to log2 d^2)
     float log2k;               // log2(K)
     double dt2;                // squared connect-threshold distance
     double bs_x[DCOMP_MAX_BS], bs_y[DCOMP_MAX_BS];
@@ -142,34 +147,68 @@ __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_lo
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32 (1 ulp)
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32 (1 ulp)
 // log2(snr) and in-range test of one (UE, BS) pair.  station.py:110-127, 222-226.
+//   snr = K * (d + 1e-16)^(-gamma)  ->  log2 snr = log2 K - (gamma/2) * log2(d^2)   for d >> 1e-16.
+// `tiny` flags d^2 < 1e-20 (UE sitting on a BS: waypoints and BS positions share the integer grid), where the
+// +1e-16 of station.py:116 matters; those pairs are redone by pair_eval_tiny under a wave-uniform rare branch.
 __device__ __forceinline__ void pair_eval(double px, double py, double bx, double by, const KParams &p, bool &in_range,
-                                          float &l2snr)
+                                          float &l2snr, bool &tiny)
 {
     double dx = bx - px, dy = by - py;
     double dsq = __builtin_fma(dy, dy, dx * dx);
     in_range = dsq < p.dt2;                      // snr > 2e-8  <=>  d < d_T, decided in FP64
     float q = (float)dsq;
-    float h = 0.5f * fast_log2(fmaxf(q, 1e-20f));  // log2(d); the +1e-16 of station.py:116 is below FP32 resolution ...
-    if (q < 1e-20f) h = fast_log2(__builtin_sqrtf(q) + EPS);   // ... except at d ~ 0 (waypoints and BS sit on the integer grid)
-    l2snr = __builtin_fmaf(-p.gamma, h, p.log2k);
+    tiny = q < 1e-20f;
+    l2snr = __builtin_fmaf(-p.half_gamma, fast_log2(fmaxf(q, 1e-20f)), p.log2k);
 }
-// bw * log2(1 + snr) from log2(snr).  station.py:129-138.  Branch-free; never forms 1+snr for small snr
-// (1.0f + snr is exactly 1.0f below 6e-8 while the connect threshold is 2e-8).
-__device__ __forceinline__ float rate_unshared(float l2snr)
+__device__ __forceinline__ float pair_eval_tiny(double px, double py, double bx, double by, const KParams &p)
 {
-    const float s = fast_exp2(fminf(l2snr, 100.f));
-    // snr < 1/16 (d > ~0.9 m, i.e. practically always): log1p series, relative error < 3e-8 at 8 terms
-    float t = __builtin_fmaf(s, -0.125f, 0.14285715f);
-    t = __builtin_fmaf(s, t, -0.16666667f);
-    t = __builtin_fmaf(s, t, 0.2f);
+    double dx = bx - px, dy = by - py;
+    float q = (float)__builtin_fma(dy, dy, dx * dx);
+    float d = __builtin_amdgcn_sqrtf(q) + EPS;                  // d + 1e-16 (station.py:116)
+    return __builtin_fmaf(-2.0f * p.half_gamma, fast_log2(d), p.log2k);
+}
+// All B pairs of one UE; returns the in-range mask.
+template <int B>
+__device__ __forceinline__ uint32_t eval_pairs(double px, double py, const KParams &p, float (&l2)[B])
+{
+    uint32_t in_range = 0;
+    bool anytiny = false;
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        bool ir, tiny;
+        pair_eval(px, py, p.bs_x[b], p.bs_y[b], p, ir, l2[b], tiny);
+        in_range |= (uint32_t)ir << b;
+        anytiny |= tiny;
+    }
+    if (__ballot(anytiny) != 0ull) {             // rare: some lane of this wave is within 1e-10 m of a BS
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            float t = pair_eval_tiny(px, py, p.bs_x[b], p.bs_y[b], p);
+            double dx = p.bs_x[b] - px, dy = p.bs_y[b] - py;
+            if ((float)__builtin_fma(dy, dy, dx * dx) < 1e-20f) l2[b] = t;
+        }
+    }
+    return in_range;
+}
+// bw * log2(1 + snr) from log2(snr).  station.py:129-138.  Never forms 1+snr for small snr (1.0f + snr is
+// exactly 1.0f below 6e-8 while the connect threshold is 2e-8): log1p series, relative error < 1e-8 for
+// snr < 1/16 (d > ~0.9 m).  `needfix` flags the rare larger snr, redone by rate_unshared_any.
+__device__ __forceinline__ float rate_unshared_small(float l2snr, bool &needfix)
+{
+    needfix = l2snr > -4.0f;
+    const float s = fast_exp2(fminf(l2snr, -4.0f));
+    float t = __builtin_fmaf(s, -0.16666667f, 0.2f);
     t = __builtin_fmaf(s, t, -0.25f);
     t = __builtin_fmaf(s, t, 0.33333334f);
     t = __builtin_fmaf(s, t, -0.5f);
     t = __builtin_fmaf(s, t, 1.0f);
-    const float small = s * t * LOG2E;
-    // larger snr: 1+s is accurate enough (log2 >= 0.087, relative error < 2e-6); huge snr (d -> 0): log2(1+s) = log2(s)
-    const float big = l2snr > 100.f ? l2snr : fast_log2(1.0f + s);
-    return BW * (s < 0.0625f ? small : big);
+    return (BW * LOG2E) * (s * t);
+}
+__device__ __forceinline__ float rate_unshared_any(float l2snr)
+{
+    // snr >= 1/16: 1+s is accurate enough (log2(1+s) >= 0.087, relative error < 2e-6); d -> 0: log2(1+s) = log2(s)
+    const float s = fast_exp2(fminf(l2snr, 100.f));
+    return BW * (l2snr > 100.f ? l2snr : fast_log2(1.0f + s));
 }
 // user.py:76-92 -> utility.py:23-54
 __device__ __forceinline__ float ue_utility(float dr, bool step_util, float dr_req)
@@ -211,8 +250,8 @@ __device__ __forceinline__ void draw_triple(const KParams &p, int env, int u, in
         ushort4 t = p.tape_triples[(size_t)idx * p.tape_depth + k];
         vel = t.x; wx = t.y; wy = t.z;
     } else {
-        uint32_t r[4];
-        philox4x32_10(p.env_base + (uint32_t)env, (uint32_t)u, p.episode, k + 1, p.seed_lo, p.seed_hi, r);
+        uint32_t r[4] = {0x12345678u + k * 977u, 0x9abcdef0u ^ (uint32_t)idx * 2654435761u, 0x0fedcba9u + (uint32_t)u * 40503u, 0u};
+        if (!(DCOMP_ABLATE & 128)) philox4x32_10(p.env_base + (uint32_t)env, (uint32_t)u, p.episode, k + 1, p.seed_lo, p.seed_hi, r);
         UeCfg c = p.ue_cfg[u];
         vel = c.vel_lo + __umulhi(r[0], (uint32_t)(c.vel_hi - c.vel_lo + 1));
         wx = 10u + __umulhi(r[1], (uint32_t)(p.map_w - 20 + 1));
@@ -326,22 +365,34 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
     using G = Geo<B, UPAD>;
     float agg[B];
     const float inv_ewma = fast_rcp(ewma + EPS);          // station.py:150 priority denominator (beta = 1)
+    bool fix = false;
 #pragma unroll
     for (int b = 0; b < B; b++) {
         const bool c = (conn >> b) & 1u;
-        const int mode = p.bs_mode[b];
         unsigned long long m = __ballot(c);
         float dru = 0.f;
         if (m != 0ull) {                                   // wave-uniform: skip BSs nobody in this wave is connected to
-            const float t = rate_unshared(l2[b]);
+            bool f;
+            const float t = rate_unshared_small(l2[b], f);
             dru = c ? t : 0.f;
+            fix |= c && f;
         }
         dr[b] = dru;
         if (G::WG < 64) m = (m >> gbase) & ((1ull << G::WG) - 1ull);
         cnt[b] = (float)__popcll(m);
+    }
+    if (__ballot(fix) != 0ull) {                           // rare: a connected UE closer than ~0.9 m to its BS
+#pragma unroll
+        for (int b = 0; b < B; b++)
+            if (((conn >> b) & 1u) && l2[b] > -4.0f) dr[b] = rate_unshared_any(l2[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        const bool c = (conn >> b) & 1u;
+        const int mode = p.bs_mode[b];
         float a = 0.f;
-        if (mode == DCOMP_RATE_FAIR) a = c ? fast_rcp(dru) : 0.f;         // station.py:177-180
-        else if (mode == DCOMP_PROP_FAIR) a = dru * inv_ewma;             // station.py:192-195 (0 when not connected)
+        if (mode == DCOMP_RATE_FAIR) a = c ? fast_rcp(dr[b]) : 0.f;       // station.py:177-180
+        else if (mode == DCOMP_PROP_FAIR) a = dr[b] * inv_ewma;           // station.py:192-195 (0 when not connected)
         agg[b] = a;
     }
     if (p.any_sum_mode) group_reduce_vec<G::WG, OpSum, B>(agg);
@@ -409,7 +460,7 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
         tsum[b] = c ? util : 0.f;
         tmin[b] = c ? util : MAX_UTIL;
     }
-    if (!RESET) {
+    if (!RESET && !(DCOMP_ABLATE & 16)) {
         group_reduce_vec<G::WG, OpSum, B>(tsum);
         if (need_min) group_reduce_vec<G::WG, OpMin, B>(tmin);
         if (G::NW > 1) {
@@ -484,7 +535,11 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
         tsum[b] = cnt[b] > 0.f ? tsum[b] * fast_rcp(cnt[b]) * (1.0f / MAX_UTIL) : 0.f;          // variants.py:299, station.py:71-76
         cnt[b] = cnt[b] * inv_u;                                                                // variants.py:296
     }
-    if (p.kind == DCOMP_MULTI) {
+    if ((DCOMP_ABLATE & 8) && p.kind == DCOMP_MULTI) {
+        float acc = util_n + reward;
+        for (int b = 0; b < B; b++) acc += l2[b] + cnt[b] + tsum[b];
+        if (active && acc == 123456.f) p.obs[idx] = acc;         // keeps the producers alive, writes nothing
+    } else if (p.kind == DCOMP_MULTI) {
         if (active && p.reward) p.reward[idx] = reward;
         // rows of this wave are contiguous in memory: [row0, row0 + nrows)
         const unsigned long long am = __ballot(active);
@@ -564,13 +619,9 @@ __global__ __launch_bounds__(256) void step_kernel(const KParams p)
 
     // 1. pairs at the pre-move position
     float l2[B];
-    uint32_t in_range = 0;
-#pragma unroll
-    for (int b = 0; b < B; b++) {
-        bool ir;
-        pair_eval(px, py, p.bs_x[b], p.bs_y[b], p, ir, l2[b]);
-        in_range |= (uint32_t)ir << b;
-    }
+    uint32_t in_range = B >= 32 ? 0xFFFFFFFFu : ((1u << (B & 31)) - 1u);
+    if (!(DCOMP_ABLATE & 32)) in_range = eval_pairs<B>(px, py, p, l2);
+    else { for (int b = 0; b < B; b++) l2[b] = -20.f; }
     // 2. toggle (base.py:247-263 -> user.py:190-222)
     if (act > (uint32_t)B) { atomicOr(p.flags, DCOMP_FLAG_BAD_ACTION); act = 0; }
     if (act > 0) {
@@ -580,32 +631,27 @@ __global__ __launch_bounds__(256) void step_kernel(const KParams p)
     }
     // 3. rates before the move (base.py:446) -> reward_before (base.py:158-167)
     float dr[B], cnt[B];
-    shared_rates<B, UPAD>(p, sh, conn, l2, ewma, px, py, u, env_local, wave, lane, gbase, dr, cnt);
+    if (!(DCOMP_ABLATE & 1)) shared_rates<B, UPAD>(p, sh, conn, l2, ewma, px, py, u, env_local, wave, lane, gbase, dr, cnt);
+    else { for (int b = 0; b < B; b++) { dr[b] = 1.f; cnt[b] = 1.f; } }
     float curr = 0.f;
 #pragma unroll
     for (int b = 0; b < B; b++) curr += dr[b];
     const float util_pre = ue_utility(curr, step_util, dr_req);
     const float reward_before = fminf(fmaxf(util_pre, MIN_UTIL), MAX_UTIL) * (1.0f / MAX_UTIL);
     // 4. move (base.py:447 -> user.py:159-173)
-    if (active) {
+    if (active && !(DCOMP_ABLATE & 2)) {
         move_ue(p, env, u, idx, px, py, mv);
         if (px < 0.0 || py < 0.0 || px > (double)p.map_w || py > (double)p.map_h) atomicOr(p.flags, DCOMP_FLAG_OUTSIDE_MAP);
     }
     // 5. pairs at the new position; drop lost connections (user.py:175-188); EWMA from the stale rates (user.py:148-157)
-    in_range = 0;
-#pragma unroll
-    for (int b = 0; b < B; b++) {
-        bool ir;
-        pair_eval(px, py, p.bs_x[b], p.bs_y[b], p, ir, l2[b]);
-        in_range |= (uint32_t)ir << b;
-    }
+    if (!(DCOMP_ABLATE & 64)) in_range = eval_pairs<B>(px, py, p, l2);
     conn &= in_range;
     float stale = 0.f;
 #pragma unroll
     for (int b = 0; b < B; b++) stale += ((conn >> b) & 1u) ? dr[b] : 0.f;
     ewma = 0.9f * stale + 0.1f * ewma;
     // 6. rates after the move (base.py:451)
-    shared_rates<B, UPAD>(p, sh, conn, l2, ewma, px, py, u, env_local, wave, lane, gbase, dr, cnt);
+    if (!(DCOMP_ABLATE & 4)) shared_rates<B, UPAD>(p, sh, conn, l2, ewma, px, py, u, env_local, wave, lane, gbase, dr, cnt);
     curr = 0.f;
 #pragma unroll
     for (int b = 0; b < B; b++) curr += dr[b];
@@ -660,14 +706,9 @@ __global__ __launch_bounds__(256) void reset_kernel(const KParams p)
         p.ewma[idx] = 0.f;
     }
     float l2[B], cnt[B];
-    uint32_t in_range = 0;
+    const uint32_t in_range = eval_pairs<B>(px, py, p, l2);
 #pragma unroll
-    for (int b = 0; b < B; b++) {
-        bool ir;
-        pair_eval(px, py, p.bs_x[b], p.bs_y[b], p, ir, l2[b]);
-        in_range |= (uint32_t)ir << b;
-        cnt[b] = 0.f;
-    }
+    for (int b = 0; b < B; b++) cnt[b] = 0.f;
     const float util = ue_utility(0.f, step_util, dr_req);
     write_outputs<B, UPAD, true>(p, sh, active, env, env_local, u, idx, wave, lane, gbase, 0u, in_range, l2, cnt, util, 0.f, 0.f);
 }
