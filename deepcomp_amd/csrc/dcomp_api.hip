@@ -13,14 +13,14 @@
 #include "dcomp_device.h"
 
 namespace dcomp {
-#define DCOMP_DECL(n) KernelPair kernels_b##n(int upad);
+#define DCOMP_DECL(n) KernelPair kernels_b##n(int upad, int mp);
 DCOMP_B_LIST(DCOMP_DECL)
 #undef DCOMP_DECL
 
-static KernelPair lookup_kernels(int B, int upad)
+static KernelPair lookup_kernels(int B, int upad, int mp)
 {
     switch (B) {
-#define DCOMP_CASE(n) case n: return kernels_b##n(upad);
+#define DCOMP_CASE(n) case n: return kernels_b##n(upad, mp);
         DCOMP_B_LIST(DCOMP_CASE)
 #undef DCOMP_CASE
     default: return KernelPair{nullptr, nullptr};
@@ -103,7 +103,13 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
     env->cfg = *cfg;
     env->cfg.bs_x = env->cfg.bs_y = nullptr;   // host arrays are not retained
     env->upad = next_pow2(U) < 4 ? 4 : next_pow2(U);
-    env->kern = dcomp::lookup_kernels(B, env->upad);
+    int mp = dcomp::MP_RES_FAIR;            // sharing pattern -> specialised kernel (dcomp_device.h bs_mode_of)
+    for (int b = 0; b < B; b++) if (cfg->bs_sharing[b] != DCOMP_RES_FAIR) mp = dcomp::MP_MIXED;
+    if (mp == dcomp::MP_MIXED) {
+        static const int cyc[3] = {DCOMP_RES_FAIR, DCOMP_RATE_FAIR, DCOMP_PROP_FAIR};   // env_setup.py:40-49
+        for (int b = 0; b < B; b++) if (cfg->bs_sharing[b] != cyc[b % 3]) mp = dcomp::MP_GENERIC;
+    }
+    env->kern = dcomp::lookup_kernels(B, env->upad, mp);
     if (!env->kern.step) { delete env; return fail(DCOMP_EUNSUPPORTED, "no kernel built for num_bs=%d (built: " DCOMP_B_LIST_STR ")", B); }
     env->grid = (E + (256 / env->upad) - 1) / (256 / env->upad);
     env->time = 0;

@@ -305,6 +305,19 @@ __device__ __forceinline__ void move_ue(const KParams &p, int env, int u, int id
 
 // ---------------------------------------------------------------------------------------------- kernels
 // LDS scratch shared by the cross-wave exchange, max-cap arg-min and the 'sum' neighbourhood reward.
+// Sharing-model pattern baked into the kernel (station.py:152-202, env_setup.py:40-49):
+//   MP_GENERIC   per-BS model read from the argument block at run time
+//   MP_RES_FAIR  every BS resource-fair (no float sums over UEs at all)
+//   MP_MIXED     the CLI default 'mixed': BS b -> [resource-fair, rate-fair, proportional-fair][b % 3]
+enum { MP_GENERIC = 0, MP_RES_FAIR = 1, MP_MIXED = 2 };
+template <int MP>
+__device__ __forceinline__ int bs_mode_of(const KParams &p, int b)
+{
+    if (MP == MP_RES_FAIR) return DCOMP_RES_FAIR;
+    if (MP == MP_MIXED) return (b % 3 == 0) ? DCOMP_RES_FAIR : (b % 3 == 1) ? DCOMP_RATE_FAIR : DCOMP_PROP_FAIR;
+    return p.bs_mode[b];
+}
+
 template <int B, int UPAD>
 struct Geo {
     static constexpr int WG = UPAD < 64 ? UPAD : 64;        // in-wave group width
@@ -357,7 +370,7 @@ __device__ __forceinline__ void xwave_reduce_(float (&v)[N], SH &sh, int wave, i
 // Shared data rates of this UE at every BS.  station.py:152-220 with S_b = {u : conn[u,b]}.
 //   in : conn mask, l2snr[b], ewma, (px,py) for the max-cap arg-min
 //   out: dr[b] (0 where not connected), cnt[b] = |S_b|
-template <int B, int UPAD>
+template <int B, int UPAD, int MP>
 __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, UPAD> &sh, uint32_t conn, const float (&l2)[B], float ewma,
                                              double px, double py, int u, int env_local, int wave, int lane, int gbase,
                                              float (&dr)[B], float (&cnt)[B])
@@ -389,19 +402,30 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
 #pragma unroll
     for (int b = 0; b < B; b++) {
         const bool c = (conn >> b) & 1u;
-        const int mode = p.bs_mode[b];
+        const int mode = bs_mode_of<MP>(p, b);
         float a = 0.f;
         if (mode == DCOMP_RATE_FAIR) a = c ? fast_rcp(dr[b]) : 0.f;       // station.py:177-180
         else if (mode == DCOMP_PROP_FAIR) a = dr[b] * inv_ewma;           // station.py:192-195 (0 when not connected)
         agg[b] = a;
     }
-    if (p.any_sum_mode) group_reduce_vec<G::WG, OpSum, B>(agg);
+    if (MP == MP_MIXED) {
+        // only the rate-/proportional-fair BSs (b % 3 != 0) need a sum over UEs
+        constexpr int NS = B - (B + 2) / 3;
+        if (NS > 0) {
+            float sv[NS > 0 ? NS : 1];
+#pragma unroll
+            for (int b = 0, k = 0; b < B; b++) if (b % 3 != 0) sv[k++] = agg[b];
+            group_reduce_vec<G::WG, OpSum, (NS > 0 ? NS : 1)>(sv);
+#pragma unroll
+            for (int b = 0, k = 0; b < B; b++) if (b % 3 != 0) agg[b] = sv[k++];
+        }
+    } else if (MP == MP_GENERIC && p.any_sum_mode) group_reduce_vec<G::WG, OpSum, B>(agg);
     if (G::NW > 1) {
         xwave_reduce_<B, G::NW, OpSum>(cnt, sh, wave, lane);
-        if (p.any_sum_mode) xwave_reduce_<B, G::NW, OpSum>(agg, sh, wave, lane);
+        if (MP == MP_MIXED || (MP == MP_GENERIC && p.any_sum_mode)) xwave_reduce_<B, G::NW, OpSum>(agg, sh, wave, lane);
     }
     uint32_t mc_winner = 0;
-    if (p.any_maxcap) {
+    if (MP == MP_GENERIC && p.any_maxcap) {
         // max-cap (station.py:183-187): only the UE with the highest unshared rate is served = the one with the
         // smallest FP64 squared distance; exact ties -> lowest UE index (the reference: oldest connection).
         const int tid = threadIdx.x;
@@ -411,7 +435,7 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
 #pragma unroll
         for (int b = 0; b < B; b++) {
             key[b] = ~0ull;
-            if (p.bs_mode[b] == DCOMP_MAX_CAP && ((conn >> b) & 1u)) {
+            if (bs_mode_of<MP>(p, b) == DCOMP_MAX_CAP && ((conn >> b) & 1u)) {
                 double dx = p.bs_x[b] - px, dy = p.bs_y[b] - py;
                 key[b] = (unsigned long long)__double_as_longlong(__builtin_fma(dy, dy, dx * dx));
                 atomicMin(&sh.mc_key[env_local * B + b], key[b]);
@@ -430,7 +454,7 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
 #pragma unroll
     for (int b = 0; b < B; b++) {
         const bool c = (conn >> b) & 1u;
-        const int mode = p.bs_mode[b];
+        const int mode = bs_mode_of<MP>(p, b);
         float dru = dr[b], out = 0.f;
         if (mode == DCOMP_RES_FAIR) out = dru * fast_rcp(fmaxf(cnt[b], 1.f));                        // station.py:171-173
         else if (mode == DCOMP_RATE_FAIR) out = fast_rcp(agg[b]);                                    // station.py:180
@@ -452,21 +476,12 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
     using SG = StageGeo<B>;
     const int U = p.U;
     // per-BS utility aggregates over connected UEs (station.py:63-83)
-    float tsum[B], tmin[B];
-    const bool need_min = (p.kind == DCOMP_MULTI && p.reward_agg == DCOMP_REWARD_MIN);
+    float tsum[B];
 #pragma unroll
-    for (int b = 0; b < B; b++) {
-        const bool c = (conn >> b) & 1u;
-        tsum[b] = c ? util : 0.f;
-        tmin[b] = c ? util : MAX_UTIL;
-    }
+    for (int b = 0; b < B; b++) tsum[b] = ((conn >> b) & 1u) ? util : 0.f;
     if (!RESET && !(DCOMP_ABLATE & 16)) {
         group_reduce_vec<G::WG, OpSum, B>(tsum);
-        if (need_min) group_reduce_vec<G::WG, OpMin, B>(tmin);
-        if (G::NW > 1) {
-            xwave_reduce_<B, G::NW, OpSum>(tsum, sh, wave, lane);
-            if (need_min) xwave_reduce_<B, G::NW, OpMin>(tmin, sh, wave, lane);
-        }
+        if (G::NW > 1) xwave_reduce_<B, G::NW, OpSum>(tsum, sh, wave, lane);
     }
     float l2max = l2[0];
 #pragma unroll
@@ -499,17 +514,22 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
                 reward = s;
             }
             __syncthreads();
-        } else if (in_range != 0) {
+        } else {
             if (p.reward_agg == DCOMP_REWARD_AVG) {                 // multi_agent.py:60-71
                 float n = 0.f, t = 0.f;
 #pragma unroll
                 for (int b = 0; b < B; b++) if ((in_range >> b) & 1u) { n += cnt[b]; t += tsum[b]; }
                 if (n > 0.f) reward = (conn == 0u) ? (t + util) / (n + 1.f) : t / n;
-            } else {                                                // multi_agent.py:81-85
+            } else {                                                // multi_agent.py:81-85, station.py:78-83
+                float tmin[B];
+#pragma unroll
+                for (int b = 0; b < B; b++) tmin[b] = ((conn >> b) & 1u) ? util : MAX_UTIL;
+                group_reduce_vec<G::WG, OpMin, B>(tmin);
+                if (G::NW > 1) xwave_reduce_<B, G::NW, OpMin>(tmin, sh, wave, lane);
                 float m = util;
 #pragma unroll
                 for (int b = 0; b < B; b++) if ((in_range >> b) & 1u) m = fminf(m, cnt[b] > 0.f ? tmin[b] : MAX_UTIL);
-                reward = m;
+                reward = (in_range != 0) ? m : util;
             }
         }
     }
@@ -589,8 +609,11 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
     }
 }
 
-template <int B, int UPAD>
-__global__ __launch_bounds__(256) void step_kernel(const KParams p)
+#ifndef DCOMP_FORCE_WAVES
+#define DCOMP_FORCE_WAVES 1
+#endif
+template <int B, int UPAD, int MP>
+__global__ __launch_bounds__(256, (B <= 10 && UPAD <= 64) ? DCOMP_FORCE_WAVES : 1) void step_kernel(const KParams p)
 {
     using G = Geo<B, UPAD>;
     __shared__ BlockSharedT<B, UPAD> sh;
@@ -631,7 +654,7 @@ __global__ __launch_bounds__(256) void step_kernel(const KParams p)
     }
     // 3. rates before the move (base.py:446) -> reward_before (base.py:158-167)
     float dr[B], cnt[B];
-    if (!(DCOMP_ABLATE & 1)) shared_rates<B, UPAD>(p, sh, conn, l2, ewma, px, py, u, env_local, wave, lane, gbase, dr, cnt);
+    if (!(DCOMP_ABLATE & 1)) shared_rates<B, UPAD, MP>(p, sh, conn, l2, ewma, px, py, u, env_local, wave, lane, gbase, dr, cnt);
     else { for (int b = 0; b < B; b++) { dr[b] = 1.f; cnt[b] = 1.f; } }
     float curr = 0.f;
 #pragma unroll
@@ -651,7 +674,7 @@ __global__ __launch_bounds__(256) void step_kernel(const KParams p)
     for (int b = 0; b < B; b++) stale += ((conn >> b) & 1u) ? dr[b] : 0.f;
     ewma = 0.9f * stale + 0.1f * ewma;
     // 6. rates after the move (base.py:451)
-    if (!(DCOMP_ABLATE & 4)) shared_rates<B, UPAD>(p, sh, conn, l2, ewma, px, py, u, env_local, wave, lane, gbase, dr, cnt);
+    if (!(DCOMP_ABLATE & 4)) shared_rates<B, UPAD, MP>(p, sh, conn, l2, ewma, px, py, u, env_local, wave, lane, gbase, dr, cnt);
     curr = 0.f;
 #pragma unroll
     for (int b = 0; b < B; b++) curr += dr[b];
@@ -717,20 +740,25 @@ using KernelFn = void (*)(const KParams);
 struct KernelPair { KernelFn step, reset; };
 
 template <int B, int UPAD>
-inline KernelPair make_pair_() { return KernelPair{step_kernel<B, UPAD>, reset_kernel<B, UPAD>}; }
+inline KernelPair make_pair_(int mp)
+{
+    if (mp == MP_RES_FAIR) return KernelPair{step_kernel<B, UPAD, MP_RES_FAIR>, reset_kernel<B, UPAD>};
+    if (mp == MP_MIXED) return KernelPair{step_kernel<B, UPAD, MP_MIXED>, reset_kernel<B, UPAD>};
+    return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>};
+}
 
 // One translation unit per B instantiates all UPAD widths (dcomp_inst_bXX.hip).
 template <int B>
-inline KernelPair kernels_for_upad(int upad)
+inline KernelPair kernels_for_upad(int upad, int mp)
 {
     switch (upad) {
-    case 1: case 2: case 4: return make_pair_<B, 4>();
-    case 8: return make_pair_<B, 8>();
-    case 16: return make_pair_<B, 16>();
-    case 32: return make_pair_<B, 32>();
-    case 64: return make_pair_<B, 64>();
-    case 128: return make_pair_<B, 128>();
-    case 256: return make_pair_<B, 256>();
+    case 1: case 2: case 4: return make_pair_<B, 4>(mp);
+    case 8: return make_pair_<B, 8>(mp);
+    case 16: return make_pair_<B, 16>(mp);
+    case 32: return make_pair_<B, 32>(mp);
+    case 64: return make_pair_<B, 64>(mp);
+    case 128: return make_pair_<B, 128>(mp);
+    case 256: return make_pair_<B, 256>(mp);
     default: return KernelPair{nullptr, nullptr};
     }
 }

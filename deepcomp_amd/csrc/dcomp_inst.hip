@@ -10,5 +10,5 @@
 #define DCOMP_CAT(a, b) DCOMP_CAT_(a, b)
 
 namespace dcomp {
-KernelPair DCOMP_CAT(kernels_b, DCOMP_B)(int upad) { return kernels_for_upad<DCOMP_B>(upad); }
+KernelPair DCOMP_CAT(kernels_b, DCOMP_B)(int upad, int mp) { return kernels_for_upad<DCOMP_B>(upad, mp); }
 }  // namespace dcomp

@@ -15,6 +15,10 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(REPO, 'deepcomp_amd', 'csrc')
 VAR = os.path.join(CSRC, 'variants')
 MASKS = [0, 1, 2, 4, 8, 16, 32, 64, 128, 1 | 4, 32 | 64, 8 | 16, 255]
+if os.environ.get('ABL_MASKS'):
+    MASKS = [int(x) for x in os.environ['ABL_MASKS'].split(',')]
+EXTRA = os.environ.get('ABL_FLAGS', '').split()
+TAG = os.environ.get('ABL_TAG', '')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast-honor-pragmas', '-DDCOMP_B_LIST(X)=X(10)',
          '-DDCOMP_B_LIST_STR="10"']
 
@@ -23,8 +27,8 @@ def build():
     os.makedirs(VAR, exist_ok=True)
     procs = []
     for m in MASKS:
-        so = os.path.join(VAR, f'libdcomp_hip_abl{m}.so')
-        cmd = ['hipcc'] + FLAGS + [f'-DDCOMP_ABLATE={m}', '-DDCOMP_B=10', '-shared', os.path.join(CSRC, 'dcomp_inst.hip'),
+        so = os.path.join(VAR, f'libdcomp_hip_abl{m}{TAG}.so')
+        cmd = ['hipcc'] + FLAGS + EXTRA + [f'-DDCOMP_ABLATE={m}', '-DDCOMP_B=10', '-shared', os.path.join(CSRC, 'dcomp_inst.hip'),
                                    os.path.join(CSRC, 'dcomp_api.hip'), '-o', so, '-lpthread']
         procs.append((m, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         if len(procs) % 6 == 0:
@@ -38,7 +42,7 @@ def build():
 def run():
     rows = []
     for m in MASKS:
-        env = dict(os.environ, DCOMP_LIB=os.path.join(VAR, f'libdcomp_hip_abl{m}.so'))
+        env = dict(os.environ, DCOMP_LIB=os.path.join(VAR, f'libdcomp_hip_abl{m}{TAG}.so'))
         r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '200', '--warmup', '20', '--no-cpu-baseline',
                             '--no-check'] + sys.argv[2:], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -47,7 +51,7 @@ def run():
             continue
         j = json.loads(line[-1])
         rows.append((m, j['roofline']['kernel_ms'], j['ms_per_step']))
-        print(f'ablate={m:3d}  kernel_ms={j["roofline"]["kernel_ms"]:.4f}  ms_per_step={j["ms_per_step"]:.4f}', flush=True)
+        print(f'{TAG} ablate={m:3d}  kernel_ms={j["roofline"]["kernel_ms"]:.4f}  ms_per_step={j["ms_per_step"]:.4f}', flush=True)
 
 
 if __name__ == '__main__':
