@@ -31,7 +31,7 @@ class DcompCfg(ctypes.Structure):
 
 class DcompState(ctypes.Structure):
     _fields_ = [('pos', ctypes.c_void_p), ('mv', ctypes.c_void_p), ('conn', ctypes.c_void_p),
-                ('ewma', ctypes.c_void_p), ('flags', ctypes.c_void_p)]
+                ('ewma', ctypes.c_void_p), ('flags', ctypes.c_void_p), ('conn_since', ctypes.c_void_p)]
 
 
 class DcompOut(ctypes.Structure):
@@ -69,7 +69,7 @@ def load():
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     L.dcomp_create.argtypes = [ctypes.POINTER(DcompCfg), ctypes.POINTER(vp)]
     L.dcomp_destroy.argtypes = [vp]
-    L.dcomp_state_sizes.argtypes = [vp] + [ctypes.POINTER(ctypes.c_size_t)] * 5
+    L.dcomp_state_sizes.argtypes = [vp] + [ctypes.POINTER(ctypes.c_size_t)] * 6
     L.dcomp_obs_dim.argtypes = [vp, _ip, _ip]
     L.dcomp_reset.argtypes = [vp, ctypes.POINTER(DcompState), ctypes.POINTER(DcompTape), ctypes.POINTER(DcompOut), vp]
     L.dcomp_step.argtypes = [vp, ctypes.POINTER(DcompState), vp, ctypes.POINTER(DcompOut), vp]

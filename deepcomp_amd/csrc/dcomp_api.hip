@@ -147,7 +147,7 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
         int m = cfg->bs_sharing[b];
         if (m < 0 || m > 3) { delete env; return fail(DCOMP_EINVAL, "bs_sharing[%d]=%d not supported", b, m); }   // station.py:22
         kp.bs_mode[b] = m;
-        if (m == DCOMP_MAX_CAP) kp.any_maxcap = 1;
+        if (m == DCOMP_MAX_CAP) { kp.any_maxcap = 1; kp.maxcap_mask |= 1u << b; }
         if (m == DCOMP_RATE_FAIR || m == DCOMP_PROP_FAIR) kp.any_sum_mode = 1;
     }
     std::vector<UeCfg> uc(U);
@@ -184,7 +184,7 @@ extern "C" int dcomp_destroy(dcomp_env *env)
 }
 
 extern "C" int dcomp_state_sizes(const dcomp_env *env, size_t *pos_bytes, size_t *mv_bytes, size_t *conn_bytes, size_t *ewma_bytes,
-                                 size_t *flags_bytes)
+                                 size_t *flags_bytes, size_t *since_bytes)
 {
     if (!env) return fail(DCOMP_EINVAL, "null env");
     size_t n = (size_t)env->cfg.num_envs * env->cfg.num_ue;
@@ -193,6 +193,7 @@ extern "C" int dcomp_state_sizes(const dcomp_env *env, size_t *pos_bytes, size_t
     if (conn_bytes) *conn_bytes = n * 4;
     if (ewma_bytes) *ewma_bytes = n * 4;
     if (flags_bytes) *flags_bytes = 16;
+    if (since_bytes) *since_bytes = env->kp.any_maxcap ? n * env->cfg.num_bs * 2 : 0;
     return DCOMP_OK;
 }
 
@@ -210,7 +211,10 @@ static int fill_params(dcomp_env *env, const dcomp_state *st, const dcomp_out *o
     if (!env || !st || !out) return fail(DCOMP_EINVAL, "null argument");
     if (!st->pos || !st->mv || !st->conn || !st->ewma || !st->flags) return fail(DCOMP_EINVAL, "state pointers must all be set");
     if (!out->obs) return fail(DCOMP_EINVAL, "out->obs is required");
+    if (env->kp.any_maxcap && !st->conn_since) return fail(DCOMP_EINVAL, "a max-cap BS needs state.conn_since (see dcomp_state_sizes)");
     kp = env->kp;
+    kp.conn_since = st->conn_since;
+    kp.time = (uint32_t)env->time;
     kp.pos = (double2 *)st->pos; kp.mv = (unsigned long long *)st->mv; kp.conn = st->conn; kp.ewma = st->ewma; kp.flags = st->flags;
     kp.obs = out->obs; kp.reward = out->reward; kp.sum_util = out->sum_utility; kp.ue_dr = out->ue_dr; kp.ue_util = out->ue_utility;
     kp.episode = (uint32_t)(env->episode < 0 ? 0 : env->episode);
@@ -261,6 +265,7 @@ extern "C" int dcomp_rollout(dcomp_env *env, const dcomp_state *st, const uint8_
     const size_t stride = (size_t)env->cfg.num_envs * env->cfg.num_ue;
     for (int t = 0; t < num_steps; t++) {
         kp.action = actions + stride * t;
+        kp.time = (uint32_t)(env->time + t);
         hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(256), 0, (hipStream_t)stream, kp);
     }
     HIP_TRY(hipGetLastError());

@@ -47,6 +47,7 @@ struct KParams {
     uint32_t *conn;
     float *ewma;
     uint32_t *flags;
+    uint16_t *conn_since;      // [E*U][B] step of connection (max-cap tie rule), NULL when no BS is max-cap
     // io (device)
     const uint8_t *action;
     float *obs, *reward, *sum_util, *ue_dr, *ue_util;
@@ -60,6 +61,8 @@ struct KParams {
     int32_t kind, reward_agg, rng_mode;
     uint32_t all_log_util;     // 1: every UE uses the log utility (skip the per-UE config load)
     uint32_t any_maxcap;
+    uint32_t maxcap_mask;      // bit b: BS b is max-cap
+    uint32_t time;             // env.time before this step (base.py:39)
     uint32_t any_sum_mode;     // some BS is rate-fair or proportional-fair (needs a sum over its UEs)
     uint32_t seed_lo, seed_hi, episode;
     uint32_t env_base;         // global id of env 0
@@ -372,7 +375,7 @@ __device__ __forceinline__ void xwave_reduce_(float (&v)[N], SH &sh, int wave, i
 //   out: dr[b] (0 where not connected), cnt[b] = |S_b|
 template <int B, int UPAD, int MP>
 __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, UPAD> &sh, uint32_t conn, const float (&l2)[B], float ewma,
-                                             double px, double py, int u, int env_local, int wave, int lane, int gbase,
+                                             double px, double py, int u, int idx, int env_local, int wave, int lane, int gbase,
                                              float (&dr)[B], float (&cnt)[B])
 {
     using G = Geo<B, UPAD>;
@@ -427,7 +430,8 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
     uint32_t mc_winner = 0;
     if (MP == MP_GENERIC && p.any_maxcap) {
         // max-cap (station.py:183-187): only the UE with the highest unshared rate is served = the one with the
-        // smallest FP64 squared distance; exact ties -> lowest UE index (the reference: oldest connection).
+        // smallest FP64 squared distance; exact ties -> first in bs.conn_ues = oldest connection, then (same step)
+        // lowest UE index, which is the order base.py:259-263 appends them in.
         const int tid = threadIdx.x;
         for (int i = tid; i < G::GPB * B; i += 256) { sh.mc_key[i] = ~0ull; sh.mc_win[i] = ~0u; }
         __syncthreads();
@@ -444,11 +448,12 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
         __syncthreads();
 #pragma unroll
         for (int b = 0; b < B; b++)
-            if (key[b] != ~0ull && key[b] == sh.mc_key[env_local * B + b]) atomicMin(&sh.mc_win[env_local * B + b], (uint32_t)u);
+            if (key[b] != ~0ull && key[b] == sh.mc_key[env_local * B + b])
+                atomicMin(&sh.mc_win[env_local * B + b], ((uint32_t)p.conn_since[(size_t)idx * B + b] << 8) | (uint32_t)u);
         __syncthreads();
 #pragma unroll
         for (int b = 0; b < B; b++)
-            if (key[b] != ~0ull && sh.mc_win[env_local * B + b] == (uint32_t)u) mc_winner |= 1u << b;
+            if (key[b] != ~0ull && (sh.mc_win[env_local * B + b] & 0xFFu) == (uint32_t)u) mc_winner |= 1u << b;
         __syncthreads();
     }
 #pragma unroll
@@ -650,11 +655,14 @@ __global__ __launch_bounds__(256, (B <= 10 && UPAD <= 64) ? DCOMP_FORCE_WAVES : 
     if (act > 0) {
         const uint32_t bit = 1u << (act - 1);
         if (conn & bit) conn &= ~bit;
-        else if (in_range & bit) conn |= bit;
+        else if (in_range & bit) {
+            conn |= bit;
+            if (MP == MP_GENERIC && (p.maxcap_mask & bit)) p.conn_since[(size_t)idx * B + (act - 1)] = (uint16_t)p.time;
+        }
     }
     // 3. rates before the move (base.py:446) -> reward_before (base.py:158-167)
     float dr[B], cnt[B];
-    if (!(DCOMP_ABLATE & 1)) shared_rates<B, UPAD, MP>(p, sh, conn, l2, ewma, px, py, u, env_local, wave, lane, gbase, dr, cnt);
+    if (!(DCOMP_ABLATE & 1)) shared_rates<B, UPAD, MP>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt);
     else { for (int b = 0; b < B; b++) { dr[b] = 1.f; cnt[b] = 1.f; } }
     float curr = 0.f;
 #pragma unroll
@@ -674,7 +682,7 @@ __global__ __launch_bounds__(256, (B <= 10 && UPAD <= 64) ? DCOMP_FORCE_WAVES : 
     for (int b = 0; b < B; b++) stale += ((conn >> b) & 1u) ? dr[b] : 0.f;
     ewma = 0.9f * stale + 0.1f * ewma;
     // 6. rates after the move (base.py:451)
-    if (!(DCOMP_ABLATE & 4)) shared_rates<B, UPAD, MP>(p, sh, conn, l2, ewma, px, py, u, env_local, wave, lane, gbase, dr, cnt);
+    if (!(DCOMP_ABLATE & 4)) shared_rates<B, UPAD, MP>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt);
     curr = 0.f;
 #pragma unroll
     for (int b = 0; b < B; b++) curr += dr[b];

@@ -114,8 +114,11 @@ class BatchedMobileEnv:
         self.sum_utility = torch.zeros(self.E, dtype=torch.float32, device=dev)
         self.ue_dr = torch.zeros((self.E, U), dtype=torch.float32, device=dev)
         self.ue_utility = torch.zeros((self.E, U), dtype=torch.float32, device=dev)
+        since_bytes = ctypes.c_size_t(0)
+        _lib.check(L.dcomp_state_sizes(self._h, None, None, None, None, None, ctypes.byref(since_bytes)))
+        self.conn_since = torch.zeros(since_bytes.value // 2, dtype=torch.int16, device=dev) if since_bytes.value else None
         self._st = _lib.DcompState(self.pos.data_ptr(), self.mv.data_ptr(), self.conn.data_ptr(), self.ewma.data_ptr(),
-                                   self.flags.data_ptr())
+                                   self.flags.data_ptr(), self.conn_since.data_ptr() if self.conn_since is not None else None)
         self._out = self._make_out(self.obs, self.reward)
         self._tape_dev = None
         self._streams = None

@@ -23,6 +23,8 @@
  *   conn  uint32[E*U]      bit b set <=> UE connected to BS b                  (user.py:34 bs_dr keys)
  *   ewma  float [E*U]      exponentially weighted average rate                 (user.py:148-157)
  *   flags uint32[4]        sticky device-side error bits, read by dcomp_check()
+ *   conn_since uint16[E*U][B]   step at which a connection was made -- only when some BS is max-cap (oldest
+ *                          connection wins rate ties, station.py:184-186); NULL otherwise
  */
 #ifndef DCOMP_H
 #define DCOMP_H
@@ -83,6 +85,7 @@ typedef struct dcomp_state {     /* device, caller-allocated; sizes via dcomp_st
     uint32_t *conn;
     float *ewma;
     uint32_t *flags;
+    uint16_t *conn_since;        /* NULL unless dcomp_state_sizes() reports since_bytes > 0 */
 } dcomp_state;
 
 /* Outputs of reset()/step().  obs layout = RLlib's flatten order of the reference's Dict spaces
@@ -110,7 +113,7 @@ typedef struct dcomp_tape {
 int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out);                 /* MobileEnv.__init__  base.py:27-84 */
 int dcomp_destroy(dcomp_env *env);
 int dcomp_state_sizes(const dcomp_env *env, size_t *pos_bytes, size_t *mv_bytes, size_t *conn_bytes,
-                      size_t *ewma_bytes, size_t *flags_bytes);
+                      size_t *ewma_bytes, size_t *flags_bytes, size_t *since_bytes);
 int dcomp_obs_dim(const dcomp_env *env, int32_t *floats_per_env, int32_t *reward_per_env);
 
 /* MobileEnv.reset (base.py:169-189): draw start positions + first waypoint, clear connections and

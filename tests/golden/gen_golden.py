@@ -115,13 +115,15 @@ def snapshot(env, kind, obs, reward=None, info=None):
 
 
 def run_trajectory(name, scn, kind, seed, num_steps, reward='avg', tape_mode='uniform', rand_episodes=False,
-                   episodes=1, eps_len=100):
+                   episodes=1, eps_len=100, scripted=None):
     """reset() then num_steps x step(); optionally several episodes (reset in between)."""
     m, bs_list, ue_list = build_ref(scn, scn.ue_specs)
     cfg = env_config(m, bs_list, ue_list, seed, eps_len=eps_len, reward=reward, rand_episodes=rand_episodes)
     env = (CentralRelNormEnv if kind == 'central' else MultiAgentMobileEnv)(cfg)
     U, B = env.num_ue, env.num_bs
     tape = action_tape(num_steps * episodes, U, B, tape_mode)
+    if scripted is not None:
+        tape[:len(scripted)] = np.asarray(scripted, dtype=np.int32)
     resets, steps = [], []
     t = 0
     for _ in range(episodes):
@@ -142,6 +144,8 @@ def run_trajectory(name, scn, kind, seed, num_steps, reward='avg', tape_mode='un
         'cfg_ue_vel': np.array([VEL_CODE.get(s['velocity'], s['velocity']) for s in scn.ue_specs], dtype=np.int32),
         'cfg_ue_util': np.array([0 if s['util_func'] == 'log' else 1 for s in scn.ue_specs], dtype=np.int32),
         'cfg_ue_dr_req': np.array([s['dr_req'] for s in scn.ue_specs], dtype=np.float64),
+        'cfg_ue_init_xy': np.array([[-1 if s['pos_x'] == 'random' else s['pos_x'], -1 if s['pos_y'] == 'random' else s['pos_y']]
+                                    for s in scn.ue_specs], dtype=np.int32),
         'cfg_seed': np.array(seed, dtype=np.int64),
         'cfg_kind': np.array(0 if kind == 'central' else 1, dtype=np.int32),
         'cfg_reward': np.array({'avg': 0, 'sum': 1, 'min': 2}[reward], dtype=np.int32),
@@ -275,6 +279,14 @@ def gen_trajectories():
                    'multi', 43, 100, tape_mode='sticky')
     run_trajectory('traj_small5x2_resfair_central_s42', S.small_map('resource-fair').with_ues(num_slow=5),
                    'central', 42, 100, tape_mode='sticky')
+    # max-cap rate ties (station.py:184-186: first maximum in bs.conn_ues = oldest connection): static UEs parked on
+    # the same spots, connecting in an order that differs from the UE-list order
+    scn = S.custom_map('max-cap').with_ues(num_static=6)
+    for i, (x, y) in enumerate([(50, 60), (50, 60), (50, 60), (97, 50), (97, 50), (137, 20)]):
+        scn.ue_specs[i]['pos_x'], scn.ue_specs[i]['pos_y'] = x, y
+    script = [[0, 0, 1, 0, 0, 0], [1, 0, 0, 0, 2, 0], [0, 1, 0, 2, 0, 2], [0, 0, 0, 0, 0, 0], [0, 0, 1, 0, 2, 0],
+              [0, 0, 0, 0, 0, 0], [0, 0, 1, 0, 2, 0], [1, 0, 0, 0, 0, 0], [1, 0, 0, 4, 4, 0], [0, 0, 0, 0, 0, 0]]
+    run_trajectory('traj_custom6x4_maxcap_ties_multi_s42', scn, 'multi', 42, 60, tape_mode='sticky', scripted=script)
     # reward aggregations
     for rew in ('sum', 'min'):
         run_trajectory(f'traj_large8x7_multi_{rew}_s42',

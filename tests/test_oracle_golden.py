@@ -112,9 +112,11 @@ def make_env_from_fixture(g, depth=64):
     U = g['cfg_ue_vel'].shape[0]
     w, h = (int(x) for x in g['cfg_map_wh'])
     vel = [int(v) for v in g['cfg_ue_vel']]
+    init = [tuple(int(v) for v in xy) for xy in g['cfg_ue_init_xy']]
     env = orc.OracleEnv(w, h, g['cfg_bs_pos'], list(g['cfg_bs_sharing']), vel, kind=int(g['cfg_kind']),
-                        reward_agg=int(g['cfg_reward']), ue_util=g['cfg_ue_util'], ue_dr_req=g['cfg_ue_dr_req'])
-    tape = orc.RefRngTape(int(g['cfg_seed']), w, h, vel, depth=depth, rand_episodes=bool(g['cfg_rand_episodes']))
+                        reward_agg=int(g['cfg_reward']), ue_util=g['cfg_ue_util'], ue_dr_req=g['cfg_ue_dr_req'], init_xy=init)
+    tape = orc.RefRngTape(int(g['cfg_seed']), w, h, vel, init_xy=init, depth=depth,
+                          rand_episodes=bool(g['cfg_rand_episodes']))
     return env, tape, U
 
 

@@ -35,7 +35,8 @@ def _entities_from_fixture(g):
     m = Map(w, h)
     bs = [Basestation(chr(65 + i), Point(x, y), inv_sh[int(s)]) for i, ((x, y), s) in enumerate(zip(g['cfg_bs_pos'], g['cfg_bs_sharing']))]
     vel = {-1: 'slow', -2: 'fast'}
-    ues = [User(str(i + 1), m, 'random', 'random', RandomWaypoint(m, vel.get(int(v), int(v))),
+    xy = [['random' if int(c) < 0 else int(c) for c in p] for p in g['cfg_ue_init_xy']]
+    ues = [User(str(i + 1), m, xy[i][0], xy[i][1], RandomWaypoint(m, vel.get(int(v), int(v))),
                 util_func='log' if int(u) == 0 else 'step', dr_req=float(r))
            for i, (v, u, r) in enumerate(zip(g['cfg_ue_vel'], g['cfg_ue_util'], g['cfg_ue_dr_req']))]
     return m, bs, ues
