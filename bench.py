@@ -63,7 +63,7 @@ def cpu_baseline(scn, kind, U, B, budget_s=15.0):
         probe.step(a)
     rate = probe.E * 5 / (time.perf_counter() - t0)
     steps = 100
-    E = int(max(threads, min(4096, rate * budget_s / steps)))
+    E = int(max(threads, min(32768, rate * budget_s / steps)))
     E = (E // threads) * threads
     batch = make(E)
     batch.reset()
@@ -88,6 +88,7 @@ def main():
     ap.add_argument('--sharing', default='mixed')
     ap.add_argument('--eps-length', type=int, default=100)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--rollout', type=int, default=0, help='issue steps in chunks of T through dcomp_rollout (one host call per chunk)')
     ap.add_argument('--no-check', action='store_true', help='skip the device error-flag check (ablation builds)')
     ap.add_argument('--traffic-bytes', type=float, default=None, help='HBM bytes per launch from a rocprofv3 --pmc pass')
     args = ap.parse_args()
@@ -118,8 +119,20 @@ def main():
     g = torch.Generator(device=dev).manual_seed(7 + rank)
     pool = torch.randint(0, B + 1, (16, E, U), generator=g, device=dev, dtype=torch.uint8)
 
+    T = args.rollout
+    if T:
+        assert L % T == 0 and K % T == 0 and W % T == 0, "--rollout T must divide the episode length, steps and warmup"
+        tape = torch.randint(0, B + 1, (4, T, E, U), generator=g, device=dev, dtype=torch.uint8)
+
     def run(nsteps, t_start, events=None):
         t = t_start
+        if T and events is None:
+            for i in range(nsteps // T):
+                if t % L == 0:
+                    env.reset()
+                env.rollout(tape[i & 3])
+                t += T
+            return t
         for i in range(nsteps):
             if t % L == 0:
                 env.reset()
@@ -166,7 +179,7 @@ def main():
             'warmup': W, 'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64 positions / f32 rates', 'data': 'synthetic',
             'config': {'workload': f'{E} envs/GPU x {U} UE x {B} BS, {args.kind}-agent obs, sharing={args.sharing}, '
-                                   f'log utility, reward avg, episode {L} (reset inside timed region), random actions',
+                                   f'log utility, reward avg, episode {L} (reset inside timed region), random actions' + (f', rollout chunks of {T}' if T else ''),
                        'envs_per_gpu': E, 'num_ue': U, 'num_bs': B, 'pair_steps_per_s': world * E * K / elapsed * U * B,
                        'parallelism': f'env-shard x{world}'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
