@@ -1,0 +1,134 @@
+"""Batched, on-device versions of the reference's heuristic baselines.
+
+The reference's heuristics (deepcomp/agent/heuristics.py) are pure functions of one UE's ``obs['dr']`` (relative
+SNR per BS) and ``obs['connected']``; here the same decisions are taken for every (env, UE) at once on the packed
+observation tensor the env kernel writes, so a whole heuristic-driven rollout stays on the GPU:
+
+    act = agents.FullCoMP()(env.obs_views())          # uint8 [E, U], feed straight into env.step(act)
+
+Tie rules follow the reference: ``np.argmax`` / strict ``>`` scans pick the first (lowest-index) maximum,
+``sorted(..., reverse=True)`` is stable.
+"""
+import random
+
+import torch
+
+
+def _first_max(values, mask=None):
+    """Index of the first maximum along the last axis (restricted to mask); B where the mask is empty."""
+    B = values.shape[-1]
+    idx = torch.arange(B, device=values.device).expand_as(values)
+    if mask is not None:
+        values = torch.where(mask, values, torch.full_like(values, float('-inf')))
+    mx = values.max(dim=-1, keepdim=True).values
+    hit = values == mx
+    if mask is not None:
+        hit = hit & mask
+    return torch.where(hit, idx, torch.full_like(idx, B)).min(dim=-1).values
+
+
+def _first_true(mask):
+    B = mask.shape[-1]
+    idx = torch.arange(B, device=mask.device).expand_as(mask)
+    return torch.where(mask, idx, torch.full_like(idx, B)).min(dim=-1).values
+
+
+def _views(obs):
+    return obs['dr'], obs['connected'] > 0.5
+
+
+class Heuristic3GPP:
+    """heuristics.py:13-38: at most one connection, to the BS with the highest SNR."""
+
+    def __call__(self, obs):
+        dr, conn = _views(obs)
+        best = _first_max(dr)
+        at_best = torch.gather(conn, -1, best.unsqueeze(-1)).squeeze(-1)
+        first_conn = _first_true(conn)
+        B = dr.shape[-1]
+        act = torch.where(at_best, torch.zeros_like(best), torch.where(first_conn < B, first_conn + 1, best + 1))
+        return act.to(torch.uint8)
+
+
+class FullCoMP:
+    """heuristics.py:41-65: greedily connect to every BS, strongest first."""
+
+    def __call__(self, obs):
+        dr, conn = _views(obs)
+        B = dr.shape[-1]
+        best = _first_max(dr, ~conn)
+        return torch.where(best < B, best + 1, torch.zeros_like(best)).to(torch.uint8)
+
+
+class DynamicSelection:
+    """heuristics.py:68-106: strongest cell plus every cell within epsilon * strongest SNR."""
+
+    def __init__(self, epsilon):
+        self.epsilon = epsilon
+
+    def __call__(self, obs):
+        dr, conn = _views(obs)
+        B = dr.shape[-1]
+        selected = dr >= dr.max(dim=-1, keepdim=True).values * self.epsilon
+        drop = _first_true(conn & ~selected)                 # disconnect cells outside the set first (index order)
+        join = _first_max(dr, selected & ~conn)              # then connect inside the set, strongest first
+        act = torch.where(drop < B, drop + 1, torch.where(join < B, join + 1, torch.zeros_like(join)))
+        return act.to(torch.uint8)
+
+
+class StaticClustering:
+    """heuristics.py:109-187: static non-overlapping clusters of `cluster_size` closest cells."""
+
+    def __init__(self, cluster_size, bs_list, seed=None, device='cpu'):
+        self.cluster_size = cluster_size
+        self.bs_xy = [(float(bs.pos.x), float(bs.pos.y)) for bs in bs_list]
+        self.rng = random.Random()
+        self.rng.seed(seed)
+        self.cluster_of = self._build()
+        B = len(self.bs_xy)
+        member = torch.zeros((B, B), dtype=torch.bool)
+        for b, cl in self.cluster_of.items():
+            for o in cl:
+                member[b, o] = True
+        self.member = member.to(device)                       # member[b] = cluster mask of BS b
+
+    def _build(self):
+        """heuristics.py:128-165 (random seed cell, then repeatedly the cell closest to the cluster centre)."""
+        clusters, remaining, cur = {}, list(range(len(self.bs_xy))), []
+        while remaining:
+            if not cur:
+                b = self.rng.choice(remaining)
+            else:
+                cx = sum(self.bs_xy[i][0] for i in cur) / len(cur)
+                cy = sum(self.bs_xy[i][1] for i in cur) / len(cur)
+                b = min(remaining, key=lambda i: ((cx - self.bs_xy[i][0]) ** 2 + (cy - self.bs_xy[i][1]) ** 2) ** 0.5)
+            cur.append(b)
+            remaining.remove(b)
+            if len(cur) == self.cluster_size:
+                for i in cur:
+                    clusters[i] = list(cur)
+                cur = []
+        for i in cur:
+            clusters[i] = list(cur)
+        return clusters
+
+    def __call__(self, obs):
+        dr, conn = _views(obs)
+        B = dr.shape[-1]
+        cluster = self.member.to(dr.device)[_first_max(dr)]   # [..., B] mask of the strongest cell's cluster
+        drop = _first_true(conn & ~cluster)
+        join = _first_max(dr, cluster & ~conn)
+        act = torch.where(drop < B, drop + 1, torch.where(join < B, join + 1, torch.zeros_like(join)))
+        return act.to(torch.uint8)
+
+
+class RandomAgent:
+    """agent/dummy.py: uniform random action in [0, B] per UE (device generator)."""
+
+    def __init__(self, num_bs, seed=0, device='cpu'):
+        self.num_bs = num_bs
+        self.gen = torch.Generator(device=device).manual_seed(seed)
+
+    def __call__(self, obs):
+        dr = obs['dr']
+        return torch.randint(0, self.num_bs + 1, dr.shape[:-1], generator=self.gen, device=dr.device, dtype=torch.uint8)

@@ -325,6 +325,30 @@ def gen_estack():
                        'central', 42 + 20000 * e, 40, tape_mode='sticky')
 
 
+def gen_heuristics():
+    """G7: decisions of the reference's heuristic agents (agent/heuristics.py) on recorded observations."""
+    from deepcomp.agent.heuristics import DynamicSelection, FullCoMP, Heuristic3GPP, StaticClustering
+    src = np.load(os.path.join(HERE, 'traj_grid32x10_multi_s42.npz'))
+    dr, conn = src['step_obs_dr'], src['step_obs_connected']
+    T, U, B = dr.shape
+    scn = scenarios.grid_map(10, 'mixed')
+    _, bs_list, _ = build_ref(scn, [])
+    agents = {'3gpp': Heuristic3GPP(), 'fullcomp': FullCoMP(), 'dynamic05': DynamicSelection(0.5),
+              'dynamic09': DynamicSelection(0.9), 'static3': StaticClustering(3, bs_list, seed=1)}
+    out = {'obs_dr': dr, 'obs_connected': conn}
+    for name, ag in agents.items():
+        acts = np.zeros((T, U), dtype=np.int32)
+        for t in range(T):
+            for u in range(U):
+                obs = {'dr': [float(x) for x in dr[t, u]], 'connected': [int(x) for x in conn[t, u]]}
+                acts[t, u] = ag.compute_action(obs, None)
+        out['act_' + name] = acts
+    st = agents['static3']
+    out['static3_member'] = np.array([[int(o in st.clusters[b]) for o in bs_list] for b in bs_list], dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, 'heuristics.npz'), **out)
+    print('heuristics: ok')
+
+
 if __name__ == '__main__':
     gen_channel()
     gen_sharing()
@@ -332,3 +356,4 @@ if __name__ == '__main__':
     gen_movement()
     gen_trajectories()
     gen_estack()
+    gen_heuristics()

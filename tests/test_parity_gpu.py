@@ -229,6 +229,38 @@ def test_oracle_parity_philox(torch_cuda, shape):
     core.check()
 
 
+@pytest.mark.parametrize('agent_name', ['fullcomp', '3gpp', 'dynamic', 'static'])
+def test_heuristic_driven_rollout_matches_oracle(torch_cuda, agent_name):
+    """Policy in the loop, everything on the device: a reference heuristic (deepcomp_amd/agents.py) reads the
+    kernel's observation tensor and its actions drive the next step; the oracle is stepped with the same
+    actions.  Sticky policies build up many simultaneous connections per BS (unlike random actions)."""
+    torch = torch_cuda
+    from deepcomp_amd import agents, scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    E, U, B = 256, 32, 10
+    scn = scenarios.grid_map(B, 'mixed').with_ues(num_static=4, num_slow=20, num_fast=8)
+    m, bs, ues = build_from_scenario(scn)
+    core = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=E, seed=77, rng='philox')
+    ob = _oracle_batch(scn, 'multi', 'avg', E, 77)
+    agent = {'fullcomp': agents.FullCoMP(), '3gpp': agents.Heuristic3GPP(), 'dynamic': agents.DynamicSelection(0.3),
+             'static': agents.StaticClustering(3, bs, seed=5, device='cuda')}[agent_name]
+    core.reset()
+    ob.reset()
+    total_conn = 0
+    for t in range(50):
+        act = agent(core.obs_views()).contiguous()
+        core.step(act)
+        o_obs, o_rew, o_conn, o_pos = ob.step(act.cpu().numpy())
+        st = core.state_host()
+        assert np.array_equal(st['conn'], o_conn) and np.array_equal(st['pos'], o_pos)
+        np.testing.assert_allclose(core.obs.cpu().numpy(), o_obs, rtol=RTOL_RATE, atol=ATOL_OBS)
+        np.testing.assert_allclose(core.reward.cpu().numpy(), o_rew, atol=ATOL_UTIL, rtol=0)
+        total_conn += int(np.unpackbits(o_conn.view(np.uint8)).sum())
+    core.check()
+    assert total_conn > E * U * 10          # the policy really holds connections
+
+
 # ------------------------------------------------------------------------------------ full-size properties
 def test_full_size_properties(torch_cuda):
     """BASELINE config 3 (65 536 envs x 32 UE x 10 BS, multi-agent): size-independent invariants."""
