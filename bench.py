@@ -89,6 +89,8 @@ def main():
     ap.add_argument('--eps-length', type=int, default=100)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--rollout', type=int, default=0, help='issue steps in chunks of T through dcomp_rollout (one host call per chunk)')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1 ('nccl' = RCCL; 'gloo' for single-GPU dry runs)")
+    ap.add_argument('--same-device', action='store_true', help='dry run: every rank uses cuda:0')
     ap.add_argument('--no-check', action='store_true', help='skip the device error-flag check (ablation builds)')
     ap.add_argument('--traffic-bytes', type=float, default=None, help='HBM bytes per launch from a rocprofv3 --pmc pass')
     args = ap.parse_args()
@@ -102,10 +104,15 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.same_device:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
@@ -157,7 +164,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     if not args.no_check:
