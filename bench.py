@@ -91,6 +91,7 @@ def main():
     ap.add_argument('--rollout', type=int, default=0, help='issue steps in chunks of T through dcomp_rollout (one host call per chunk)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1 ('nccl' = RCCL; 'gloo' for single-GPU dry runs)")
     ap.add_argument('--same-device', action='store_true', help='dry run: every rank uses cuda:0')
+    ap.add_argument('--no-gather', action='store_true', help='N>1: skip the per-episode all-gather of the rollout summary')
     ap.add_argument('--no-check', action='store_true', help='skip the device error-flag check (ablation builds)')
     ap.add_argument('--traffic-bytes', type=float, default=None, help='HBM bytes per launch from a rocprofv3 --pmc pass')
     args = ap.parse_args()
@@ -131,6 +132,27 @@ def main():
         assert L % T == 0 and K % T == 0 and W % T == 0, "--rollout T must divide the episode length, steps and warmup"
         tape = torch.randint(0, B + 1, (4, T, E, U), generator=g, device=dev, dtype=torch.uint8)
 
+    # N>1: the learner hand-off.  Each GPU keeps its observations (data-parallel learner); what every rank
+    # needs from the others is the per-env episode summary (return + utility): ONE RCCL all-gather per episode, issued
+    # asynchronously on a side stream.  (All-gathering the observations themselves would be 8 x 344 MB per step.)
+    gather = None
+    ep_return = torch.zeros(E, dtype=torch.float32, device=dev)
+    pending = []
+    if world > 1 and not args.no_gather:
+        from deepcomp_amd.sharded import RolloutGather
+        gather = RolloutGather(use_side_stream=(args.backend == 'nccl'))
+
+    def end_of_episode():
+        if gather is None:
+            return
+        frag = {'episode_return': ep_return.clone(), 'sum_utility': env.sum_utility.clone()}
+        if args.backend != 'nccl':
+            frag = {k: v.cpu() for k, v in frag.items()}
+        pending.append(gather.all_gather_async(frag))
+        ep_return.zero_()
+        if len(pending) > 2:
+            pending.pop(0).wait()
+
     def run(nsteps, t_start, events=None):
         t = t_start
         if T and events is None:
@@ -149,6 +171,10 @@ def main():
             if events is not None:
                 events[i][1].record()
             t += 1
+            if gather is not None:
+                ep_return.add_(env.reward.sum(dim=-1) if env.reward.dim() > 1 else env.reward)
+                if t % L == 0:
+                    end_of_episode()
         return t
 
     def fence():
@@ -161,6 +187,9 @@ def main():
     fence()
     t0 = time.perf_counter()
     t_env = run(K, t_env)
+    for h in pending:
+        h.wait()
+    pending.clear()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -188,7 +217,9 @@ def main():
             'config': {'workload': f'{E} envs/GPU x {U} UE x {B} BS, {args.kind}-agent obs, sharing={args.sharing}, '
                                    f'log utility, reward avg, episode {L} (reset inside timed region), random actions' + (f', rollout chunks of {T}' if T else ''),
                        'envs_per_gpu': E, 'num_ue': U, 'num_bs': B, 'pair_steps_per_s': world * E * K / elapsed * U * B,
-                       'parallelism': f'env-shard x{world}'},
+                       'parallelism': f'env-shard x{world}',
+                       'collective': (f'all-gather of per-env episode summary ({2 * 4 * E * world / 1e6:.1f} MB) every {L} steps, async'
+                                      if gather is not None else 'none on the data path')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,
                          'traffic': args.traffic_bytes, 'kernel': 'dcomp::step_kernel', 'kernel_ms': kern_ms,
