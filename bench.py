@@ -133,10 +133,9 @@ def main():
         tape = torch.randint(0, B + 1, (4, T, E, U), generator=g, device=dev, dtype=torch.uint8)
 
     # N>1: the learner hand-off.  Each GPU keeps its observations (data-parallel learner); what every rank
-    # needs from the others is the per-env episode summary (return + utility): ONE RCCL all-gather per episode, issued
+    # needs from the others is the per-env end-of-episode summary (rewards + utility): ONE RCCL all-gather per episode, issued
     # asynchronously on a side stream.  (All-gathering the observations themselves would be 8 x 344 MB per step.)
     gather = None
-    ep_return = torch.zeros(E, dtype=torch.float32, device=dev)
     pending = []
     if world > 1 and not args.no_gather:
         from deepcomp_amd.sharded import RolloutGather
@@ -145,11 +144,10 @@ def main():
     def end_of_episode():
         if gather is None:
             return
-        frag = {'episode_return': ep_return.clone(), 'sum_utility': env.sum_utility.clone()}
+        frag = {'reward': env.reward.clone(), 'sum_utility': env.sum_utility.clone()}    # end-of-episode state of every env
         if args.backend != 'nccl':
             frag = {k: v.cpu() for k, v in frag.items()}
         pending.append(gather.all_gather_async(frag))
-        ep_return.zero_()
         if len(pending) > 2:
             pending.pop(0).wait()
 
@@ -171,10 +169,8 @@ def main():
             if events is not None:
                 events[i][1].record()
             t += 1
-            if gather is not None:
-                ep_return.add_(env.reward.sum(dim=-1) if env.reward.dim() > 1 else env.reward)
-                if t % L == 0:
-                    end_of_episode()
+            if gather is not None and t % L == 0:
+                end_of_episode()
         return t
 
     def fence():
@@ -218,7 +214,7 @@ def main():
                                    f'log utility, reward avg, episode {L} (reset inside timed region), random actions' + (f', rollout chunks of {T}' if T else ''),
                        'envs_per_gpu': E, 'num_ue': U, 'num_bs': B, 'pair_steps_per_s': world * E * K / elapsed * U * B,
                        'parallelism': f'env-shard x{world}',
-                       'collective': (f'all-gather of per-env episode summary ({2 * 4 * E * world / 1e6:.1f} MB) every {L} steps, async'
+                       'collective': (f'all-gather of end-of-episode rewards + sum_utility ({4 * E * (env.reward.numel() // E + 1) * world / 1e6:.1f} MB) every {L} steps, async'
                                       if gather is not None else 'none on the data path')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,
