@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -23,7 +24,7 @@ static KernelPair lookup_kernels(int B, int upad, int mp)
 #define DCOMP_CASE(n) case n: return kernels_b##n(upad, mp);
         DCOMP_B_LIST(DCOMP_CASE)
 #undef DCOMP_CASE
-    default: return KernelPair{nullptr, nullptr};
+    default: return KernelPair{nullptr, nullptr, nullptr};
     }
 }
 }  // namespace dcomp
@@ -171,6 +172,7 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
     if (e == hipSuccess) e = hipMemcpy(env->d_ue_cfg, uc.data(), sizeof(UeCfg) * U, hipMemcpyHostToDevice);
     if (e != hipSuccess) { delete env; return fail(DCOMP_EHIP, "device setup failed: %s", hipGetErrorString(e)); }
     kp.ue_cfg = env->d_ue_cfg;
+    if (env->kern.step_wide && !kp.any_maxcap && !getenv("DCOMP_NO_WIDE")) env->kern.step = env->kern.step_wide;
     *out = env;
     return DCOMP_OK;
 }

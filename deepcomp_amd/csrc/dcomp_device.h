@@ -744,15 +744,28 @@ __global__ __launch_bounds__(256) void reset_kernel(const KParams p)
     write_outputs<B, UPAD, true>(p, sh, active, env, env_local, u, idx, wave, lane, gbase, 0u, in_range, l2, cnt, util, 0.f, 0.f);
 }
 
+}  // namespace dcomp
+#include "dcomp_wide.h"
+namespace dcomp {
+
 using KernelFn = void (*)(const KParams);
-struct KernelPair { KernelFn step, reset; };
+// step_wide: organisation for envs of >= 64 lanes (dcomp_wide.h); nullptr for narrower envs.  It has no max-cap
+// path, the host falls back to `step` when a BS is max-cap.
+struct KernelPair { KernelFn step, reset, step_wide; };
+
+template <int B, int UPAD, int MP>
+inline KernelFn wide_or_null()
+{
+    if constexpr (UPAD >= 64) return step_kernel_wide<B, UPAD, MP>;
+    else return nullptr;
+}
 
 template <int B, int UPAD>
 inline KernelPair make_pair_(int mp)
 {
-    if (mp == MP_RES_FAIR) return KernelPair{step_kernel<B, UPAD, MP_RES_FAIR>, reset_kernel<B, UPAD>};
-    if (mp == MP_MIXED) return KernelPair{step_kernel<B, UPAD, MP_MIXED>, reset_kernel<B, UPAD>};
-    return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>};
+    if (mp == MP_RES_FAIR) return KernelPair{step_kernel<B, UPAD, MP_RES_FAIR>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_RES_FAIR>()};
+    if (mp == MP_MIXED) return KernelPair{step_kernel<B, UPAD, MP_MIXED>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_MIXED>()};
+    return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_GENERIC>()};
 }
 
 // One translation unit per B instantiates all UPAD widths (dcomp_inst_bXX.hip).
@@ -767,7 +780,7 @@ inline KernelPair kernels_for_upad(int upad, int mp)
     case 64: return make_pair_<B, 64>(mp);
     case 128: return make_pair_<B, 128>(mp);
     case 256: return make_pair_<B, 256>(mp);
-    default: return KernelPair{nullptr, nullptr};
+    default: return KernelPair{nullptr, nullptr, nullptr};
     }
 }
 
