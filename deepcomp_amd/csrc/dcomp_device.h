@@ -756,7 +756,9 @@ struct KernelPair { KernelFn step, reset, step_wide; };
 template <int B, int UPAD, int MP>
 inline KernelFn wide_or_null()
 {
-    if constexpr (UPAD >= 64) return step_kernel_wide<B, UPAD, MP>;
+    // measured on MI355X: the chunked organisation only pays once the unrolled per-BS register arrays of
+    // step_kernel no longer fit (B > 24); below that step_kernel is 1.0-1.7x faster
+    if constexpr (UPAD >= 64 && B > 24) return step_kernel_wide<B, UPAD, MP>;
     else return nullptr;
 }
 
