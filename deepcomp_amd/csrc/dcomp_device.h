@@ -336,11 +336,7 @@ struct StageGeo {
     static constexpr int ROW = 4 * B + 1;
     static constexpr int NPASS = (64 * ROW * 4 <= 6144) ? 1 : (32 * ROW * 4 <= 6144) ? 2 : (16 * ROW * 4 <= 6144) ? 4 : 8;
     static constexpr int RPP = 64 / NPASS;                  // rows per pass
-    // central layout (connected | dr | utility blocks per env): staged per wave when 64 UEs x (2B+1) floats fit
-    static constexpr bool CENTRAL = (64 * (2 * B + 1) * 4 <= 6144);
-    static constexpr int WORDS_MULTI = RPP * ROW + 4;       // + alignment phase
-    static constexpr int WORDS_CENTRAL = CENTRAL ? 64 * (2 * B + 1) + 4 : 0;
-    static constexpr int WORDS = WORDS_MULTI > WORDS_CENTRAL ? WORDS_MULTI : WORDS_CENTRAL;
+    static constexpr int WORDS = RPP * ROW + 4;             // + alignment phase
 };
 
 template <int B, int UPAD>
@@ -606,47 +602,15 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
             }
             wave_lds_fence();
         }
-    } else {
-        if (active && p.reward && u == 0) p.reward[env] = reward;
-        const int S = U * (2 * B + 1);                                     // floats per env (central.py:147-151)
-        if constexpr (UPAD <= 64 && SG::CENTRAL) {
-            // the envs of one wave are contiguous in memory: stage them and copy out linearly (coalesced 16-B stores)
-            constexpr int GPW = 64 / UPAD;
-            const int e_w = lane / UPAD;
-            const int env0 = env - e_w;                                    // first env of this wave (wave-uniform)
-            const int n_envs = min(GPW, max(0, p.E - env0));
-            float *st = sh.stage[wave];
-            const size_t g0 = (size_t)env0 * S;
-            const int ph = (int)((((size_t)p.obs >> 2) + g0) & 3);
-            if (active) {
-                float *eb = st + ph + e_w * S;
+    } else if (active) {
+        if (p.reward && u == 0) p.reward[env] = reward;
+        float *base = p.obs + (size_t)env * U * (2 * B + 1);
 #pragma unroll
-                for (int b = 0; b < B; b++) {
-                    eb[u * B + b] = (float)((conn >> b) & 1u);
-                    eb[U * B + u * B + b] = l2[b];
-                }
-                eb[2 * U * B + u] = util_n;
-            }
-            wave_lds_fence();
-            const int n_end = ph + n_envs * S;
-            float *gptr = p.obs + g0 - ph;
-            for (int j = lane * 4; j < n_end; j += 256) {
-                if (j >= ph && j + 4 <= n_end) {
-                    *reinterpret_cast<float4 *>(gptr + j) = *reinterpret_cast<const float4 *>(st + j);
-                } else {
-                    for (int k = max(j, ph); k < min(j + 4, n_end); k++) gptr[k] = st[k];
-                }
-            }
-            wave_lds_fence();
-        } else if (active) {
-            float *base = p.obs + (size_t)env * S;
-#pragma unroll
-            for (int b = 0; b < B; b++) {
-                base[u * B + b] = (float)((conn >> b) & 1u);
-                base[U * B + u * B + b] = l2[b];
-            }
-            base[2 * U * B + u] = util_n;
+        for (int b = 0; b < B; b++) {
+            base[u * B + b] = (float)((conn >> b) & 1u);
+            base[U * B + u * B + b] = l2[b];
         }
+        base[2 * U * B + u] = util_n;
     }
 }
 
