@@ -76,6 +76,34 @@ def cpu_baseline(scn, kind, U, B, budget_s=15.0):
             'sample': f'{E} envs x {steps} steps ({U} UE x {B} BS, {kind}), oracle/dcomp_oracle.c with OpenMP over envs, {dt:.1f} s'}
 
 
+def measure_small(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev, steps=2000):
+    """BASELINE config 2 (4 096 envs x 10 UE x 5 BS, central obs): launch-latency-bound; stepped through dcomp_rollout in
+    chunks of 50 (one host call per chunk).  Secondary figure, not the headline."""
+    E, U, B, L, T = 4096, 10, 5, 100, 50
+    scn = scenarios.grid_map(B, 'mixed').with_ues(num_slow=U)
+    m, bs, ues = build_from_scenario(scn)
+    env = BatchedMobileEnv(m, bs, ues, 'central', num_envs=E, seed=42, episode_length=L, rng='philox', rand_episodes=True, device=dev)
+    g = torch.Generator(device=dev).manual_seed(7)
+    tape = torch.randint(0, B + 1, (4, T, E, U), generator=g, device=dev, dtype=torch.uint8)
+
+    def run(n):
+        t = 0
+        for i in range(n // T):
+            if t % L == 0:
+                env.reset()
+            env.rollout(tape[i & 3])
+            t += T
+    run(200)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    env.check()
+    return {'value': E * steps / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps,
+            'bytes_per_env_step': bytes_per_env_step(U, B, 'central')}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -92,6 +120,7 @@ def main():
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1 ('nccl' = RCCL; 'gloo' for single-GPU dry runs)")
     ap.add_argument('--same-device', action='store_true', help='dry run: every rank uses cuda:0')
     ap.add_argument('--no-gather', action='store_true', help='N>1: skip the per-episode all-gather of the rollout summary')
+    ap.add_argument('--no-also', action='store_true', help='skip the secondary BASELINE config 2 measurement')
     ap.add_argument('--no-check', action='store_true', help='skip the device error-flag check (ablation builds)')
     ap.add_argument('--traffic-bytes', type=float, default=None, help='HBM bytes per launch from a rocprofv3 --pmc pass')
     args = ap.parse_args()
@@ -221,6 +250,14 @@ def main():
                          'traffic': args.traffic_bytes, 'kernel': 'dcomp::step_kernel', 'kernel_ms': kern_ms,
                          'bytes_per_env_step': bpe, 'survey_bytes_per_env_step': survey_bytes_per_env_step(U, B, args.kind)},
         }
+        default_workload = (E, U, B, args.kind, args.sharing) == (65536, 32, 10, 'multi', 'mixed')
+        if args.traffic_bytes is None and default_workload:
+            # PMC pass of this exact workload (profiles/r01c_final_step_kernel_summary.txt): FETCH_SIZE 33 945 KB x2 (gfx950
+            # wide-read correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE 426 245 KB, per launch
+            out['roofline']['traffic'] = (2 * 33945.36 + 426245.41) * 1024
+            out['roofline']['traffic_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01c_final_step_kernel_summary.txt'
+        if world == 1 and not args.no_also and default_workload:
+            out['also'] = {'config2_4096x10x5_central': measure_small(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(scn, args.kind, U, B)
         print(json.dumps(out), flush=True)

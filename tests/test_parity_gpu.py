@@ -313,6 +313,33 @@ def test_full_size_properties(torch_cuda):
     assert torch.allclose(full.sum_utility, full.ue_utility.sum(1), atol=1e-3)
 
 
+def test_full_size_oracle_parity(torch_cuda):
+    """BASELINE config 3 at full size (65 536 x 32 x 10, multi-agent, mixed sharing): 6 steps of the HIP path against
+    the CPU oracle on all 2 097 152 UEs -- masks and FP64 positions bit-exact, observation / reward within tolerance."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    E, U, B = 65536, 32, 10
+    scn = scenarios.grid_map(B, 'mixed').with_ues(num_slow=U)
+    m, bs, ues = build_from_scenario(scn)
+    core = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=E, seed=42, rng='philox')
+    ob = _oracle_batch(scn, 'multi', 'avg', E, 42)
+    rng = np.random.default_rng(11)
+    obs = core.reset()
+    np.testing.assert_allclose(obs.cpu().numpy(), ob.reset(), rtol=RTOL_RATE, atol=ATOL_OBS)
+    for t in range(6):
+        a = rng.integers(0, B + 1, size=(E, U)).astype(np.uint8)
+        core.step(torch.from_numpy(a).cuda())
+        o_obs, o_rew, o_conn, o_pos = ob.step(a)
+        st = core.state_host()
+        assert np.array_equal(st['conn'], o_conn), f'step {t}: connection masks differ'
+        assert np.array_equal(st['pos'], o_pos), f'step {t}: positions differ'
+        np.testing.assert_allclose(core.obs.cpu().numpy(), o_obs, rtol=RTOL_RATE, atol=ATOL_OBS)
+        np.testing.assert_allclose(core.reward.cpu().numpy(), o_rew, atol=ATOL_UTIL, rtol=0)
+    core.check()
+
+
 def test_bad_action_flag(torch_cuda):
     torch = torch_cuda
     from deepcomp_amd import scenarios
