@@ -55,13 +55,15 @@ def cpu_baseline(scn, kind, U, B, budget_s=15.0):
         return orc.OracleBatch(envs, num_threads=threads)
 
     rng = np.random.default_rng(7)
-    probe = make(threads * 2)
+    probe = make(threads * 8)
     probe.reset()
     a = rng.integers(0, B + 1, size=(probe.E, U)).astype(np.uint8)
-    t0 = time.perf_counter()
-    for _ in range(5):
+    probe.step(a)                                    # thread-pool start-up outside the probe
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 1.0:
         probe.step(a)
-    rate = probe.E * 5 / (time.perf_counter() - t0)
+        n += 1
+    rate = probe.E * n / (time.perf_counter() - t0)
     steps = 100
     E = int(max(threads, min(32768, rate * budget_s / steps)))
     E = (E // threads) * threads
