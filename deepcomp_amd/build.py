@@ -25,12 +25,12 @@ CXXFLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contra
 
 def b_list():
     txt = open(os.path.join(CSRC, 'dcomp_blist.h')).read()
-    line = re.search(r'#define DCOMP_B_LIST\(X\)(.*)', txt).group(1)
+    line = re.search(r'#define DCOMP_B_LIST\(X\)((?:.*\\\n)*.*)', txt).group(1)
     return [int(x) for x in re.findall(r'X\((\d+)\)', line)]
 
 
 def _sources():
-    return [os.path.join(CSRC, f) for f in ('dcomp_device.h', 'dcomp_blist.h', 'dcomp_inst.hip', 'dcomp_api.hip')] + \
+    return [os.path.join(CSRC, f) for f in ('dcomp_device.h', 'dcomp_wide.h', 'dcomp_blist.h', 'dcomp_inst.hip', 'dcomp_api.hip')] + \
         [os.path.join(os.path.dirname(HERE), 'include', 'dcomp.h')]
 
 
