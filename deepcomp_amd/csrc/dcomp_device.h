@@ -617,7 +617,7 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
                     *reinterpret_cast<float4 *>(gbase_ptr + j) = *reinterpret_cast<const float4 *>(st + j);
 #endif
                 } else {
-                    for (int k = max(j, ph); k < min(j + 4, n_end); k++) stream_store(&gbase_ptr[k], st[k]);
+                    for (int k = max(j, ph); k < min(j + 4, n_end); k++) gbase_ptr[k] = st[k];
                 }
             }
             wave_lds_fence();

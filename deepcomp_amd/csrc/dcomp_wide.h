@@ -307,9 +307,9 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
         if (active && u == 0) p.sum_util[env] = s[0];
     }
     if (active) {
-        if (p.ue_dr) stream_store(&p.ue_dr[idx], curr);
-        if (p.ue_util) stream_store(&p.ue_util[idx], util);
-        if (p.reward) { if (multi) stream_store(&p.reward[idx], reward); else if (u == 0) p.reward[env] = reward; }
+        if (p.ue_dr) p.ue_dr[idx] = curr;
+        if (p.ue_util) p.ue_util[idx] = util;
+        if (p.reward) { if (multi) p.reward[idx] = reward; else if (u == 0) p.reward[env] = reward; }
     }
     const float util_n = util * (1.0f / MAX_UTIL);
 
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
                 if (c < B) v = (float)((conn_r >> c) & 1u);
                 else if (c < 2 * B) v = st[r * (B + 1) + (c - B)];
                 else if (c == 4 * B) v = util_r;
-                stream_store(&orow[c], v);
+                orow[c] = v;                 // plain store: non-temporal 4-byte stores bypass L2 write-combining (measured slower)
             }
         }
     }
