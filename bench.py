@@ -254,10 +254,10 @@ def main():
         }
         default_workload = (E, U, B, args.kind, args.sharing) == (65536, 32, 10, 'multi', 'mixed')
         if args.traffic_bytes is None and default_workload:
-            # PMC pass of this exact workload (profiles/r01c_final_step_kernel_summary.txt): FETCH_SIZE 33 945 KB x2 (gfx950
-            # wide-read correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE 426 245 KB, per launch
-            out['roofline']['traffic'] = (2 * 33945.36 + 426245.41) * 1024
-            out['roofline']['traffic_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01c_final_step_kernel_summary.txt'
+            # PMC pass of this exact workload (profiles/r01d_nt_stores_step_kernel_summary.txt): FETCH_SIZE 33 941 KB x2 (gfx950
+            # wide-read correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE 426 261 KB, per launch
+            out['roofline']['traffic'] = (2 * 33940.93 + 426260.63) * 1024
+            out['roofline']['traffic_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01d_nt_stores_step_kernel_summary.txt'
         if world == 1 and not args.no_also and default_workload:
             out['also'] = {'config2_4096x10x5_central': measure_small(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev)}
         if world == 1 and not args.no_cpu_baseline:
