@@ -359,6 +359,59 @@ def test_bad_action_flag(torch_cuda):
     core.check()                                     # flag was cleared
 
 
+def test_tape_exhaustion_is_reported(torch_cuda):
+    """Reference-RNG mode with a deliberately short draw tape: the kernel flags it, check() raises (no silent reuse)."""
+    torch = torch_cuda
+    from deepcomp_amd import _lib, scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    scn = scenarios.small_map('mixed').with_ues(num_fast=6)
+    m, bs, ues = build_from_scenario(scn)
+    core = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=4, seed=1, rng='reference', tape_depth=1, episode_length=400)
+    core.reset()
+    a = torch.zeros((4, 6), dtype=torch.uint8, device='cuda')
+    for _ in range(200):
+        core.step(a)
+    with pytest.raises(_lib.DcompError, match='tape'):
+        core.check()
+
+
+def test_rollout_buffer_and_unaligned_outputs(torch_cuda):
+    """step_into() writes rows into arbitrary (4-byte aligned) slices of a rollout buffer: odd sizes exercise the
+    alignment phase of the LDS copy-out; rollout() == the same steps issued one by one."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    from deepcomp_amd.sharded import RolloutBuffer
+    scn = scenarios.medium_map('mixed').with_ues(num_slow=2, num_fast=1)        # U = 3, B = 3: 13-float rows
+    m, bs, ues = build_from_scenario(scn)
+    T, E = 7, 5
+    g = torch.Generator(device='cuda').manual_seed(5)
+    acts = torch.randint(0, 4, (T, E, 3), generator=g, device='cuda', dtype=torch.uint8)
+
+    ref = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=E, seed=9, rng='philox')
+    ref.reset()
+    want_obs, want_rew = [], []
+    for t in range(T):
+        o, r, _, _ = ref.step(acts[t])
+        want_obs.append(o.clone()); want_rew.append(r.clone())
+
+    env = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=E, seed=9, rng='philox')
+    env.reset()
+    buf = RolloutBuffer(env, T)
+    assert (buf.obs[1].data_ptr() - buf.obs[0].data_ptr()) % 16 != 0           # 5*3*13*4 B = 780 B: misaligned slices
+    it = iter(range(T))
+    frag = buf.collect(lambda obs: acts[next(it)])
+    env.check()
+    assert torch.equal(frag['obs'], torch.stack(want_obs)) and torch.equal(frag['reward'], torch.stack(want_rew))
+
+    env2 = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=E, seed=9, rng='philox')
+    env2.reset()
+    o, r = env2.rollout(acts)
+    assert torch.equal(o, want_obs[-1]) and torch.equal(r, want_rew[-1]) and env2.time == T
+
+
 def test_reference_surface_single_env(torch_cuda):
     """The drop-in classes (E = 1) return the reference's Python structures and match a golden trajectory."""
     from deepcomp_amd import scenarios
