@@ -22,6 +22,10 @@
 #endif
 // Write-once output streams (observation rows, rewards, info) use non-temporal stores: measured 0.1008 -> 0.0875 ms
 // per step at config 3 (they no longer compete with the read-modify-write state lines for L2).
+// Experiment switch (tools/ablate.py): read the BS table from an LDS copy instead of SGPRs (north_star wording).
+#ifndef DCOMP_BS_IN_LDS
+#define DCOMP_BS_IN_LDS 0
+#endif
 #ifndef DCOMP_NT_OBS
 #define DCOMP_NT_OBS 1
 #endif
@@ -185,6 +189,14 @@ __device__ __forceinline__ float pair_eval_tiny(double px, double py, double bx,
     return __builtin_fmaf(-2.0f * p.half_gamma, fast_log2(d), p.log2k);
 }
 // All B pairs of one UE; returns the in-range mask.
+#if DCOMP_BS_IN_LDS
+__shared__ double g_bs_lds[2 * DCOMP_MAX_BS];
+#define DCOMP_BSX(b) (*(volatile double *)&g_bs_lds[b])
+#define DCOMP_BSY(b) (*(volatile double *)&g_bs_lds[DCOMP_MAX_BS + (b)])
+#else
+#define DCOMP_BSX(b) p.bs_x[b]
+#define DCOMP_BSY(b) p.bs_y[b]
+#endif
 template <int B>
 __device__ __forceinline__ uint32_t eval_pairs(double px, double py, const KParams &p, float (&l2)[B])
 {
@@ -193,7 +205,7 @@ __device__ __forceinline__ uint32_t eval_pairs(double px, double py, const KPara
 #pragma unroll
     for (int b = 0; b < B; b++) {
         bool ir, tiny;
-        pair_eval(px, py, p.bs_x[b], p.bs_y[b], p, ir, l2[b], tiny);
+        pair_eval(px, py, DCOMP_BSX(b), DCOMP_BSY(b), p, ir, l2[b], tiny);
         in_range |= (uint32_t)ir << b;
         anytiny |= tiny;
     }
@@ -649,6 +661,11 @@ __global__ __launch_bounds__(256, (B <= 10 && UPAD <= 64) ? DCOMP_FORCE_WAVES : 
     const int idx = env * p.U + u;
     const int gbase = lane & ~(G::WG - 1);
 
+#if DCOMP_BS_IN_LDS
+#pragma unroll
+    for (int b = 0; b < B; b++) if (tid == b) { g_bs_lds[b] = p.bs_x[b]; g_bs_lds[DCOMP_MAX_BS + b] = p.bs_y[b]; }
+    __syncthreads();
+#endif
     double px = 0.0, py = 0.0;
     unsigned long long mv = 0;
     uint32_t conn = 0, act = 0;
