@@ -129,6 +129,9 @@ def main():
 
     import torch
     import torch.distributed as dist
+    from deepcomp_amd import build as hip_build
+    if not hip_build.up_to_date() and int(os.environ.get('RANK', '0')) == 0:
+        hip_build.build()                    # fresh checkout without binaries (they are git-ignored)
     from deepcomp_amd import scenarios
     from deepcomp_amd.entities import build_from_scenario
     from deepcomp_amd.env import BatchedMobileEnv
