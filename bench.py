@@ -130,8 +130,14 @@ def main():
     import torch
     import torch.distributed as dist
     from deepcomp_amd import build as hip_build
-    if not hip_build.up_to_date() and int(os.environ.get('RANK', '0')) == 0:
-        hip_build.build()                    # fresh checkout without binaries (they are git-ignored)
+    if not hip_build.up_to_date():           # fresh checkout without binaries (they are git-ignored)
+        if int(os.environ.get('RANK', '0')) == 0:
+            hip_build.build()
+        else:
+            for _ in range(600):
+                if hip_build.up_to_date():
+                    break
+                time.sleep(1.0)
     from deepcomp_amd import scenarios
     from deepcomp_amd.entities import build_from_scenario
     from deepcomp_amd.env import BatchedMobileEnv
