@@ -31,7 +31,16 @@
 #define BORDER_BUFFER 10
 
 struct orc_env {
-    int U, B, map_w, map_h, kind, reward_agg;
+    int U;                    /* capacity = max_ues (base.py:79-84); strides of the per-UE arrays */
+    int nU, U0;               /* UEs currently in ue_list / at reset (base.py:177-182) */
+    int B, map_w, map_h, kind, reward_agg;
+    int32_t *uid;             /* [U] int(ue.id) per slot (slot = position in ue_list) */
+    int ev_nrem, ev_nadd;     /* pending arrival / departure for the next step (base.py:433-443) */
+    int32_t ev_rem[64], ev_add_xy[128];
+    int ev_given;
+    int tape_ids;             /* draw tapes are keyed by uid-1; number of ids they cover */
+    uint32_t n_arrivals, n_removals;   /* per-episode counters (Philox draw words) */
+    int32_t *orig_consumed;   /* [U] movement triples an initial UE had consumed when it was removed (-1: still listed) */
     double *bs_x, *bs_y;
     int32_t *bs_sharing, *ue_util, *vel_lo, *vel_hi, *init_x, *init_y;
     double *ue_dr_req;
@@ -53,6 +62,19 @@ struct orc_env {
     uint64_t seed;
     int64_t global_env, episode;
 };
+
+/* per-UE config is keyed by the UE id; ids beyond the initial list are UEs that arrived during the episode:
+ * base.py:592-599 creates them with velocity 'slow', log utility, dr_req 1 and a fixed start position */
+#define UID_BORN 0x8000                 /* set in uid[]: the UE arrived during the episode (add_new_ue) */
+static int ue_born(const orc_env *e, int u) { return (e->uid[u] & UID_BORN) != 0; }
+static int ue_idnum(const orc_env *e, int u) { return e->uid[u] & 0x7FFF; }
+/* index into the draw tapes: initial UEs [0, U0) by list position, arrived UEs U0 + id - 1 (an id can be re-used,
+ * and a re-created UE is always 'slow' and re-seeded, whatever the initial UE with that id was) */
+static int cfg_id(const orc_env *e, int u) { return ue_born(e, u) ? e->U0 + ue_idnum(e, u) - 1 : ue_idnum(e, u) - 1; }
+static int ue_util_kind(const orc_env *e, int u) { return ue_born(e, u) ? ORC_UTIL_LOG : e->ue_util[ue_idnum(e, u) - 1]; }
+static double ue_req(const orc_env *e, int u) { return ue_born(e, u) ? 1.0 : e->ue_dr_req[ue_idnum(e, u) - 1]; }
+static int ue_vlo(const orc_env *e, int u) { return ue_born(e, u) ? 1 : e->vel_lo[ue_idnum(e, u) - 1]; }
+static int ue_vhi(const orc_env *e, int u) { return ue_born(e, u) ? 3 : e->vel_hi[ue_idnum(e, u) - 1]; }
 
 /* ------------------------------------------------------------------ channel: station.py:110-138,222-226 */
 static double path_loss(double distance)
@@ -106,7 +128,7 @@ static double ue_curr_dr(const orc_env *e, int u)
 static double ue_utility(const orc_env *e, int u)
 {   /* user.py:76-92 */
     double dr = ue_curr_dr(e, u);
-    return e->ue_util[u] == ORC_UTIL_STEP ? orc_step_utility(dr, e->ue_dr_req[u]) : orc_log_utility(dr);
+    return ue_util_kind(e, u) == ORC_UTIL_STEP ? orc_step_utility(dr, ue_req(e, u)) : orc_log_utility(dr);
 }
 
 /* ------------------------------------------------------------------ sharing: station.py:140-220 */
@@ -201,16 +223,16 @@ static void philox_draw(const orc_env *e, int u, uint32_t draw, uint32_t r[4])
 {
     /* counter = (global env id, ue, episode, draw#); key = 64-bit seed.  draw 0 = start position,
      * draw k>=1 = k-th movement triple of the episode. */
-    uint32_t ctr[4] = {(uint32_t)e->global_env, (uint32_t)u, (uint32_t)e->episode, draw};
+    uint32_t ctr[4] = {(uint32_t)e->global_env, (uint32_t)((ue_idnum(e, u) - 1) | (ue_born(e, u) ? UID_BORN : 0)), (uint32_t)e->episode, draw};
     uint32_t key[2] = {(uint32_t)e->seed, (uint32_t)(e->seed >> 32)};
     orc_philox4x32_10(ctr, key, r);
 }
 static void draw_start_pos(orc_env *e, int u)
 {   /* user.py:98-109: randint(0, W), randint(0, H) unless a fixed coordinate was given */
     int x, y;
-    if (e->rng_mode == ORC_RNG_TAPE) { x = e->tape_pos0[u * 2]; y = e->tape_pos0[u * 2 + 1]; }
+    if (e->rng_mode == ORC_RNG_TAPE) { x = e->tape_pos0[cfg_id(e, u) * 2]; y = e->tape_pos0[cfg_id(e, u) * 2 + 1]; }
     else { uint32_t r[4]; philox_draw(e, u, 0, r); x = (int)mulhi32(r[0], (uint32_t)e->map_w + 1); y = (int)mulhi32(r[1], (uint32_t)e->map_h + 1); }
-    e->px[u] = e->init_x[u] >= 0 ? e->init_x[u] : x;
+    e->px[u] = e->init_x[u] >= 0 ? e->init_x[u] : x;       /* reset only: slot == list position of an initial UE */
     e->py[u] = e->init_y[u] >= 0 ? e->init_y[u] : y;
 }
 static void movement_reset(orc_env *e, int u)
@@ -218,11 +240,11 @@ static void movement_reset(orc_env *e, int u)
     int k = e->cursor[u]++;
     if (e->rng_mode == ORC_RNG_TAPE) {
         if (k >= e->tape_depth) k = e->tape_depth - 1; /* caller checks orc_tape_cursor() against depth */
-        const int32_t *t = &e->tape_triples[(u * e->tape_depth + k) * 3];
+        const int32_t *t = &e->tape_triples[(cfg_id(e, u) * e->tape_depth + k) * 3];
         e->vel[u] = t[0]; e->wx[u] = t[1]; e->wy[u] = t[2];
     } else {
         uint32_t r[4]; philox_draw(e, u, (uint32_t)k + 1, r);
-        e->vel[u] = e->vel_lo[u] + (int)mulhi32(r[0], (uint32_t)(e->vel_hi[u] - e->vel_lo[u] + 1));
+        e->vel[u] = ue_vlo(e, u) + (int)mulhi32(r[0], (uint32_t)(ue_vhi(e, u) - ue_vlo(e, u) + 1));
         e->wx[u] = BORDER_BUFFER + (int)mulhi32(r[1], (uint32_t)(e->map_w - 2 * BORDER_BUFFER + 1));
         e->wy[u] = BORDER_BUFFER + (int)mulhi32(r[2], (uint32_t)(e->map_h - 2 * BORDER_BUFFER + 1));
     }
@@ -254,7 +276,7 @@ static void movement_step(orc_env *e, int u)
 /* ------------------------------------------------------------------ env: single_ue/base.py */
 static void update_ue_drs_rewards(orc_env *e, int update_only)
 {   /* base.py:315-335 -> user.py:143-146 ; calc_reward base.py:158-167 */
-    for (int u = 0; u < e->U; u++) {
+    for (int u = 0; u < e->nU; u++) {
         for (int k = 0; k < e->ue_nbs[u]; k++) e->ue_dr[u * e->B + k] = bs_data_rate(e, e->ue_bs[u * e->B + k], u);
         if (!update_only) {
             double cu = clipd(ue_utility(e, u), MIN_UTILITY, MAX_UTILITY);
@@ -264,7 +286,7 @@ static void update_ue_drs_rewards(orc_env *e, int update_only)
 }
 static void step_reward(orc_env *e)
 {
-    int U = e->U, B = e->B;
+    int U = e->nU, B = e->B, CAP = e->U;
     if (e->kind == ORC_CENTRAL) {   /* multi_ue/central.py:65-73 */
         double r;
         if (e->reward_agg == ORC_AVG) { double s = 0.0; for (int u = 0; u < U; u++) s += e->reward_before[u]; r = s / U; }
@@ -286,7 +308,7 @@ static void step_reward(orc_env *e)
                     double tot = 0.0;
                     for (int b = 0; b < B; b++) if (orc_can_connect(bs_dist(e, b, u))) {
                         double tb = 0.0;   /* station.py:63-69 */
-                        for (int k = 0; k < e->bs_nues[b]; k++) tb += ue_utility(e, e->bs_ues[b * U + k]);
+                        for (int k = 0; k < e->bs_nues[b]; k++) tb += ue_utility(e, e->bs_ues[b * CAP + k]);
                         tot += tb;
                     }
                     agg = e->ue_nbs[u] == 0 ? (tot + ue_utility(e, u)) / (nn + 1) : tot / nn;
@@ -304,7 +326,7 @@ static void step_reward(orc_env *e)
                 agg = ue_utility(e, u);
                 for (int b = 0; b < B; b++) if (orc_can_connect(bs_dist(e, b, u))) {
                     double mb = MAX_UTILITY;
-                    if (e->bs_nues[b] > 0) { mb = ue_utility(e, e->bs_ues[b * U]); for (int k = 1; k < e->bs_nues[b]; k++) { double v = ue_utility(e, e->bs_ues[b * U + k]); if (v < mb) mb = v; } }
+                    if (e->bs_nues[b] > 0) { mb = ue_utility(e, e->bs_ues[b * CAP]); for (int k = 1; k < e->bs_nues[b]; k++) { double v = ue_utility(e, e->bs_ues[b * CAP + k]); if (v < mb) mb = v; } }
                     if (mb < agg) agg = mb;
                 }
             }
@@ -313,10 +335,94 @@ static void step_reward(orc_env *e)
     }
 }
 
+/* base.py:608-618: ue_list.pop(idx) + disconnect_from_all; later list positions move up by one */
+static void remove_ue(orc_env *e, int idx)
+{
+    int B = e->B, CAP = e->U;
+    if (!ue_born(e, idx)) e->orig_consumed[ue_idnum(e, idx) - 1] = e->cursor[idx];
+    while (e->ue_nbs[idx] > 0) ue_disconnect(e, idx, e->ue_bs[idx * B]);
+    for (int u = idx; u + 1 < e->nU; u++) {
+        e->px[u] = e->px[u + 1]; e->py[u] = e->py[u + 1]; e->wx[u] = e->wx[u + 1]; e->wy[u] = e->wy[u + 1];
+        e->vel[u] = e->vel[u + 1]; e->ewma[u] = e->ewma[u + 1]; e->pausing[u] = e->pausing[u + 1];
+        e->curr_pause[u] = e->curr_pause[u + 1]; e->cursor[u] = e->cursor[u + 1]; e->uid[u] = e->uid[u + 1];
+        e->reward_before[u] = e->reward_before[u + 1];
+        e->ue_nbs[u] = e->ue_nbs[u + 1];
+        for (int k = 0; k < B; k++) { e->ue_bs[u * B + k] = e->ue_bs[(u + 1) * B + k]; e->ue_dr[u * B + k] = e->ue_dr[(u + 1) * B + k]; }
+    }
+    e->nU -= 1;
+    e->uid[e->nU] = 0; e->ue_nbs[e->nU] = 0;
+    for (int b = 0; b < B; b++) for (int k = 0; k < e->bs_nues[b]; k++) if (e->bs_ues[b * CAP + k] > idx) e->bs_ues[b * CAP + k] -= 1;
+}
+/* base.py:592-606: new UE at a border point, id = last id + 1, seeded env_seed + 100*id, velocity 'slow' */
+static void add_ue(orc_env *e, int x, int y)
+{
+    int u = e->nU;
+    e->uid[u] = ((e->uid[u - 1] & 0x7FFF) + 1) | UID_BORN;
+    e->nU += 1;
+    e->px[u] = x; e->py[u] = y;
+    e->cursor[u] = 0;
+    movement_reset(e, u);
+    e->ue_nbs[u] = 0; e->ewma[u] = 0.0; e->reward_before[u] = 0.0; e->reward[u] = 0.0;
+}
+static void apply_events(orc_env *e)
+{
+    int nrem = e->ev_nrem, nadd = e->ev_nadd;
+    for (int k = 0; k < nrem; k++) {
+        int idx;
+        if (e->ev_given) idx = e->ev_rem[k];
+        else {   /* Philox: random.randint(0, num_ue - 1) replaced by a keyed draw */
+            uint32_t ctr[4] = {(uint32_t)e->global_env, 0xFFFE0000u + e->n_removals, (uint32_t)e->episode, 0u}, r[4];
+            uint32_t key[2] = {(uint32_t)e->seed, (uint32_t)(e->seed >> 32)};
+            orc_philox4x32_10(ctr, key, r);
+            idx = (int)mulhi32(r[0], (uint32_t)e->nU);
+        }
+        e->n_removals++;
+        remove_ue(e, idx);
+    }
+    for (int k = 0; k < nadd; k++) {
+        int x, y;
+        if (e->ev_given) { x = e->ev_add_xy[2 * k]; y = e->ev_add_xy[2 * k + 1]; }
+        else {   /* Philox version of map.rand_border_point (map.py:52-65) */
+            uint32_t ctr[4] = {(uint32_t)e->global_env, 0xFFFF0000u + e->n_arrivals, (uint32_t)e->episode, 0u}, r[4];
+            uint32_t key[2] = {(uint32_t)e->seed, (uint32_t)(e->seed >> 32)};
+            orc_philox4x32_10(ctr, key, r);
+            int rx = (int)mulhi32(r[0], (uint32_t)e->map_w + 1), ry = (int)mulhi32(r[1], (uint32_t)e->map_h + 1);
+            int border = (int)mulhi32(r[2], 4u);    /* left, right, top, bottom */
+            x = border == 0 ? 0 : border == 1 ? e->map_w - 1 : rx;
+            y = border == 2 ? e->map_h - 1 : border == 3 ? 0 : ry;
+            if (border <= 1) y = ry;
+        }
+        e->n_arrivals++;
+        add_ue(e, x, y);
+    }
+    e->ev_nrem = e->ev_nadd = e->ev_given = 0;
+}
+void orc_set_events(orc_env *e, int n_remove, const int32_t *remove_idx, int n_add, const int32_t *add_xy)
+{
+    e->ev_nrem = n_remove; e->ev_nadd = n_add;
+    e->ev_given = (remove_idx != NULL) || (add_xy != NULL);
+    for (int k = 0; k < n_remove && remove_idx; k++) e->ev_rem[k] = remove_idx[k];
+    for (int k = 0; k < 2 * n_add && add_xy; k++) e->ev_add_xy[k] = add_xy[k];
+}
+void orc_set_initial_ues(orc_env *e, int num_initial) { e->U0 = num_initial; }
+int orc_num_ue(const orc_env *e) { return e->nU; }
+/* per initial UE: movement triples consumed this episode (at removal, or so far if still listed) */
+void orc_get_orig_consumed(const orc_env *e, int32_t *out)
+{
+    for (int i = 0; i < e->U0; i++) out[i] = e->orig_consumed[i];
+    for (int u = 0; u < e->nU; u++) if (!ue_born(e, u)) out[ue_idnum(e, u) - 1] = e->cursor[u];
+}
+int orc_slot_born(const orc_env *e, int slot) { return slot < e->nU ? ue_born(e, slot) : 0; }
+void orc_get_uids(const orc_env *e, int32_t *uids) { for (int u = 0; u < e->U; u++) uids[u] = e->uid[u] & 0x7FFF; }
+
 void orc_reset(orc_env *e)
 {   /* base.py:169-189 -> user.py:111-116, station.py:106-108 (seeding is the caller's tape / the philox key) */
     e->time = 0;
-    for (int u = 0; u < e->U; u++) {
+    e->nU = e->U0;                                  /* base.py:177-182: restore the original ue_list */
+    e->n_arrivals = e->n_removals = 0;
+    e->ev_nrem = e->ev_nadd = e->ev_given = 0;
+    for (int u = 0; u < e->U; u++) { e->uid[u] = u < e->U0 ? u + 1 : 0; e->ue_nbs[u] = 0; e->orig_consumed[u] = -1; }
+    for (int u = 0; u < e->nU; u++) {
         e->cursor[u] = 0;
         draw_start_pos(e, u);
         movement_reset(e, u);
@@ -330,10 +436,11 @@ void orc_reset(orc_env *e)
 
 int orc_step(orc_env *e, const int32_t *action)
 {   /* base.py:413-466 */
-    for (int u = 0; u < e->U; u++) if (action[u] < 0 || action[u] > e->B) return -1;   /* central.py:61 */
-    for (int u = 0; u < e->U; u++) if (action[u] > 0) ue_connect_toggle(e, u, action[u] - 1);   /* base.py:247-263 */
+    for (int u = 0; u < e->nU; u++) if (action[u] < 0 || action[u] > e->B) return -1;   /* central.py:61 */
+    for (int u = 0; u < e->nU; u++) if (action[u] > 0) ue_connect_toggle(e, u, action[u] - 1);   /* base.py:247-263 */
+    apply_events(e);                                                                      /* base.py:433-443 */
     update_ue_drs_rewards(e, 0);                                                          /* base.py:446 */
-    for (int u = 0; u < e->U; u++) {                                                      /* base.py:447 -> user.py:159-173 */
+    for (int u = 0; u < e->nU; u++) {                                                     /* base.py:447 -> user.py:159-173 */
         movement_step(e, u);
         ue_check_bs_connection(e, u);
         e->ewma[u] = 0.9 * ue_curr_dr(e, u) + (1 - 0.9) * e->ewma[u];                     /* user.py:148-157 (stale rates) */
@@ -348,7 +455,7 @@ int orc_step(orc_env *e, const int32_t *action)
 double orc_sum_utility(const orc_env *e)
 {   /* base.py:105-107 */
     double s = 0.0;
-    for (int u = 0; u < e->U; u++) s += ue_utility(e, u);
+    for (int u = 0; u < e->nU; u++) s += ue_utility(e, u);
     return s;
 }
 int orc_time(const orc_env *e) { return e->time; }
@@ -357,7 +464,11 @@ void orc_set_episode(orc_env *e, int64_t episode) { e->episode = episode; }
 
 void orc_get_obs(const orc_env *e, double *connected, double *dr, double *utility, double *ues_at_bs, double *util_at_bs)
 {   /* single_ue/variants.py:271-305 per UE; central.py:31-57 / multi_agent.py:32-37 only re-arrange */
-    int U = e->U, B = e->B;
+    int U = e->nU, B = e->B, CAP = e->U;
+    for (int u = U; u < CAP; u++) {          /* slots without a UE: zero padding (central.py:46-55) */
+        for (int b = 0; b < B; b++) { connected[u * B + b] = 0.0; dr[u * B + b] = 0.0; if (ues_at_bs) ues_at_bs[u * B + b] = 0.0; if (util_at_bs) util_at_bs[u * B + b] = 0.0; }
+        utility[u] = 0.0;
+    }
     for (int u = 0; u < U; u++) {
         double mx = 0.0;
         for (int b = 0; b < B; b++) {
@@ -371,7 +482,7 @@ void orc_get_obs(const orc_env *e, double *connected, double *dr, double *utilit
         if (ues_at_bs) for (int b = 0; b < B; b++) ues_at_bs[u * B + b] = (double)e->bs_nues[b] / U;
         if (util_at_bs) for (int b = 0; b < B; b++) {
             double avg = 0.0;   /* station.py:71-76 */
-            if (e->bs_nues[b] > 0) { double s = 0.0; for (int k = 0; k < e->bs_nues[b]; k++) s += ue_utility(e, e->bs_ues[b * U + k]); avg = s / e->bs_nues[b]; }
+            if (e->bs_nues[b] > 0) { double s = 0.0; for (int k = 0; k < e->bs_nues[b]; k++) s += ue_utility(e, e->bs_ues[b * CAP + k]); avg = s / e->bs_nues[b]; }
             util_at_bs[u * B + b] = avg / MAX_UTILITY;
         }
     }
@@ -379,23 +490,24 @@ void orc_get_obs(const orc_env *e, double *connected, double *dr, double *utilit
 void orc_get_reward(const orc_env *e, double *reward)
 {
     int n = e->kind == ORC_CENTRAL ? 1 : e->U;
-    for (int i = 0; i < n; i++) reward[i] = e->reward[i];
+    for (int i = 0; i < n; i++) reward[i] = (e->kind == ORC_CENTRAL || i < e->nU) ? e->reward[i] : 0.0;
 }
 void orc_get_state(const orc_env *e, double *pos, double *wp, double *vel, int32_t *pausing, int32_t *curr_pause,
                    uint8_t *conn, double *dr, double *curr_dr, double *ewma, double *utility, int32_t *conn_order)
 {
     int U = e->U, B = e->B;
     for (int u = 0; u < U; u++) {
-        if (pos) { pos[2 * u] = e->px[u]; pos[2 * u + 1] = e->py[u]; }
-        if (wp) { wp[2 * u] = e->wx[u]; wp[2 * u + 1] = e->wy[u]; }
-        if (vel) vel[u] = e->vel[u];
-        if (pausing) pausing[u] = e->pausing[u];
-        if (curr_pause) curr_pause[u] = e->curr_pause[u];
-        if (curr_dr) curr_dr[u] = ue_curr_dr(e, u);
-        if (ewma) ewma[u] = e->ewma[u];
-        if (utility) utility[u] = ue_utility(e, u);
+        const int live = u < e->nU;
+        if (pos) { pos[2 * u] = live ? e->px[u] : 0.0; pos[2 * u + 1] = live ? e->py[u] : 0.0; }
+        if (wp) { wp[2 * u] = live ? e->wx[u] : 0.0; wp[2 * u + 1] = live ? e->wy[u] : 0.0; }
+        if (vel) vel[u] = live ? e->vel[u] : 0.0;
+        if (pausing) pausing[u] = live ? e->pausing[u] : 0;
+        if (curr_pause) curr_pause[u] = live ? e->curr_pause[u] : 0;
+        if (curr_dr) curr_dr[u] = live ? ue_curr_dr(e, u) : 0.0;
+        if (ewma) ewma[u] = live ? e->ewma[u] : 0.0;
+        if (utility) utility[u] = live ? ue_utility(e, u) : 0.0;
         for (int b = 0; b < B; b++) {
-            int k = ue_find_bs(e, u, b);
+            int k = live ? ue_find_bs(e, u, b) : -1;
             if (conn) conn[u * B + b] = k >= 0;
             if (dr) dr[u * B + b] = k >= 0 ? e->ue_dr[u * B + k] : 0.0;
         }
@@ -427,6 +539,10 @@ orc_env *orc_create(int U, int B, int map_w, int map_h, int kind, int reward_agg
     e->cursor = dup_mem(NULL, sizeof(int32_t) * U); e->ue_nbs = dup_mem(NULL, sizeof(int32_t) * U);
     e->ue_bs = dup_mem(NULL, sizeof(int32_t) * U * B); e->ue_dr = dup_mem(NULL, sizeof(double) * U * B);
     e->bs_ues = dup_mem(NULL, sizeof(int32_t) * U * B); e->bs_nues = dup_mem(NULL, sizeof(int32_t) * B);
+    e->uid = dup_mem(NULL, sizeof(int32_t) * U);
+    e->orig_consumed = dup_mem(NULL, sizeof(int32_t) * U);
+    e->U0 = e->nU = U; e->tape_ids = U;
+    for (int u = 0; u < U; u++) e->uid[u] = u + 1;
     e->rng_mode = ORC_RNG_PHILOX; e->seed = 42;
     return e;
 }
@@ -436,15 +552,19 @@ void orc_destroy(orc_env *e)
     free(e->bs_x); free(e->bs_y); free(e->bs_sharing); free(e->ue_util); free(e->ue_dr_req); free(e->vel_lo); free(e->vel_hi);
     free(e->init_x); free(e->init_y); free(e->px); free(e->py); free(e->wx); free(e->wy); free(e->vel); free(e->ewma);
     free(e->reward_before); free(e->reward); free(e->pausing); free(e->curr_pause); free(e->cursor); free(e->ue_nbs);
-    free(e->ue_bs); free(e->ue_dr); free(e->bs_ues); free(e->bs_nues); free(e->tape_pos0); free(e->tape_triples);
+    free(e->ue_bs); free(e->ue_dr); free(e->bs_ues); free(e->bs_nues); free(e->tape_pos0); free(e->tape_triples); free(e->uid); free(e->orig_consumed);
     free(e);
+}
+void orc_set_tape_ids(orc_env *e, int depth, int num_ids, const int32_t *pos0, const int32_t *triples)
+{   /* tapes are keyed by UE id - 1 (ids beyond the initial list: UEs that arrive during the episode) */
+    free(e->tape_pos0); free(e->tape_triples);
+    e->rng_mode = ORC_RNG_TAPE; e->tape_depth = depth; e->tape_ids = num_ids;
+    e->tape_pos0 = dup_mem(pos0, sizeof(int32_t) * num_ids * 2);
+    e->tape_triples = dup_mem(triples, sizeof(int32_t) * num_ids * depth * 3);
 }
 void orc_set_tape(orc_env *e, int depth, const int32_t *pos0, const int32_t *triples)
 {
-    free(e->tape_pos0); free(e->tape_triples);
-    e->rng_mode = ORC_RNG_TAPE; e->tape_depth = depth;
-    e->tape_pos0 = dup_mem(pos0, sizeof(int32_t) * e->U * 2);
-    e->tape_triples = dup_mem(triples, sizeof(int32_t) * e->U * depth * 3);
+    orc_set_tape_ids(e, depth, e->U, pos0, triples);
 }
 void orc_set_philox(orc_env *e, uint64_t seed, int64_t global_env_id)
 {
@@ -499,8 +619,8 @@ void orc_batch_step(orc_env **envs, int E, const uint8_t *action, float *obs, fl
         orc_step(e, act);
         int stride = e->kind == ORC_MULTI ? 4 * B + 1 : 2 * B + 1;
         if (obs) pack_obs(e, obs + (size_t)i * U * stride);
-        if (reward) { if (e->kind == ORC_MULTI) for (int u = 0; u < U; u++) reward[(size_t)i * U + u] = (float)e->reward[u]; else reward[i] = (float)e->reward[0]; }
-        if (conn_bits) for (int u = 0; u < U; u++) { uint32_t m = 0; for (int k = 0; k < e->ue_nbs[u]; k++) m |= 1u << e->ue_bs[u * B + k]; conn_bits[(size_t)i * U + u] = m; }
-        if (pos) for (int u = 0; u < U; u++) { pos[((size_t)i * U + u) * 2] = e->px[u]; pos[((size_t)i * U + u) * 2 + 1] = e->py[u]; }
+        if (reward) { if (e->kind == ORC_MULTI) for (int u = 0; u < U; u++) reward[(size_t)i * U + u] = u < e->nU ? (float)e->reward[u] : 0.f; else reward[i] = (float)e->reward[0]; }
+        if (conn_bits) for (int u = 0; u < U; u++) { uint32_t m = 0; if (u < e->nU) for (int k = 0; k < e->ue_nbs[u]; k++) m |= 1u << e->ue_bs[u * B + k]; conn_bits[(size_t)i * U + u] = m; }
+        if (pos) for (int u = 0; u < U; u++) { pos[((size_t)i * U + u) * 2] = u < e->nU ? e->px[u] : 0.0; pos[((size_t)i * U + u) * 2 + 1] = u < e->nU ? e->py[u] : 0.0; }
     }
 }

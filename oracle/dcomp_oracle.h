@@ -43,6 +43,20 @@ void orc_destroy(orc_env *e);
 void orc_set_tape(orc_env *e, int depth, const int32_t *pos0 /*[U][2]*/, const int32_t *triples /*[U][depth][3]*/);
 void orc_set_philox(orc_env *e, uint64_t seed, int64_t global_env_id);
 
+/* UE arrival / departure (base.py:433-443, 592-618).  orc_create's num_ue is the CAPACITY (max_ues, base.py:79-84);
+ * orc_set_initial_ues says how many of the configured UEs exist after reset().  orc_set_events arms the events of
+ * the NEXT step (applied after the actions, before the rates): departures by list position, then arrivals at the
+ * given border points -- tape mode hands both in (reference draws: global random.randint, map.rand_border_point);
+ * with NULL arrays the Philox mapping shared with the device kernels is used.  Tapes may cover more ids than the
+ * capacity (orc_set_tape_ids): a UE's draws are keyed by its id. */
+void orc_set_initial_ues(orc_env *e, int num_initial);
+void orc_set_events(orc_env *e, int n_remove, const int32_t *remove_idx, int n_add, const int32_t *add_xy);
+void orc_set_tape_ids(orc_env *e, int depth, int num_ids, const int32_t *pos0, const int32_t *triples);
+int  orc_num_ue(const orc_env *e);
+void orc_get_uids(const orc_env *e, int32_t *uids /*[capacity], 0 = empty slot*/);
+int  orc_slot_born(const orc_env *e, int slot);          /* the UE in this slot arrived during the episode */
+void orc_get_orig_consumed(const orc_env *e, int32_t *out /*[initial UEs]*/);
+
 void orc_reset(orc_env *e);                      /* base.py:169-189 (state part; obs via orc_get_obs) */
 int  orc_step(orc_env *e, const int32_t *action /*[U]*/);   /* base.py:413-466; returns 0 or <0 on bad action */
 

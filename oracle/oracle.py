@@ -74,6 +74,13 @@ def lib():
         L.orc_can_connect.argtypes = [ctypes.c_double]
         L.orc_connect_threshold_distance.restype = ctypes.c_double
         L.orc_philox4x32_10.argtypes = [_c_u32p, _c_u32p, _c_u32p]
+        L.orc_set_initial_ues.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_set_events.argtypes = [ctypes.c_void_p, ctypes.c_int, _c_ip, ctypes.c_int, _c_ip]
+        L.orc_set_tape_ids.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _c_ip, _c_ip]
+        L.orc_num_ue.argtypes = [ctypes.c_void_p]
+        L.orc_get_uids.argtypes = [ctypes.c_void_p, _c_ip]
+        L.orc_slot_born.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_get_orig_consumed.argtypes = [ctypes.c_void_p, _c_ip]
         L.orc_batch_reset.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _c_fp, ctypes.c_int]
         L.orc_batch_step.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _c_u8p, _c_fp, _c_fp, _c_u32p,
                                      _c_dp, ctypes.c_int]
@@ -150,11 +157,20 @@ class OracleEnv:
     """One env instance of the oracle."""
 
     def __init__(self, map_w, map_h, bs_pos, bs_sharing, vel_specs, kind=MULTI, reward_agg=AVG, ue_util=None,
-                 ue_dr_req=None, init_xy=None):
+                 ue_dr_req=None, init_xy=None, max_ues=None):
         L = lib()
-        self.U, self.B = len(vel_specs), len(bs_pos)
+        self.U0 = len(vel_specs)                      # UEs in the configured ue_list
+        self.U, self.B = max(max_ues or 0, self.U0), len(bs_pos)     # capacity (max_ues, base.py:79-84)
         self.kind = kind
         U, B = self.U, self.B
+        pad = U - self.U0
+        vel_specs = list(vel_specs) + ['slow'] * pad
+        if ue_util is not None:
+            ue_util = list(ue_util) + [0] * pad
+        if ue_dr_req is not None:
+            ue_dr_req = list(ue_dr_req) + [1.0] * pad
+        if init_xy is not None:
+            init_xy = [tuple(p) for p in init_xy] + [(-1, -1)] * pad
         bs = np.asarray(bs_pos, dtype=np.float64).reshape(B, 2)
         self._bx, self._by = np.ascontiguousarray(bs[:, 0]), np.ascontiguousarray(bs[:, 1])
         self._sh = np.asarray([SHARING_CODE.get(s, s) for s in bs_sharing], dtype=np.int32)
@@ -169,6 +185,41 @@ class OracleEnv:
                               _p(self._sh, _c_ip), _p(self._util, _c_ip), _p(self._req, _c_dp), _p(self._vlo, _c_ip),
                               _p(self._vhi, _c_ip), _p(self._ix, _c_ip), _p(self._iy, _c_ip))
         self.h = ctypes.c_void_p(self.h)
+        if pad:
+            L.orc_set_initial_ues(self.h, self.U0)
+
+    def set_events(self, remove_idx=(), add_xy=()):
+        """Arrival / departure of the NEXT step (base.py:433-443).  Lists: tape mode (reference draws)."""
+        r = np.ascontiguousarray(remove_idx, dtype=np.int32).reshape(-1)
+        a = np.ascontiguousarray(add_xy, dtype=np.int32).reshape(-1, 2)
+        lib().orc_set_events(self.h, len(r), _p(r, _c_ip) if len(r) else None, len(a), _p(a, _c_ip) if len(a) else None)
+
+    def set_event_counts(self, n_remove, n_add):
+        """Philox mode: only the counts; indices / border points come from the keyed draws."""
+        lib().orc_set_events(self.h, int(n_remove), None, int(n_add), None)
+
+    def set_tape_ids(self, pos0, triples):
+        pos0 = np.ascontiguousarray(pos0, dtype=np.int32)
+        triples = np.ascontiguousarray(triples, dtype=np.int32)
+        lib().orc_set_tape_ids(self.h, triples.shape[1], triples.shape[0], _p(pos0, _c_ip), _p(triples, _c_ip))
+
+    def num_ue(self):
+        return lib().orc_num_ue(self.h)
+
+    def uids(self):
+        u = np.zeros(self.U, dtype=np.int32)
+        lib().orc_get_uids(self.h, _p(u, _c_ip))
+        return u
+
+    def end_of_episode_list(self):
+        """[(id, born)] in ue_list order -- what MobileEnv.seed iterates at the next reset (base.py:138-143)."""
+        ids = self.uids()
+        return [(int(ids[s]), bool(lib().orc_slot_born(self.h, s))) for s in range(self.num_ue())]
+
+    def orig_consumed(self):
+        c = np.zeros(self.U0, dtype=np.int32)
+        lib().orc_get_orig_consumed(self.h, _p(c, _c_ip))
+        return c
 
     def __del__(self):
         if getattr(self, 'h', None) is not None and _lib is not None:
@@ -228,6 +279,95 @@ class OracleEnv:
 
     def cursors(self):
         return np.array([lib().orc_tape_cursor(self.h, u) for u in range(self.U)], dtype=np.int32)
+
+
+def arrival_schedule(episode_length, ue_arrival=None, new_ue_interval=None):
+    """Per-step (n_remove, n_add) as MobileEnv.step applies them (base.py:433-443); the step index is env.time
+    BEFORE the step.  ue_arrival disables the interval (base.py:52-56)."""
+    sched = [(0, 0)] * episode_length
+    if ue_arrival:
+        for t, n in ue_arrival.items():
+            if 0 <= int(t) < episode_length:
+                sched[int(t)] = (-n, 0) if n < 0 else (0, n)
+    elif new_ue_interval:
+        for t in range(1, episode_length):
+            if t % new_ue_interval == 0:
+                sched[t] = (0, 1)
+    return sched
+
+
+class DynRefStreams:
+    """Streams of the INITIAL UEs when UEs arrive / depart (base.py:433-443).  Their ``random.Random`` objects live as
+    long as the env: at reset the reference restores the original ue_list but re-seeds (rand_episodes=False) the UEs
+    of the list as it stood at the END of the previous episode, BY POSITION in that list (base.py:171-173 -> 138-143)
+    -- so an initial UE that moved up in the list gets another UE's seed, and one that had left keeps its old stream.
+    This class keeps that exact bookkeeping; arrived UEs are always freshly seeded (base.py:602-604)."""
+
+    def __init__(self, seed, map_w, map_h, vel_specs, depth=48, rand_episodes=False, init_xy=None):
+        self.seed, self.w, self.h, self.depth, self.rand_episodes = seed, int(map_w), int(map_h), depth, rand_episodes
+        self.vel = [vel_range(v) for v in vel_specs]
+        self.U0 = len(self.vel)
+        self.init_xy = init_xy if init_xy is not None else [(-1, -1)] * self.U0
+        self.pos_rng = [random.Random(seed + 100 * (i + 1)) for i in range(self.U0)]
+        self.mov_rng = [random.Random(seed + 100 * (i + 1)) for i in range(self.U0)]
+        self._states = None
+
+    def draw_episode(self, end_list=None, consumed=None):
+        if self._states is not None:
+            for i in range(self.U0):
+                self.mov_rng[i].setstate(self._states[i][int(consumed[i])])
+        if not self.rand_episodes:
+            order = [(i + 1, False) for i in range(self.U0)] if end_list is None else end_list
+            for pos, (uid, born) in enumerate(order):
+                if not born:
+                    self.pos_rng[uid - 1].seed(self.seed + 100 * (pos + 1))
+                    self.mov_rng[uid - 1].seed(self.seed + 100 * (pos + 1))
+        pos0 = np.zeros((self.U0, 2), dtype=np.int32)
+        trip = np.zeros((self.U0, self.depth, 3), dtype=np.int32)
+        self._states = []
+        for i in range(self.U0):
+            ix, iy = self.init_xy[i]
+            pos0[i, 0] = self.pos_rng[i].randint(0, self.w) if ix < 0 else ix
+            pos0[i, 1] = self.pos_rng[i].randint(0, self.h) if iy < 0 else iy
+            lo, hi = self.vel[i]
+            st = [self.mov_rng[i].getstate()]
+            for k in range(self.depth):
+                v = self.mov_rng[i].randint(lo, hi) if lo != hi else lo
+                trip[i, k] = (v, self.mov_rng[i].randint(10, self.w - 10), self.mov_rng[i].randint(10, self.h - 10))
+                st.append(self.mov_rng[i].getstate())
+            self._states.append(st)
+        return pos0, trip
+
+
+class RefEventDraws:
+    """The reference's draws for arrivals / departures: ``map.rng`` (map.py:52-65) and the GLOBAL ``random``
+    (base.py:611), both seeded with the env seed by MobileEnv.seed (base.py:132-136)."""
+
+    def __init__(self, seed, map_w, map_h, rand_episodes=False):
+        self.seed, self.w, self.h, self.rand_episodes = seed, int(map_w), int(map_h), rand_episodes
+        self._seed()
+
+    def _seed(self):
+        self.map_rng, self.glob = random.Random(self.seed), random.Random(self.seed)
+
+    def new_episode(self):
+        if not self.rand_episodes:
+            self._seed()
+
+    def departures(self, n_remove, num_ue):
+        out = []
+        for _ in range(n_remove):
+            out.append(self.glob.randint(0, num_ue - 1))
+            num_ue -= 1
+        return out
+
+    def arrivals(self, n_add):
+        out = []
+        for _ in range(n_add):
+            x, y = self.map_rng.randint(0, self.w), self.map_rng.randint(0, self.h)
+            border = self.map_rng.choice(['left', 'right', 'top', 'bottom'])
+            out.append({'left': (0, y), 'right': (self.w - 1, y), 'top': (x, self.h - 1), 'bottom': (x, 0)}[border])
+        return out
 
 
 class OracleBatch:

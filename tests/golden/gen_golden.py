@@ -325,6 +325,93 @@ def gen_estack():
                        'central', 42 + 20000 * e, 40, tape_mode='sticky')
 
 
+def run_dynamic_trajectory(name, scn, kind, seed, num_steps, ue_arrival=None, new_ue_interval=None, episodes=1,
+                           rand_episodes=False, reward='avg'):
+    """G8: UE arrival / departure (base.py:433-443, 592-618).  Per-UE arrays are padded to max_ues; `num_ue` and
+    `ue_ids` say which slots are alive (slot = position in env.ue_list, the order central observations use)."""
+    m, bs_list, ue_list = build_ref(scn, scn.ue_specs)
+    cfg = env_config(m, bs_list, ue_list, seed, eps_len=num_steps, reward=reward, rand_episodes=rand_episodes)
+    cfg['ue_arrival'] = None if ue_arrival is None else {str(k): v for k, v in ue_arrival.items()}
+    cfg['new_ue_interval'] = new_ue_interval
+    env = (CentralRelNormEnv if kind == 'central' else MultiAgentMobileEnv)(cfg)
+    M, B = env.max_ues, env.num_bs
+    tape = action_tape(num_steps * episodes, M, B, 'sticky', seed=11)
+
+    def snap(obs, reward_v=None, info=None):
+        n = env.num_ue
+        s = snapshot(env, kind, {k: (v[:n * B] if k != 'utility' else v[:n]) for k, v in obs.items()} if kind == 'central' else obs,
+                     reward_v, info)
+        out = {'num_ue': np.array(n, dtype=np.int32),
+               'ue_ids': np.array([int(ue.id) for ue in env.ue_list] + [0] * (M - n), dtype=np.int32)}
+        for k, v in s.items():
+            if k in ('reward',) and kind == 'central':
+                out[k] = v
+            elif k in ('sum_utility', 'time'):
+                out[k] = v
+            elif k == 'conn_order':
+                pad = -np.ones((B, M), dtype=v.dtype)
+                pad[:, :n] = v
+                out[k] = pad
+            else:
+                pad = np.zeros((M,) + v.shape[1:], dtype=v.dtype)
+                pad[:n] = v
+                out[k] = pad
+        if kind == 'central':      # zero padding the reference itself adds (central.py:46-55)
+            assert len(obs['connected']) == M * B and all(x == 0 for x in obs['connected'][n * B:])
+            assert len(obs['utility']) == M and all(x == 0 for x in obs['utility'][n:])
+        return out
+
+    resets, steps = [], []
+    t = 0
+    for _ in range(episodes):
+        obs = env.reset()
+        resets.append(snap(obs))
+        for _ in range(num_steps):
+            a = tape[t]
+            action = [int(x) for x in a] if kind == 'central' else {ue.id: int(a[i]) for i, ue in enumerate(env.ue_list)}
+            obs, reward_v, done, info = env.step(action)
+            steps.append(snap(obs, reward_v, info))
+            t += 1
+    arr = ue_arrival or {}
+    out = {
+        'cfg_map_wh': np.array([m.width, m.height], dtype=np.int32),
+        'cfg_map_wh_raw': np.array([scn.width, scn.height], dtype=np.float64),
+        'cfg_bs_pos': np.array(scn.bs_pos, dtype=np.float64),
+        'cfg_bs_sharing': np.array([SHARING_CODE[s] for s in scn.bs_sharing], dtype=np.int32),
+        'cfg_ue_vel': np.array([VEL_CODE.get(s['velocity'], s['velocity']) for s in scn.ue_specs], dtype=np.int32),
+        'cfg_seed': np.array(seed, dtype=np.int64), 'cfg_kind': np.array(0 if kind == 'central' else 1, dtype=np.int32),
+        'cfg_reward': np.array({'avg': 0, 'sum': 1, 'min': 2}[reward], dtype=np.int32),
+        'cfg_rand_episodes': np.array(int(rand_episodes), dtype=np.int32), 'cfg_episodes': np.array(episodes, dtype=np.int32),
+        'cfg_eps_len': np.array(num_steps, dtype=np.int32), 'cfg_max_ues': np.array(M, dtype=np.int32),
+        'cfg_new_ue_interval': np.array(-1 if new_ue_interval is None else new_ue_interval, dtype=np.int32),
+        'cfg_arrival_t': np.array(sorted(arr.keys()), dtype=np.int32),
+        'cfg_arrival_n': np.array([arr[k] for k in sorted(arr.keys())], dtype=np.int32),
+        'actions': tape,
+    }
+    for k in resets[0]:
+        out['reset_' + k] = np.stack([r[k] for r in resets])
+    for k in steps[0]:
+        out['step_' + k] = np.stack([s[k] for s in steps])
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}: {os.path.getsize(path) / 1024:.0f} KiB  max_ues={M} B={B} steps={num_steps * episodes}')
+
+
+def gen_dynamic():
+    S = scenarios
+    largeupdown = {20: 1, 30: -1, 40: 1, 45: 1, 50: 1, 55: 2, 60: 3, 65: 2, 70: 1, 75: -1, 80: -2, 85: -3, 90: -3, 95: -2}
+    run_dynamic_trajectory('dyn_custom_multi_updown_s42', S.custom_map('mixed').with_ues(num_slow=2), 'multi', 42, 40,
+                           ue_arrival={3: 2, 6: -1, 8: 1, 10: -2, 15: 3, 22: -2})
+    run_dynamic_trajectory('dyn_medium_central_largeupdown_s42', S.medium_map('mixed').with_ues(num_slow=1), 'central', 42, 100,
+                           ue_arrival=largeupdown)
+    run_dynamic_trajectory('dyn_custom_central_interval_s43', S.custom_map('mixed').with_ues(num_slow=1, num_fast=1), 'central', 43,
+                           30, new_ue_interval=7)
+    run_dynamic_trajectory('dyn_large_multi_2eps_rand_s42', S.large_map('mixed').with_ues(num_static=1, num_slow=2), 'multi', 42, 30,
+                           ue_arrival={2: 2, 9: -1, 12: 2, 20: -3}, episodes=2, rand_episodes=True)
+    run_dynamic_trajectory('dyn_large_multi_2eps_fixed_s43', S.large_map('mixed').with_ues(num_slow=3), 'multi', 43, 30,
+                           ue_arrival={2: 2, 9: -1, 12: 2, 20: -3}, episodes=2, rand_episodes=False, reward='min')
+
+
 def gen_heuristics():
     """G7: decisions of the reference's heuristic agents (agent/heuristics.py) on recorded observations."""
     from deepcomp.agent.heuristics import DynamicSelection, FullCoMP, Heuristic3GPP, StaticClustering
@@ -357,3 +444,4 @@ if __name__ == '__main__':
     gen_trajectories()
     gen_estack()
     gen_heuristics()
+    gen_dynamic()

@@ -178,3 +178,68 @@ def test_philox_known_answers():
     assert orc.philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert orc.philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+# ------------------------------------------------------------------ G8 UE arrival / departure (base.py:433-443, 592-618)
+DYN = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'dyn_*.npz')))
+
+
+def dyn_setup(g, depth=48):
+    """Oracle env + the reference's draws for a dynamic-UE fixture.  Tapes: initial UEs by list position, then one
+    'slow' tape per possible id of an arriving UE (seed + 100*id, base.py:602-604)."""
+    w, h = (int(x) for x in g['cfg_map_wh'])
+    vel = [int(v) for v in g['cfg_ue_vel']]
+    U0, M, seed = len(vel), int(g['cfg_max_ues']), int(g['cfg_seed'])
+    L = int(g['cfg_eps_len'])
+    arr = {int(t): int(n) for t, n in zip(g['cfg_arrival_t'], g['cfg_arrival_n'])} or None
+    interval = int(g['cfg_new_ue_interval'])
+    sched = orc.arrival_schedule(L, arr, interval if interval > 0 else None)
+    max_id = U0 + sum(a for _, a in sched)
+    env = orc.OracleEnv(w, h, g['cfg_bs_pos'], list(g['cfg_bs_sharing']), vel, kind=int(g['cfg_kind']),
+                        reward_agg=int(g['cfg_reward']), max_ues=M)
+    init_tape = orc.DynRefStreams(seed, w, h, vel, depth=depth, rand_episodes=bool(g['cfg_rand_episodes']))
+    new_tape = orc.RefRngTape(seed, w, h, ['slow'] * max_id, depth=depth)      # re-seeded at every arrival
+    events = orc.RefEventDraws(seed, w, h, rand_episodes=bool(g['cfg_rand_episodes']))
+    return env, init_tape, new_tape, events, sched, U0, M
+
+
+def dyn_check(env, g, prefix, i, kind, M):
+    n = int(g[f'{prefix}_num_ue'][i])
+    assert env.num_ue() == n
+    assert np.array_equal(env.uids(), g[f'{prefix}_ue_ids'][i])
+    s, o = env.state(), env.obs()
+    for k in ('pos', 'wp', 'vel', 'pausing', 'curr_pause', 'conn', 'conn_order'):
+        assert np.array_equal(s[k], g[f'{prefix}_{k}'][i]), f'{prefix}[{i}] {k}'
+    for k in ('dr', 'curr_dr', 'ewma', 'utility'):
+        np.testing.assert_allclose(s[k], g[f'{prefix}_{k}'][i], rtol=1e-9, atol=1e-12, err_msg=f'{prefix}[{i}] {k}')
+    assert np.array_equal(o['connected'], g[f'{prefix}_obs_connected'][i])
+    np.testing.assert_allclose(o['dr'], g[f'{prefix}_obs_dr'][i], rtol=RTOL, atol=1e-300)
+    np.testing.assert_allclose(o['utility'], g[f'{prefix}_obs_utility'][i], rtol=1e-9, atol=1e-12)
+    if kind == orc.MULTI:
+        np.testing.assert_allclose(o['ues_at_bs'], g[f'{prefix}_obs_ues_at_bs'][i], rtol=RTOL)
+        np.testing.assert_allclose(o['util_at_bs'], g[f'{prefix}_obs_util_at_bs'][i], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize('name', DYN)
+def test_dynamic_ue_trajectory(name):
+    g = load(name)
+    env, init_tape, new_tape, events, sched, U0, M = dyn_setup(g)
+    kind, episodes, L = int(g['cfg_kind']), int(g['cfg_episodes']), int(g['cfg_eps_len'])
+    t, consumed, end_list = 0, None, None
+    for ep in range(episodes):
+        p0, t0 = init_tape.draw_episode(end_list, consumed)
+        p1, t1 = new_tape.draw_episode()
+        env.set_tape_ids(np.concatenate([p0, p1]), np.concatenate([t0, t1]))
+        events.new_episode()
+        env.reset()
+        dyn_check(env, g, 'reset', ep, kind, M)
+        for k in range(L):
+            n_rem, n_add = sched[k]
+            if n_rem or n_add:
+                env.set_events(events.departures(n_rem, env.num_ue()), events.arrivals(n_add))
+            env.step(g['actions'][t])
+            dyn_check(env, g, 'step', t, kind, M)
+            np.testing.assert_allclose(env.reward(), g['step_reward'][t], rtol=1e-9, atol=1e-12, err_msg=f'reward[{t}]')
+            assert env.sum_utility() == pytest.approx(float(g['step_sum_utility'][t]), rel=1e-9, abs=1e-12)
+            t += 1
+        consumed, end_list = env.orig_consumed(), env.end_of_episode_list()
