@@ -23,7 +23,7 @@ class DcompCfg(ctypes.Structure):
     _fields_ = [('num_envs', ctypes.c_int32), ('num_ue', ctypes.c_int32), ('num_bs', ctypes.c_int32),
                 ('map_w', ctypes.c_int32), ('map_h', ctypes.c_int32), ('env_kind', ctypes.c_int32),
                 ('reward_agg', ctypes.c_int32), ('rng_mode', ctypes.c_int32), ('tape_depth', ctypes.c_int32),
-                ('device', ctypes.c_int32), ('reserved', ctypes.c_int32), ('seed', ctypes.c_uint64),
+                ('device', ctypes.c_int32), ('max_ues', ctypes.c_int32), ('seed', ctypes.c_uint64),
                 ('env_id_base', ctypes.c_int64), ('bs_x', _dp), ('bs_y', _dp), ('bs_sharing', _ip),
                 ('ue_util', _ip), ('ue_dr_req', _fp), ('ue_vel_lo', _ip), ('ue_vel_hi', _ip),
                 ('ue_init_x', _ip), ('ue_init_y', _ip)]
@@ -31,7 +31,8 @@ class DcompCfg(ctypes.Structure):
 
 class DcompState(ctypes.Structure):
     _fields_ = [('pos', ctypes.c_void_p), ('mv', ctypes.c_void_p), ('conn', ctypes.c_void_p),
-                ('ewma', ctypes.c_void_p), ('flags', ctypes.c_void_p), ('conn_since', ctypes.c_void_p)]
+                ('ewma', ctypes.c_void_p), ('flags', ctypes.c_void_p), ('conn_since', ctypes.c_void_p),
+                ('uid', ctypes.c_void_p), ('orig_consumed', ctypes.c_void_p)]
 
 
 class DcompOut(ctypes.Structure):
@@ -40,10 +41,16 @@ class DcompOut(ctypes.Structure):
 
 
 class DcompTape(ctypes.Structure):
-    _fields_ = [('pos0', ctypes.c_void_p), ('triples', ctypes.c_void_p)]
+    _fields_ = [('pos0', ctypes.c_void_p), ('triples', ctypes.c_void_p), ('num_ids', ctypes.c_int32)]
+
+
+class DcompEvents(ctypes.Structure):
+    _fields_ = [('n_remove', ctypes.c_int32), ('n_add', ctypes.c_int32), ('remove_idx', ctypes.c_void_p),
+                ('add_xy', ctypes.c_void_p)]
 
 
 EXPORTS = ['dcomp_create', 'dcomp_destroy', 'dcomp_state_sizes', 'dcomp_obs_dim', 'dcomp_reset', 'dcomp_step',
+           'dcomp_step_dyn', 'dcomp_num_ue',
            'dcomp_rollout', 'dcomp_check', 'dcomp_time', 'dcomp_episode', 'dcomp_set_episode', 'dcomp_mt_draw_tape',
            'dcomp_connect_threshold', 'dcomp_last_error', 'dcomp_version', 'dcomp_selftest']
 
@@ -73,6 +80,8 @@ def load():
     L.dcomp_obs_dim.argtypes = [vp, _ip, _ip]
     L.dcomp_reset.argtypes = [vp, ctypes.POINTER(DcompState), ctypes.POINTER(DcompTape), ctypes.POINTER(DcompOut), vp]
     L.dcomp_step.argtypes = [vp, ctypes.POINTER(DcompState), vp, ctypes.POINTER(DcompOut), vp]
+    L.dcomp_step_dyn.argtypes = [vp, ctypes.POINTER(DcompState), vp, ctypes.POINTER(DcompOut), ctypes.POINTER(DcompEvents), vp]
+    L.dcomp_num_ue.argtypes = [vp]
     L.dcomp_rollout.argtypes = [vp, ctypes.POINTER(DcompState), vp, i32, ctypes.POINTER(DcompOut), vp]
     L.dcomp_check.argtypes = [vp, ctypes.POINTER(DcompState), vp]
     L.dcomp_time.argtypes = [vp]

@@ -30,7 +30,7 @@ def b_list():
 
 
 def _sources():
-    return [os.path.join(CSRC, f) for f in ('dcomp_device.h', 'dcomp_wide.h', 'dcomp_blist.h', 'dcomp_inst.hip', 'dcomp_api.hip')] + \
+    return [os.path.join(CSRC, f) for f in ('dcomp_device.h', 'dcomp_wide.h', 'dcomp_dyn.h', 'dcomp_blist.h', 'dcomp_inst.hip', 'dcomp_api.hip')] + \
         [os.path.join(os.path.dirname(HERE), 'include', 'dcomp.h')]
 
 

@@ -53,6 +53,8 @@ struct dcomp_env {
     dcomp::KernelPair kern;
     UeCfg *d_ue_cfg;
     int upad, grid;
+    int cap, cur_ue;            // slots per env; UEs currently listed
+    uint32_t n_removed, n_arrived;   // this episode (Philox draw words)
     int time;
     int64_t episode;            // index of the current episode (-1 before the first reset)
 };
@@ -90,7 +92,10 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
     const int E = cfg->num_envs, U = cfg->num_ue, B = cfg->num_bs;
     if (E < 1 || U < 1 || U > DCOMP_MAX_UE || B < 1 || B > DCOMP_MAX_BS)
         return fail(DCOMP_EINVAL, "need num_envs>=1, 1<=num_ue<=%d, 1<=num_bs<=%d (got %d, %d, %d)", DCOMP_MAX_UE, DCOMP_MAX_BS, E, U, B);
-    if ((int64_t)E * U > (int64_t)1 << 30) return fail(DCOMP_EINVAL, "num_envs*num_ue too large");
+    const int CAP = cfg->max_ues > 0 ? cfg->max_ues : U;           // slots per env (base.py:79-84)
+    if (CAP < U) return fail(DCOMP_EINVAL, "max_ues (%d) < num_ue (%d)", CAP, U);                 // base.py:84
+    if (CAP > U && CAP > 64) return fail(DCOMP_EUNSUPPORTED, "UE arrival/departure needs max_ues <= 64 (got %d)", CAP);
+    if ((int64_t)E * CAP > (int64_t)1 << 30) return fail(DCOMP_EINVAL, "num_envs*max_ues too large");
     if (cfg->map_w < 21 || cfg->map_h < 21 || cfg->map_w > 65535 || cfg->map_h > 65535)
         return fail(DCOMP_EINVAL, "map must be 21..65535 in both dimensions (waypoints live in [10, size-10])");
     if (cfg->env_kind != DCOMP_CENTRAL && cfg->env_kind != DCOMP_MULTI) return fail(DCOMP_EINVAL, "bad env_kind");
@@ -103,7 +108,8 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
     dcomp_env *env = new dcomp_env();
     env->cfg = *cfg;
     env->cfg.bs_x = env->cfg.bs_y = nullptr;   // host arrays are not retained
-    env->upad = next_pow2(U) < 4 ? 4 : next_pow2(U);
+    env->cap = CAP; env->cur_ue = U; env->n_removed = env->n_arrived = 0;
+    env->upad = next_pow2(CAP) < 4 ? 4 : next_pow2(CAP);
     int mp = dcomp::MP_RES_FAIR;            // sharing pattern -> specialised kernel (dcomp_device.h bs_mode_of)
     for (int b = 0; b < B; b++) if (cfg->bs_sharing[b] != DCOMP_RES_FAIR) mp = dcomp::MP_MIXED;
     if (mp == dcomp::MP_MIXED) {
@@ -118,7 +124,7 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
 
     KParams &kp = env->kp;
     std::memset(&kp, 0, sizeof(kp));
-    kp.E = E; kp.U = U;
+    kp.E = E; kp.U = CAP; kp.U0 = U; kp.cur_ue = U; kp.tape_ids = U;
     kp.map_w = cfg->map_w; kp.map_h = cfg->map_h;
     kp.kind = cfg->env_kind; kp.reward_agg = cfg->reward_agg; kp.rng_mode = cfg->rng_mode;
     kp.tape_depth = cfg->tape_depth;
@@ -173,6 +179,11 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
     if (e != hipSuccess) { delete env; return fail(DCOMP_EHIP, "device setup failed: %s", hipGetErrorString(e)); }
     kp.ue_cfg = env->d_ue_cfg;
     if (env->kern.step_wide && !kp.any_maxcap && !getenv("DCOMP_NO_WIDE")) env->kern.step = env->kern.step_wide;
+    if (CAP > U) {
+        if (kp.any_maxcap) { dcomp_destroy(env); return fail(DCOMP_EUNSUPPORTED, "UE arrival/departure with a max-cap BS is not supported"); }
+        if (!env->kern.step_dyn) { dcomp_destroy(env); return fail(DCOMP_EUNSUPPORTED, "no dynamic-UE kernel for this shape"); }
+        env->kern.step = env->kern.step_dyn;
+    }
     *out = env;
     return DCOMP_OK;
 }
@@ -189,7 +200,7 @@ extern "C" int dcomp_state_sizes(const dcomp_env *env, size_t *pos_bytes, size_t
                                  size_t *flags_bytes, size_t *since_bytes)
 {
     if (!env) return fail(DCOMP_EINVAL, "null env");
-    size_t n = (size_t)env->cfg.num_envs * env->cfg.num_ue;
+    size_t n = (size_t)env->cfg.num_envs * env->cap;
     if (pos_bytes) *pos_bytes = n * 16;
     if (mv_bytes) *mv_bytes = n * 8;
     if (conn_bytes) *conn_bytes = n * 4;
@@ -202,7 +213,7 @@ extern "C" int dcomp_state_sizes(const dcomp_env *env, size_t *pos_bytes, size_t
 extern "C" int dcomp_obs_dim(const dcomp_env *env, int32_t *floats_per_env, int32_t *reward_per_env)
 {
     if (!env) return fail(DCOMP_EINVAL, "null env");
-    const int U = env->cfg.num_ue, B = env->cfg.num_bs;
+    const int U = env->cap, B = env->cfg.num_bs;
     if (floats_per_env) *floats_per_env = env->cfg.env_kind == DCOMP_MULTI ? U * (4 * B + 1) : U * (2 * B + 1);
     if (reward_per_env) *reward_per_env = env->cfg.env_kind == DCOMP_MULTI ? U : 1;
     return DCOMP_OK;
@@ -214,7 +225,11 @@ static int fill_params(dcomp_env *env, const dcomp_state *st, const dcomp_out *o
     if (!st->pos || !st->mv || !st->conn || !st->ewma || !st->flags) return fail(DCOMP_EINVAL, "state pointers must all be set");
     if (!out->obs) return fail(DCOMP_EINVAL, "out->obs is required");
     if (env->kp.any_maxcap && !st->conn_since) return fail(DCOMP_EINVAL, "a max-cap BS needs state.conn_since (see dcomp_state_sizes)");
+    if (env->cap > env->cfg.num_ue && !st->uid) return fail(DCOMP_EINVAL, "UE arrival/departure needs state.uid");
     kp = env->kp;
+    kp.uid = st->uid;
+    kp.orig_consumed = st->orig_consumed;
+    kp.cur_ue = env->cur_ue;
     kp.conn_since = st->conn_since;
     kp.time = (uint32_t)env->time;
     kp.pos = (double2 *)st->pos; kp.mv = (unsigned long long *)st->mv; kp.conn = st->conn; kp.ewma = st->ewma; kp.flags = st->flags;
@@ -232,10 +247,13 @@ extern "C" int dcomp_reset(dcomp_env *env, const dcomp_state *st, const dcomp_ta
         if (!tape || !tape->pos0 || !tape->triples) return fail(DCOMP_EINVAL, "tape mode: reset needs the episode's draw tape");
         env->kp.tape_pos0 = tape->pos0;                     // borrowed until the next reset
         env->kp.tape_triples = (const ushort4 *)tape->triples;
-        kp.tape_pos0 = env->kp.tape_pos0; kp.tape_triples = env->kp.tape_triples;
+        env->kp.tape_ids = tape->num_ids > 0 ? tape->num_ids : env->cfg.num_ue;
+        kp.tape_pos0 = env->kp.tape_pos0; kp.tape_triples = env->kp.tape_triples; kp.tape_ids = env->kp.tape_ids;
     }
     env->episode += 1;
     env->time = 0;
+    env->cur_ue = env->cfg.num_ue; env->n_removed = env->n_arrived = 0;      // base.py:177-182
+    kp.cur_ue = env->cur_ue;
     kp.episode = (uint32_t)env->episode;
     hipLaunchKernelGGL(env->kern.reset, dim3(env->grid), dim3(256), 0, (hipStream_t)stream, kp);
     HIP_TRY(hipGetLastError());
@@ -250,11 +268,44 @@ extern "C" int dcomp_step(dcomp_env *env, const dcomp_state *st, const uint8_t *
     if (!action) return fail(DCOMP_EINVAL, "null action");
     if (env->episode < 0) return fail(DCOMP_EINVAL, "step() before reset()");
     kp.action = action;
+    kp.n_remove = kp.n_add = 0;
     hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(256), 0, (hipStream_t)stream, kp);
     HIP_TRY(hipGetLastError());
     env->time += 1;
     return DCOMP_OK;
 }
+
+extern "C" int dcomp_step_dyn(dcomp_env *env, const dcomp_state *st, const uint8_t *action, const dcomp_out *out,
+                              const dcomp_events *ev, void *stream)
+{
+    if (!env) return fail(DCOMP_EINVAL, "null env");
+    if (env->cap == env->cfg.num_ue) {
+        if (ev && (ev->n_remove || ev->n_add)) return fail(DCOMP_EINVAL, "handle was created without max_ues > num_ue");
+        return dcomp_step(env, st, action, out, stream);
+    }
+    KParams kp;
+    int rc = fill_params(env, st, out, kp);
+    if (rc) return rc;
+    if (!action) return fail(DCOMP_EINVAL, "null action");
+    if (env->episode < 0) return fail(DCOMP_EINVAL, "step() before reset()");
+    const int nrem = ev ? ev->n_remove : 0, nadd = ev ? ev->n_add : 0;
+    if (nrem < 0 || nadd < 0 || (nrem > 0 && nadd > 0)) return fail(DCOMP_EINVAL, "one step either adds or removes UEs (base.py:436-443)");
+    if (env->cur_ue - nrem < 1) return fail(DCOMP_EINVAL, "cannot remove %d of %d UEs", nrem, env->cur_ue);
+    if (env->cur_ue + nadd > env->cap) return fail(DCOMP_EINVAL, "%d + %d UEs exceed max_ues = %d", env->cur_ue, nadd, env->cap);
+    if (env->cfg.rng_mode == DCOMP_RNG_TAPE && ((nrem && !ev->remove_idx) || (nadd && !ev->add_xy)))
+        return fail(DCOMP_EINVAL, "tape mode: events need the host-drawn indices / border points");
+    kp.action = action;
+    kp.n_remove = nrem; kp.n_add = nadd;
+    kp.ev_remove = ev ? ev->remove_idx : nullptr; kp.ev_add_xy = ev ? ev->add_xy : nullptr;
+    kp.ev_rem_base = env->n_removed; kp.ev_add_base = env->n_arrived;
+    hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(256), 0, (hipStream_t)stream, kp);
+    HIP_TRY(hipGetLastError());
+    env->time += 1;
+    env->cur_ue += nadd - nrem;
+    env->n_removed += (uint32_t)nrem; env->n_arrived += (uint32_t)nadd;
+    return DCOMP_OK;
+}
+extern "C" int dcomp_num_ue(const dcomp_env *env) { return env ? env->cur_ue : -1; }
 
 extern "C" int dcomp_rollout(dcomp_env *env, const dcomp_state *st, const uint8_t *actions, int32_t num_steps, const dcomp_out *out,
                              void *stream)
@@ -264,7 +315,7 @@ extern "C" int dcomp_rollout(dcomp_env *env, const dcomp_state *st, const uint8_
     if (rc) return rc;
     if (!actions || num_steps < 1) return fail(DCOMP_EINVAL, "bad action tape");
     if (env->episode < 0) return fail(DCOMP_EINVAL, "rollout() before reset()");
-    const size_t stride = (size_t)env->cfg.num_envs * env->cfg.num_ue;
+    const size_t stride = (size_t)env->cfg.num_envs * env->cap;
     for (int t = 0; t < num_steps; t++) {
         kp.action = actions + stride * t;
         kp.time = (uint32_t)(env->time + t);

@@ -57,6 +57,8 @@ struct KParams {
     float *ewma;
     uint32_t *flags;
     uint16_t *conn_since;      // [E*U][B] step of connection (max-cap tie rule), NULL when no BS is max-cap
+    uint16_t *uid;             // [E*U] UE id per slot (bit 15: arrived during the episode), NULL unless UEs arrive / depart
+    uint16_t *orig_consumed;   // [E*U0] movement triples an initial UE had used when it left (0xFFFF: never left), optional
     // io (device)
     const uint8_t *action;
     float *obs, *reward, *sum_util, *ue_dr, *ue_util;
@@ -65,7 +67,13 @@ struct KParams {
     const ushort4 *tape_triples;
     const UeCfg *ue_cfg;
     int32_t tape_depth;
-    int32_t E, U;
+    int32_t tape_ids;          // tapes per env: initial UEs by position, then one per id of an arriving UE
+    int32_t E, U;              // U = slots per env (max_ues, base.py:79-84)
+    int32_t U0, cur_ue;        // UEs after reset / currently in the list (same in every env: the schedule is config)
+    int32_t n_remove, n_add;   // arrival / departure of THIS step (base.py:433-443)
+    const int32_t *ev_remove;  // tape mode: [E][n_remove] list positions (global random.randint, base.py:611)
+    const int32_t *ev_add_xy;  // tape mode: [E][n_add][2] border points (map.py:52-65)
+    uint32_t ev_rem_base, ev_add_base;   // Philox: departures / arrivals so far this episode
     int32_t map_w, map_h;
     int32_t kind, reward_agg, rng_mode;
     uint32_t all_log_util;     // 1: every UE uses the log utility (skip the per-UE config load)
@@ -271,18 +279,25 @@ __device__ __forceinline__ unsigned long long mv_pack(uint32_t wx, uint32_t wy, 
 }
 
 // movement.py:110-130 (RandomWaypoint.reset): k-th movement triple of this UE in this episode.
-__device__ __forceinline__ void draw_triple(const KParams &p, int env, int u, int idx, uint32_t k, uint32_t &vel, uint32_t &wx,
+// uidw = UE id (1-based) | UID_BORN for UEs that arrived during the episode (base.py:592-606: always 'slow', freshly
+// seeded).  Draws are keyed by the id, not by the slot: slots shift when a UE leaves.
+constexpr uint32_t UID_BORN = 0x8000u;
+__device__ __forceinline__ void draw_triple(const KParams &p, int env, uint32_t uidw, uint32_t k, uint32_t &vel, uint32_t &wx,
                                             uint32_t &wy)
 {
+    const uint32_t id0 = (uidw & 0x7FFFu) - 1u;
+    const bool born = (uidw & UID_BORN) != 0u;
     if (p.rng_mode == DCOMP_RNG_TAPE) {
         if (k >= (uint32_t)p.tape_depth) { atomicOr(p.flags, DCOMP_FLAG_TAPE_EMPTY); k = p.tape_depth - 1; }
-        ushort4 t = p.tape_triples[(size_t)idx * p.tape_depth + k];
+        const uint32_t slot = born ? (uint32_t)p.U0 + id0 : id0;
+        ushort4 t = p.tape_triples[((size_t)env * p.tape_ids + slot) * p.tape_depth + k];
         vel = t.x; wx = t.y; wy = t.z;
     } else {
-        uint32_t r[4] = {0x12345678u + k * 977u, 0x9abcdef0u ^ (uint32_t)idx * 2654435761u, 0x0fedcba9u + (uint32_t)u * 40503u, 0u};
-        if (!(DCOMP_ABLATE & 128)) philox4x32_10(p.env_base + (uint32_t)env, (uint32_t)u, p.episode, k + 1, p.seed_lo, p.seed_hi, r);
-        UeCfg c = p.ue_cfg[u];
-        vel = c.vel_lo + __umulhi(r[0], (uint32_t)(c.vel_hi - c.vel_lo + 1));
+        uint32_t r[4] = {0x12345678u + k * 977u, 0x9abcdef0u ^ uidw * 2654435761u, 0x0fedcba9u + (uint32_t)env * 40503u, 0u};
+        if (!(DCOMP_ABLATE & 128)) philox4x32_10(p.env_base + (uint32_t)env, id0 | (born ? UID_BORN : 0u), p.episode, k + 1, p.seed_lo, p.seed_hi, r);
+        uint32_t vlo = 1u, vhi = 3u;
+        if (!born) { UeCfg c = p.ue_cfg[id0]; vlo = c.vel_lo; vhi = c.vel_hi; }
+        vel = vlo + __umulhi(r[0], vhi - vlo + 1u);
         wx = 10u + __umulhi(r[1], (uint32_t)(p.map_w - 20 + 1));
         wy = 10u + __umulhi(r[2], (uint32_t)(p.map_h - 20 + 1));
     }
@@ -290,7 +305,7 @@ __device__ __forceinline__ void draw_triple(const KParams &p, int env, int u, in
 
 // One RandomWaypoint step in FP64, in the reference's operation order.  movement.py:132-181.
 // Contraction is off: the only fused op is the explicit fma of the 2-element dot product (numpy).
-__device__ __forceinline__ void move_ue(const KParams &p, int env, int u, int idx, double &px, double &py, unsigned long long &mv)
+__device__ __forceinline__ void move_ue(const KParams &p, int env, uint32_t uidw, double &px, double &py, unsigned long long &mv)
 {
 #pragma clang fp contract(off)
     uint32_t wxi = (uint32_t)(mv & 0xFFFF), wyi = (uint32_t)((mv >> 16) & 0xFFFF), vel = (uint32_t)((mv >> 32) & 0xFF);
@@ -302,7 +317,7 @@ __device__ __forceinline__ void move_ue(const KParams &p, int env, int u, int id
     if (pausing) {
         if (cp < 2) { cp += 1; stay = true; }                       // movement.py:172-175 (pause_duration = 2)
         else {                                                      // movement.py:176 -> reset()
-            draw_triple(p, env, u, idx, cursor, vel, wxi, wyi);
+            draw_triple(p, env, uidw, cursor, vel, wxi, wyi);
             cursor += 1; pausing = 0; cp = 0;
             wx = (double)wxi; wy = (double)wyi;
         }
@@ -497,11 +512,13 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
 
 // Observation row + reward of one UE.  variants.py:271-305, central.py:31-73, multi_agent.py:32-95.
 // l2 / cnt are consumed (overwritten with the observation entries).
+// `active`: this lane owns a slot (row) of the env; `alive`: a UE currently sits in that slot (always the same unless
+// UEs arrive / depart, then dead slots produce zero rows: central.py:46-55); n_eff = UEs currently in the env.
 template <int B, int UPAD, bool RESET>
 __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, UPAD> &sh, bool active, int env, int env_local, int u, int idx,
                                               int wave, int lane, int gbase, uint32_t conn, uint32_t in_range,
                                               float (&l2)[B], float (&cnt)[B], float util, float curr_dr,
-                                              float reward_before)
+                                              float reward_before, bool alive, int n_eff)
 {
     using G = Geo<B, UPAD>;
     using SG = StageGeo<B>;
@@ -523,19 +540,19 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
     if (p.kind == DCOMP_CENTRAL) {
         float r[1];
         if (p.reward_agg == DCOMP_REWARD_MIN) {
-            r[0] = group_reduce<G::WG, OpMin>(active ? reward_before : 1.f);
+            r[0] = group_reduce<G::WG, OpMin>(alive ? reward_before : 1.f);
             xwave_reduce_<1, G::NW, OpMin>(r, sh, wave, lane);
         } else {
-            r[0] = group_reduce<G::WG, OpSum>(active ? reward_before : 0.f);
+            r[0] = group_reduce<G::WG, OpSum>(alive ? reward_before : 0.f);
             xwave_reduce_<1, G::NW, OpSum>(r, sh, wave, lane);
-            if (p.reward_agg == DCOMP_REWARD_AVG) r[0] = r[0] / (float)U;
+            if (p.reward_agg == DCOMP_REWARD_AVG) r[0] = r[0] / (float)n_eff;
         }
         reward = r[0];
     } else if (!RESET) {
         reward = util;                                              // multi_agent.py:52 (own utility, NOT normalised)
         if (p.reward_agg == DCOMP_REWARD_SUM) {
             // multi_agent.py:73-79: sum of rewards_before over UEs sharing any BS with this UE
-            sh.nb_conn[threadIdx.x] = active ? conn : 0u;
+            sh.nb_conn[threadIdx.x] = alive ? conn : 0u;
             sh.nb_rb[threadIdx.x] = reward_before;
             __syncthreads();
             if (in_range != 0) {
@@ -568,30 +585,30 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
     // ---- info (base.py:383-411)
     if (p.sum_util) {
         float s[1];
-        s[0] = group_reduce<G::WG, OpSum>(active ? util : 0.f);
+        s[0] = group_reduce<G::WG, OpSum>(alive ? util : 0.f);
         xwave_reduce_<1, G::NW, OpSum>(s, sh, wave, lane);
         if (active && u == 0) p.sum_util[env] = s[0];
     }
     if (active) {
-        if (p.ue_dr) stream_store(&p.ue_dr[idx], curr_dr);
-        if (p.ue_util) stream_store(&p.ue_util[idx], util);
+        if (p.ue_dr) stream_store(&p.ue_dr[idx], alive ? curr_dr : 0.f);
+        if (p.ue_util) stream_store(&p.ue_util[idx], alive ? util : 0.f);
     }
 
     // ---- observation entries (in place): l2 -> snr_b / max snr, tsum -> avg utility at BS, cnt -> UEs at BS / U
-    const float inv_u = 1.0f / (float)U;
-    const float util_n = util * (1.0f / MAX_UTIL);
+    const float inv_u = 1.0f / (float)n_eff;
+    const float util_n = alive ? util * (1.0f / MAX_UTIL) : 0.f;
 #pragma unroll
     for (int b = 0; b < B; b++) {
-        l2[b] = fast_exp2(l2[b] - l2max);                                                       // variants.py:276-284
-        tsum[b] = cnt[b] > 0.f ? tsum[b] * fast_rcp(cnt[b]) * (1.0f / MAX_UTIL) : 0.f;          // variants.py:299, station.py:71-76
-        cnt[b] = cnt[b] * inv_u;                                                                // variants.py:296
+        l2[b] = alive ? fast_exp2(l2[b] - l2max) : 0.f;                                         // variants.py:276-284
+        tsum[b] = (alive && cnt[b] > 0.f) ? tsum[b] * fast_rcp(cnt[b]) * (1.0f / MAX_UTIL) : 0.f;   // variants.py:299, station.py:71-76
+        cnt[b] = alive ? cnt[b] * inv_u : 0.f;                                                  // variants.py:296
     }
     if ((DCOMP_ABLATE & 8) && p.kind == DCOMP_MULTI) {
         float acc = util_n + reward;
         for (int b = 0; b < B; b++) acc += l2[b] + cnt[b] + tsum[b];
         if (active && acc == 123456.f) p.obs[idx] = acc;         // keeps the producers alive, writes nothing
     } else if (p.kind == DCOMP_MULTI) {
-        if (active && p.reward) stream_store(&p.reward[idx], reward);
+        if (active && p.reward) stream_store(&p.reward[idx], alive ? reward : 0.f);
         // rows of this wave are contiguous in memory: [row0, row0 + nrows)
         const unsigned long long am = __ballot(active);
         const int nrows = __popcll(am);
@@ -708,7 +725,7 @@ __global__ __launch_bounds__(256, (B <= 10 && UPAD <= 64) ? DCOMP_FORCE_WAVES : 
     const float reward_before = fminf(fmaxf(util_pre, MIN_UTIL), MAX_UTIL) * (1.0f / MAX_UTIL);
     // 4. move (base.py:447 -> user.py:159-173)
     if (active && !(DCOMP_ABLATE & 2)) {
-        move_ue(p, env, u, idx, px, py, mv);
+        move_ue(p, env, (uint32_t)u + 1u, px, py, mv);
         if (px < 0.0 || py < 0.0 || px > (double)p.map_w || py > (double)p.map_h) atomicOr(p.flags, DCOMP_FLAG_OUTSIDE_MAP);
     }
     // 5. pairs at the new position; drop lost connections (user.py:175-188); EWMA from the stale rates (user.py:148-157)
@@ -733,7 +750,7 @@ __global__ __launch_bounds__(256, (B <= 10 && UPAD <= 64) ? DCOMP_FORCE_WAVES : 
     }
     // 8. observation, reward, info
     write_outputs<B, UPAD, false>(p, sh, active, env, env_local, u, idx, wave, lane, gbase, conn, in_range, l2, cnt, util, curr,
-                                  reward_before);
+                                  reward_before, active, p.U);
 }
 
 // MobileEnv.reset (base.py:169-189): user.py:98-116 + movement.py:110-122 + first observation.
@@ -749,14 +766,15 @@ __global__ __launch_bounds__(256) void reset_kernel(const KParams p)
     const int idx = env * p.U + u;
     const int gbase = lane & ~(G::WG - 1);
 
+    const bool alive = active && u < p.U0;            // slots beyond the initial ue_list are empty after reset (base.py:177-182)
     double px = 0.0, py = 0.0;
     bool step_util = false;
     float dr_req = 1.f;
-    if (active) {
+    if (alive) {
         UeCfg c = p.ue_cfg[u];
         step_util = c.util == DCOMP_UTIL_STEP; dr_req = c.dr_req;
         int x, y;
-        if (p.rng_mode == DCOMP_RNG_TAPE) { x = p.tape_pos0[2 * idx]; y = p.tape_pos0[2 * idx + 1]; }
+        if (p.rng_mode == DCOMP_RNG_TAPE) { const size_t t = (size_t)env * p.U0 + u; x = p.tape_pos0[2 * t]; y = p.tape_pos0[2 * t + 1]; }
         else {
             uint32_t r[4];
             philox4x32_10(p.env_base + (uint32_t)env, (uint32_t)u, p.episode, 0u, p.seed_lo, p.seed_hi, r);
@@ -767,28 +785,38 @@ __global__ __launch_bounds__(256) void reset_kernel(const KParams p)
         if (c.init_y >= 0) y = c.init_y;
         px = (double)x; py = (double)y;
         uint32_t vel, wx, wy;
-        draw_triple(p, env, u, idx, 0u, vel, wx, wy);
+        draw_triple(p, env, (uint32_t)u + 1u, 0u, vel, wx, wy);
         p.pos[idx] = make_double2(px, py);
         p.mv[idx] = mv_pack(wx, wy, vel, 0u, 0u, 1u);
         p.conn[idx] = 0u;
         p.ewma[idx] = 0.f;
+        if (p.uid) p.uid[idx] = (uint16_t)(u + 1);
+        if (p.orig_consumed) p.orig_consumed[(size_t)env * p.U0 + u] = 0xFFFFu;
+    } else if (active) {
+        p.pos[idx] = make_double2(0.0, 0.0);
+        p.mv[idx] = 0ull;
+        p.conn[idx] = 0u;
+        p.ewma[idx] = 0.f;
+        if (p.uid) p.uid[idx] = 0;
     }
     float l2[B], cnt[B];
     const uint32_t in_range = eval_pairs<B>(px, py, p, l2);
 #pragma unroll
     for (int b = 0; b < B; b++) cnt[b] = 0.f;
     const float util = ue_utility(0.f, step_util, dr_req);
-    write_outputs<B, UPAD, true>(p, sh, active, env, env_local, u, idx, wave, lane, gbase, 0u, in_range, l2, cnt, util, 0.f, 0.f);
+    write_outputs<B, UPAD, true>(p, sh, active, env, env_local, u, idx, wave, lane, gbase, 0u, in_range, l2, cnt, util, 0.f, 0.f, alive,
+                                 p.U0);
 }
 
 }  // namespace dcomp
 #include "dcomp_wide.h"
+#include "dcomp_dyn.h"
 namespace dcomp {
 
 using KernelFn = void (*)(const KParams);
 // step_wide: organisation for envs of >= 64 lanes (dcomp_wide.h); nullptr for narrower envs.  It has no max-cap
 // path, the host falls back to `step` when a BS is max-cap.
-struct KernelPair { KernelFn step, reset, step_wide; };
+struct KernelPair { KernelFn step, reset, step_wide, step_dyn; };   // step_dyn: UEs arrive / depart (dcomp_dyn.h), UPAD <= 64
 
 template <int B, int UPAD, int MP>
 inline KernelFn wide_or_null()
@@ -800,11 +828,18 @@ inline KernelFn wide_or_null()
 }
 
 template <int B, int UPAD>
+inline KernelFn dyn_or_null()
+{
+    if constexpr (UPAD <= 64) return step_kernel_dyn<B, UPAD>;
+    else return nullptr;
+}
+
+template <int B, int UPAD>
 inline KernelPair make_pair_(int mp)
 {
-    if (mp == MP_RES_FAIR) return KernelPair{step_kernel<B, UPAD, MP_RES_FAIR>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_RES_FAIR>()};
-    if (mp == MP_MIXED) return KernelPair{step_kernel<B, UPAD, MP_MIXED>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_MIXED>()};
-    return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_GENERIC>()};
+    if (mp == MP_RES_FAIR) return KernelPair{step_kernel<B, UPAD, MP_RES_FAIR>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_RES_FAIR>(), dyn_or_null<B, UPAD>()};
+    if (mp == MP_MIXED) return KernelPair{step_kernel<B, UPAD, MP_MIXED>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_MIXED>(), dyn_or_null<B, UPAD>()};
+    return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_GENERIC>(), dyn_or_null<B, UPAD>()};
 }
 
 // One translation unit per B instantiates all UPAD widths (dcomp_inst_bXX.hip).
@@ -819,7 +854,7 @@ inline KernelPair kernels_for_upad(int upad, int mp)
     case 64: return make_pair_<B, 64>(mp);
     case 128: return make_pair_<B, 128>(mp);
     case 256: return make_pair_<B, 256>(mp);
-    default: return KernelPair{nullptr, nullptr, nullptr};
+    default: return KernelPair{nullptr, nullptr, nullptr, nullptr};
     }
 }
 

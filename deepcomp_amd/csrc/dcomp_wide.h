@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
     // move first (base.py:447 -> user.py:159-173); keep the old position for the pre-move pairs
     const double ox = px, oy = py;
     if (active) {
-        move_ue(p, env, u, idx, px, py, mv);
+        move_ue(p, env, (uint32_t)u + 1u, px, py, mv);
         if (px < 0.0 || py < 0.0 || px > (double)p.map_w || py > (double)p.map_h) atomicOr(p.flags, DCOMP_FLAG_OUTSIDE_MAP);
     }
 

@@ -126,12 +126,13 @@ def build_from_scenario(scn: scenarios.Scenario):
     return m, bs_list, ue_list
 
 
-def make_env_config(scn, seed=42, episode_length=100, reward='avg', rand_episodes=False, num_envs=1, **extra):
+def make_env_config(scn, seed=42, episode_length=100, reward='avg', rand_episodes=False, num_envs=1, ue_arrival=None,
+                    new_ue_interval=None, **extra):
     """The env_config dict of env_setup.create_env_config (env_setup.py:247-256) for a scenario table."""
     m, bs_list, ue_list = build_from_scenario(scn)
     cfg = {'episode_length': episode_length, 'seed': seed, 'map': m, 'bs_list': bs_list, 'ue_list': ue_list,
-           'rand_episodes': rand_episodes, 'new_ue_interval': None, 'reward': reward, 'max_ues': None,
-           'ue_arrival': None, 'log_metrics': True, 'dashboard': False, 'ue_details': False,
+           'rand_episodes': rand_episodes, 'new_ue_interval': new_ue_interval, 'reward': reward, 'max_ues': None,
+           'ue_arrival': ue_arrival, 'log_metrics': True, 'dashboard': False, 'ue_details': False,
            'num_envs': num_envs}
     cfg.update(extra)
     return cfg

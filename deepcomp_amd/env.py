@@ -32,7 +32,7 @@ class BatchedMobileEnv:
 
     def __init__(self, map, bs_list, ue_list, kind, num_envs=1, seed=42, episode_length=100, reward='avg',
                  rand_episodes=False, rng='philox', device='cuda', env_id_base=0, env_seeds=None, log_metrics=True,
-                 tape_depth=None):
+                 tape_depth=None, ue_arrival=None, new_ue_interval=None, max_ues=None):
         L = _lib.load()
         self._L = L
         self.device = torch.device(device)
@@ -41,7 +41,19 @@ class BatchedMobileEnv:
         if self.device.index is None:
             self.device = torch.device('cuda', torch.cuda.current_device())
         self.kind = _lib.MULTI if kind in ('multi', _lib.MULTI) else _lib.CENTRAL
-        self.E, self.U, self.B = int(num_envs), len(ue_list), len(bs_list)
+        # UE arrival / departure (base.py:52-56, 433-443): U = slots per env = max_ues (base.py:79-84), U0 = initial list
+        self.ue_arrival = {int(k): int(v) for k, v in ue_arrival.items()} if ue_arrival else None
+        self.new_ue_interval = None if self.ue_arrival else new_ue_interval
+        self.U0 = len(ue_list)
+        self.dynamic = bool(self.ue_arrival) or self.new_ue_interval is not None
+        auto_max = _rng.max_num_ue(self.U0, int(episode_length), self.ue_arrival, self.new_ue_interval)
+        cap = int(max_ues) if max_ues else auto_max
+        assert cap >= self.U0                                                         # base.py:84
+        if self.dynamic and cap < auto_max:
+            raise ValueError(f"max_ues={cap} is smaller than the schedule needs ({auto_max})")
+        self.schedule = _rng.arrival_schedule(int(episode_length), self.ue_arrival, self.new_ue_interval) if self.dynamic else None
+        self.max_id = self.U0 + (sum(a for _, a in self.schedule) if self.dynamic else 0)
+        self.E, self.U, self.B = int(num_envs), (cap if self.dynamic else self.U0), len(bs_list)
         self.map_w, self.map_h = int(map.width), int(map.height)
         self.episode_length = int(episode_length)
         self.rand_episodes = bool(rand_episodes)
@@ -59,7 +71,7 @@ class BatchedMobileEnv:
         self.env_seeds = (np.asarray(env_seeds, dtype=np.int64) if env_seeds is not None
                           else self.seed_value + 20000 * (self.env_id_base + np.arange(self.E, dtype=np.int64)))
 
-        U, B = self.U, self.B
+        U, B = self.U, self.B          # U: slots per env
         self._bs_x = np.array([float(bs.pos.x) for bs in bs_list], dtype=np.float64)
         self._bs_y = np.array([float(bs.pos.y) for bs in bs_list], dtype=np.float64)
         for bs in bs_list:
@@ -79,7 +91,8 @@ class BatchedMobileEnv:
         self._iy = np.array([p[1] for p in self.init_xy], dtype=np.int32)
 
         c = _lib.DcompCfg()
-        c.num_envs, c.num_ue, c.num_bs = self.E, U, B
+        c.num_envs, c.num_ue, c.num_bs = self.E, self.U0, B
+        c.max_ues = self.U if self.dynamic else 0
         c.map_w, c.map_h = self.map_w, self.map_h
         c.env_kind, c.reward_agg = self.kind, _lib.REWARD[reward]
         c.rng_mode, c.tape_depth = self.rng_mode, self.tape_depth
@@ -117,8 +130,14 @@ class BatchedMobileEnv:
         since_bytes = ctypes.c_size_t(0)
         _lib.check(L.dcomp_state_sizes(self._h, None, None, None, None, None, ctypes.byref(since_bytes)))
         self.conn_since = torch.zeros(since_bytes.value // 2, dtype=torch.int16, device=dev) if since_bytes.value else None
+        self.uid = torch.zeros(n, dtype=torch.int16, device=dev) if self.dynamic else None
+        self.orig_consumed = torch.zeros(self.E * self.U0, dtype=torch.int16, device=dev) if self.dynamic else None
         self._st = _lib.DcompState(self.pos.data_ptr(), self.mv.data_ptr(), self.conn.data_ptr(), self.ewma.data_ptr(),
-                                   self.flags.data_ptr(), self.conn_since.data_ptr() if self.conn_since is not None else None)
+                                   self.flags.data_ptr(), self.conn_since.data_ptr() if self.conn_since is not None else None,
+                                   self.uid.data_ptr() if self.dynamic else None,
+                                   self.orig_consumed.data_ptr() if self.dynamic else None)
+        self._dyn_streams = None
+        self._ev_keep = None
         self._out = self._make_out(self.obs, self.reward)
         self._tape_dev = None
         self._streams = None
@@ -157,7 +176,32 @@ class BatchedMobileEnv:
         if self.rng_mode == _lib.RNG_PHILOX:
             raise NotImplementedError("re-seeding a Philox env: create a new env with the new seed")
 
+    def _draw_tape_dynamic(self):
+        """Reference-exact draws with UE arrival: see rng.DynamicStdlibStreams (initial UEs keep their generators)."""
+        first = self._dyn_streams is None
+        if first:
+            self._dyn_streams = _rng.DynamicStdlibStreams(self.env_seeds, self.map_w, self.map_h, self.vel_specs, self.init_xy,
+                                                         self.tape_depth, self.rand_episodes, self.max_id)
+            return self._dyn_streams.draw_episode()
+        E, U, U0 = self.E, self.U, self.U0
+        uid = self.uid.cpu().numpy().astype(np.uint16).reshape(E, U)
+        cursor = ((self.mv >> 48) & 0xFFFF).cpu().numpy().reshape(E, U)
+        left = self.orig_consumed.cpu().numpy().astype(np.uint16).reshape(E, U0)
+        n = self.num_ue
+        end_lists, consumed = [], []
+        for e in range(E):
+            end_lists.append([(int(w & 0x7FFF), bool(w & 0x8000)) for w in uid[e, :n]])
+            c = [int(x) for x in left[e]]                       # 0xFFFF: never left -> still listed, cursor of its slot
+            for slot in range(n):
+                w = int(uid[e, slot])
+                if not (w & 0x8000):
+                    c[(w & 0x7FFF) - 1] = int(cursor[e, slot])
+            consumed.append(c)
+        return self._dyn_streams.draw_episode(end_lists, consumed)
+
     def _draw_tape(self):
+        if self.dynamic:
+            return self._draw_tape_dynamic()
         if self.rand_episodes:
             if self._streams is None:
                 self._streams = _rng.StdlibStreams(self.env_seeds, self.map_w, self.map_h, self.vel_specs, self.init_xy,
@@ -178,7 +222,8 @@ class BatchedMobileEnv:
             if self.rng_mode == _lib.RNG_TAPE:
                 pos0, trip = self._draw_tape()
                 self._tape_dev = (torch.from_numpy(pos0).to(self.device), torch.from_numpy(trip.view(np.int16)).to(self.device))
-                tape = _lib.DcompTape(self._tape_dev[0].data_ptr(), self._tape_dev[1].data_ptr())
+                tape = _lib.DcompTape(self._tape_dev[0].data_ptr(), self._tape_dev[1].data_ptr(),
+                                      self.U0 + self.max_id if self.dynamic else 0)
             elif not self.rand_episodes:
                 self._L.dcomp_set_episode(self._h, 0)     # fixed episodes: same Philox counter word every reset
             _lib.check(self._L.dcomp_reset(self._h, ctypes.byref(self._st), ctypes.byref(tape) if tape else None,
@@ -191,20 +236,41 @@ class BatchedMobileEnv:
                 action.numel() != self.E * self.U:
             raise ValueError(f"action must be a contiguous uint8 tensor with {self.E}x{self.U} entries on {self.device}")
         with torch.cuda.device(self.device):
-            _lib.check(self._L.dcomp_step(self._h, ctypes.byref(self._st), ctypes.c_void_p(action.data_ptr()),
-                                          ctypes.byref(self._out), self._stream()))
+            self._launch_step(action, self._out)
         return self.obs, self.reward, None, self.info()
+
+    def _launch_step(self, action, out):
+        if not self.dynamic:
+            _lib.check(self._L.dcomp_step(self._h, ctypes.byref(self._st), ctypes.c_void_p(action.data_ptr()),
+                                          ctypes.byref(out), self._stream()))
+            return
+        t = self.time
+        n_rem, n_add = self.schedule[t] if t < len(self.schedule) else (0, 0)      # base.py:433-443
+        ev = _lib.DcompEvents(n_rem, n_add, None, None)
+        if (n_rem or n_add) and self.rng_mode == _lib.RNG_TAPE:
+            rem = torch.from_numpy(self._dyn_streams.departures(n_rem, self.num_ue)).to(self.device) if n_rem else None
+            add = torch.from_numpy(self._dyn_streams.arrivals(n_add)).to(self.device) if n_add else None
+            self._ev_keep = (rem, add)                         # keep the device buffers alive until the launch has run
+            ev = _lib.DcompEvents(n_rem, n_add, rem.data_ptr() if n_rem else None, add.data_ptr() if n_add else None)
+        _lib.check(self._L.dcomp_step_dyn(self._h, ctypes.byref(self._st), ctypes.c_void_p(action.data_ptr()),
+                                          ctypes.byref(out), ctypes.byref(ev), self._stream()))
+
+    @property
+    def num_ue(self):
+        """UEs currently in every env's list (the arrival schedule is configuration, identical for all envs)."""
+        return self._L.dcomp_num_ue(self._h)
 
     def step_into(self, action, obs, reward):
         """Like step() but writes observation / reward into caller-provided tensors (rollout buffers)."""
         out = self._make_out(obs, reward)
         with torch.cuda.device(self.device):
-            _lib.check(self._L.dcomp_step(self._h, ctypes.byref(self._st), ctypes.c_void_p(action.data_ptr()),
-                                          ctypes.byref(out), self._stream()))
+            self._launch_step(action, out)
 
     def rollout(self, actions):
         """T steps from an action tape [T, E, U] (uint8); outputs of the last step."""
         T = actions.shape[0]
+        if self.dynamic:
+            raise NotImplementedError("rollout() has no event feed; step an env with UE arrival one step at a time")
         with torch.cuda.device(self.device):
             _lib.check(self._L.dcomp_rollout(self._h, ctypes.byref(self._st), ctypes.c_void_p(actions.data_ptr()), T,
                                              ctypes.byref(self._out), self._stream()))
@@ -245,6 +311,8 @@ class BatchedMobileEnv:
             'cursor': ((mv >> 48) & 0xFFFF).astype(np.int32).reshape(E, U),
             'conn': self.conn.cpu().numpy().astype(np.uint32).reshape(E, U),
             'ewma': self.ewma.cpu().numpy().reshape(E, U),
+            'uid': (self.uid.cpu().numpy().astype(np.uint16).reshape(E, U) & 0x7FFF) if self.dynamic else
+                   np.tile(np.arange(1, U + 1, dtype=np.uint16), (E, 1)),
         }
 
 
@@ -262,15 +330,17 @@ class _RefSurfaceEnv:
         self.original_ue_list = list(self.ue_list)
         self.new_ue_interval = env_config.get('new_ue_interval')
         self.ue_arrival = env_config.get('ue_arrival')
-        if self.new_ue_interval is not None or self.ue_arrival is not None:
-            raise NotImplementedError("dynamic UE arrival/departure (base.py:433-443) is not part of the device path")
+        if self.ue_arrival is not None:                                               # base.py:52-56
+            self.ue_arrival = {int(k): v for k, v in sorted((int(k), v) for k, v in self.ue_arrival.items())}
+            self.new_ue_interval = None
         self.env_seed = env_config['seed']
         self.rand_episodes = env_config['rand_episodes']
         self.log_metrics = env_config.get('log_metrics', True)
         self.dashboard = env_config.get('dashboard', False)
         self.ue_details = env_config.get('ue_details', False)
         self.reward_agg = env_config['reward']
-        self.max_ues = env_config.get('max_ues') or len(self.ue_list)
+        self.max_ues = env_config.get('max_ues') or _rng.max_num_ue(len(self.ue_list), self.episode_length, self.ue_arrival,
+                                                                    self.new_ue_interval)      # base.py:79-83, 191-210
         assert self.max_ues >= self.num_ue                                            # base.py:84
         self.num_envs = int(env_config.get('num_envs', 1))
         self.batched = bool(env_config.get('batched', self.num_envs > 1))
@@ -281,7 +351,8 @@ class _RefSurfaceEnv:
                                      rand_episodes=self.rand_episodes, rng=env_config.get('rng', 'reference' if not self.batched else 'philox'),
                                      device=env_config.get('device', 'cuda'), env_id_base=env_config.get('env_id_base', 0),
                                      env_seeds=env_config.get('env_seeds'),
-                                     log_metrics=True)
+                                     log_metrics=True, ue_arrival=self.ue_arrival, new_ue_interval=self.new_ue_interval,
+                                     max_ues=self.max_ues if (self.ue_arrival or self.new_ue_interval) else None)
         for i, ue in enumerate(self.ue_list):
             if hasattr(ue, '_env'):
                 ue._env, ue._idx = self, i
@@ -325,6 +396,26 @@ class _RefSurfaceEnv:
     def done(self):
         return None                                                                   # base.py:371-381
 
+    def _refresh_ue_list(self):
+        """Mirror env 0's UE list (base.py:592-618): original objects for the initial UEs, new config holders for UEs
+        that arrived during the episode."""
+        if not self.core.dynamic:
+            return
+        from .entities import RandomWaypoint, User
+        words = self.core.uid[:self.core.U].cpu().numpy().astype(np.uint16)[:self.core.num_ue]
+        pos = self.core.pos[:self.core.U].cpu().numpy()
+        lst = []
+        for slot, w in enumerate(words):
+            uid, born = int(w & 0x7FFF), bool(w & 0x8000)
+            if not born:
+                ue = self.original_ue_list[uid - 1]
+            else:
+                ue = User(str(uid), self.map, float(pos[slot][0]), float(pos[slot][1]), RandomWaypoint(self.map, velocity='slow'))
+                ue._env = self
+            ue._idx = slot
+            lst.append(ue)
+        self.ue_list = lst
+
     # ---- reset / step
     def reset(self):
         self.total_utility = 0
@@ -332,6 +423,10 @@ class _RefSurfaceEnv:
         obs = self.core.reset()
         if self.batched:
             return obs
+        self.ue_list = list(self.original_ue_list)                                    # base.py:177-182
+        for i, ue in enumerate(self.ue_list):
+            if hasattr(ue, '_idx'):
+                ue._idx = i
         self.obs = self._format_obs(obs)
         return self.obs
 
@@ -342,6 +437,7 @@ class _RefSurfaceEnv:
         a = self._action_tensor(action)
         obs, reward, _, info = self.core.step(a)
         self.core.check()
+        self._refresh_ue_list()
         self.total_utility += float(info['scalar_metrics']['sum_utility'][0].item())
         self.obs = self._format_obs(obs)
         return self.obs, self._format_reward(reward), self.done(), self.info()
@@ -373,12 +469,13 @@ class CentralRelNormEnv(_RefSurfaceEnv):
 
     def _action_tensor(self, action):
         assert self.action_space.contains(action), f"Action {action} does not fit action space {self.action_space}"   # central.py:61
-        a = np.asarray(action, dtype=np.uint8)[:self.num_ue].reshape(1, -1)
-        return torch.from_numpy(np.ascontiguousarray(a)).to(self.core.device)
+        a = np.zeros((1, self.core.U), dtype=np.uint8)
+        a[0, :self.num_ue] = np.asarray(action, dtype=np.uint8)[:self.num_ue]            # central.py:63: by list position
+        return torch.from_numpy(a).to(self.core.device)
 
     def _format_obs(self, obs):
         v = {k: t[0].cpu().numpy() for k, t in self.core.obs_views(obs).items()}
-        pad = self.max_ues - self.num_ue                                               # central.py:46-55
+        pad = self.max_ues - self.core.U                                               # central.py:46-55 (dead slots are already zero rows)
         out = {'connected': [int(x) for x in v['connected']] + [0] * (pad * self.num_bs),
                'dr': [float(x) for x in v['dr']] + [0] * (pad * self.num_bs),
                'utility': [float(x) for x in v['utility']] + [0] * pad}
@@ -408,7 +505,7 @@ class MultiAgentMobileEnv(_RefSurfaceEnv):
         self.observation_space = spaces.Dict(self.obs_space_dict)
 
     def _action_tensor(self, action):
-        a = np.zeros((1, self.num_ue), dtype=np.uint8)
+        a = np.zeros((1, self.core.U), dtype=np.uint8)
         for i, ue in enumerate(self.ue_list):                                          # multi_agent.py:30 (missing ids: no-op)
             if ue.id in action:
                 v = int(action[ue.id])

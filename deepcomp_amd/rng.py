@@ -87,3 +87,117 @@ class StdlibStreams:
                 st_e.append(st)
             self._states.append(st_e)
         return pos0, trip
+
+
+def arrival_schedule(episode_length, ue_arrival=None, new_ue_interval=None):
+    """Per-step (n_remove, n_add) as MobileEnv.step applies them (base.py:433-443), indexed by env.time before the
+    step.  A ue_arrival sequence disables the interval (base.py:52-56)."""
+    sched = [(0, 0)] * int(episode_length)
+    if ue_arrival:
+        for t, n in ue_arrival.items():
+            t, n = int(t), int(n)
+            if 0 <= t < episode_length:
+                sched[t] = (-n, 0) if n < 0 else (0, n)
+    elif new_ue_interval:
+        for t in range(1, int(episode_length)):
+            if t % int(new_ue_interval) == 0:
+                sched[t] = (0, 1)
+    return sched
+
+
+def max_num_ue(num_ue, episode_length, ue_arrival=None, new_ue_interval=None):
+    """MobileEnv.get_max_num_ue (base.py:191-210)."""
+    max_ues = num_ue
+    if new_ue_interval is not None and not ue_arrival:
+        max_ues = num_ue + int((episode_length - 1) / new_ue_interval)
+    if ue_arrival:
+        cur = max_ues = num_ue
+        for _, n in sorted((int(t), int(n)) for t, n in ue_arrival.items()):
+            cur += n
+            max_ues = max(max_ues, cur)
+    return max_ues
+
+
+class DynamicStdlibStreams:
+    """Reference-exact draws when UEs arrive / depart (`rng='reference'`), for E envs.
+
+    * initial UEs: ``random.Random`` pairs that live as long as the env.  At reset the reference re-seeds
+      (rand_episodes=False) the UEs of the list as it stood at the END of the previous episode, by their POSITION in
+      that list (base.py:171-173 -> 138-143), then restores the original list (base.py:177-182): an initial UE that
+      moved up gets another seed, one that had left keeps its old stream.  Kept exactly.
+    * arriving UEs: always freshly seeded ``seed + 100*id`` and 'slow' (base.py:592-606): one tape per possible id.
+    * departures: ``random.randint(0, num_ue-1)`` of the GLOBAL generator (base.py:611); arrivals:
+      ``map.rand_border_point()`` (map.py:52-65); both seeded with the env seed by MobileEnv.seed (base.py:132-136).
+    """
+
+    def __init__(self, seeds, map_w, map_h, vel_specs, init_xy, depth, rand_episodes, max_id):
+        self.seeds = [int(s) for s in seeds]
+        self.w, self.h, self.depth, self.rand_episodes = int(map_w), int(map_h), int(depth), bool(rand_episodes)
+        self.vel = [vel_range(v) for v in vel_specs]
+        self.init_xy = list(init_xy)
+        self.U0, self.max_id = len(self.vel), int(max_id)
+        self.pos_rng = [[random.Random(s + 100 * (i + 1)) for i in range(self.U0)] for s in self.seeds]
+        self.mov_rng = [[random.Random(s + 100 * (i + 1)) for i in range(self.U0)] for s in self.seeds]
+        self.map_rng = [random.Random(s) for s in self.seeds]
+        self.glob = [random.Random(s) for s in self.seeds]
+        self._states = None
+
+    def draw_episode(self, end_lists=None, consumed=None):
+        """end_lists[e] = [(id, born)] of env e's list at the end of the previous episode; consumed[e][i] = movement
+        triples initial UE i used in it.  Returns (pos0[E*U0,2], triples[E*(U0+max_id), depth, 4])."""
+        E, U0, D = len(self.seeds), self.U0, self.depth
+        if self._states is not None:
+            for e in range(E):
+                for i in range(U0):
+                    self.mov_rng[e][i].setstate(self._states[e][i][int(consumed[e][i])])
+        if not self.rand_episodes:
+            for e, s in enumerate(self.seeds):
+                self.map_rng[e].seed(s)
+                self.glob[e].seed(s)
+                order = [(i + 1, False) for i in range(U0)] if end_lists is None else end_lists[e]
+                for pos, (uid, born) in enumerate(order):
+                    if not born:
+                        self.pos_rng[e][uid - 1].seed(s + 100 * (pos + 1))
+                        self.mov_rng[e][uid - 1].seed(s + 100 * (pos + 1))
+        ids = U0 + self.max_id
+        pos0 = np.zeros((E * U0, 2), dtype=np.int32)
+        trip = np.zeros((E * ids, D, 4), dtype=np.uint16)
+        self._states = []
+        for e, s in enumerate(self.seeds):
+            st_e = []
+            for i in range(U0):
+                ix, iy = self.init_xy[i]
+                pr, mr = self.pos_rng[e][i], self.mov_rng[e][i]
+                pos0[e * U0 + i] = (pr.randint(0, self.w) if ix < 0 else ix, pr.randint(0, self.h) if iy < 0 else iy)
+                lo, hi = self.vel[i]
+                st = [mr.getstate()]
+                for k in range(D):
+                    trip[e * ids + i, k, :3] = (mr.randint(lo, hi) if lo != hi else lo, mr.randint(10, self.w - 10),
+                                                mr.randint(10, self.h - 10))
+                    st.append(mr.getstate())
+                st_e.append(st)
+            self._states.append(st_e)
+            for j in range(self.max_id):                      # arriving UE with id j+1: fresh stream, 'slow'
+                mr = random.Random(s + 100 * (j + 1))
+                for k in range(D):
+                    trip[e * ids + U0 + j, k, :3] = (mr.randint(1, 3), mr.randint(10, self.w - 10), mr.randint(10, self.h - 10))
+        return pos0, trip
+
+    def departures(self, n_remove, num_ue):
+        out = np.zeros((len(self.seeds), n_remove), dtype=np.int32)
+        for e in range(len(self.seeds)):
+            n = num_ue
+            for k in range(n_remove):
+                out[e, k] = self.glob[e].randint(0, n - 1)
+                n -= 1
+        return out
+
+    def arrivals(self, n_add):
+        out = np.zeros((len(self.seeds), n_add, 2), dtype=np.int32)
+        for e in range(len(self.seeds)):
+            r = self.map_rng[e]
+            for k in range(n_add):
+                x, y = r.randint(0, self.w), r.randint(0, self.h)
+                border = r.choice(['left', 'right', 'top', 'bottom'])
+                out[e, k] = {'left': (0, y), 'right': (self.w - 1, y), 'top': (x, self.h - 1), 'bottom': (x, 0)}[border]
+        return out

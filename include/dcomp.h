@@ -23,6 +23,8 @@
  *   conn  uint32[E*U]      bit b set <=> UE connected to BS b                  (user.py:34 bs_dr keys)
  *   ewma  float [E*U]      exponentially weighted average rate                 (user.py:148-157)
  *   flags uint32[4]        sticky device-side error bits, read by dcomp_check()
+ *   With UE arrival / departure (cfg.max_ues > cfg.num_ue) every per-UE array has max_ues slots per env; slot =
+ *   position in the reference's env.ue_list; uid uint16[E*max_ues] holds the UE ids.
  *   conn_since uint16[E*U][B]   step at which a connection was made -- only when some BS is max-cap (oldest
  *                          connection wins rate ties, station.py:184-186); NULL otherwise
  */
@@ -60,7 +62,7 @@ typedef struct dcomp_env dcomp_env;
  * bs_sharing; ue_list -> ue_*; 'reward' -> reward_agg; 'seed' -> seed; 'episode_length'. */
 typedef struct dcomp_cfg {
     int32_t num_envs;            /* E: envs owned by this handle (one GPU's shard) */
-    int32_t num_ue;              /* U <= DCOMP_MAX_UE */
+    int32_t num_ue;              /* U <= DCOMP_MAX_UE: UEs in the configured ue_list (= after every reset) */
     int32_t num_bs;              /* B <= DCOMP_MAX_BS */
     int32_t map_w, map_h;
     int32_t env_kind;            /* DCOMP_CENTRAL | DCOMP_MULTI */
@@ -68,7 +70,7 @@ typedef struct dcomp_cfg {
     int32_t rng_mode;            /* DCOMP_RNG_TAPE (reference-exact draws supplied by the host) | DCOMP_RNG_PHILOX */
     int32_t tape_depth;          /* movement triples per UE per episode in tape mode */
     int32_t device;              /* HIP device ordinal */
-    int32_t reserved;
+    int32_t max_ues;             /* slots per env when UEs arrive / depart (base.py:79-84); 0 = num_ue (fixed list) */
     uint64_t seed;               /* Philox key */
     int64_t env_id_base;         /* global id of this shard's env 0 (results do not depend on the GPU count) */
     const double *bs_x, *bs_y;   /* host [B] */
@@ -86,6 +88,9 @@ typedef struct dcomp_state {     /* device, caller-allocated; sizes via dcomp_st
     float *ewma;
     uint32_t *flags;
     uint16_t *conn_since;        /* NULL unless dcomp_state_sizes() reports since_bytes > 0 */
+    uint16_t *uid;               /* [E*max_ues] UE id per slot, bit 15 = arrived during the episode; only with max_ues > num_ue */
+    uint16_t *orig_consumed;     /* [E*num_ue] optional: movement triples an initial UE had consumed when it left the
+                                  * list (0xFFFF = never left) -- lets a tape-mode host continue that UE's stream */
 } dcomp_state;
 
 /* Outputs of reset()/step().  obs layout = RLlib's flatten order of the reference's Dict spaces
@@ -106,9 +111,21 @@ typedef struct dcomp_out {
  * triples[E*U][depth] of {velocity, wx, wy, 0} uint16 -- the values the reference's per-UE
  * random.Random streams hand out. */
 typedef struct dcomp_tape {
-    const int32_t *pos0;
-    const uint16_t *triples;
+    const int32_t *pos0;         /* [E*num_ue][2] */
+    const uint16_t *triples;     /* [E*num_ids][depth][4]; per env: the initial UEs by position, then (UE arrival) one
+                                  * 'slow' tape per id an arriving UE can get (seed + 100*id, base.py:602-604) */
+    int32_t num_ids;             /* tapes per env; 0 = num_ue */
 } dcomp_tape;
+
+/* UE departure / arrival applied by one step, after the actions and before the rates (base.py:433-443).  The counts
+ * are the same in every env (the schedule is configuration).  Tape mode: remove_idx[E][n_remove] = the reference's
+ * random.randint(0, num_ue-1) list positions (base.py:611), add_xy[E][n_add][2] = map.rand_border_point()
+ * (map.py:52-65), both device arrays; Philox mode: NULL (keyed draws in the kernel). */
+typedef struct dcomp_events {
+    int32_t n_remove, n_add;
+    const int32_t *remove_idx;
+    const int32_t *add_xy;
+} dcomp_events;
 
 int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out);                 /* MobileEnv.__init__  base.py:27-84 */
 int dcomp_destroy(dcomp_env *env);
@@ -124,6 +141,12 @@ int dcomp_reset(dcomp_env *env, const dcomp_state *st, const dcomp_tape *tape, c
  * k = toggle BS k-1; base.py:259-263).  One fused kernel: toggle -> rates -> move -> drop -> EWMA ->
  * rates -> obs/reward. */
 int dcomp_step(dcomp_env *env, const dcomp_state *st, const uint8_t *action, const dcomp_out *out, void *stream);
+
+/* dcomp_step with this step's UE departures / arrivals (MobileEnv.step incl. base.py:433-443, add_new_ue / remove_ue
+ * base.py:592-618).  Needs cfg.max_ues > cfg.num_ue, state.uid and max_ues <= 64.  ev may be NULL (no event). */
+int dcomp_step_dyn(dcomp_env *env, const dcomp_state *st, const uint8_t *action, const dcomp_out *out,
+                   const dcomp_events *ev, void *stream);
+int dcomp_num_ue(const dcomp_env *env);               /* UEs currently in every env's list */
 
 /* T consecutive steps from an action tape actions[T][E][U] (one launch per step, no host work in
  * between); outputs of the last step only.  Used for launch-overhead-free measurement. */

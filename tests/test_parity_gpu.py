@@ -264,6 +264,159 @@ def test_heuristic_driven_rollout_matches_oracle(torch_cuda, agent_name):
     assert total_conn > E * U * 10          # the policy really holds connections
 
 
+# ------------------------------------------------------------------------------------ UE arrival / departure
+DYN = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'dyn_*.npz')))
+
+
+def _dyn_kwargs(g):
+    arr = {int(t): int(n) for t, n in zip(g['cfg_arrival_t'], g['cfg_arrival_n'])} or None
+    interval = int(g['cfg_new_ue_interval'])
+    return dict(ue_arrival=arr, new_ue_interval=interval if interval > 0 else None, max_ues=int(g['cfg_max_ues']))
+
+
+@pytest.mark.parametrize('name', DYN)
+def test_golden_dynamic_ue_trajectory(torch_cuda, name):
+    """UE arrival / departure (base.py:433-443, 592-618) against reference-run fixtures: slot order, ids, masks,
+    FP64 positions exact (incl. the reference's reseed-by-list-position behaviour across episodes)."""
+    torch = torch_cuda
+    from deepcomp_amd.entities import Basestation, Map, Point, RandomWaypoint, User
+    from deepcomp_amd.env import BatchedMobileEnv
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    inv_sh = {0: 'resource-fair', 1: 'rate-fair', 2: 'max-cap', 3: 'proportional-fair'}
+    w, h = (float(x) for x in g['cfg_map_wh_raw'])
+    m = Map(w, h)
+    bs = [Basestation(chr(65 + i), Point(x, y), inv_sh[int(s)]) for i, ((x, y), s) in enumerate(zip(g['cfg_bs_pos'], g['cfg_bs_sharing']))]
+    vel = {-1: 'slow', -2: 'fast'}
+    ues = [User(str(i + 1), m, 'random', 'random', RandomWaypoint(m, vel.get(int(v), int(v)))) for i, v in enumerate(g['cfg_ue_vel'])]
+    kind = 'central' if int(g['cfg_kind']) == 0 else 'multi'
+    core = BatchedMobileEnv(m, bs, ues, kind, num_envs=1, seed=int(g['cfg_seed']), episode_length=int(g['cfg_eps_len']),
+                            reward={0: 'avg', 1: 'sum', 2: 'min'}[int(g['cfg_reward'])], rand_episodes=bool(g['cfg_rand_episodes']),
+                            rng='reference', tape_depth=48, **_dyn_kwargs(g))
+    M, B = core.U, core.B
+    assert M == int(g['cfg_max_ues'])
+
+    def cmp(prefix, i, with_reward):
+        st = core.state_host()
+        n = int(g[f'{prefix}_num_ue'][i])
+        assert core.num_ue == n
+        assert np.array_equal(st['uid'][0], g[f'{prefix}_ue_ids'][i]), f'{prefix}[{i}] ids'
+        for k in ('pos', 'wp', 'vel'):
+            assert np.array_equal(st[k][0], g[f'{prefix}_{k}'][i]), f'{prefix}[{i}] {k} not bit-exact'
+        assert np.array_equal(st['pausing'][0], g[f'{prefix}_pausing'][i]) and np.array_equal(st['curr_pause'][0], g[f'{prefix}_curr_pause'][i])
+        conn = ((st['conn'][0][:, None] >> np.arange(B)[None, :]) & 1).astype(np.uint8)
+        assert np.array_equal(conn, g[f'{prefix}_conn'][i]), f'{prefix}[{i}] connection mask'
+        np.testing.assert_allclose(st['ewma'][0], g[f'{prefix}_ewma'][i], rtol=RTOL_RATE, atol=1e-30)
+        v = {k: t.cpu().numpy()[0] for k, t in core.obs_views().items()}
+        assert np.array_equal(v['connected'].reshape(M, B), g[f'{prefix}_obs_connected'][i])
+        np.testing.assert_allclose(v['dr'].reshape(M, B), g[f'{prefix}_obs_dr'][i], rtol=RTOL_RATE, atol=1e-30)
+        np.testing.assert_allclose(v['utility'].reshape(M), g[f'{prefix}_obs_utility'][i], atol=ATOL_OBS, rtol=0)
+        if kind == 'multi':
+            np.testing.assert_allclose(v['ues_at_bs'], g[f'{prefix}_obs_ues_at_bs'][i], atol=1e-6, rtol=0)
+            np.testing.assert_allclose(v['util_at_bs'], g[f'{prefix}_obs_util_at_bs'][i], atol=ATOL_OBS, rtol=0)
+        if with_reward:
+            np.testing.assert_allclose(core.ue_dr.cpu().numpy()[0], g['step_curr_dr'][i], rtol=RTOL_RATE, atol=1e-30)
+            np.testing.assert_allclose(core.ue_utility.cpu().numpy()[0], g['step_utility'][i], atol=ATOL_UTIL, rtol=0)
+            r = np.atleast_1d(core.reward.cpu().numpy()[0])
+            np.testing.assert_allclose(r, g['step_reward'][i], atol=ATOL_UTIL if kind == 'multi' else ATOL_OBS, rtol=0)
+            assert float(core.sum_utility.cpu().numpy()[0]) == pytest.approx(float(g['step_sum_utility'][i]), abs=ATOL_UTIL * M)
+
+    t = 0
+    for ep in range(int(g['cfg_episodes'])):
+        core.reset()
+        cmp('reset', ep, False)
+        for _ in range(int(g['cfg_eps_len'])):
+            core.step(torch.from_numpy(g['actions'][t].astype(np.uint8).reshape(1, -1)).cuda())
+            cmp('step', t, True)
+            t += 1
+        core.check()
+
+
+@pytest.mark.parametrize('kind,reward', [('multi', 'avg'), ('central', 'avg'), ('multi', 'min'), ('central', 'sum')])
+def test_oracle_parity_dynamic_philox(torch_cuda, kind, reward):
+    """UE arrival / departure at scale: Philox-keyed departures (which UE leaves differs per env) and border points,
+    identical mapping in kernel and oracle; masks / positions / ids exact."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    from oracle import oracle as orc
+    E, U0, B, L = 333, 6, 7, 60
+    arrival = {2: 3, 5: -2, 9: 4, 14: -3, 20: 2, 21: 2, 30: -4, 41: 5, 50: -6}
+    scn = scenarios.large_map('mixed').with_ues(num_static=1, num_slow=3, num_fast=2)
+    m, bs, ues = build_from_scenario(scn)
+    core = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=5, episode_length=L, reward=reward, rng='philox', rand_episodes=True,
+                            ue_arrival=arrival)
+    M = core.U
+    sched = orc.arrival_schedule(L, arrival)
+    oenvs = []
+    for e in range(E):
+        o = orc.OracleEnv(int(scn.width), int(scn.height), scn.bs_pos, scn.bs_sharing, [s['velocity'] for s in scn.ue_specs],
+                          kind=orc.MULTI if kind == 'multi' else orc.CENTRAL, reward_agg={'avg': 0, 'sum': 1, 'min': 2}[reward], max_ues=M)
+        o.set_philox(5, e)
+        oenvs.append(o)
+    ob = orc.OracleBatch(oenvs)
+    rng = np.random.default_rng(3)
+    for ep in range(2):
+        for o in oenvs:
+            o.set_episode(ep)
+        core.reset()
+        want = ob.reset()
+        got = core.obs.cpu().numpy()
+        if kind == 'central':
+            want = np.concatenate([want[:, :, :B].reshape(E, -1), want[:, :, B:2 * B].reshape(E, -1), want[:, :, 2 * B]], axis=1)
+        np.testing.assert_allclose(got, want, rtol=RTOL_RATE, atol=ATOL_OBS)
+        for t in range(L):
+            a = rng.integers(0, B + 1, size=(E, M)).astype(np.uint8)
+            a[rng.random((E, M)) < 0.5] = 0
+            n_rem, n_add = sched[t]
+            if n_rem or n_add:
+                for o in oenvs:
+                    o.set_event_counts(n_rem, n_add)
+            core.step(torch.from_numpy(a).cuda())
+            o_obs, o_rew, o_conn, o_pos = ob.step(a)
+            st = core.state_host()
+            assert core.num_ue == oenvs[0].num_ue()
+            assert np.array_equal(st['uid'], np.stack([o.uids() for o in oenvs])), f'step {t}: UE ids differ'
+            assert np.array_equal(st['conn'], o_conn) and np.array_equal(st['pos'], o_pos), f'step {t}'
+            got = core.obs.cpu().numpy()
+            want = o_obs if kind == 'multi' else np.concatenate([o_obs[:, :, :B].reshape(E, -1), o_obs[:, :, B:2 * B].reshape(E, -1), o_obs[:, :, 2 * B]], axis=1)
+            np.testing.assert_allclose(got, want, rtol=RTOL_RATE, atol=ATOL_OBS)
+            tol = (ATOL_UTIL if kind == 'multi' else ATOL_OBS) * (M if reward == 'sum' else 1)
+            np.testing.assert_allclose(core.reward.cpu().numpy(), o_rew, atol=tol, rtol=0)
+    core.check()
+
+
+def test_reference_surface_with_ue_arrival(torch_cuda):
+    """Drop-in class with env_config['ue_arrival']: observation / reward dicts follow the UE ids of the moment."""
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import make_env_config
+    from deepcomp_amd.env import CentralRelNormEnv, MultiAgentMobileEnv
+    g = np.load(os.path.join(GOLDEN, 'dyn_custom_multi_updown_s42.npz'))
+    arr = {str(int(t)): int(n) for t, n in zip(g['cfg_arrival_t'], g['cfg_arrival_n'])}
+    env = MultiAgentMobileEnv(make_env_config(scenarios.custom_map('mixed').with_ues(num_slow=2), seed=42, episode_length=40,
+                                              ue_arrival=arr))
+    assert env.max_ues == int(g['cfg_max_ues'])
+    obs = env.reset()
+    assert sorted(obs.keys()) == ['1', '2']
+    for t in range(40):
+        ids = [ue.id for ue in env.ue_list]
+        obs, rew, done, info = env.step({uid: int(g['actions'][t][i]) for i, uid in enumerate(ids)})
+        want_ids = [str(x) for x in g['step_ue_ids'][t][:int(g['step_num_ue'][t])]]
+        assert [ue.id for ue in env.ue_list] == want_ids and sorted(obs.keys()) == sorted(want_ids) == sorted(rew.keys())
+        np.testing.assert_allclose([rew[i] for i in want_ids], g['step_reward'][t][:len(want_ids)], atol=ATOL_UTIL)
+        assert [obs[i]['connected'] for i in want_ids] == g['step_obs_connected'][t][:len(want_ids)].astype(int).tolist()
+    g = np.load(os.path.join(GOLDEN, 'dyn_custom_central_interval_s43.npz'))
+    env = CentralRelNormEnv(make_env_config(scenarios.custom_map('mixed').with_ues(num_slow=1, num_fast=1), seed=43, episode_length=30,
+                                            new_ue_interval=7))
+    assert env.max_ues == 6 and env.action_space.shape == (6,)
+    obs = env.reset()
+    for t in range(30):
+        obs, rew, done, info = env.step([int(x) for x in g['actions'][t]])
+        assert len(obs['connected']) == 6 * 4 and env.num_ue == int(g['step_num_ue'][t])
+        assert obs['connected'] == g['step_obs_connected'][t].astype(int).reshape(-1).tolist()
+        assert rew == pytest.approx(float(g['step_reward'][t][0]), abs=ATOL_OBS)
+
+
 # ------------------------------------------------------------------------------------ full-size properties
 def test_full_size_properties(torch_cuda):
     """BASELINE config 3 (65 536 envs x 32 UE x 10 BS, multi-agent): size-independent invariants."""
