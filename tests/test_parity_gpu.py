@@ -386,6 +386,53 @@ def test_oracle_parity_dynamic_philox(torch_cuda, kind, reward):
     core.check()
 
 
+def test_rllib_style_adapters(torch_cuda):
+    """VectorEnv / BaseEnv protocol adapters over one batch == E independent single-env drop-in instances
+    (same seeds: env e of the batch is seeded seed + 20000*e)."""
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import make_env_config
+    from deepcomp_amd.env import CentralRelNormEnv, MultiAgentMobileEnv
+    from deepcomp_amd.rllib_adapter import CentralVectorEnv, MultiAgentBaseEnv
+    E, T = 3, 12
+    rng = np.random.default_rng(2)
+    # central
+    scn = lambda: scenarios.medium_map('mixed').with_ues(num_slow=2, num_fast=1)      # noqa: E731
+    vec = CentralVectorEnv(make_env_config(scn(), seed=7, num_envs=E, rng='reference'))
+    singles = [CentralRelNormEnv(make_env_config(scn(), seed=7 + 20000 * e)) for e in range(E)]
+    obs = vec.vector_reset()
+    for e, s in enumerate(singles):
+        o = s.reset()
+        assert obs[e]['connected'].tolist() == o['connected'] and np.allclose(obs[e]['dr'], o['dr'], atol=1e-6)
+    for t in range(T):
+        acts = rng.integers(0, 4, size=(E, 3))
+        obs, rew, dones, infos = vec.vector_step([a.tolist() for a in acts])
+        assert dones == [False] * E and infos[0]['time'] == t + 1
+        for e, s in enumerate(singles):
+            o, r, _, _ = s.step(acts[e].tolist())
+            assert obs[e]['connected'].tolist() == o['connected'] and rew[e] == pytest.approx(r, abs=1e-6)
+            assert np.allclose(obs[e]['utility'], o['utility'], atol=1e-6)
+    assert vec.observation_space.spaces['dr'].shape == (9,) and vec.num_envs == E
+    # multi-agent
+    scn = lambda: scenarios.custom_map('mixed').with_ues(num_slow=3)                  # noqa: E731
+    base = MultiAgentBaseEnv(make_env_config(scn(), seed=11, num_envs=E, rng='reference'))
+    singles = [MultiAgentMobileEnv(make_env_config(scn(), seed=11 + 20000 * e)) for e in range(E)]
+    obs, rew, dones, infos, _ = base.poll()
+    for e, s in enumerate(singles):
+        o = s.reset()
+        assert sorted(obs[e].keys()) == ['1', '2', '3'] and obs[e]['2']['connected'].tolist() == o['2']['connected']
+    for t in range(T):
+        acts = {e: {str(i + 1): int(rng.integers(0, 5)) for i in range(3)} for e in range(E)}
+        base.send_actions(acts)
+        obs, rew, dones, infos, _ = base.poll()
+        for e, s in enumerate(singles):
+            o, r, _, _ = s.step(acts[e])
+            for aid in ('1', '2', '3'):
+                assert obs[e][aid]['connected'].tolist() == o[aid]['connected']
+                assert rew[e][aid] == pytest.approx(r[aid], abs=1e-5)
+                assert np.allclose(obs[e][aid]['util_at_bs'], o[aid]['util_at_bs'], atol=1e-6)
+        assert dones[0] == {'__all__': False}
+
+
 def test_reference_surface_with_ue_arrival(torch_cuda):
     """Drop-in class with env_config['ue_arrival']: observation / reward dicts follow the UE ids of the moment."""
     from deepcomp_amd import scenarios
