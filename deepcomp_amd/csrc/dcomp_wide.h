@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
     const unsigned long long am = __ballot(active);
     const int nrows = __popcll(am);                                               // active lanes are lanes [0, nrows)
     const size_t row0 = (size_t)env * p.U + (size_t)(wave % NW) * 64;
-    for (int r = 0; r < nrows; r++) {
+    for (int r = 0; r < ((DCOMP_ABLATE & 8) ? 0 : nrows); r++) {
         const uint32_t conn_r = (uint32_t)__builtin_amdgcn_readlane((int)conn, r);
         const float util_r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(util_n), r));
         float *orow = p.obs + (row0 + r) * ROW;

@@ -19,8 +19,9 @@ if os.environ.get('ABL_MASKS'):
     MASKS = [int(x) for x in os.environ['ABL_MASKS'].split(',')]
 EXTRA = os.environ.get('ABL_FLAGS', '').split()
 TAG = os.environ.get('ABL_TAG', '')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast-honor-pragmas', '-DDCOMP_B_LIST(X)=X(10)',
-         '-DDCOMP_B_LIST_STR="10"']
+ABL_B = os.environ.get('ABL_B', '10')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast-honor-pragmas', f'-DDCOMP_B_LIST(X)=X({ABL_B})',
+         f'-DDCOMP_B_LIST_STR="{ABL_B}"']
 
 
 def build():
@@ -28,7 +29,7 @@ def build():
     procs = []
     for m in MASKS:
         so = os.path.join(VAR, f'libdcomp_hip_abl{m}{TAG}.so')
-        cmd = ['hipcc'] + FLAGS + EXTRA + [f'-DDCOMP_ABLATE={m}', '-DDCOMP_B=10', '-shared', os.path.join(CSRC, 'dcomp_inst.hip'),
+        cmd = ['hipcc'] + FLAGS + EXTRA + [f'-DDCOMP_ABLATE={m}', f'-DDCOMP_B={ABL_B}', '-shared', os.path.join(CSRC, 'dcomp_inst.hip'),
                                    os.path.join(CSRC, 'dcomp_api.hip'), '-o', so, '-lpthread']
         procs.append((m, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         if len(procs) % 6 == 0:
