@@ -27,6 +27,34 @@ def _coord(v):
     return -1 if v == 'random' else int(v)
 
 
+def parse_entities(map, bs_list, ue_list):
+    """Objects of an env_config (env_setup.py:247-256) -> flat config arrays.  Duck-typed on purpose: works with
+    deepcomp_amd.entities AND with the reference's own Map / Basestation / User / RandomWaypoint objects
+    (map.py:20-21, station.py:16-19, user.py:27-40, movement.py:96-97), which is what makes the classes below drop-in
+    behind the reference's unchanged scenario factory."""
+    for bs in bs_list:
+        assert bs.sharing_model in _lib.SHARING, f"{bs.sharing_model=} not supported."       # station.py:22
+    for ue in ue_list:
+        if ue.util_func not in _lib.UTILITY:
+            raise NotImplementedError(f"Utility function {ue.util_func} not implemented!")   # user.py:92
+    vel_specs = [ue.movement.init_velocity for ue in ue_list]
+    vr = [_rng.vel_range(v) for v in vel_specs]
+    init_xy = [(_coord(ue.init_pos_x), _coord(ue.init_pos_y)) for ue in ue_list]
+    return {
+        'map_w': int(map.width), 'map_h': int(map.height),
+        'bs_x': np.array([float(bs.pos.x) for bs in bs_list], dtype=np.float64),
+        'bs_y': np.array([float(bs.pos.y) for bs in bs_list], dtype=np.float64),
+        'bs_sharing': np.array([_lib.SHARING[bs.sharing_model] for bs in bs_list], dtype=np.int32),
+        'ue_ids': [ue.id for ue in ue_list],
+        'ue_util': np.array([_lib.UTILITY[ue.util_func] for ue in ue_list], dtype=np.int32),
+        'ue_dr_req': np.array([float(ue.dr_req) for ue in ue_list], dtype=np.float32),
+        'vel_specs': vel_specs,
+        'vel_lo': np.array([r[0] for r in vr], dtype=np.int32), 'vel_hi': np.array([r[1] for r in vr], dtype=np.int32),
+        'init_xy': init_xy,
+        'init_x': np.array([p[0] for p in init_xy], dtype=np.int32), 'init_y': np.array([p[1] for p in init_xy], dtype=np.int32),
+    }
+
+
 class BatchedMobileEnv:
     """E lock-stepped envs on one GPU.  All heavy lifting is in libdcomp_hip.so (include/dcomp.h)."""
 
@@ -72,23 +100,11 @@ class BatchedMobileEnv:
                           else self.seed_value + 20000 * (self.env_id_base + np.arange(self.E, dtype=np.int64)))
 
         U, B = self.U, self.B          # U: slots per env
-        self._bs_x = np.array([float(bs.pos.x) for bs in bs_list], dtype=np.float64)
-        self._bs_y = np.array([float(bs.pos.y) for bs in bs_list], dtype=np.float64)
-        for bs in bs_list:
-            assert bs.sharing_model in _lib.SHARING, f"{bs.sharing_model=} not supported."       # station.py:22
-        self._bs_sh = np.array([_lib.SHARING[bs.sharing_model] for bs in bs_list], dtype=np.int32)
-        for ue in ue_list:
-            if ue.util_func not in _lib.UTILITY:
-                raise NotImplementedError(f"Utility function {ue.util_func} not implemented!")   # user.py:92
-        self._ue_util = np.array([_lib.UTILITY[ue.util_func] for ue in ue_list], dtype=np.int32)
-        self._ue_req = np.array([float(ue.dr_req) for ue in ue_list], dtype=np.float32)
-        self.vel_specs = [ue.movement.init_velocity for ue in ue_list]
-        vr = [_rng.vel_range(v) for v in self.vel_specs]
-        self._vlo = np.array([r[0] for r in vr], dtype=np.int32)
-        self._vhi = np.array([r[1] for r in vr], dtype=np.int32)
-        self.init_xy = [(_coord(ue.init_pos_x), _coord(ue.init_pos_y)) for ue in ue_list]
-        self._ix = np.array([p[0] for p in self.init_xy], dtype=np.int32)
-        self._iy = np.array([p[1] for p in self.init_xy], dtype=np.int32)
+        ent = parse_entities(map, bs_list, ue_list)
+        self._bs_x, self._bs_y, self._bs_sh = ent['bs_x'], ent['bs_y'], ent['bs_sharing']
+        self._ue_util, self._ue_req = ent['ue_util'], ent['ue_dr_req']
+        self.vel_specs, self._vlo, self._vhi = ent['vel_specs'], ent['vel_lo'], ent['vel_hi']
+        self.init_xy, self._ix, self._iy = ent['init_xy'], ent['init_x'], ent['init_y']
 
         c = _lib.DcompCfg()
         c.num_envs, c.num_ue, c.num_bs = self.E, self.U0, B

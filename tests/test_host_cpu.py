@@ -139,3 +139,31 @@ def test_spaces_and_entities():
         Basestation('A', Point(0, 0), 'nope')
     with pytest.raises(AssertionError):
         User('1', m, 0, 0, RandomWaypoint(m, 1), util_func='quadratic')
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/deepcomp'), reason='needs the reference checkout (build container only)')
+def test_parse_entities_accepts_the_references_own_objects():
+    """Drop-in contract: the env constructors read the reference's unmodified Map / Basestation / User /
+    RandomWaypoint objects (built here behind the third-party stand-ins of tests/golden/_ref_shims.py)."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, 'tests', 'golden'))
+    sys.path.insert(0, '/root/reference')
+    import _ref_shims
+    _ref_shims.install()
+    from shapely.geometry import Point
+    from deepcomp.env.entities.map import Map
+    from deepcomp.env.entities.station import Basestation
+    from deepcomp.env.entities.user import User
+    from deepcomp.env.util.movement import RandomWaypoint
+    from deepcomp_amd.env import parse_entities
+    m = Map(width=194, height=120.7)
+    bs = [Basestation('A', Point(10, 60), 'resource-fair'), Basestation('B', Point(97.5, 10), 'proportional-fair')]
+    ues = [User('1', m, 'random', 'random', RandomWaypoint(m, velocity='slow')),
+           User('2', m, 30, 'random', RandomWaypoint(m, velocity='fast'), util_func='step', dr_req=2),
+           User('3', m, 'random', 7, RandomWaypoint(m, velocity=0))]
+    e = parse_entities(m, bs, ues)
+    assert (e['map_w'], e['map_h']) == (194, 120)
+    assert e['bs_x'].tolist() == [10.0, 97.5] and e['bs_sharing'].tolist() == [0, 3]
+    assert e['ue_ids'] == ['1', '2', '3'] and e['ue_util'].tolist() == [0, 1, 0] and e['ue_dr_req'].tolist() == [1.0, 2.0, 1.0]
+    assert e['vel_lo'].tolist() == [1, 5, 0] and e['vel_hi'].tolist() == [3, 10, 0]
+    assert e['init_xy'] == [(-1, -1), (30, -1), (-1, 7)]
