@@ -132,17 +132,21 @@ class BatchedMobileEnv:
         self.conn = torch.zeros(n, dtype=torch.int32, device=dev)
         self.ewma = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flags = torch.zeros(4, dtype=torch.int32, device=dev)
-        if self.kind == _lib.MULTI:
-            self.obs_dim = 4 * B + 1
-            self.obs = torch.zeros((self.E, U, self.obs_dim), dtype=torch.float32, device=dev)
-            self.reward = torch.zeros((self.E, U), dtype=torch.float32, device=dev)
-        else:
-            self.obs_dim = U * (2 * B + 1)
-            self.obs = torch.zeros((self.E, self.obs_dim), dtype=torch.float32, device=dev)
-            self.reward = torch.zeros(self.E, dtype=torch.float32, device=dev)
-        self.sum_utility = torch.zeros(self.E, dtype=torch.float32, device=dev)
-        self.ue_dr = torch.zeros((self.E, U), dtype=torch.float32, device=dev)
-        self.ue_utility = torch.zeros((self.E, U), dtype=torch.float32, device=dev)
+        # all outputs of one step live in ONE flat buffer (sections 16-byte aligned): the single-env compatibility mode
+        # fetches everything a step returns with a single device->host copy
+        self.obs_dim = 4 * B + 1 if self.kind == _lib.MULTI else U * (2 * B + 1)
+        obs_shape = (self.E, U, self.obs_dim) if self.kind == _lib.MULTI else (self.E, self.obs_dim)
+        rew_shape = (self.E, U) if self.kind == _lib.MULTI else (self.E,)
+        sections = [('obs', obs_shape), ('reward', rew_shape), ('sum_utility', (self.E,)), ('ue_dr', (self.E, U)),
+                    ('ue_utility', (self.E, U))]
+        off, self._sections = 0, {}
+        for name, shape in sections:
+            cnt = int(np.prod(shape))
+            self._sections[name] = (off, cnt, shape)
+            off += (cnt + 3) // 4 * 4
+        self._outbuf = torch.zeros(off, dtype=torch.float32, device=dev)
+        for name, (o, cnt, shape) in self._sections.items():
+            setattr(self, name, self._outbuf[o:o + cnt].view(shape))
         since_bytes = ctypes.c_size_t(0)
         _lib.check(L.dcomp_state_sizes(self._h, None, None, None, None, None, ctypes.byref(since_bytes)))
         self.conn_since = torch.zeros(since_bytes.value // 2, dtype=torch.int16, device=dev) if since_bytes.value else None
@@ -299,6 +303,19 @@ class BatchedMobileEnv:
         return {'time': self.time, 'scalar_metrics': {'sum_utility': self.sum_utility},
                 'vector_metrics': {'dr': self.ue_dr, 'utility': self.ue_utility}}
 
+    def outputs_host(self):
+        """ONE device->host copy of everything the last reset()/step() produced; dict of numpy views."""
+        h = self._outbuf.cpu().numpy()
+        return {name: h[o:o + cnt].reshape(shape) for name, (o, cnt, shape) in self._sections.items()}
+
+    def obs_views_host(self, host):
+        B, U = self.B, self.U
+        o = host['obs']
+        if self.kind == _lib.MULTI:
+            return {'connected': o[..., 0:B], 'dr': o[..., B:2 * B], 'ues_at_bs': o[..., 2 * B:3 * B],
+                    'util_at_bs': o[..., 3 * B:4 * B], 'utility': o[..., 4 * B:4 * B + 1]}
+        return {'connected': o[..., 0:U * B], 'dr': o[..., U * B:2 * U * B], 'utility': o[..., 2 * U * B:]}
+
     def check(self):
         """Synchronise and raise what the reference would have asserted (bad action, UE outside the map)."""
         with torch.cuda.device(self.device):
@@ -362,6 +379,7 @@ class _RefSurfaceEnv:
         self.batched = bool(env_config.get('batched', self.num_envs > 1))
         self.total_utility = 0
         self.obs = None
+        self._host = None
         self.core = BatchedMobileEnv(self.map, self.bs_list, self.ue_list, self.KIND, num_envs=self.num_envs,
                                      seed=self.env_seed, episode_length=self.episode_length, reward=self.reward_agg,
                                      rand_episodes=self.rand_episodes, rng=env_config.get('rng', 'reference' if not self.batched else 'philox'),
@@ -393,7 +411,7 @@ class _RefSurfaceEnv:
 
     @property
     def current_total_utility(self):
-        return float(self.core.sum_utility[0].item())
+        return float(self._host['sum_utility'][0])
 
     def seed(self, seed=None):
         self.core.seed(seed)
@@ -404,7 +422,7 @@ class _RefSurfaceEnv:
             conn = c.conn[:c.U].cpu().numpy().astype(np.uint32)
             self._view_cache = {
                 'pos': c.pos[:c.U].cpu().numpy(), 'ewma': c.ewma[:c.U].cpu().numpy().tolist(),
-                'curr_dr': c.ue_dr[0].cpu().numpy().tolist(), 'utility': c.ue_utility[0].cpu().numpy().tolist(),
+                'curr_dr': self._host['ue_dr'][0].tolist(), 'utility': self._host['ue_utility'][0].tolist(),
                 'num_conn': [int(((conn >> b) & 1).sum()) for b in range(c.B)],
             }
         return self._view_cache
@@ -443,7 +461,8 @@ class _RefSurfaceEnv:
         for i, ue in enumerate(self.ue_list):
             if hasattr(ue, '_idx'):
                 ue._idx = i
-        self.obs = self._format_obs(obs)
+        self._host = self.core.outputs_host()
+        self.obs = self._format_obs(self._host)
         return self.obs
 
     def step(self, action):
@@ -454,18 +473,18 @@ class _RefSurfaceEnv:
         obs, reward, _, info = self.core.step(a)
         self.core.check()
         self._refresh_ue_list()
-        self.total_utility += float(info['scalar_metrics']['sum_utility'][0].item())
-        self.obs = self._format_obs(obs)
-        return self.obs, self._format_reward(reward), self.done(), self.info()
+        self._host = self.core.outputs_host()                                          # one D2H copy per step
+        self.total_utility += float(self._host['sum_utility'][0])
+        self.obs = self._format_obs(self._host)
+        return self.obs, self._format_reward(self._host), self.done(), self.info()
 
     def _info_dict(self):
         """base.py:383-411"""
         if not self.log_metrics:
             return {'time': self.time}
-        dr = self.core.ue_dr[0].cpu().numpy()
-        ut = self.core.ue_utility[0].cpu().numpy()
+        dr, ut = self._host['ue_dr'][0], self._host['ue_utility'][0]
         return {'time': self.time,
-                'scalar_metrics': {'sum_utility': float(self.core.sum_utility[0].item())},
+                'scalar_metrics': {'sum_utility': float(self._host['sum_utility'][0])},
                 'vector_metrics': {'dr': {f'UE {ue}': float(dr[i]) for i, ue in enumerate(self.ue_list)},
                                    'utility': {f'UE {ue}': float(ut[i]) for i, ue in enumerate(self.ue_list)}}}
 
@@ -489,16 +508,16 @@ class CentralRelNormEnv(_RefSurfaceEnv):
         a[0, :self.num_ue] = np.asarray(action, dtype=np.uint8)[:self.num_ue]            # central.py:63: by list position
         return torch.from_numpy(a).to(self.core.device)
 
-    def _format_obs(self, obs):
-        v = {k: t[0].cpu().numpy() for k, t in self.core.obs_views(obs).items()}
+    def _format_obs(self, host):
+        v = {k: t[0] for k, t in self.core.obs_views_host(host).items()}
         pad = self.max_ues - self.core.U                                               # central.py:46-55 (dead slots are already zero rows)
         out = {'connected': [int(x) for x in v['connected']] + [0] * (pad * self.num_bs),
                'dr': [float(x) for x in v['dr']] + [0] * (pad * self.num_bs),
                'utility': [float(x) for x in v['utility']] + [0] * pad}
         return out
 
-    def _format_reward(self, reward):
-        return float(reward[0].item())
+    def _format_reward(self, host):
+        return float(host['reward'][0])
 
     def info(self):
         return self._info_dict()
@@ -530,8 +549,8 @@ class MultiAgentMobileEnv(_RefSurfaceEnv):
                 a[0, i] = v
         return torch.from_numpy(a).to(self.core.device)
 
-    def _format_obs(self, obs):
-        v = {k: t[0].cpu().numpy() for k, t in self.core.obs_views(obs).items()}
+    def _format_obs(self, host):
+        v = {k: t[0] for k, t in self.core.obs_views_host(host).items()}
         out = {}
         for i, ue in enumerate(self.ue_list):                                          # multi_agent.py:32-37, variants.py:302-303
             out[ue.id] = {'connected': [int(x) for x in v['connected'][i]], 'dr': [float(x) for x in v['dr'][i]],
@@ -539,8 +558,8 @@ class MultiAgentMobileEnv(_RefSurfaceEnv):
                           'util_at_bs': [float(x) for x in v['util_at_bs'][i]]}
         return out
 
-    def _format_reward(self, reward):
-        r = reward[0].cpu().numpy()
+    def _format_reward(self, host):
+        r = host['reward'][0]
         return {ue.id: float(r[i]) for i, ue in enumerate(self.ue_list)}
 
     def done(self):
