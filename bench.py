@@ -120,6 +120,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--rollout', type=int, default=0, help='issue steps in chunks of T through dcomp_rollout (one host call per chunk)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1 ('nccl' = RCCL; 'gloo' for single-GPU dry runs)")
+    ap.add_argument('--force-dist', action='store_true', help='initialise torch.distributed even with one rank (exercises the RCCL path on one GPU)')
     ap.add_argument('--same-device', action='store_true', help='dry run: every rank uses cuda:0')
     ap.add_argument('--no-gather', action='store_true', help='N>1: skip the per-episode all-gather of the rollout summary')
     ap.add_argument('--no-also', action='store_true', help='skip the secondary BASELINE config 2 measurement')
@@ -147,8 +148,13 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.same_device:
         local_rank = 0
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         torch.cuda.set_device(local_rank)
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
@@ -177,7 +183,7 @@ def main():
     # asynchronously on a side stream.  (All-gathering the observations themselves would be 8 x 344 MB per step.)
     gather = None
     pending = []
-    if world > 1 and not args.no_gather:
+    if use_dist and not args.no_gather:
         from deepcomp_amd.sharded import RolloutGather
         gather = RolloutGather(use_side_stream=(args.backend == 'nccl'))
 
@@ -215,7 +221,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -228,7 +234,7 @@ def main():
     pending.clear()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -272,7 +278,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(scn, args.kind, U, B)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
