@@ -277,10 +277,18 @@ def main():
             out['also'] = {'config2_4096x10x5_central': measure_small(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(scn, args.kind, U, B)
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio; flush it first so that the JSON line is the LAST line of output
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:      # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':
