@@ -663,11 +663,8 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
     }
 }
 
-#ifndef DCOMP_FORCE_WAVES
-#define DCOMP_FORCE_WAVES 1
-#endif
 template <int B, int UPAD, int MP>
-__global__ __launch_bounds__(256, (B <= 10 && UPAD <= 64) ? DCOMP_FORCE_WAVES : 1) void step_kernel(const KParams p)
+__global__ __launch_bounds__(256) void step_kernel(const KParams p)
 {
     using G = Geo<B, UPAD>;
     __shared__ BlockSharedT<B, UPAD> sh;
