@@ -118,7 +118,11 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
     }
     env->kern = dcomp::lookup_kernels(B, env->upad, mp);
     if (!env->kern.step) { delete env; return fail(DCOMP_EUNSUPPORTED, "no kernel built for num_bs=%d (built: " DCOMP_B_LIST_STR ")", B); }
-    env->grid = (E + (256 / env->upad) - 1) / (256 / env->upad);
+    {
+        // the wide kernel (UPAD >= 64) always uses 256-thread workgroups; the others DCOMP_BLOCK
+        const int gpb = DCOMP_BLOCK >= env->upad ? DCOMP_BLOCK / env->upad : 1;
+        env->grid = (E + gpb - 1) / gpb;
+    }
     env->time = 0;
     env->episode = -1;
 
@@ -255,7 +259,7 @@ extern "C" int dcomp_reset(dcomp_env *env, const dcomp_state *st, const dcomp_ta
     env->cur_ue = env->cfg.num_ue; env->n_removed = env->n_arrived = 0;      // base.py:177-182
     kp.cur_ue = env->cur_ue;
     kp.episode = (uint32_t)env->episode;
-    hipLaunchKernelGGL(env->kern.reset, dim3(env->grid), dim3(256), 0, (hipStream_t)stream, kp);
+    hipLaunchKernelGGL(env->kern.reset, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
     HIP_TRY(hipGetLastError());
     return DCOMP_OK;
 }
@@ -269,7 +273,7 @@ extern "C" int dcomp_step(dcomp_env *env, const dcomp_state *st, const uint8_t *
     if (env->episode < 0) return fail(DCOMP_EINVAL, "step() before reset()");
     kp.action = action;
     kp.n_remove = kp.n_add = 0;
-    hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(256), 0, (hipStream_t)stream, kp);
+    hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
     HIP_TRY(hipGetLastError());
     env->time += 1;
     return DCOMP_OK;
@@ -298,7 +302,7 @@ extern "C" int dcomp_step_dyn(dcomp_env *env, const dcomp_state *st, const uint8
     kp.n_remove = nrem; kp.n_add = nadd;
     kp.ev_remove = ev ? ev->remove_idx : nullptr; kp.ev_add_xy = ev ? ev->add_xy : nullptr;
     kp.ev_rem_base = env->n_removed; kp.ev_add_base = env->n_arrived;
-    hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(256), 0, (hipStream_t)stream, kp);
+    hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
     HIP_TRY(hipGetLastError());
     env->time += 1;
     env->cur_ue += nadd - nrem;
@@ -319,7 +323,7 @@ extern "C" int dcomp_rollout(dcomp_env *env, const dcomp_state *st, const uint8_
     for (int t = 0; t < num_steps; t++) {
         kp.action = actions + stride * t;
         kp.time = (uint32_t)(env->time + t);
-        hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(256), 0, (hipStream_t)stream, kp);
+        hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
     }
     HIP_TRY(hipGetLastError());
     env->time += num_steps;

@@ -26,6 +26,10 @@
 #ifndef DCOMP_BS_IN_LDS
 #define DCOMP_BS_IN_LDS 0
 #endif
+// Workgroup size (threads).  256 in the product; tools/ablate.py also times 64 (one wavefront per workgroup).
+#ifndef DCOMP_BLOCK
+#define DCOMP_BLOCK 256
+#endif
 #ifndef DCOMP_NT_OBS
 #define DCOMP_NT_OBS 1
 #endif
@@ -366,7 +370,7 @@ template <int B, int UPAD>
 struct Geo {
     static constexpr int WG = UPAD < 64 ? UPAD : 64;        // in-wave group width
     static constexpr int NW = UPAD > 64 ? UPAD / 64 : 1;    // waves per env
-    static constexpr int GPB = 256 / UPAD;                  // envs per block
+    static constexpr int GPB = DCOMP_BLOCK >= UPAD ? DCOMP_BLOCK / UPAD : 1;   // envs per block
     static constexpr int ROW_MULTI = 4 * B + 1;
 };
 
@@ -382,7 +386,7 @@ struct StageGeo {
 
 template <int B, int UPAD>
 struct alignas(16) BlockSharedT {
-    alignas(16) float stage[4][(StageGeo<B>::WORDS + 3) / 4 * 4];   // per-wave observation staging (multi-agent layout)
+    alignas(16) float stage[DCOMP_BLOCK / 64][(StageGeo<B>::WORDS + 3) / 4 * 4];   // per-wave observation staging (multi-agent layout)
     float xw[4][B + 4];                                     // per-wave partials of the cross-wave exchange
     unsigned long long mc_key[Geo<B, UPAD>::GPB * B];       // max-cap: min squared-distance bits per (env-in-block, bs)
     uint32_t mc_win[Geo<B, UPAD>::GPB * B];
@@ -474,7 +478,7 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
         // smallest FP64 squared distance; exact ties -> first in bs.conn_ues = oldest connection, then (same step)
         // lowest UE index, which is the order base.py:259-263 appends them in.
         const int tid = threadIdx.x;
-        for (int i = tid; i < G::GPB * B; i += 256) { sh.mc_key[i] = ~0ull; sh.mc_win[i] = ~0u; }
+        for (int i = tid; i < G::GPB * B; i += DCOMP_BLOCK) { sh.mc_key[i] = ~0ull; sh.mc_win[i] = ~0u; }
         __syncthreads();
         unsigned long long key[B];
 #pragma unroll
@@ -664,7 +668,7 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
 }
 
 template <int B, int UPAD, int MP>
-__global__ __launch_bounds__(256) void step_kernel(const KParams p)
+__global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel(const KParams p)
 {
     using G = Geo<B, UPAD>;
     __shared__ BlockSharedT<B, UPAD> sh;
@@ -752,7 +756,7 @@ __global__ __launch_bounds__(256) void step_kernel(const KParams p)
 
 // MobileEnv.reset (base.py:169-189): user.py:98-116 + movement.py:110-122 + first observation.
 template <int B, int UPAD>
-__global__ __launch_bounds__(256) void reset_kernel(const KParams p)
+__global__ __launch_bounds__(DCOMP_BLOCK) void reset_kernel(const KParams p)
 {
     using G = Geo<B, UPAD>;
     __shared__ BlockSharedT<B, UPAD> sh;

@@ -22,7 +22,7 @@ __device__ __forceinline__ T shift_up(bool take, T mine, T next)
 }
 
 template <int B, int UPAD>
-__global__ __launch_bounds__(256) void step_kernel_dyn(const KParams p)
+__global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel_dyn(const KParams p)
 {
     static_assert(UPAD <= 64, "dynamic UE lists: one env must fit a wavefront");
     using G = Geo<B, UPAD>;
