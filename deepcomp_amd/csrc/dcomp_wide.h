@@ -18,7 +18,10 @@
 
 namespace dcomp {
 
-constexpr int WIDE_BC = 4;
+#ifndef DCOMP_WIDE_BC
+#define DCOMP_WIDE_BC 4
+#endif
+constexpr int WIDE_BC = DCOMP_WIDE_BC;   // BSs per chunk: 4 -> ~100 VGPRs (4-5 waves/SIMD), 8 -> ~145 (3 waves/SIMD)
 
 template <int B, int UPAD>
 struct alignas(16) WideShared {
