@@ -12,7 +12,7 @@ from .entities import Basestation, Map, Point, RandomWaypoint, User, make_env_co
 
 def __getattr__(name):
     # env classes need torch + the HIP extension; import them lazily so scenario / config code stays importable
-    if name in ('BatchedMobileEnv', 'CentralRelNormEnv', 'MultiAgentMobileEnv', 'get_env_class'):
+    if name in ('BatchedMobileEnv', 'CentralRelNormEnv', 'MultiAgentMobileEnv', 'RelNormEnv', 'get_env_class'):
         from . import env
         return getattr(env, name)
     raise AttributeError(name)

@@ -237,7 +237,7 @@ static int fill_params(dcomp_env *env, const dcomp_state *st, const dcomp_out *o
     kp.conn_since = st->conn_since;
     kp.time = (uint32_t)env->time;
     kp.pos = (double2 *)st->pos; kp.mv = (unsigned long long *)st->mv; kp.conn = st->conn; kp.ewma = st->ewma; kp.flags = st->flags;
-    kp.obs = out->obs; kp.reward = out->reward; kp.sum_util = out->sum_utility; kp.ue_dr = out->ue_dr; kp.ue_util = out->ue_utility;
+    kp.obs = out->obs; kp.reward = out->reward; kp.sum_util = out->sum_utility; kp.ue_dr = out->ue_dr; kp.ue_util = out->ue_utility; kp.rb_out = out->reward_before;
     kp.episode = (uint32_t)(env->episode < 0 ? 0 : env->episode);
     return DCOMP_OK;
 }

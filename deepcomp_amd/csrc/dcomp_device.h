@@ -65,7 +65,7 @@ struct KParams {
     uint16_t *orig_consumed;   // [E*U0] movement triples an initial UE had used when it left (0xFFFF: never left), optional
     // io (device)
     const uint8_t *action;
-    float *obs, *reward, *sum_util, *ue_dr, *ue_util;
+    float *obs, *reward, *sum_util, *ue_dr, *ue_util, *rb_out;
     // tape (device)
     const int32_t *tape_pos0;
     const ushort4 *tape_triples;
@@ -596,6 +596,7 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
     if (active) {
         if (p.ue_dr) stream_store(&p.ue_dr[idx], alive ? curr_dr : 0.f);
         if (p.ue_util) stream_store(&p.ue_util[idx], alive ? util : 0.f);
+        if (p.rb_out) stream_store(&p.rb_out[idx], alive ? reward_before : 0.f);
     }
 
     // ---- observation entries (in place): l2 -> snr_b / max snr, tsum -> avg utility at BS, cnt -> UEs at BS / U

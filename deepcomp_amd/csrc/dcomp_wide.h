@@ -312,6 +312,7 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
     if (active) {
         if (p.ue_dr) p.ue_dr[idx] = curr;
         if (p.ue_util) p.ue_util[idx] = util;
+        if (p.rb_out) p.rb_out[idx] = reward_before;
         if (p.reward) { if (multi) p.reward[idx] = reward; else if (u == 0) p.reward[env] = reward; }
     }
     const float util_n = util * (1.0f / MAX_UTIL);

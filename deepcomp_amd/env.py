@@ -86,6 +86,7 @@ class BatchedMobileEnv:
         self.episode_length = int(episode_length)
         self.rand_episodes = bool(rand_episodes)
         self.log_metrics = bool(log_metrics)
+        self.want_reward_before = False      # per-UE pre-move reward (single-agent env), off by default: 4 B/UE of extra traffic
         if reward not in _lib.REWARD:
             raise NotImplementedError(f"Unexpected reward aggregation: {reward}")       # central.py:73
         self.reward_agg = reward
@@ -138,7 +139,7 @@ class BatchedMobileEnv:
         obs_shape = (self.E, U, self.obs_dim) if self.kind == _lib.MULTI else (self.E, self.obs_dim)
         rew_shape = (self.E, U) if self.kind == _lib.MULTI else (self.E,)
         sections = [('obs', obs_shape), ('reward', rew_shape), ('sum_utility', (self.E,)), ('ue_dr', (self.E, U)),
-                    ('ue_utility', (self.E, U))]
+                    ('ue_utility', (self.E, U)), ('reward_before', (self.E, U))]
         off, self._sections = 0, {}
         for name, shape in sections:
             cnt = int(np.prod(shape))
@@ -167,7 +168,8 @@ class BatchedMobileEnv:
     def _make_out(self, obs, reward):
         m = self.log_metrics
         return _lib.DcompOut(obs.data_ptr(), reward.data_ptr(), self.sum_utility.data_ptr() if m else None,
-                             self.ue_dr.data_ptr() if m else None, self.ue_utility.data_ptr() if m else None)
+                             self.ue_dr.data_ptr() if m else None, self.ue_utility.data_ptr() if m else None,
+                             self.reward_before.data_ptr() if self.want_reward_before else None)
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -302,6 +304,11 @@ class BatchedMobileEnv:
             return {'time': self.time}
         return {'time': self.time, 'scalar_metrics': {'sum_utility': self.sum_utility},
                 'vector_metrics': {'dr': self.ue_dr, 'utility': self.ue_utility}}
+
+    def enable_reward_before(self):
+        """Also write the per-UE pre-move reward clip(utility)/20 (base.py:158-167, 446): the single-agent env's reward."""
+        self.want_reward_before = True
+        self._out = self._make_out(self.obs, self.reward)
 
     def outputs_host(self):
         """ONE device->host copy of everything the last reset()/step() produced; dict of numpy views."""
@@ -572,7 +579,48 @@ class MultiAgentMobileEnv(_RefSurfaceEnv):
         return {ue.id: info for ue in self.ue_list}
 
 
+class RelNormEnv(_RefSurfaceEnv):
+    """Single-agent env ('--agent single', env_setup.py:27-30): ONE UE acts per step, round robin over the UE list
+    (base.py:227-245); the observation is the next UE's RelNorm observation (base.py:350-358, variants.py:271-305), the
+    reward the acting UE's pre-move reward (base.py:360-369).  All UEs still move and share rates every step."""
+    KIND = 'multi'
+
+    def __init__(self, env_config):
+        env_config = dict(env_config)
+        env_config.setdefault('reward', 'avg')          # MobileEnv itself never reads it (base.py:27-84)
+        super().__init__(env_config)
+        self.core.enable_reward_before()
+
+    def _define_spaces(self):
+        B = self.num_bs
+        self.action_space = spaces.Discrete(B + 1)                                     # variants.py:17
+        self.obs_space_dict = {'connected': spaces.MultiBinary(B), 'dr': spaces.Box(low=0, high=1, shape=(B,)),
+                               'utility': spaces.Box(low=-1, high=1, shape=(1,)),
+                               'ues_at_bs': spaces.Box(low=0, high=1, shape=(B,)),
+                               'util_at_bs': spaces.Box(low=-1, high=1, shape=(B,))}     # variants.py:255-268
+        self.observation_space = spaces.Dict(self.obs_space_dict)
+
+    def _action_tensor(self, action):
+        assert self.action_space.contains(action), f"Action {action} does not fit action space {self.action_space}"   # base.py:238
+        a = np.zeros((1, self.core.U), dtype=np.uint8)
+        a[0, self.time % self.num_ue] = int(action)                                    # base.py:243-244
+        return torch.from_numpy(a).to(self.core.device)
+
+    def _format_obs(self, host):
+        v = {k: t[0] for k, t in self.core.obs_views_host(host).items()}
+        i = self.time % self.num_ue                                                    # base.py:357
+        return {'connected': [int(x) for x in v['connected'][i]], 'dr': [float(x) for x in v['dr'][i]],
+                'utility': [float(v['utility'][i][0])], 'ues_at_bs': [float(x) for x in v['ues_at_bs'][i]],
+                'util_at_bs': [float(x) for x in v['util_at_bs'][i]]}
+
+    def _format_reward(self, host):
+        return float(host['reward_before'][0][(self.time - 1) % self.num_ue])          # base.py:367-369
+
+    def info(self):
+        return self._info_dict()
+
+
 def get_env_class(env_type):
     """env_setup.py:23-37"""
-    assert env_type in ('central', 'multi'), f"Environment type was {env_type} but has to be 'central' or 'multi'."
-    return CentralRelNormEnv if env_type == 'central' else MultiAgentMobileEnv
+    assert env_type in ('single', 'central', 'multi'), f"Environment type was {env_type} but has to be one of single/central/multi."
+    return {'single': RelNormEnv, 'central': CentralRelNormEnv, 'multi': MultiAgentMobileEnv}[env_type]

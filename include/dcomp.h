@@ -105,6 +105,8 @@ typedef struct dcomp_out {
     float *sum_utility;
     float *ue_dr;
     float *ue_utility;
+    float *reward_before;        /* optional [E][U]: clip(utility at the pre-move rates)/20 per UE (base.py:158-167, 446) --
+                                  * the reward the single-agent env hands out (base.py:358-369); NULL to skip */
 } dcomp_out;
 
 /* Tape-mode draws for one episode (device): pos0[E*U][2] int32 start positions and

@@ -487,6 +487,9 @@ void orc_get_obs(const orc_env *e, double *connected, double *dr, double *utilit
         }
     }
 }
+/* per-UE reward of base.py:446 (clip(utility)/20 at the pre-move rates): what the single-agent env returns for the
+ * UE that acted (base.py:360-369) */
+void orc_get_reward_before(const orc_env *e, double *out) { for (int u = 0; u < e->U; u++) out[u] = u < e->nU ? e->reward_before[u] : 0.0; }
 void orc_get_reward(const orc_env *e, double *reward)
 {
     int n = e->kind == ORC_CENTRAL ? 1 : e->U;

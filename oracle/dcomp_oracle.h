@@ -64,6 +64,7 @@ int  orc_step(orc_env *e, const int32_t *action /*[U]*/);   /* base.py:413-466; 
 void orc_get_obs(const orc_env *e, double *connected /*[U*B]*/, double *dr /*[U*B]*/, double *utility /*[U]*/,
                  double *ues_at_bs /*[U*B] or NULL*/, double *util_at_bs /*[U*B] or NULL*/);
 void orc_get_reward(const orc_env *e, double *reward /*[1] central, [U] multi*/);
+void orc_get_reward_before(const orc_env *e, double *out /*[U]*/);   /* base.py:446 rewards, single-agent env base.py:360-369 */
 void orc_get_state(const orc_env *e, double *pos /*[U*2]*/, double *wp /*[U*2]*/, double *vel /*[U]*/,
                    int32_t *pausing, int32_t *curr_pause, uint8_t *conn /*[U*B]*/, double *dr /*[U*B]*/,
                    double *curr_dr, double *ewma, double *utility, int32_t *conn_order /*[B*U], -1 padded*/);

@@ -60,6 +60,7 @@ def lib():
         L.orc_step.restype = ctypes.c_int
         L.orc_get_obs.argtypes = [ctypes.c_void_p, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]
         L.orc_get_reward.argtypes = [ctypes.c_void_p, _c_dp]
+        L.orc_get_reward_before.argtypes = [ctypes.c_void_p, _c_dp]
         L.orc_get_state.argtypes = [ctypes.c_void_p, _c_dp, _c_dp, _c_dp, _c_ip, _c_ip, _c_u8p, _c_dp, _c_dp, _c_dp,
                                     _c_dp, _c_ip]
         L.orc_sum_utility.argtypes = [ctypes.c_void_p]
@@ -258,6 +259,11 @@ class OracleEnv:
     def reward(self):
         r = np.zeros(1 if self.kind == CENTRAL else self.U)
         lib().orc_get_reward(self.h, _p(r, _c_dp))
+        return r
+
+    def reward_before(self):
+        r = np.zeros(self.U)
+        lib().orc_get_reward_before(self.h, _p(r, _c_dp))
         return r
 
     def state(self):

@@ -39,6 +39,7 @@ from deepcomp.env.util.movement import RandomWaypoint  # noqa: E402
 from deepcomp.env.util import utility as ref_utility  # noqa: E402
 from deepcomp.env.multi_ue.central import CentralRelNormEnv  # noqa: E402
 from deepcomp.env.multi_ue.multi_agent import MultiAgentMobileEnv  # noqa: E402
+from deepcomp.env.single_ue.variants import RelNormEnv  # noqa: E402
 
 from deepcomp_amd import scenarios  # noqa: E402  (geometry numbers only)
 
@@ -412,6 +413,38 @@ def gen_dynamic():
                            ue_arrival={2: 2, 9: -1, 12: 2, 20: -3}, episodes=2, rand_episodes=False, reward='min')
 
 
+def gen_single():
+    """G9: the single-agent env ('--agent single' -> RelNormEnv, env_setup.py:27-30): one UE acts per step."""
+    for name, scn, seed in [('single_custom3x4_s42', scenarios.custom_map('mixed').with_ues(num_slow=2, num_fast=1), 42),
+                            ('single_small2x2_s43', scenarios.small_map('mixed').with_ues(num_slow=2), 43)]:
+        m, bs_list, ue_list = build_ref(scn, scn.ue_specs)
+        env = RelNormEnv(env_config(m, bs_list, ue_list, seed, eps_len=60))
+        U, B, T = env.num_ue, env.num_bs, 60
+        rng = random.Random(5)
+        acts = np.array([rng.randint(0, B) for _ in range(T)], dtype=np.int32)
+        keys = ('connected', 'dr', 'utility', 'ues_at_bs', 'util_at_bs')
+        rec = {k: [] for k in keys}
+        rec.update(reward=[], pos=[], conn=[])
+
+        def put(obs):
+            for k in keys:
+                rec[k].append(np.array(obs[k], dtype=np.float64))
+        put(env.reset())
+        for t in range(T):
+            obs, r, done, info = env.step(int(acts[t]))
+            assert done is None
+            put(obs)
+            rec['reward'].append(float(r))
+            rec['pos'].append([[ue.pos.x, ue.pos.y] for ue in ue_list])
+            rec['conn'].append([[int(bs in ue.bs_dr) for bs in bs_list] for ue in ue_list])
+        out = {'cfg_seed': np.array(seed), 'actions': acts, 'reward': np.array(rec['reward']), 'pos': np.array(rec['pos']),
+               'conn': np.array(rec['conn'], dtype=np.uint8)}
+        for k in keys:
+            out['obs_' + k] = np.stack(rec[k])          # [T+1, ...]: reset obs first
+        np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+        print(f'{name}: ok U={U} B={B}')
+
+
 def gen_heuristics():
     """G7: decisions of the reference's heuristic agents (agent/heuristics.py) on recorded observations."""
     from deepcomp.agent.heuristics import DynamicSelection, FullCoMP, Heuristic3GPP, StaticClustering
@@ -445,3 +478,4 @@ if __name__ == '__main__':
     gen_estack()
     gen_heuristics()
     gen_dynamic()
+    gen_single()

@@ -243,3 +243,34 @@ def test_dynamic_ue_trajectory(name):
             assert env.sum_utility() == pytest.approx(float(g['step_sum_utility'][t]), rel=1e-9, abs=1e-12)
             t += 1
         consumed, end_list = env.orig_consumed(), env.end_of_episode_list()
+
+
+# ------------------------------------------------------------------ G9 single-agent env (base.py:227-245, 350-369)
+@pytest.mark.parametrize('name,scn_args', [('single_custom3x4_s42', ('custom', 2, 1)), ('single_small2x2_s43', ('small', 2, 0))])
+def test_single_agent_env(name, scn_args):
+    """'--agent single' -> RelNormEnv: one UE acts per step (round robin), obs of the next UE, reward of the acting UE."""
+    from deepcomp_amd import scenarios
+    g = load(name)
+    scn = scenarios.get_scenario(scn_args[0], 'mixed').with_ues(num_slow=scn_args[1], num_fast=scn_args[2])
+    vel = [s['velocity'] for s in scn.ue_specs]
+    U, B = len(vel), scn.num_bs
+    env = orc.OracleEnv(int(scn.width), int(scn.height), scn.bs_pos, scn.bs_sharing, vel, kind=orc.MULTI)
+    tape = orc.RefRngTape(int(g['cfg_seed']), int(scn.width), int(scn.height), vel, depth=40)
+    env.set_tape(*tape.draw_episode())
+    env.reset()
+
+    def check_obs(t):
+        o, i = env.obs(), env.time() % U
+        assert np.array_equal(o['connected'][i], g['obs_connected'][t])
+        np.testing.assert_allclose(o['dr'][i], g['obs_dr'][t], rtol=1e-12)
+        np.testing.assert_allclose(o['utility'][i], g['obs_utility'][t][0], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(o['ues_at_bs'][i], g['obs_ues_at_bs'][t], rtol=1e-12)
+        np.testing.assert_allclose(o['util_at_bs'][i], g['obs_util_at_bs'][t], rtol=1e-9, atol=1e-12)
+    check_obs(0)
+    for t in range(len(g['actions'])):
+        a = np.zeros(U, np.int32)
+        a[env.time() % U] = g['actions'][t]
+        env.step(a)
+        check_obs(t + 1)
+        assert env.reward_before()[(env.time() - 1) % U] == pytest.approx(float(g['reward'][t]), rel=1e-9, abs=1e-12)
+        assert np.array_equal(env.state()['pos'], g['pos'][t]) and np.array_equal(env.state()['conn'], g['conn'][t])

@@ -386,6 +386,32 @@ def test_oracle_parity_dynamic_philox(torch_cuda, kind, reward):
     core.check()
 
 
+def test_single_agent_env_matches_reference(torch_cuda):
+    """'--agent single' drop-in (RelNormEnv): fixtures recorded from the reference's RelNormEnv."""
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import make_env_config
+    from deepcomp_amd.env import RelNormEnv, get_env_class
+    assert get_env_class('single') is RelNormEnv
+    for name, scn in [('single_custom3x4_s42', scenarios.custom_map('mixed').with_ues(num_slow=2, num_fast=1)),
+                      ('single_small2x2_s43', scenarios.small_map('mixed').with_ues(num_slow=2))]:
+        g = np.load(os.path.join(GOLDEN, name + '.npz'))
+        env = RelNormEnv(make_env_config(scn, seed=int(g['cfg_seed']), episode_length=60))
+        obs = env.reset()
+        assert obs['connected'] == g['obs_connected'][0].astype(int).tolist()
+        np.testing.assert_allclose(obs['dr'], g['obs_dr'][0], rtol=RTOL_RATE)
+        for t, a in enumerate(g['actions']):
+            obs, rew, done, info = env.step(int(a))
+            assert done is None and isinstance(rew, float)
+            assert rew == pytest.approx(float(g['reward'][t]), abs=ATOL_OBS)
+            assert obs['connected'] == g['obs_connected'][t + 1].astype(int).tolist()
+            np.testing.assert_allclose(obs['dr'], g['obs_dr'][t + 1], rtol=RTOL_RATE, atol=1e-30)
+            np.testing.assert_allclose(obs['utility'], g['obs_utility'][t + 1], atol=ATOL_OBS)
+            np.testing.assert_allclose(obs['ues_at_bs'], g['obs_ues_at_bs'][t + 1], atol=1e-6)
+            np.testing.assert_allclose(obs['util_at_bs'], g['obs_util_at_bs'][t + 1], atol=ATOL_OBS)
+        with pytest.raises(AssertionError):
+            env.step(env.num_bs + 1)                                               # base.py:238
+
+
 def test_rllib_style_adapters(torch_cuda):
     """VectorEnv / BaseEnv protocol adapters over one batch == E independent single-env drop-in instances
     (same seeds: env e of the batch is seeded seed + 20000*e)."""
