@@ -6,7 +6,9 @@
 // a wavefront and one LDS exchange across wavefronts when U > 64.  The BS table (x, y, sharing mode) is
 // wave-uniform: it lives in the kernel-argument segment and is read with scalar loads into SGPRs, the B
 // loop is fully unrolled (B is a template parameter).  No [U,B] intermediate ever reaches HBM: one read
-// and one write of the UE state, one write of the observation row.
+// and one write of the UE state, one write of the observation row (staged through LDS so that every store
+// instruction covers 1 KiB contiguous, non-temporal).  Variants: dcomp_wide.h (B > 24 with >= 64 lanes per env),
+// dcomp_dyn.h (UE arrival / departure).
 //
 // Numerics: position / movement / connect-drop decisions in FP64 with the reference's operation order
 // (bit-exact masks); SNR, rates, utility, observation in FP32 in the log2 domain (no overflow at d -> 0).
@@ -16,22 +18,23 @@
 
 #include "../../include/dcomp.h"
 
-// Ablation builds (tools/ablate.py) compile timing-only variants with stages removed; the product build has 0.
+// Build switches.  The product build uses the defaults; tools/ablate.py builds timing-only variants.
+// DCOMP_ABLATE    bit mask of pipeline stages to leave out (results are wrong by construction; timing only)
+// DCOMP_NT_OBS    1: write-once output streams (observation rows, rewards, info) use non-temporal stores -- measured
+//                 0.1008 -> 0.0875 ms per step at config 3 (they stop competing with the state lines for L2)
+// DCOMP_BS_IN_LDS 1: read the BS table from an LDS copy instead of SGPRs (north_star wording) -- measured 10 % slower
+// DCOMP_BLOCK     workgroup size; 128 / 64 measured 3-6 % slower than 256
 #ifndef DCOMP_ABLATE
 #define DCOMP_ABLATE 0
 #endif
-// Write-once output streams (observation rows, rewards, info) use non-temporal stores: measured 0.1008 -> 0.0875 ms
-// per step at config 3 (they no longer compete with the read-modify-write state lines for L2).
-// Experiment switch (tools/ablate.py): read the BS table from an LDS copy instead of SGPRs (north_star wording).
+#ifndef DCOMP_NT_OBS
+#define DCOMP_NT_OBS 1
+#endif
 #ifndef DCOMP_BS_IN_LDS
 #define DCOMP_BS_IN_LDS 0
 #endif
-// Workgroup size (threads).  256 in the product; tools/ablate.py also times 64 (one wavefront per workgroup).
 #ifndef DCOMP_BLOCK
 #define DCOMP_BLOCK 256
-#endif
-#ifndef DCOMP_NT_OBS
-#define DCOMP_NT_OBS 1
 #endif
 
 namespace dcomp {
