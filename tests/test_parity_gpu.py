@@ -567,6 +567,38 @@ def test_full_size_oracle_parity(torch_cuda):
     core.check()
 
 
+def test_long_horizon_soak(torch_cuda):
+    """3 000 steps (30 episodes, resets in between) of 64 envs against the oracle: FP64 positions and masks must
+    still be bit-identical at the end -- no drift, no error flag (UE outside the map, bad action)."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    E, U, B, L = 64, 32, 10, 100
+    scn = scenarios.grid_map(B, 'mixed').with_ues(num_static=2, num_slow=22, num_fast=8)
+    m, bs, ues = build_from_scenario(scn)
+    core = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=E, seed=2024, rng='philox', rand_episodes=True, episode_length=L)
+    ob = _oracle_batch(scn, 'multi', 'avg', E, 2024)
+    rng = np.random.default_rng(99)
+    for ep in range(30):
+        for o in ob.envs:
+            o.set_episode(ep)
+        core.reset()
+        ob.reset()
+        acts = rng.integers(0, B + 1, size=(L, E, U)).astype(np.uint8)
+        acts[rng.random((L, E, U)) < 0.6] = 0
+        dev_acts = torch.from_numpy(acts).cuda()
+        for t in range(L):
+            core.step(dev_acts[t])
+            o_obs, o_rew, o_conn, o_pos = ob.step(acts[t])
+        st = core.state_host()
+        assert np.array_equal(st['pos'], o_pos) and np.array_equal(st['conn'], o_conn), f'episode {ep}'
+        np.testing.assert_allclose(core.obs.cpu().numpy(), o_obs, rtol=RTOL_RATE, atol=ATOL_OBS)
+        np.testing.assert_allclose(core.ewma.cpu().numpy().reshape(E, U), np.stack([o.state()['ewma'] for o in ob.envs]),
+                                   rtol=2e-5, atol=1e-12)
+    core.check()
+
+
 def test_bad_action_flag(torch_cuda):
     torch = torch_cuda
     from deepcomp_amd import scenarios
