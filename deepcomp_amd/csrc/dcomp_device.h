@@ -36,6 +36,9 @@
 #ifndef DCOMP_BLOCK
 #define DCOMP_BLOCK 256
 #endif
+#ifndef DCOMP_NT_STATE
+#define DCOMP_NT_STATE 0     // experiment: bit 0 non-temporal state loads, bit 1 non-temporal state stores
+#endif
 
 namespace dcomp {
 
@@ -695,12 +698,22 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel(const KParams p)
     bool step_util = false;
     float dr_req = 1.f;
     if (active) {
+#if DCOMP_NT_STATE & 1
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        d2v q = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p.pos) + idx);
+        px = q.x; py = q.y;
+        mv = __builtin_nontemporal_load(p.mv + idx);
+        conn = __builtin_nontemporal_load(p.conn + idx);
+        ewma = __builtin_nontemporal_load(p.ewma + idx);
+        act = __builtin_nontemporal_load(p.action + idx);
+#else
         double2 q = p.pos[idx];
         px = q.x; py = q.y;
         mv = p.mv[idx];
         conn = p.conn[idx];
         ewma = p.ewma[idx];
         act = p.action[idx];
+#endif
         if (!p.all_log_util) { UeCfg c = p.ue_cfg[u]; step_util = c.util == DCOMP_UTIL_STEP; dr_req = c.dr_req; }
     }
 
@@ -748,10 +761,19 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel(const KParams p)
     const float util = ue_utility(curr, step_util, dr_req);
     // 7. state write-back
     if (active) {
+#if DCOMP_NT_STATE & 2
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        d2v q; q.x = px; q.y = py;
+        __builtin_nontemporal_store(q, reinterpret_cast<d2v *>(p.pos) + idx);
+        __builtin_nontemporal_store(mv, p.mv + idx);
+        __builtin_nontemporal_store(conn, p.conn + idx);
+        __builtin_nontemporal_store(ewma, p.ewma + idx);
+#else
         p.pos[idx] = make_double2(px, py);
         p.mv[idx] = mv;
         p.conn[idx] = conn;
         p.ewma[idx] = ewma;
+#endif
     }
     // 8. observation, reward, info
     write_outputs<B, UPAD, false>(p, sh, active, env, env_local, u, idx, wave, lane, gbase, conn, in_range, l2, cnt, util, curr,
