@@ -36,6 +36,9 @@
 #ifndef DCOMP_BLOCK
 #define DCOMP_BLOCK 256
 #endif
+#ifndef DCOMP_LOG2_MODE
+#define DCOMP_LOG2_MODE 2    // log2(d^2): 0 = plain v_log_f32, 1 = frexp range reduction, 2 = 2^-12 prescale (default)
+#endif
 #ifndef DCOMP_NT_STATE
 #define DCOMP_NT_STATE 0     // experiment: bit 0 non-temporal state loads, bit 1 non-temporal state stores
 #endif
@@ -95,6 +98,7 @@ struct KParams {
     uint32_t env_base;         // global id of env 0
     float half_gamma;          // path-loss exponent c2/10, halved (applied to log2 d^2)
     float log2k;               // log2(K)
+    float log2k_s;             // log2(K) - 12 * half_gamma  (pair_eval scales d^2 by 2^-12)
     double dt2;                // squared connect-threshold distance
     double bs_x[DCOMP_MAX_BS], bs_y[DCOMP_MAX_BS];
     int32_t bs_mode[DCOMP_MAX_BS];
@@ -197,7 +201,20 @@ __device__ __forceinline__ void pair_eval(double px, double py, double bx, doubl
     in_range = dsq < p.dt2;                      // snr > 2e-8  <=>  d < d_T, decided in FP64
     float q = (float)dsq;
     tiny = q < 1e-20f;
+    // v_log_f32's absolute error scales with |result| (log2 d^2 ~ 12 near the connect range -> ~1e-6, i.e. ~1.1e-6
+    // relative in snr = 2^l2snr).  Scaling d^2 by 2^-12 first puts every in-range pair at |log2| < 4 for the price
+    // of one multiply (the exact alternative, frexp + two FMAs, costs 3 % of the step; tools/numerics_report.py has
+    // the measured errors of all three).  Tiny pairs give -inf/NaN here and are replaced by eval_pairs' fix-up.
+#if DCOMP_LOG2_MODE == 0
     l2snr = __builtin_fmaf(-p.half_gamma, fast_log2(fmaxf(q, 1e-20f)), p.log2k);
+#elif DCOMP_LOG2_MODE == 1
+    const float qc = fmaxf(q, 1e-20f);
+    const float lm = fast_log2(__builtin_amdgcn_frexp_mantf(qc));
+    const float ef = (float)__builtin_amdgcn_frexp_expf(qc);
+    l2snr = __builtin_fmaf(-p.half_gamma, ef, __builtin_fmaf(-p.half_gamma, lm, p.log2k));
+#else
+    l2snr = __builtin_fmaf(-p.half_gamma, fast_log2(q * 0x1p-12f), p.log2k_s);
+#endif
 }
 __device__ __forceinline__ float pair_eval_tiny(double px, double py, double bx, double by, const KParams &p)
 {
