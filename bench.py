@@ -106,6 +106,27 @@ def measure_small(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev, 
             'bytes_per_env_step': bytes_per_env_step(U, B, 'central')}
 
 
+def stream_ceiling(torch, dev, write_bytes, rw_bytes, iters=100):
+    """"also report against a measured device-copy bandwidth on the box".  torch's own elementwise kernels
+    (fill = write-only, out-of-place add = read + write) on buffers of the step kernel's traffic, HIP-event timed."""
+    def timed(fn):
+        for _ in range(10):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b) / iters * 1e-3
+    dst = torch.empty(write_bytes // 4, dtype=torch.float32, device=dev)
+    src = torch.ones(rw_bytes // 4, dtype=torch.float32, device=dev)
+    t_fill = timed(lambda: dst.fill_(1.0))
+    t_copy = timed(lambda: torch.add(src, 1.0, out=dst[:src.numel()]))
+    return {'fill_GBps': write_bytes / t_fill / 1e9, 'copy_GBps': 2 * rw_bytes / t_copy / 1e9,
+            'what': f'torch fill_ of {write_bytes / 1e6:.0f} MB (write-only) / out-of-place add of {rw_bytes / 1e6:.0f} MB (read+write)'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -124,6 +145,7 @@ def main():
     ap.add_argument('--same-device', action='store_true', help='dry run: every rank uses cuda:0')
     ap.add_argument('--no-gather', action='store_true', help='N>1: skip the per-episode all-gather of the rollout summary')
     ap.add_argument('--no-also', action='store_true', help='skip the secondary BASELINE config 2 measurement')
+    ap.add_argument('--no-stream', action='store_true', help='skip the measured fill/copy bandwidth (roofline.measured_stream)')
     ap.add_argument('--no-check', action='store_true', help='skip the device error-flag check (ablation builds)')
     ap.add_argument('--traffic-bytes', type=float, default=None, help='HBM bytes per launch from a rocprofv3 --pmc pass')
     args = ap.parse_args()
@@ -269,10 +291,16 @@ def main():
         }
         default_workload = (E, U, B, args.kind, args.sharing) == (65536, 32, 10, 'multi', 'mixed')
         if args.traffic_bytes is None and default_workload:
-            # PMC pass of this exact workload (profiles/r01d_nt_stores_step_kernel_summary.txt): FETCH_SIZE 33 941 KB x2 (gfx950
-            # wide-read correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE 426 261 KB, per launch
-            out['roofline']['traffic'] = (2 * 33940.93 + 426260.63) * 1024
-            out['roofline']['traffic_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01d_nt_stores_step_kernel_summary.txt'
+            # PMC pass of this exact workload (profiles/r01e_final_step_kernel_summary.txt): FETCH_SIZE 33 958 KB x2 (gfx950
+            # wide-read correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE 426 299 KB, per launch
+            out['roofline']['traffic'] = (2 * 33957.98 + 426298.89) * 1024
+            out['roofline']['traffic_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01e_final_step_kernel_summary.txt'
+        if world == 1 and not args.no_stream:
+            # the launch writes (obs + reward + info + state) and reads (state + actions); ceiling for that mix
+            wr = E * (bpe - U * 33)
+            sc = stream_ceiling(torch, dev, wr // 4 * 4, E * U * 33 // 4 * 4)
+            sc['frac_of_fill'] = achieved / sc['fill_GBps']
+            out['roofline']['measured_stream'] = sc
         if world == 1 and not args.no_also and default_workload:
             out['also'] = {'config2_4096x10x5_central': measure_small(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev)}
         if world == 1 and not args.no_cpu_baseline:

@@ -44,7 +44,7 @@ def run():
     rows = []
     for m in MASKS:
         env = dict(os.environ, DCOMP_LIB=os.path.join(VAR, f'libdcomp_hip_abl{m}{TAG}.so'))
-        r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '200', '--warmup', '20', '--no-cpu-baseline', '--no-also',
+        r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '200', '--warmup', '20', '--no-cpu-baseline', '--no-also', '--no-stream',
                             '--no-check'] + sys.argv[2:], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith('{')]
         if not line:
