@@ -186,7 +186,9 @@ def _oracle_batch(scn, kind, reward, E, seed, env_id_base=0):
                                    ('multi', 20, 7, 300, 'sum'), ('multi', 100, 12, 64, 'avg'), ('central', 130, 6, 40, 'min'),
                                    ('multi', 64, 9, 96, 'sum'), ('multi', 70, 5, 50, 'min'), ('central', 128, 32, 12, 'avg'),
                                    ('multi', 256, 3, 10, 'avg'), ('central', 60, 16, 33, 'sum'), ('multi', 16, 11, 64, 'avg'),
-                                   ('central', 8, 27, 32, 'avg'), ('multi', 5, 1, 128, 'min'), ('multi', 128, 29, 6, 'sum')])
+                                   ('central', 8, 27, 32, 'avg'), ('multi', 5, 1, 128, 'min'), ('multi', 128, 29, 6, 'sum'),
+                                   ('multi', 128, 32, 8, 'avg'), ('multi', 100, 32, 5, 'min'), ('multi', 64, 25, 8, 'avg'),
+                                   ('multi', 200, 26, 3, 'avg'), ('central', 128, 32, 4, 'min'), ('central', 256, 31, 2, 'sum')])
 def test_oracle_parity_philox(torch_cuda, shape):
     """HIP path vs CPU oracle, same Philox draws, random actions, 60 steps incl. one mid-run reset."""
     torch = torch_cuda
