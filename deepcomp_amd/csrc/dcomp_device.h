@@ -36,6 +36,9 @@
 #ifndef DCOMP_BLOCK
 #define DCOMP_BLOCK 256
 #endif
+#ifndef DCOMP_COMPILER_DIV
+#define DCOMP_COMPILER_DIV 0 // 1 = the compiler's generic FP64 sqrt / division in move_ue (A/B of norm_and_unit)
+#endif
 #ifndef DCOMP_LOG2_MODE
 #define DCOMP_LOG2_MODE 2    // log2(d^2): 0 = plain v_log_f32, 1 = frexp range reduction, 2 = 2^-12 prescale (default)
 #endif
@@ -330,6 +333,35 @@ __device__ __forceinline__ void draw_triple(const KParams &p, int env, uint32_t 
     }
 }
 
+// nrm = sqrt(vy*vy + vx*vx), nx = vx / nrm, ny = vy / nrm, correctly rounded: the compiler's own FP64 sqrt and division
+// sequences (v_rsq_f64 / v_rcp_f64 + Newton steps + residual correction) without their range scaling and special-value
+// fix-ups (v_div_scale / v_div_fmas / v_div_fixup / v_ldexp / v_cmp_class) -- the argument is a squared distance on the
+// map, 0 < q < 2^41, the numerators are below 2^17 in magnitude -- and with ONE reciprocal shared by both divisions.
+// 21 instead of 48 instructions; tests/test_parity_gpu.py holds the positions bit-exact against the CPU oracle.
+__device__ __forceinline__ void norm_and_unit(double vx, double vy, double &nrm, double &nx, double &ny)
+{
+#pragma clang fp contract(off)
+    const double x = __builtin_fma(vy, vy, vx * vx);
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    nrm = g;
+    double rc = __builtin_amdgcn_rcp(g);
+    double e = __builtin_fma(-g, rc, 1.0);
+    rc = __builtin_fma(rc, e, rc);
+    e = __builtin_fma(-g, rc, 1.0);
+    rc = __builtin_fma(rc, e, rc);
+    const double qx = vx * rc, qy = vy * rc;
+    nx = __builtin_fma(__builtin_fma(-g, qx, vx), rc, qx);
+    ny = __builtin_fma(__builtin_fma(-g, qy, vy), rc, qy);
+}
+
 // One RandomWaypoint step in FP64, in the reference's operation order.  movement.py:132-181.
 // Contraction is off: the only fused op is the explicit fma of the 2-element dot product (numpy).
 __device__ __forceinline__ void move_ue(const KParams &p, int env, uint32_t uidw, double &px, double &py, unsigned long long &mv)
@@ -365,8 +397,13 @@ __device__ __forceinline__ void move_ue(const KParams &p, int env, uint32_t uidw
         if (q <= qmax) { px = wx; py = wy; }                        // snap onto the waypoint
         else {
             double vx = wx - px, vy = wy - py;
-            double nrm = __builtin_sqrt(__builtin_fma(vy, vy, vx * vx));   // np.linalg.norm (movement.py:151)
-            double nx = vx / nrm, ny = vy / nrm;
+            double nrm, nx, ny;
+#if DCOMP_COMPILER_DIV
+            nrm = __builtin_sqrt(__builtin_fma(vy, vy, vx * vx));
+            nx = vx / nrm; ny = vy / nrm;
+#else
+            norm_and_unit(vx, vy, nrm, nx, ny);                            // np.linalg.norm, then two divisions (movement.py:151)
+#endif
             px = px + (double)vel * nx;
             py = py + (double)vel * ny;
         }
