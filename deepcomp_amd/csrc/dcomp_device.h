@@ -144,13 +144,22 @@ __device__ __forceinline__ float group_reduce(float v)
 #endif
     return v;
 }
-// Number of lanes of my W-group whose predicate holds (ballot + popcount: scalar mask, 3 VALU).
+// Set bits of a ballot mask inside my W-lane group.  All in 32-bit pieces: `(float)__popcll(m >> gbase & mask)` makes the
+// compiler carry the count as a 64-bit integer and expand a u64 -> f32 conversion (7 VALU per count instead of 3).
+template <int W>
+__device__ __forceinline__ int group_popcount(unsigned long long m, int gbase)
+{
+    const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+    if (W == 64) return __builtin_popcount(lo) + __builtin_popcount(hi);              // scalar
+    if (W == 32) { const int cl = __builtin_popcount(lo), ch = __builtin_popcount(hi); return gbase ? ch : cl; }   // 2 x s_bcnt1 + v_cndmask
+    const uint32_t half = (gbase & 32) ? hi : lo;
+    return __builtin_popcount((half >> (gbase & 31)) & ((1u << W) - 1u));
+}
+// Number of lanes of my W-group whose predicate holds.
 template <int W>
 __device__ __forceinline__ int group_count(bool pred, int gbase)
 {
-    unsigned long long m = __ballot(pred);
-    if (W < 64) m = (m >> gbase) & ((1ull << W) - 1ull);
-    return __popcll(m);
+    return group_popcount<W>(__ballot(pred), gbase);
 }
 
 // N independent all-reduces, stage by stage: the N butterflies interleave, so no DPP read-after-write stalls.
@@ -499,8 +508,7 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
             fix |= c && f;
         }
         dr[b] = dru;
-        if (G::WG < 64) m = (m >> gbase) & ((1ull << G::WG) - 1ull);
-        cnt[b] = (float)__popcll(m);
+        cnt[b] = (float)group_popcount<G::WG>(m, gbase);
     }
     if (__ballot(fix) != 0ull) {                           // rare: a connected UE closer than ~0.9 m to its BS
 #pragma unroll
@@ -676,7 +684,7 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
         if (active && p.reward) stream_store(&p.reward[idx], alive ? reward : 0.f);
         // rows of this wave are contiguous in memory: [row0, row0 + nrows)
         const unsigned long long am = __ballot(active);
-        const int nrows = __popcll(am);
+        const int nrows = group_popcount<64>(am, 0);
         const int row0 = __shfl(idx, am ? __ffsll((long long)am) - 1 : 0, 64);
         const int r = idx - row0;
         float *st = sh.stage[wave];

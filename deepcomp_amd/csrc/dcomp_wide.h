@@ -74,7 +74,7 @@ __device__ __forceinline__ void wide_chunk_rates(const KParams &p, SH &sh, int &
                 dr[j] = c[j] ? t : 0.f;
                 fix |= c[j] && f;
             }
-            ex[j] = (float)__popcll(m);
+            ex[j] = (float)group_popcount<64>(m, 0);
         }
     }
     if (__ballot(fix) != 0ull) {
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
         for (int j = 0; j < BC; j++) {
             const int b = c0 + j;
             const bool cb = b < B ? (bool)((conn >> b) & 1u) : false;
-            ex[j] = b < B ? (float)__popcll(__ballot(cb)) : 0.f;
+            ex[j] = b < B ? (float)group_popcount<64>(__ballot(cb), 0) : 0.f;
             ex[BC + j] = cb ? util : 0.f;
             mn[j] = cb ? util : MAX_UTIL;
         }
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
         else if (c >= 3 * B && c < 4 * B) pre[k] = sh.tab_ub[env_local][c - 3 * B];
     }
     const unsigned long long am = __ballot(active);
-    const int nrows = __popcll(am);                                               // active lanes are lanes [0, nrows)
+    const int nrows = group_popcount<64>(am, 0);                                              // active lanes are lanes [0, nrows)
     const size_t row0 = (size_t)env * p.U + (size_t)(wave % NW) * 64;
     for (int r = 0; r < ((DCOMP_ABLATE & 8) ? 0 : nrows); r++) {
         const uint32_t conn_r = (uint32_t)__builtin_amdgcn_readlane((int)conn, r);
