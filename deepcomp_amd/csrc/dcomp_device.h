@@ -201,6 +201,10 @@ __device__ __forceinline__ void wave_lds_fence()
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32 (1 ulp)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32 (1 ulp)
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32 (1 ulp)
+// min / clamp as ONE v_med3_f32: fminf / fmaxf on a value the compiler cannot prove quiet (a select, a DPP move) cost an
+// extra canonicalising v_max_f32 x, x, x each under IEEE mode.  No NaN reaches these.
+__device__ __forceinline__ float min_med3(float x, float c) { return __builtin_amdgcn_fmed3f(x, -3.0e38f, c); }   // (-inf would be folded back into fminf)
+__device__ __forceinline__ float clamp_med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 // log2(snr) and in-range test of one (UE, BS) pair.  station.py:110-127, 222-226.
 //   snr = K * (d + 1e-16)^(-gamma)  ->  log2 snr = log2 K - (gamma/2) * log2(d^2)   for d >> 1e-16.
 // `tiny` flags d^2 < 1e-20 (UE sitting on a BS: waypoints and BS positions share the integer grid), where the
@@ -272,7 +276,7 @@ __device__ __forceinline__ uint32_t eval_pairs(double px, double py, const KPara
 __device__ __forceinline__ float rate_unshared_small(float l2snr, bool &needfix)
 {
     needfix = l2snr > -4.0f;
-    const float s = fast_exp2(fminf(l2snr, -4.0f));
+    const float s = fast_exp2(min_med3(l2snr, -4.0f));
     float t = __builtin_fmaf(s, -0.16666667f, 0.2f);
     t = __builtin_fmaf(s, t, -0.25f);
     t = __builtin_fmaf(s, t, 0.33333334f);
@@ -292,7 +296,7 @@ __device__ __forceinline__ float ue_utility(float dr, bool step_util, float dr_r
     if (step_util) return dr >= dr_req ? MAX_UTIL : MIN_UTIL;
     if (dr == 0.f) return MIN_UTIL;
     float u = TEN_LOG10_2 * fast_log2(dr);
-    return fminf(fmaxf(u, MIN_UTIL), MAX_UTIL);
+    return clamp_med3(u, MIN_UTIL, MAX_UTIL);
 }
 
 // ---------------------------------------------------------------------------------------------- RNG
@@ -802,7 +806,7 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel(const KParams p)
 #pragma unroll
     for (int b = 0; b < B; b++) curr += dr[b];
     const float util_pre = ue_utility(curr, step_util, dr_req);
-    const float reward_before = fminf(fmaxf(util_pre, MIN_UTIL), MAX_UTIL) * (1.0f / MAX_UTIL);
+    const float reward_before = clamp_med3(util_pre, MIN_UTIL, MAX_UTIL) * (1.0f / MAX_UTIL);
     // 4. move (base.py:447 -> user.py:159-173)
     if (active && !(DCOMP_ABLATE & 2)) {
         move_ue(p, env, (uint32_t)u + 1u, px, py, mv);

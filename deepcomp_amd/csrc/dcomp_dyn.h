@@ -121,7 +121,7 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel_dyn(const KParams p)
 #pragma unroll
     for (int b = 0; b < B; b++) curr += dr[b];
     const float util_pre = ue_utility(curr, step_util, dr_req);
-    const float reward_before = fminf(fmaxf(util_pre, MIN_UTIL), MAX_UTIL) * (1.0f / MAX_UTIL);
+    const float reward_before = clamp_med3(util_pre, MIN_UTIL, MAX_UTIL) * (1.0f / MAX_UTIL);
     // 4. move
     if (alive) {
         move_ue(p, env, uidw, px, py, mv);

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
         }
     }
     const float util_pre = ue_utility(curr, step_util, dr_req);
-    const float reward_before = fminf(fmaxf(util_pre, MIN_UTIL), MAX_UTIL) * (1.0f / MAX_UTIL);
+    const float reward_before = clamp_med3(util_pre, MIN_UTIL, MAX_UTIL) * (1.0f / MAX_UTIL);
     conn &= inr_new;                                                              // user.py:175-188
     ewma = 0.9f * stale + 0.1f * ewma;                                            // user.py:148-157
 
