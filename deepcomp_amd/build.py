@@ -8,6 +8,7 @@ for gfx950 without a GPU present.
 """
 import argparse
 import concurrent.futures
+import hashlib
 import os
 import re
 import subprocess
@@ -34,11 +35,24 @@ def _sources():
         [os.path.join(os.path.dirname(HERE), 'include', 'dcomp.h')]
 
 
-def up_to_date():
-    if not os.path.exists(LIB):
+STAMP = LIB + '.stamp'
+
+
+def _fingerprint(extra_flags=()):
+    """Content hash of every source + the flags: an mtime test calls a library built from OTHER sources (a `git checkout`
+    of older files, an experiment that was reverted) up to date."""
+    h = hashlib.sha256()
+    for f in _sources():
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    h.update(' '.join(CXXFLAGS + list(extra_flags)).encode())
+    return h.hexdigest()
+
+
+def up_to_date(extra_flags=()):
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
         return False
-    t = os.path.getmtime(LIB)
-    return all(os.path.getmtime(s) <= t for s in _sources())
+    return open(STAMP).read().strip() == _fingerprint(extra_flags)
 
 
 def _run(cmd):
@@ -49,7 +63,7 @@ def _run(cmd):
 
 
 def build(force=False, jobs=None, extra_flags=()):
-    if not force and up_to_date():
+    if not force and up_to_date(extra_flags):
         return LIB
     hipcc = os.environ.get('HIPCC', 'hipcc')
     os.makedirs(OBJ, exist_ok=True)
@@ -66,6 +80,8 @@ def build(force=False, jobs=None, extra_flags=()):
             if out.strip():
                 sys.stderr.write(out)
     _run([hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + [t[0] for t in tasks] + ['-lpthread'])
+    with open(STAMP, 'w') as f:
+        f.write(_fingerprint(extra_flags) + '\n')
     return LIB
 
 
