@@ -60,8 +60,12 @@ class BatchedMobileEnv:
 
     def __init__(self, map, bs_list, ue_list, kind, num_envs=1, seed=42, episode_length=100, reward='avg',
                  rand_episodes=False, rng='philox', device='cuda', env_id_base=0, env_seeds=None, log_metrics=True,
-                 tape_depth=None, ue_arrival=None, new_ue_interval=None, max_ues=None):
+                 tape_depth=None, ue_arrival=None, new_ue_interval=None, max_ues=None, host_io=False):
         L = _lib.load()
+        # host_io: outputs and actions live in PINNED HOST memory that the kernels read / write directly over PCIe (a few
+        # hundred bytes per step at num_envs = 1): the single-env compatibility classes then need no copy calls at all,
+        # only the stream synchronisation of check().  Batched envs keep everything in HBM.
+        self.host_io = bool(host_io)
         self._L = L
         self.device = torch.device(device)
         if self.device.type != 'cuda':
@@ -145,7 +149,8 @@ class BatchedMobileEnv:
             cnt = int(np.prod(shape))
             self._sections[name] = (off, cnt, shape)
             off += (cnt + 3) // 4 * 4
-        self._outbuf = torch.zeros(off, dtype=torch.float32, device=dev)
+        self._outbuf = torch.zeros(off, dtype=torch.float32).pin_memory() if self.host_io else torch.zeros(off, dtype=torch.float32, device=dev)
+        self.action_host = torch.zeros((self.E, U), dtype=torch.uint8).pin_memory() if self.host_io else None
         for name, (o, cnt, shape) in self._sections.items():
             setattr(self, name, self._outbuf[o:o + cnt].view(shape))
         since_bytes = ctypes.c_size_t(0)
@@ -172,7 +177,10 @@ class BatchedMobileEnv:
                              self.reward_before.data_ptr() if self.want_reward_before else None)
 
     def _stream(self):
-        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        try:                                   # raw handle of torch's current stream without building a Stream object (~4 us)
+            return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(self.device.index))
+        except AttributeError:                 # pragma: no cover - private torch API moved
+            return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def __del__(self):
         h = getattr(self, '_h', None)
@@ -254,8 +262,8 @@ class BatchedMobileEnv:
 
     def step(self, action):
         """MobileEnv.step (base.py:413-466).  action: uint8 tensor [E, U] on this device, values in [0, B]."""
-        if action.dtype != torch.uint8 or action.device != self.device or not action.is_contiguous() or \
-                action.numel() != self.E * self.U:
+        on_dev = action.device == self.device or (self.host_io and action.data_ptr() == self.action_host.data_ptr())
+        if action.dtype != torch.uint8 or not on_dev or not action.is_contiguous() or action.numel() != self.E * self.U:
             raise ValueError(f"action must be a contiguous uint8 tensor with {self.E}x{self.U} entries on {self.device}")
         with torch.cuda.device(self.device):
             self._launch_step(action, self._out)
@@ -310,9 +318,12 @@ class BatchedMobileEnv:
         self.want_reward_before = True
         self._out = self._make_out(self.obs, self.reward)
 
-    def outputs_host(self):
-        """ONE device->host copy of everything the last reset()/step() produced; dict of numpy views."""
-        h = self._outbuf.cpu().numpy()
+    def outputs_host(self, synced=False):
+        """Everything the last reset()/step() produced as a dict of numpy views: ONE device->host copy, or (host_io) the
+        pinned buffer itself -- then the caller has synchronised (check()) and consumes the views before the next step."""
+        if self.host_io and not synced:
+            torch.cuda.current_stream(self.device).synchronize()
+        h = self._outbuf.numpy() if self.host_io else self._outbuf.cpu().numpy()
         return {name: h[o:o + cnt].reshape(shape) for name, (o, cnt, shape) in self._sections.items()}
 
     def obs_views_host(self, host):
@@ -393,7 +404,8 @@ class _RefSurfaceEnv:
                                      device=env_config.get('device', 'cuda'), env_id_base=env_config.get('env_id_base', 0),
                                      env_seeds=env_config.get('env_seeds'),
                                      log_metrics=True, ue_arrival=self.ue_arrival, new_ue_interval=self.new_ue_interval,
-                                     max_ues=self.max_ues if (self.ue_arrival or self.new_ue_interval) else None)
+                                     max_ues=self.max_ues if (self.ue_arrival or self.new_ue_interval) else None,
+                                     host_io=not self.batched)
         for i, ue in enumerate(self.ue_list):
             if hasattr(ue, '_env'):
                 ue._env, ue._idx = self, i
@@ -480,20 +492,27 @@ class _RefSurfaceEnv:
         obs, reward, _, info = self.core.step(a)
         self.core.check()
         self._refresh_ue_list()
-        self._host = self.core.outputs_host()                                          # one D2H copy per step
+        self._host = self.core.outputs_host(synced=True)                               # pinned views (check() synchronised)
         self.total_utility += float(self._host['sum_utility'][0])
         self.obs = self._format_obs(self._host)
         return self.obs, self._format_reward(self._host), self.done(), self.info()
+
+    def _action_buf(self):
+        """Zeroed numpy view of the pinned action buffer the kernel reads (the previous step has completed: step() ends with
+        check(), which synchronises)."""
+        a = self.core.action_host.numpy()
+        a[:] = 0
+        return a
 
     def _info_dict(self):
         """base.py:383-411"""
         if not self.log_metrics:
             return {'time': self.time}
-        dr, ut = self._host['ue_dr'][0], self._host['ue_utility'][0]
+        dr, ut = self._host['ue_dr'][0].tolist(), self._host['ue_utility'][0].tolist()
         return {'time': self.time,
                 'scalar_metrics': {'sum_utility': float(self._host['sum_utility'][0])},
-                'vector_metrics': {'dr': {f'UE {ue}': float(dr[i]) for i, ue in enumerate(self.ue_list)},
-                                   'utility': {f'UE {ue}': float(ut[i]) for i, ue in enumerate(self.ue_list)}}}
+                'vector_metrics': {'dr': {f'UE {ue}': dr[i] for i, ue in enumerate(self.ue_list)},
+                                   'utility': {f'UE {ue}': ut[i] for i, ue in enumerate(self.ue_list)}}}
 
 
 class CentralRelNormEnv(_RefSurfaceEnv):
@@ -511,16 +530,16 @@ class CentralRelNormEnv(_RefSurfaceEnv):
 
     def _action_tensor(self, action):
         assert self.action_space.contains(action), f"Action {action} does not fit action space {self.action_space}"   # central.py:61
-        a = np.zeros((1, self.core.U), dtype=np.uint8)
+        a = self._action_buf()
         a[0, :self.num_ue] = np.asarray(action, dtype=np.uint8)[:self.num_ue]            # central.py:63: by list position
-        return torch.from_numpy(a).to(self.core.device)
+        return self.core.action_host
 
     def _format_obs(self, host):
         v = {k: t[0] for k, t in self.core.obs_views_host(host).items()}
         pad = self.max_ues - self.core.U                                               # central.py:46-55 (dead slots are already zero rows)
-        out = {'connected': [int(x) for x in v['connected']] + [0] * (pad * self.num_bs),
-               'dr': [float(x) for x in v['dr']] + [0] * (pad * self.num_bs),
-               'utility': [float(x) for x in v['utility']] + [0] * pad}
+        out = {'connected': v['connected'].astype(np.int64).tolist() + [0] * (pad * self.num_bs),
+               'dr': v['dr'].tolist() + [0] * (pad * self.num_bs),
+               'utility': v['utility'].tolist() + [0] * pad}
         return out
 
     def _format_reward(self, host):
@@ -547,27 +566,26 @@ class MultiAgentMobileEnv(_RefSurfaceEnv):
         self.observation_space = spaces.Dict(self.obs_space_dict)
 
     def _action_tensor(self, action):
-        a = np.zeros((1, self.core.U), dtype=np.uint8)
+        a = self._action_buf()
         for i, ue in enumerate(self.ue_list):                                          # multi_agent.py:30 (missing ids: no-op)
             if ue.id in action:
                 v = int(action[ue.id])
                 if not 0 <= v <= self.num_bs:
                     raise IndexError(f"action {v} of UE {ue.id} is outside [0, {self.num_bs}]")
                 a[0, i] = v
-        return torch.from_numpy(a).to(self.core.device)
+        return self.core.action_host
 
     def _format_obs(self, host):
         v = {k: t[0] for k, t in self.core.obs_views_host(host).items()}
-        out = {}
-        for i, ue in enumerate(self.ue_list):                                          # multi_agent.py:32-37, variants.py:302-303
-            out[ue.id] = {'connected': [int(x) for x in v['connected'][i]], 'dr': [float(x) for x in v['dr'][i]],
-                          'utility': [float(v['utility'][i][0])], 'ues_at_bs': [float(x) for x in v['ues_at_bs'][i]],
-                          'util_at_bs': [float(x) for x in v['util_at_bs'][i]]}
-        return out
+        conn = v['connected'].astype(np.int64).tolist()          # whole-array conversions: one C loop each, not one per element
+        dr, ut = v['dr'].tolist(), v['utility'].tolist()
+        nb, ub = v['ues_at_bs'].tolist(), v['util_at_bs'].tolist()
+        return {ue.id: {'connected': conn[i], 'dr': dr[i], 'utility': ut[i], 'ues_at_bs': nb[i], 'util_at_bs': ub[i]}
+                for i, ue in enumerate(self.ue_list)}                                  # multi_agent.py:32-37, variants.py:302-303
 
     def _format_reward(self, host):
-        r = host['reward'][0]
-        return {ue.id: float(r[i]) for i, ue in enumerate(self.ue_list)}
+        r = host['reward'][0].tolist()
+        return {ue.id: r[i] for i, ue in enumerate(self.ue_list)}
 
     def done(self):
         d = {ue.id: None for ue in self.ue_list}                                       # multi_agent.py:97-102
@@ -602,9 +620,9 @@ class RelNormEnv(_RefSurfaceEnv):
 
     def _action_tensor(self, action):
         assert self.action_space.contains(action), f"Action {action} does not fit action space {self.action_space}"   # base.py:238
-        a = np.zeros((1, self.core.U), dtype=np.uint8)
+        a = self._action_buf()
         a[0, self.time % self.num_ue] = int(action)                                    # base.py:243-244
-        return torch.from_numpy(a).to(self.core.device)
+        return self.core.action_host
 
     def _format_obs(self, host):
         v = {k: t[0] for k, t in self.core.obs_views_host(host).items()}
