@@ -51,7 +51,8 @@ class CentralVectorEnv(_VectorEnvBase):
 
     def _obs_list(self):
         U, B = self.core.U, self.core.B
-        self._host = self.core.obs.cpu().numpy()                       # one D2H copy; below are views
+        self._all = self.core.outputs_host()                           # ONE D2H copy of obs + reward + info; below are views
+        self._host = self._all['obs']
         return [{'connected': row[:U * B], 'dr': row[U * B:2 * U * B], 'utility': row[2 * U * B:]} for row in self._host]
 
     def vector_reset(self):
@@ -69,11 +70,11 @@ class CentralVectorEnv(_VectorEnvBase):
         a = torch.from_numpy(np.ascontiguousarray(np.asarray(actions, dtype=np.uint8).reshape(self.core.E, self.core.U)))
         self.core.step(a.to(self.core.device))
         self.core.check()
-        rew = self.core.reward.cpu().numpy()
-        su = self.core.sum_utility.cpu().numpy()
+        obs = self._obs_list()
+        rew, su = self._all['reward'].tolist(), self._all['sum_utility'].tolist()
         t = self.core.time
-        infos = [{'time': t, 'scalar_metrics': {'sum_utility': float(su[e])}} for e in range(self.core.E)]
-        return self._obs_list(), [float(r) for r in rew], [False] * self.core.E, infos
+        infos = [{'time': t, 'scalar_metrics': {'sum_utility': su[e]}} for e in range(self.core.E)]
+        return obs, rew, [False] * self.core.E, infos
 
     def get_unwrapped(self):
         return [self.core]
@@ -97,7 +98,8 @@ class MultiAgentBaseEnv(_BaseEnvBase):
 
     def _views(self):
         B = self.core.B
-        host = self.core.obs.cpu().numpy()                              # [E, U, 4B+1], one copy
+        self._all = self.core.outputs_host()                            # ONE D2H copy of obs + reward + info
+        host = self._all['obs']                                         # [E, U, 4B+1]
         return {e: {aid: {'connected': host[e, i, 0:B], 'dr': host[e, i, B:2 * B], 'ues_at_bs': host[e, i, 2 * B:3 * B],
                           'util_at_bs': host[e, i, 3 * B:4 * B], 'utility': host[e, i, 4 * B:4 * B + 1]}
                     for i, aid in enumerate(self.agent_ids)} for e in range(self.core.E)}
@@ -110,8 +112,8 @@ class MultiAgentBaseEnv(_BaseEnvBase):
             zeros = {e: {a: 0.0 for a in self.agent_ids} for e in range(E)}
             dones = {e: {'__all__': False} for e in range(E)}
             return obs, zeros, dones, {e: {} for e in range(E)}, {}
-        rew = self.core.reward.cpu().numpy()
-        rewards = {e: {a: float(rew[e, i]) for i, a in enumerate(self.agent_ids)} for e in range(E)}
+        rew = self._all['reward'].tolist()
+        rewards = {e: dict(zip(self.agent_ids, rew[e])) for e in range(E)}
         dones = {e: {'__all__': False} for e in range(E)}
         infos = {e: {a: {'time': self.core.time} for a in self.agent_ids} for e in range(E)}
         return obs, rewards, dones, infos, {}
