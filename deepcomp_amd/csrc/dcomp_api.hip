@@ -464,7 +464,12 @@ __global__ void selftest_fp64(int op, const double *x, const double *y, double *
     double a = x[i], b = y[i], r;
     if (op == 0) r = __builtin_sqrt(a);
     else if (op == 1) r = a / b;
-    else r = __builtin_fma(b, b, a * a);
+    else if (op == 2) r = __builtin_fma(b, b, a * a);
+    else {                                             // 4, 5, 6: move_ue's norm_and_unit(vx = x, vy = y) -> nrm, nx, ny
+        double nrm, nx, ny;
+        dcomp::norm_and_unit(a, b, nrm, nx, ny);
+        r = op == 4 ? nrm : op == 5 ? nx : ny;
+    }
     out[i] = r;
 }
 template <int W>
@@ -485,7 +490,7 @@ extern "C" int dcomp_selftest(int op, int width, const double *x, const double *
     if (!x || !out || n < 1) return fail(DCOMP_EINVAL, "bad argument");
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (op >= 0 && op <= 2) {
+    if ((op >= 0 && op <= 2) || (op >= 4 && op <= 6)) {
         if (!y) return fail(DCOMP_EINVAL, "y required");
         hipLaunchKernelGGL(selftest_fp64, grid, block, 0, s, op, x, y, out, n);
     } else if (op == 3) {

@@ -176,7 +176,8 @@ const char *dcomp_version(void);
 
 /* Device self-test of the cross-lane reductions and the FP64 sqrt/div/fma used by the movement
  * step: fills out[n] (device) from x[n], y[n] (device doubles).  op: 0 sqrt(x) 1 x/y 2 fma(y,y,x*x)
- * 3 segmented all-reduce sums of (float)x over groups of `width` lanes. */
+ * 3 segmented all-reduce sums of (float)x over groups of `width` lanes; 4 / 5 / 6: norm, x/norm, y/norm of the
+ * vector (x, y) as the movement step computes them (one shared reciprocal; must equal sqrt and two divisions). */
 int dcomp_selftest(int op, int width, const double *x, const double *y, double *out, int64_t n, void *stream);
 
 #ifdef __cplusplus

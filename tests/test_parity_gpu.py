@@ -109,6 +109,36 @@ def test_fp64_sqrt_div_fma_bit_exact(torch_cuda):
     assert math.isfinite(got.sum())
 
 
+def test_move_norm_and_unit_equals_sqrt_and_division(torch_cuda):
+    """move_ue's own FP64 sequence (v_rsq_f64 / v_rcp_f64 + Newton steps, ONE reciprocal for both divisions, no range
+    scaling) must give the correctly rounded np.linalg.norm and quotients of movement.py:151 on its whole domain:
+    waypoint minus position on maps up to 65535 m, incl. tiny residuals next to the waypoint and exact zeros."""
+    torch = torch_cuda
+    from deepcomp_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(3)
+    n = 1 << 21
+    k = n // 8
+    vx = np.concatenate([rng.uniform(-600, 600, 3 * k), rng.integers(-600, 601, k).astype(np.float64),
+                         rng.uniform(-65535, 65535, k), rng.uniform(-1, 1, k) * 1e-9, np.zeros(k), rng.uniform(-3, 3, k)])
+    vy = np.concatenate([rng.uniform(-600, 600, 3 * k), rng.integers(-600, 601, k).astype(np.float64),
+                         rng.uniform(-65535, 65535, k), rng.uniform(1, 10, k), rng.uniform(0.5, 600, k), rng.uniform(-3, 3, k)])
+    vy[(vx == 0) & (vy == 0)] = 1.0                       # the move never normalises a zero vector (snap branch)
+    xd, yd = torch.from_numpy(vx).cuda(), torch.from_numpy(vy).cuda()
+    out = torch.zeros(n, dtype=torch.float64, device='cuda')
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(op):
+        _lib.check(L.dcomp_selftest(op, 0, xd.data_ptr(), yd.data_ptr(), out.data_ptr(), n, s))
+        torch.cuda.synchronize()
+        return out.cpu().numpy().copy()
+    q = run(2)                                           # fma(vy, vy, vx*vx): checked exactly in the test above
+    nrm = np.sqrt(q)
+    assert np.array_equal(run(4), nrm), 'norm is not the correctly rounded sqrt'
+    assert np.array_equal(run(5), vx / nrm), 'vx / norm is not the correctly rounded quotient'
+    assert np.array_equal(run(6), vy / nrm), 'vy / norm is not the correctly rounded quotient'
+
+
 @pytest.mark.parametrize('width', [2, 4, 8, 16, 32, 64])
 def test_group_reductions(torch_cuda, width):
     """DPP / ds_swizzle segmented all-reduce against numpy."""
@@ -188,15 +218,20 @@ def _oracle_batch(scn, kind, reward, E, seed, env_id_base=0):
                                    ('multi', 256, 3, 10, 'avg'), ('central', 60, 16, 33, 'sum'), ('multi', 16, 11, 64, 'avg'),
                                    ('central', 8, 27, 32, 'avg'), ('multi', 5, 1, 128, 'min'), ('multi', 128, 29, 6, 'sum'),
                                    ('multi', 128, 32, 8, 'avg'), ('multi', 100, 32, 5, 'min'), ('multi', 64, 25, 8, 'avg'),
-                                   ('multi', 200, 26, 3, 'avg'), ('central', 128, 32, 4, 'min'), ('central', 256, 31, 2, 'sum')])
+                                   ('multi', 200, 26, 3, 'avg'), ('central', 128, 32, 4, 'min'), ('central', 256, 31, 2, 'sum'),
+                                   ('central', 1, 1, 64, 'avg'), ('multi', 1, 2, 64, 'sum'), ('multi', 2, 32, 16, 'min'),
+                                   ('multi', 40, 6, 24, 'avg', 'max-cap'), ('multi', 128, 32, 4, 'avg', 'proportional-fair'),
+                                   ('multi', 64, 26, 6, 'sum', 'rate-fair'), ('central', 100, 30, 3, 'avg', 'max-cap'),
+                                   ('multi', 32, 10, 64, 'min', 'resource-fair')])
 def test_oracle_parity_philox(torch_cuda, shape):
     """HIP path vs CPU oracle, same Philox draws, random actions, 60 steps incl. one mid-run reset."""
     torch = torch_cuda
     from deepcomp_amd import scenarios
     from deepcomp_amd.entities import build_from_scenario
     from deepcomp_amd.env import BatchedMobileEnv
-    kind, U, B, E, reward = shape
-    scn = scenarios.grid_map(B, 'mixed').with_ues(num_static=U // 8, num_slow=U - U // 8 - U // 4, num_fast=U // 4)
+    kind, U, B, E, reward = shape[:5]
+    sharing = shape[5] if len(shape) > 5 else 'mixed'
+    scn = scenarios.grid_map(B, sharing).with_ues(num_static=U // 8, num_slow=U - U // 8 - U // 4, num_fast=U // 4)
     m, bs, ues = build_from_scenario(scn)
     core = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=1234, reward=reward, rng='philox', rand_episodes=True, env_id_base=5)
     ob = _oracle_batch(scn, kind, reward, E, 1234, env_id_base=5)
