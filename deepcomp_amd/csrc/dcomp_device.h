@@ -123,8 +123,10 @@ __device__ __forceinline__ float swz_xor16(float v)
 #define DCOMP_DPP_ROW_MIRROR 0x140  // i <-> 15-i in each 16
 
 struct OpSum { __device__ __forceinline__ static float f(float a, float b) { return a + b; } };
-struct OpMin { __device__ __forceinline__ static float f(float a, float b) { return fminf(a, b); } };
-struct OpMax { __device__ __forceinline__ static float f(float a, float b) { return fmaxf(a, b); } };
+// min / max of finite values as ONE v_med3_f32: fminf / fmaxf of lane-exchanged values cost two canonicalising v_max_f32
+// x, x, x on top under IEEE mode (the compiler cannot prove a DPP / swizzle result quiet)
+struct OpMin { __device__ __forceinline__ static float f(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -3.0e38f); } };
+struct OpMax { __device__ __forceinline__ static float f(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, 3.0e38f); } };
 
 // All-reduce over aligned groups of W lanes (W = 1,2,4,...,64).  Every lane of a group ends with the
 // bit-identical result (each butterfly stage combines the same two partial results in both partners).
