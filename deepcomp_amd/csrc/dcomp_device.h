@@ -273,24 +273,26 @@ __device__ __forceinline__ uint32_t eval_pairs(double px, double py, const KPara
     return in_range;
 }
 // bw * log2(1 + snr) from log2(snr).  station.py:129-138.  Never forms 1+snr for small snr (1.0f + snr is
-// exactly 1.0f below 6e-8 while the connect threshold is 2e-8): log1p series, relative error < 1e-8 for
-// snr < 1/16 (d > ~0.9 m).  `needfix` flags the rare larger snr, redone by rate_unshared_any.
+// exactly 1.0f below 6e-8 while the connect threshold is 2e-8): log1p(s)/s = 1 - s/2 + s^2/3 - s^3/4, truncation error
+// s^4/5 < 1.2e-8 for snr < 1/64 (d > ~1.4 m).  `needfix` flags the rare larger snr, redone by rate_unshared_any.
+constexpr float RATE_SMALL_L2 = -6.0f;            // log2 of the largest snr the short series takes
 __device__ __forceinline__ float rate_unshared_small(float l2snr, bool &needfix)
 {
-    needfix = l2snr > -4.0f;
-    const float s = fast_exp2(min_med3(l2snr, -4.0f));
-    float t = __builtin_fmaf(s, -0.16666667f, 0.2f);
-    t = __builtin_fmaf(s, t, -0.25f);
-    t = __builtin_fmaf(s, t, 0.33333334f);
+    needfix = l2snr > RATE_SMALL_L2;
+    const float s = fast_exp2(min_med3(l2snr, RATE_SMALL_L2));
+    float t = __builtin_fmaf(s, -0.25f, 0.33333334f);
     t = __builtin_fmaf(s, t, -0.5f);
     t = __builtin_fmaf(s, t, 1.0f);
     return (BW * LOG2E) * (s * t);
 }
 __device__ __forceinline__ float rate_unshared_any(float l2snr)
 {
-    // snr >= 1/16: 1+s is accurate enough (log2(1+s) >= 0.087, relative error < 2e-6); d -> 0: log2(1+s) = log2(s)
+    // snr >= 1/64.  u = fl(1 + s) loses the low bits of s; log(1+s) = log(u) * s / (u - 1) puts them back (u - 1 is exact),
+    // relative error ~2e-7 for any s.  d -> 0 (snr up to 3.5e52): log2(1+s) = log2(s) to f32 precision.
     const float s = fast_exp2(fminf(l2snr, 100.f));
-    return BW * (l2snr > 100.f ? l2snr : fast_log2(1.0f + s));
+    const float u = 1.0f + s;
+    const float l = fast_log2(u) * (s * fast_rcp(u - 1.0f));
+    return BW * (l2snr > 100.f ? l2snr : l);
 }
 // user.py:76-92 -> utility.py:23-54
 __device__ __forceinline__ float ue_utility(float dr, bool step_util, float dr_req)
@@ -522,10 +524,10 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
         dr[b] = dru;
         cnt[b] = (float)group_popcount<G::WG>(m, gbase);
     }
-    if (__ballot(fix) != 0ull) {                           // rare: a connected UE closer than ~0.9 m to its BS
+    if (__ballot(fix) != 0ull) {                           // rare: a connected UE closer than ~1.4 m to its BS
 #pragma unroll
         for (int b = 0; b < B; b++)
-            if (((conn >> b) & 1u) && l2[b] > -4.0f) dr[b] = rate_unshared_any(l2[b]);
+            if (((conn >> b) & 1u) && l2[b] > RATE_SMALL_L2) dr[b] = rate_unshared_any(l2[b]);
     }
 #pragma unroll
     for (int b = 0; b < B; b++) {

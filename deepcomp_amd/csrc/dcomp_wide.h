@@ -79,7 +79,7 @@ __device__ __forceinline__ void wide_chunk_rates(const KParams &p, SH &sh, int &
     }
     if (__ballot(fix) != 0ull) {
 #pragma unroll
-        for (int j = 0; j < WIDE_BC; j++) if (c0 + j < B && c[j] && l2[j] > -4.0f) dr[j] = rate_unshared_any(l2[j]);
+        for (int j = 0; j < WIDE_BC; j++) if (c0 + j < B && c[j] && l2[j] > RATE_SMALL_L2) dr[j] = rate_unshared_any(l2[j]);
     }
     bool any_sum = false;
 #pragma unroll
