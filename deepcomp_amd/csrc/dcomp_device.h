@@ -200,6 +200,7 @@ __device__ __forceinline__ void wave_lds_fence()
 }
 
 // ---------------------------------------------------------------------------------------------- channel
+constexpr float NEAR_D2 = 1.6f;   // squared distance under which the rare fix-ups run (see eval_pairs)
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32 (1 ulp)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32 (1 ulp)
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32 (1 ulp)
@@ -218,7 +219,7 @@ __device__ __forceinline__ void pair_eval(double px, double py, double bx, doubl
     double dsq = __builtin_fma(dy, dy, dx * dx);
     in_range = dsq < p.dt2;                      // snr > 2e-8  <=>  d < d_T, decided in FP64
     float q = (float)dsq;
-    tiny = q < 1e-20f;
+    tiny = q < NEAR_D2;                          // "near": superset of the d^2 < 1e-20 pairs the fix-up replaces
     // v_log_f32's absolute error scales with |result| (log2 d^2 ~ 12 near the connect range -> ~1e-6, i.e. ~1.1e-6
     // relative in snr = 2^l2snr).  Scaling d^2 by 2^-12 first puts every in-range pair at |log2| < 4 for the price
     // of one multiply (the exact alternative, frexp + two FMAs, costs 3 % of the step; tools/numerics_report.py has
@@ -250,19 +251,24 @@ __shared__ double g_bs_lds[2 * DCOMP_MAX_BS];
 #define DCOMP_BSX(b) p.bs_x[b]
 #define DCOMP_BSY(b) p.bs_y[b]
 #endif
+// `near_wave` (optional, wave-uniform): some lane of this wave is within NEAR_D2^(1/2) = 1.26 m of a BS.  That one test
+// triggers both rare fix-ups: the exact d + 1e-16 of a UE sitting ON a BS (here) and, in shared_rates, the rate of a pair
+// with snr > 1/64 (d < 1.24 m), which the short log1p series does not cover.
 template <int B>
-__device__ __forceinline__ uint32_t eval_pairs(double px, double py, const KParams &p, float (&l2)[B])
+__device__ __forceinline__ uint32_t eval_pairs(double px, double py, const KParams &p, float (&l2)[B], bool *near_wave = nullptr)
 {
     uint32_t in_range = 0;
-    bool anytiny = false;
+    bool anynear = false;
 #pragma unroll
     for (int b = 0; b < B; b++) {
-        bool ir, tiny;
-        pair_eval(px, py, DCOMP_BSX(b), DCOMP_BSY(b), p, ir, l2[b], tiny);
+        bool ir, near;
+        pair_eval(px, py, DCOMP_BSX(b), DCOMP_BSY(b), p, ir, l2[b], near);
         in_range |= (uint32_t)ir << b;
-        anytiny |= tiny;
+        anynear |= near;
     }
-    if (__ballot(anytiny) != 0ull) {             // rare: some lane of this wave is within 1e-10 m of a BS
+    const bool nw = __ballot(anynear) != 0ull;
+    if (near_wave) *near_wave = nw;
+    if (nw) {                                    // rare (~3 % of the wavefronts): a lane within 1.26 m of a BS
 #pragma unroll
         for (int b = 0; b < B; b++) {
             float t = pair_eval_tiny(px, py, p.bs_x[b], p.bs_y[b], p);
@@ -274,16 +280,17 @@ __device__ __forceinline__ uint32_t eval_pairs(double px, double py, const KPara
 }
 // bw * log2(1 + snr) from log2(snr).  station.py:129-138.  Never forms 1+snr for small snr (1.0f + snr is
 // exactly 1.0f below 6e-8 while the connect threshold is 2e-8): log1p(s)/s = 1 - s/2 + s^2/3 - s^3/4, truncation error
-// s^4/5 < 1.2e-8 for snr < 1/64 (d > ~1.4 m).  `needfix` flags the rare larger snr, redone by rate_unshared_any.
+// s^4/5 < 1.2e-8 for snr < 1/64 (d > 1.24 m).  `needfix` flags the rare larger snr, redone by rate_unshared_any.
 constexpr float RATE_SMALL_L2 = -6.0f;            // log2 of the largest snr the short series takes
 __device__ __forceinline__ float rate_unshared_small(float l2snr, bool &needfix)
 {
     needfix = l2snr > RATE_SMALL_L2;
     const float s = fast_exp2(min_med3(l2snr, RATE_SMALL_L2));
-    float t = __builtin_fmaf(s, -0.25f, 0.33333334f);
-    t = __builtin_fmaf(s, t, -0.5f);
-    t = __builtin_fmaf(s, t, 1.0f);
-    return (BW * LOG2E) * (s * t);
+    constexpr float K = BW * LOG2E;               // bw / ln 2 folded into the coefficients: one multiply less
+    float t = __builtin_fmaf(s, -0.25f * K, 0.33333334f * K);
+    t = __builtin_fmaf(s, t, -0.5f * K);
+    t = __builtin_fmaf(s, t, K);
+    return s * t;
 }
 __device__ __forceinline__ float rate_unshared_any(float l2snr)
 {
@@ -504,8 +511,10 @@ __device__ __forceinline__ void xwave_reduce_(float (&v)[N], SH &sh, int wave, i
 template <int B, int UPAD, int MP>
 __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, UPAD> &sh, uint32_t conn, const float (&l2)[B], float ewma,
                                              double px, double py, int u, int idx, int env_local, int wave, int lane, int gbase,
-                                             float (&dr)[B], float (&cnt)[B])
+                                             float (&dr)[B], float (&cnt)[B], int near_hint = -1)
 {
+    // near_hint (wave-uniform): eval_pairs' "a lane of this wave is within 1.26 m of a BS" for the position l2 belongs to
+    // (1 / 0), or -1 = unknown, then the per-pair snr > 1/64 test is made here.
     using G = Geo<B, UPAD>;
     float agg[B];
     const float inv_ewma = fast_rcp(ewma + EPS);          // station.py:150 priority denominator (beta = 1)
@@ -519,12 +528,12 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
             bool f;
             const float t = rate_unshared_small(l2[b], f);
             dru = c ? t : 0.f;
-            fix |= c && f;
+            if (near_hint < 0) fix |= c && f;
         }
         dr[b] = dru;
         cnt[b] = (float)group_popcount<G::WG>(m, gbase);
     }
-    if (__ballot(fix) != 0ull) {                           // rare: a connected UE closer than ~1.4 m to its BS
+    if (near_hint < 0 ? (__ballot(fix) != 0ull) : (near_hint != 0)) {   // rare: a connected UE closer than 1.24 m to its BS (snr > 1/64)
 #pragma unroll
         for (int b = 0; b < B; b++)
             if (((conn >> b) & 1u) && l2[b] > RATE_SMALL_L2) dr[b] = rate_unshared_any(l2[b]);
@@ -796,7 +805,8 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel(const KParams p)
     // 1. pairs at the pre-move position
     float l2[B];
     uint32_t in_range = B >= 32 ? 0xFFFFFFFFu : ((1u << (B & 31)) - 1u);
-    if (!(DCOMP_ABLATE & 32)) in_range = eval_pairs<B>(px, py, p, l2);
+    bool near_pre = false, near_post = false;
+    if (!(DCOMP_ABLATE & 32)) in_range = eval_pairs<B>(px, py, p, l2, &near_pre);
     else { for (int b = 0; b < B; b++) l2[b] = -20.f; }
     // 2. toggle (base.py:247-263 -> user.py:190-222)
     if (act > (uint32_t)B) { atomicOr(p.flags, DCOMP_FLAG_BAD_ACTION); act = 0; }
@@ -810,7 +820,7 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel(const KParams p)
     }
     // 3. rates before the move (base.py:446) -> reward_before (base.py:158-167)
     float dr[B], cnt[B];
-    if (!(DCOMP_ABLATE & 1)) shared_rates<B, UPAD, MP>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt);
+    if (!(DCOMP_ABLATE & 1)) shared_rates<B, UPAD, MP>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, (int)near_pre);
     else { for (int b = 0; b < B; b++) { dr[b] = 1.f; cnt[b] = 1.f; } }
     float curr = 0.f;
 #pragma unroll
@@ -823,14 +833,14 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel(const KParams p)
         if (px < 0.0 || py < 0.0 || px > (double)p.map_w || py > (double)p.map_h) atomicOr(p.flags, DCOMP_FLAG_OUTSIDE_MAP);
     }
     // 5. pairs at the new position; drop lost connections (user.py:175-188); EWMA from the stale rates (user.py:148-157)
-    if (!(DCOMP_ABLATE & 64)) in_range = eval_pairs<B>(px, py, p, l2);
+    if (!(DCOMP_ABLATE & 64)) in_range = eval_pairs<B>(px, py, p, l2, &near_post);
     conn &= in_range;
     float stale = 0.f;
 #pragma unroll
     for (int b = 0; b < B; b++) stale += ((conn >> b) & 1u) ? dr[b] : 0.f;
     ewma = 0.9f * stale + 0.1f * ewma;
     // 6. rates after the move (base.py:451)
-    if (!(DCOMP_ABLATE & 4)) shared_rates<B, UPAD, MP>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt);
+    if (!(DCOMP_ABLATE & 4)) shared_rates<B, UPAD, MP>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, (int)near_post);
     curr = 0.f;
 #pragma unroll
     for (int b = 0; b < B; b++) curr += dr[b];
