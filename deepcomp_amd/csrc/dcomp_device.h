@@ -609,7 +609,7 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
 // l2 / cnt are consumed (overwritten with the observation entries).
 // `active`: this lane owns a slot (row) of the env; `alive`: a UE currently sits in that slot (always the same unless
 // UEs arrive / depart, then dead slots produce zero rows: central.py:46-55); n_eff = UEs currently in the env.
-template <int B, int UPAD, bool RESET>
+template <int B, int UPAD, bool RESET, bool DYN = false>
 __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, UPAD> &sh, bool active, int env, int env_local, int u, int idx,
                                               int wave, int lane, int gbase, uint32_t conn, uint32_t in_range,
                                               float (&l2)[B], float (&cnt)[B], float util, float curr_dr,
@@ -692,12 +692,17 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
 
     // ---- observation entries (in place): l2 -> snr_b / max snr, tsum -> avg utility at BS, cnt -> UEs at BS / U
     const float inv_u = 1.0f / (float)n_eff;
-    const float util_n = alive ? util * (1.0f / MAX_UTIL) : 0.f;
+    // DYN (UE lists that change, and reset of such envs): dead slots produce zero rows.  Otherwise every row that is stored
+    // belongs to a live UE (alive == active), so the entries need no select.
+    const bool live = DYN ? alive : true;
+    const float util_n = live ? util * (1.0f / MAX_UTIL) : 0.f;
 #pragma unroll
     for (int b = 0; b < B; b++) {
-        l2[b] = alive ? fast_exp2(l2[b] - l2max) : 0.f;                                         // variants.py:276-284
-        tsum[b] = (alive && cnt[b] > 0.f) ? tsum[b] * fast_rcp(cnt[b]) * (1.0f / MAX_UTIL) : 0.f;   // variants.py:299, station.py:71-76
-        cnt[b] = alive ? cnt[b] * inv_u : 0.f;                                                  // variants.py:296
+        l2[b] = live ? fast_exp2(l2[b] - l2max) : 0.f;                                          // variants.py:276-284
+        // avg utility of the UEs at b, 0 for an idle BS (its sum is 0): variants.py:299, station.py:71-76
+        const float avg = tsum[b] * fast_rcp(fmaxf(cnt[b], 1.f)) * (1.0f / MAX_UTIL);
+        tsum[b] = live ? avg : 0.f;
+        cnt[b] = live ? cnt[b] * inv_u : 0.f;                                                   // variants.py:296
     }
     if ((DCOMP_ABLATE & 8) && p.kind == DCOMP_MULTI) {
         float acc = util_n + reward;
@@ -917,7 +922,7 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void reset_kernel(const KParams p)
 #pragma unroll
     for (int b = 0; b < B; b++) cnt[b] = 0.f;
     const float util = ue_utility(0.f, step_util, dr_req);
-    write_outputs<B, UPAD, true>(p, sh, active, env, env_local, u, idx, wave, lane, gbase, 0u, in_range, l2, cnt, util, 0.f, 0.f, alive,
+    write_outputs<B, UPAD, true, true>(p, sh, active, env, env_local, u, idx, wave, lane, gbase, 0u, in_range, l2, cnt, util, 0.f, 0.f, alive,
                                  p.U0);
 }
 

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel_dyn(const KParams p)
         p.uid[idx] = alive ? (uint16_t)uidw : (uint16_t)0;
     }
     // 8. observation, reward, info
-    write_outputs<B, UPAD, false>(p, sh, active, env, env_local, u, idx, wave, lane, gbase, alive ? conn : 0u, in_range, l2, cnt, util,
+    write_outputs<B, UPAD, false, true>(p, sh, active, env, env_local, u, idx, wave, lane, gbase, alive ? conn : 0u, in_range, l2, cnt, util,
                                   curr, reward_before, alive, cur);
 }
 
