@@ -291,10 +291,10 @@ def main():
         }
         default_workload = (E, U, B, args.kind, args.sharing) == (65536, 32, 10, 'multi', 'mixed')
         if args.traffic_bytes is None and default_workload:
-            # PMC pass of this exact workload (profiles/r01f_final_step_kernel_summary.txt): FETCH_SIZE 33 959 KB x2 (gfx950
-            # wide-read correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE 426 306 KB, per launch
-            out['roofline']['traffic'] = (2 * 33959.10 + 426306.47) * 1024
-            out['roofline']['traffic_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01f_final_step_kernel_summary.txt'
+            # PMC pass of this exact workload (profiles/r01g_final_step_kernel_summary.txt): FETCH_SIZE 33 938 KB x2 (gfx950
+            # wide-read correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE 426 319 KB, per launch
+            out['roofline']['traffic'] = (2 * 33938.45 + 426318.91) * 1024
+            out['roofline']['traffic_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01g_final_step_kernel_summary.txt'
         if world == 1 and not args.no_stream:
             # the launch writes (obs + reward + info + state) and reads (state + actions); ceiling for that mix
             wr = E * (bpe - U * 33)
