@@ -136,6 +136,12 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
     kp.env_base = (uint32_t)cfg->env_id_base;
     {   // snr = K * (d + eps)^(-gamma): gamma = c2/10, K = snr(1 m)   (station.py:110-127)
         double c2 = 44.9 - 6.55 * std::log10(50.0);
+        {   // the same two constants as ref_snr, for the kernel's FP64 max-cap rate key
+            const double f = 2500.0, hb = 50.0, hu = 1.5;
+            const double ch = 0.8 + (1.1 * std::log10(f) - 0.7) * hu - 1.56 * std::log10(f);
+            kp.pl_c1 = 69.55 + 26.16 * std::log10(f) - 13.82 * std::log10(hb) - ch;
+            kp.pl_c2 = c2;
+        }
         kp.half_gamma = (float)(c2 / 20.0);
         kp.log2k = (float)std::log2(ref_snr(1.0));
         kp.log2k_s = (float)(std::log2(ref_snr(1.0)) - 12.0 * (c2 / 20.0));

@@ -95,6 +95,7 @@ struct KParams {
     uint32_t all_log_util;     // 1: every UE uses the log utility (skip the per-UE config load)
     uint32_t any_maxcap;
     uint32_t maxcap_mask;      // bit b: BS b is max-cap
+    double pl_c1, pl_c2;       // Okumura-Hata constants of station.py:110-116 (FP64, for the max-cap rate key)
     uint32_t time;             // env.time before this step (base.py:39)
     uint32_t any_sum_mode;     // some BS is rate-fair or proportional-fair (needs a sum over its UEs)
     uint32_t seed_lo, seed_hi, episode;
@@ -476,7 +477,9 @@ struct alignas(16) BlockSharedT {
         alignas(16) float stage[DCOMP_BLOCK / 64][(StageGeo<B>::WORDS + 3) / 4 * 4];   // per-wave observation staging (multi-agent layout)
         struct {
             unsigned long long mc_key[Geo<B, UPAD>::GPB * B];   // max-cap: min squared-distance bits per (env-in-block, bs)
-            uint32_t mc_win[Geo<B, UPAD>::GPB * B];
+            unsigned long long mc_u[Geo<B, UPAD>::GPB * B];     //          max FP64 rate key 1 + snr among the contenders
+            uint32_t mc_win[Geo<B, UPAD>::GPB * B];             //          (step of connection << 8 | UE) of the winner
+            uint32_t mc_cnt[Geo<B, UPAD>::GPB * B];             //          number of contenders
             uint32_t nb_conn[256];                              // 'sum' reward: conn' and reward_before of the block's UEs
             float nb_rb[256];
         };
@@ -503,6 +506,20 @@ __device__ __forceinline__ void xwave_reduce_(float (&v)[N], SH &sh, int wave, i
         v[i] = a;
     }
     __syncthreads();
+}
+
+// What the reference's max-cap argmax actually compares (station.py:129-138, 183-187): bw * log2(1 + snr) in FP64, and
+// 1 + snr absorbs all but ~30 bits of an snr of 1e-6 -- UEs whose squared distances differ by up to ~1e-8 relative get the
+// SAME rate and the first one in connection order wins.  This returns that collapsing quantity, fl(1 + snr), through the
+// reference's own operation chain (distance, path loss via log10, 10^x, / noise).  Rare path, kept out of line.
+__device__ __noinline__ unsigned long long maxcap_rate_key(double pl_c1, double pl_c2, double px, double py, double bx, double by)
+{
+#pragma clang fp contract(off)
+    const double dx = bx - px, dy = by - py;
+    const double d = __builtin_sqrt(dx * dx + dy * dy);                  // shapely Point.distance
+    const double pl = pl_c1 + pl_c2 * log10(d + 1e-16);                  // station.py:110-116
+    const double snr = pow(10.0, (30.0 - pl) / 10.0) / 1e-9;             // station.py:118-127
+    return (unsigned long long)__double_as_longlong(1.0 + snr);          // positive doubles order like their bit patterns
 }
 
 // Shared data rates of this UE at every BS.  station.py:152-220 with S_b = {u : conn[u,b]}.
@@ -565,11 +582,14 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
     }
     uint32_t mc_winner = 0;
     if (MP == MP_GENERIC && p.any_maxcap) {
-        // max-cap (station.py:183-187): only the UE with the highest unshared rate is served = the one with the
-        // smallest FP64 squared distance; exact ties -> first in bs.conn_ues = oldest connection, then (same step)
-        // lowest UE index, which is the order base.py:259-263 appends them in.
+        // max-cap (station.py:183-187): only the UE with the highest FP64 unshared rate is served; equal rates -> first in
+        // bs.conn_ues = oldest connection, then (same step) lowest UE index, the order base.py:259-263 appends them in.
+        // Stage 1: smallest FP64 squared distance per (env, BS).  Stage 2: contenders = UEs within 1e-7 (relative) of it --
+        // anything farther has a strictly smaller rate (the 1 + snr rounding collapses at most 1.1e-8 at the cell edge).
+        // Stage 3, only where a BS has more than one contender: the exact collapsing key (maxcap_rate_key).  Stage 4: among
+        // the UEs holding the maximal key, the smallest (step of connection, UE index).
         const int tid = threadIdx.x;
-        for (int i = tid; i < G::GPB * B; i += DCOMP_BLOCK) { sh.mc_key[i] = ~0ull; sh.mc_win[i] = ~0u; }
+        for (int i = tid; i < G::GPB * B; i += DCOMP_BLOCK) { sh.mc_key[i] = ~0ull; sh.mc_u[i] = 0ull; sh.mc_win[i] = ~0u; sh.mc_cnt[i] = 0u; }
         __syncthreads();
         unsigned long long key[B];
 #pragma unroll
@@ -582,14 +602,34 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
             }
         }
         __syncthreads();
+        uint32_t cand = 0;
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            if (key[b] != ~0ull) {
+                const double mn = __longlong_as_double((long long)sh.mc_key[env_local * B + b]);
+                if (__longlong_as_double((long long)key[b]) <= mn * (1.0 + 1e-7)) { cand |= 1u << b; atomicAdd(&sh.mc_cnt[env_local * B + b], 1u); }
+            }
+        }
+        __syncthreads();
+        uint32_t contested = 0;
+#pragma unroll
+        for (int b = 0; b < B; b++) if (((cand >> b) & 1u) && sh.mc_cnt[env_local * B + b] > 1u) contested |= 1u << b;
+        const bool heavy = __ballot(contested != 0u) != 0ull;                   // wave-uniform, rare
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            key[b] = 1ull;                                                     // sole contender: any key wins
+            if (heavy && ((contested >> b) & 1u)) key[b] = maxcap_rate_key(p.pl_c1, p.pl_c2, px, py, p.bs_x[b], p.bs_y[b]);
+            if ((cand >> b) & 1u) atomicMax(&sh.mc_u[env_local * B + b], key[b]);
+        }
+        __syncthreads();
 #pragma unroll
         for (int b = 0; b < B; b++)
-            if (key[b] != ~0ull && key[b] == sh.mc_key[env_local * B + b])
+            if (((cand >> b) & 1u) && key[b] == sh.mc_u[env_local * B + b])
                 atomicMin(&sh.mc_win[env_local * B + b], ((uint32_t)p.conn_since[(size_t)idx * B + b] << 8) | (uint32_t)u);
         __syncthreads();
 #pragma unroll
         for (int b = 0; b < B; b++)
-            if (key[b] != ~0ull && (sh.mc_win[env_local * B + b] & 0xFFu) == (uint32_t)u) mc_winner |= 1u << b;
+            if (((cand >> b) & 1u) && (sh.mc_win[env_local * B + b] & 0xFFu) == (uint32_t)u) mc_winner |= 1u << b;
         __syncthreads();
     }
 #pragma unroll

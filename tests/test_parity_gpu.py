@@ -269,6 +269,37 @@ def test_oracle_parity_philox(torch_cuda, shape):
     core.check()
 
 
+def test_random_configurations_slice(torch_cuda):
+    """A fixed-seed slice of tools/fuzz_parity.py: random shapes, BS layouts, sharing models (incl. max-cap), utilities,
+    velocities, start positions (incl. UEs parked ON a BS), rewards and agent kinds against the oracle.  (The full
+    fuzzer found the max-cap near-tie case: squared distances one ulp apart have the same FP64 rate in the reference.)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), '..', 'tools'))
+    import fuzz_parity
+    rng = np.random.default_rng(0)
+    for i in range(40):
+        c = fuzz_parity.random_case(rng)
+        try:
+            fuzz_parity.run_case(c, torch_cuda)
+        except AssertionError as ex:
+            raise AssertionError(f'case {i}: {fuzz_parity.describe(c)}\n{ex}') from None
+
+
+def test_max_cap_near_tie_goes_to_the_oldest_connection(torch_cuda):
+    """station.py:183-187 compares bw*log2(1+snr) in FP64: two UEs whose squared distances to the BS differ in the last
+    bits (here: mirrored positions reached by FP64 movement) have the SAME rate, and the first in connection order is
+    served.  Cases 6 and 102 of the seed-0 fuzz run."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), '..', 'tools'))
+    import fuzz_parity
+    rng = np.random.default_rng(0)
+    for i in range(103):
+        c = fuzz_parity.random_case(rng)
+        if i in (6, 102):
+            assert 'max-cap' in c['sh']
+            fuzz_parity.run_case(c, torch_cuda)
+
+
 @pytest.mark.parametrize('agent_name', ['fullcomp', '3gpp', 'dynamic', 'static'])
 def test_heuristic_driven_rollout_matches_oracle(torch_cuda, agent_name):
     """Policy in the loop, everything on the device: a reference heuristic (deepcomp_amd/agents.py) reads the

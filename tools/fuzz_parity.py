@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Randomised differential test on the GPU box: random env configurations (shape, BS layout, sharing models incl. max-cap,
+utility kinds, velocities, fixed start positions incl. UEs parked ON a BS, reward aggregation, agent kind) stepped with
+random actions on the HIP path and on the CPU oracle (same Philox draws); masks / FP64 positions bit-exact, floats at the
+parity bar.  `python tools/fuzz_parity.py [--cases 200] [--seed 0]`;  tests/test_parity_gpu.py runs a short fixed-seed slice.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+RTOL_RATE, ATOL_UTIL, ATOL_OBS = 1e-5, 1e-4, 1e-5
+SHARING = ['resource-fair', 'rate-fair', 'max-cap', 'proportional-fair']
+
+
+def random_case(rng):
+    from deepcomp_amd.entities import Basestation, Map, Point, RandomWaypoint, User
+    U = int(rng.choice([1, 2, 3, 5, 8, 10, 17, 32, 33, 64, 70, 128, 130]))
+    B = int(rng.choice([1, 2, 3, 5, 7, 10, 16, 25, 32]))
+    if U * B > 2500:
+        U = max(1, 2500 // B)
+    E = int(rng.choice([1, 3, 8, 21]))
+    w, h = int(rng.integers(60, 500)), int(rng.integers(60, 400))
+    m = Map(w, h)
+    style = rng.integers(0, 4)
+    if style == 0:
+        sh = [SHARING[int(rng.integers(0, 4))]] * B
+    elif style == 1:
+        sh = [SHARING[int(x)] for x in rng.integers(0, 4, B)]
+    elif style == 2:
+        sh = [['resource-fair', 'rate-fair', 'proportional-fair'][b % 3] for b in range(B)]
+    else:
+        sh = [SHARING[int(x)] for x in rng.choice([0, 1, 3], B)]
+    integer_bs = rng.random() < 0.5
+    bs_xy = [(float(rng.integers(0, w + 1)), float(rng.integers(0, h + 1))) if integer_bs else
+             (float(rng.uniform(0, w)), float(rng.uniform(0, h))) for _ in range(B)]
+    bs = [Basestation(f'B{i}', Point(*xy), s) for i, (xy, s) in enumerate(zip(bs_xy, sh))]
+    ues, vel, util, req, init = [], [], [], [], []
+    for i in range(U):
+        v = [0, 'slow', 'fast', int(rng.integers(1, 30))][int(rng.integers(0, 4))]
+        uf = 'step' if rng.random() < 0.25 else 'log'
+        rq = float(rng.choice([1.0, 0.5, 3.0, 20.0]))
+        r = rng.random()
+        if r < 0.15 and integer_bs:                    # parked on a BS: the d + 1e-16 path
+            bx, by = bs_xy[int(rng.integers(0, B))]
+            ix, iy = int(bx), int(by)
+        elif r < 0.3:
+            ix, iy = int(rng.integers(0, w + 1)), -1
+        else:
+            ix, iy = -1, -1
+        ues.append(User(str(i + 1), m, 'random' if ix < 0 else ix, 'random' if iy < 0 else iy, RandomWaypoint(m, v), util_func=uf, dr_req=rq))
+        vel.append(v); util.append(0 if uf == 'log' else 1); req.append(rq); init.append((ix, iy))
+    kind = 'multi' if rng.random() < 0.6 else 'central'
+    reward = ['avg', 'sum', 'min'][int(rng.integers(0, 3))]
+    return dict(m=m, bs=bs, ues=ues, kind=kind, reward=reward, E=E, U=U, B=B, w=w, h=h, bs_xy=bs_xy, sh=sh, vel=vel, util=util,
+                req=req, init=init, seed=int(rng.integers(0, 2 ** 31)), base=int(rng.integers(0, 1000)),
+                steps=int(rng.integers(15, 45)), p_noop=float(rng.choice([0.0, 0.5, 0.9])))
+
+
+def run_case(c, torch):
+    from deepcomp_amd.env import BatchedMobileEnv
+    from oracle import oracle as orc
+    E, U, B, kind, reward = c['E'], c['U'], c['B'], c['kind'], c['reward']
+    core = BatchedMobileEnv(c['m'], c['bs'], c['ues'], kind, num_envs=E, seed=c['seed'], reward=reward, rng='philox',
+                            rand_episodes=True, env_id_base=c['base'], episode_length=1000)
+    envs = []
+    for e in range(E):
+        o = orc.OracleEnv(c['w'], c['h'], c['bs_xy'], c['sh'], c['vel'], kind=orc.MULTI if kind == 'multi' else orc.CENTRAL,
+                          reward_agg={'avg': 0, 'sum': 1, 'min': 2}[reward], ue_util=c['util'], ue_dr_req=c['req'], init_xy=c['init'])
+        o.set_philox(c['seed'], c['base'] + e)
+        envs.append(o)
+    ob = orc.OracleBatch(envs)
+    arng = np.random.default_rng(c['seed'] ^ 0x5bd1e995)
+
+    def cmp(tag, obs_o, rew_o, conn_o, pos_o):
+        st = core.state_host()
+        if pos_o is not None:
+            assert np.array_equal(st['pos'], pos_o), f'{tag}: positions not bit-exact'
+            assert np.array_equal(st['conn'], conn_o), f'{tag}: connection masks differ'
+        got = core.obs.cpu().numpy()
+        want = obs_o if kind == 'multi' else np.concatenate(
+            [obs_o[:, :, :B].reshape(E, -1), obs_o[:, :, B:2 * B].reshape(E, -1), obs_o[:, :, 2 * B]], axis=1)
+        np.testing.assert_allclose(got, want, rtol=RTOL_RATE, atol=ATOL_OBS, err_msg=f'{tag}: obs')
+        if rew_o is not None:
+            tol = (ATOL_UTIL if kind == 'multi' else ATOL_OBS) * (U if reward == 'sum' else 1)
+            np.testing.assert_allclose(core.reward.cpu().numpy(), rew_o, atol=tol, rtol=0, err_msg=f'{tag}: reward')
+
+    core.reset()
+    cmp('reset', ob.reset(), None, None, None)
+    for t in range(c['steps']):
+        if t == c['steps'] // 2:
+            for o in ob.envs:
+                o.set_episode(1)
+            core.reset()
+            cmp('reset2', ob.reset(), None, None, None)
+        a = arng.integers(0, B + 1, size=(E, U)).astype(np.uint8)
+        a[arng.random((E, U)) < c['p_noop']] = 0
+        core.step(torch.from_numpy(a).cuda())
+        cmp(f'step {t}', *ob.step(a))
+    core.check()
+
+
+def describe(c):
+    return (f"{c['kind']} U={c['U']} B={c['B']} E={c['E']} map={c['w']}x{c['h']} reward={c['reward']} sharing={sorted(set(c['sh']))} "
+            f"seed={c['seed']} base={c['base']} steps={c['steps']} p_noop={c['p_noop']}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cases', type=int, default=200)
+    ap.add_argument('--seed', type=int, default=0)
+    a = ap.parse_args()
+    import torch
+    rng = np.random.default_rng(a.seed)
+    bad = 0
+    for i in range(a.cases):
+        c = random_case(rng)
+        try:
+            run_case(c, torch)
+        except (AssertionError, Exception) as ex:      # noqa: BLE001
+            bad += 1
+            print(f'case {i} FAILED: {describe(c)}\n   {str(ex)[:600]}', flush=True)
+    print(f'{a.cases - bad} / {a.cases} random configurations agree with the oracle')
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == '__main__':
+    main()
