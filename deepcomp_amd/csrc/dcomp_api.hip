@@ -52,6 +52,7 @@ struct dcomp_env {
     KParams kp;                 // constant part pre-filled
     dcomp::KernelPair kern;
     UeCfg *d_ue_cfg;
+    bool dyn;                  // UE list changes during an episode (cfg.max_ues > 0)
     int upad, grid;
     int cap, cur_ue;            // slots per env; UEs currently listed
     uint32_t n_removed, n_arrived;   // this episode (Philox draw words)
@@ -94,7 +95,8 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
         return fail(DCOMP_EINVAL, "need num_envs>=1, 1<=num_ue<=%d, 1<=num_bs<=%d (got %d, %d, %d)", DCOMP_MAX_UE, DCOMP_MAX_BS, E, U, B);
     const int CAP = cfg->max_ues > 0 ? cfg->max_ues : U;           // slots per env (base.py:79-84)
     if (CAP < U) return fail(DCOMP_EINVAL, "max_ues (%d) < num_ue (%d)", CAP, U);                 // base.py:84
-    if (CAP > U && CAP > 64) return fail(DCOMP_EUNSUPPORTED, "UE arrival/departure needs max_ues <= 64 (got %d)", CAP);
+    const bool DYN = cfg->max_ues > 0;                             // departures alone need no extra slots: max_ues == num_ue
+    if (DYN && CAP > 64) return fail(DCOMP_EUNSUPPORTED, "UE arrival/departure needs max_ues <= 64 (got %d)", CAP);
     if ((int64_t)E * CAP > (int64_t)1 << 30) return fail(DCOMP_EINVAL, "num_envs*max_ues too large");
     if (cfg->map_w < 21 || cfg->map_h < 21 || cfg->map_w > 65535 || cfg->map_h > 65535)
         return fail(DCOMP_EINVAL, "map must be 21..65535 in both dimensions (waypoints live in [10, size-10])");
@@ -108,7 +110,7 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
     dcomp_env *env = new dcomp_env();
     env->cfg = *cfg;
     env->cfg.bs_x = env->cfg.bs_y = nullptr;   // host arrays are not retained
-    env->cap = CAP; env->cur_ue = U; env->n_removed = env->n_arrived = 0;
+    env->cap = CAP; env->dyn = DYN; env->cur_ue = U; env->n_removed = env->n_arrived = 0;
     env->upad = next_pow2(CAP) < 4 ? 4 : next_pow2(CAP);
     int mp = dcomp::MP_RES_FAIR;            // sharing pattern -> specialised kernel (dcomp_device.h bs_mode_of)
     for (int b = 0; b < B; b++) if (cfg->bs_sharing[b] != DCOMP_RES_FAIR) mp = dcomp::MP_MIXED;
@@ -190,7 +192,7 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
     if (e != hipSuccess) { delete env; return fail(DCOMP_EHIP, "device setup failed: %s", hipGetErrorString(e)); }
     kp.ue_cfg = env->d_ue_cfg;
     if (env->kern.step_wide && !kp.any_maxcap && !getenv("DCOMP_NO_WIDE")) env->kern.step = env->kern.step_wide;
-    if (CAP > U) {
+    if (DYN) {
         if (kp.any_maxcap) { dcomp_destroy(env); return fail(DCOMP_EUNSUPPORTED, "UE arrival/departure with a max-cap BS is not supported"); }
         if (!env->kern.step_dyn) { dcomp_destroy(env); return fail(DCOMP_EUNSUPPORTED, "no dynamic-UE kernel for this shape"); }
         env->kern.step = env->kern.step_dyn;
@@ -236,7 +238,7 @@ static int fill_params(dcomp_env *env, const dcomp_state *st, const dcomp_out *o
     if (!st->pos || !st->mv || !st->conn || !st->ewma || !st->flags) return fail(DCOMP_EINVAL, "state pointers must all be set");
     if (!out->obs) return fail(DCOMP_EINVAL, "out->obs is required");
     if (env->kp.any_maxcap && !st->conn_since) return fail(DCOMP_EINVAL, "a max-cap BS needs state.conn_since (see dcomp_state_sizes)");
-    if (env->cap > env->cfg.num_ue && !st->uid) return fail(DCOMP_EINVAL, "UE arrival/departure needs state.uid");
+    if (env->dyn && !st->uid) return fail(DCOMP_EINVAL, "UE arrival/departure needs state.uid");
     kp = env->kp;
     kp.uid = st->uid;
     kp.orig_consumed = st->orig_consumed;
@@ -290,8 +292,8 @@ extern "C" int dcomp_step_dyn(dcomp_env *env, const dcomp_state *st, const uint8
                               const dcomp_events *ev, void *stream)
 {
     if (!env) return fail(DCOMP_EINVAL, "null env");
-    if (env->cap == env->cfg.num_ue) {
-        if (ev && (ev->n_remove || ev->n_add)) return fail(DCOMP_EINVAL, "handle was created without max_ues > num_ue");
+    if (!env->dyn) {
+        if (ev && (ev->n_remove || ev->n_add)) return fail(DCOMP_EINVAL, "handle was created without max_ues (fixed UE list)");
         return dcomp_step(env, st, action, out, stream);
     }
     KParams kp;

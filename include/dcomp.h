@@ -23,7 +23,7 @@
  *   conn  uint32[E*U]      bit b set <=> UE connected to BS b                  (user.py:34 bs_dr keys)
  *   ewma  float [E*U]      exponentially weighted average rate                 (user.py:148-157)
  *   flags uint32[4]        sticky device-side error bits, read by dcomp_check()
- *   With UE arrival / departure (cfg.max_ues > cfg.num_ue) every per-UE array has max_ues slots per env; slot =
+ *   With UE arrival / departure (cfg.max_ues >= cfg.num_ue; 0 = fixed list) every per-UE array has max_ues slots per env; slot =
  *   position in the reference's env.ue_list; uid uint16[E*max_ues] holds the UE ids.
  *   conn_since uint16[E*U][B]   step at which a connection was made -- only when some BS is max-cap (oldest
  *                          connection wins rate ties, station.py:184-186); NULL otherwise
@@ -70,7 +70,7 @@ typedef struct dcomp_cfg {
     int32_t rng_mode;            /* DCOMP_RNG_TAPE (reference-exact draws supplied by the host) | DCOMP_RNG_PHILOX */
     int32_t tape_depth;          /* movement triples per UE per episode in tape mode */
     int32_t device;              /* HIP device ordinal */
-    int32_t max_ues;             /* slots per env when UEs arrive / depart (base.py:79-84); 0 = num_ue (fixed list) */
+    int32_t max_ues;             /* slots per env when UEs arrive / depart (base.py:79-84), >= num_ue; 0 = fixed list */
     uint64_t seed;               /* Philox key */
     int64_t env_id_base;         /* global id of this shard's env 0 (results do not depend on the GPU count) */
     const double *bs_x, *bs_y;   /* host [B] */
@@ -88,7 +88,7 @@ typedef struct dcomp_state {     /* device, caller-allocated; sizes via dcomp_st
     float *ewma;
     uint32_t *flags;
     uint16_t *conn_since;        /* NULL unless dcomp_state_sizes() reports since_bytes > 0 */
-    uint16_t *uid;               /* [E*max_ues] UE id per slot, bit 15 = arrived during the episode; only with max_ues > num_ue */
+    uint16_t *uid;               /* [E*max_ues] UE id per slot, bit 15 = arrived during the episode; only with max_ues > 0 */
     uint16_t *orig_consumed;     /* [E*num_ue] optional: movement triples an initial UE had consumed when it left the
                                   * list (0xFFFF = never left) -- lets a tape-mode host continue that UE's stream */
 } dcomp_state;
@@ -145,7 +145,7 @@ int dcomp_reset(dcomp_env *env, const dcomp_state *st, const dcomp_tape *tape, c
 int dcomp_step(dcomp_env *env, const dcomp_state *st, const uint8_t *action, const dcomp_out *out, void *stream);
 
 /* dcomp_step with this step's UE departures / arrivals (MobileEnv.step incl. base.py:433-443, add_new_ue / remove_ue
- * base.py:592-618).  Needs cfg.max_ues > cfg.num_ue, state.uid and max_ues <= 64.  ev may be NULL (no event). */
+ * base.py:592-618).  Needs cfg.max_ues >= cfg.num_ue (> 0), state.uid and max_ues <= 64.  ev may be NULL (no event). */
 int dcomp_step_dyn(dcomp_env *env, const dcomp_state *st, const uint8_t *action, const dcomp_out *out,
                    const dcomp_events *ev, void *stream);
 int dcomp_num_ue(const dcomp_env *env);               /* UEs currently in every env's list */

@@ -56,7 +56,18 @@ def random_case(rng):
         vel.append(v); util.append(0 if uf == 'log' else 1); req.append(rq); init.append((ix, iy))
     kind = 'multi' if rng.random() < 0.6 else 'central'
     reward = ['avg', 'sum', 'min'][int(rng.integers(0, 3))]
-    return dict(m=m, bs=bs, ues=ues, kind=kind, reward=reward, E=E, U=U, B=B, w=w, h=h, bs_xy=bs_xy, sh=sh, vel=vel, util=util,
+    arrival = None
+    if U <= 20 and 'max-cap' not in sh and rng.random() < 0.5:      # UE arrival / departure (base.py:433-443); max_ues <= 64
+        arrival, cur, steps_max = {}, U, 44
+        for t in sorted(set(int(x) for x in rng.integers(1, steps_max, int(rng.integers(1, 9))))):
+            n = int(rng.integers(-3, 5))
+            n = max(n, 1 - cur)                                      # keep at least one UE in the list
+            n = min(n, 60 - cur)
+            if n:
+                arrival[t] = n
+                cur += n
+        arrival = arrival or None
+    return dict(arrival=arrival, m=m, bs=bs, ues=ues, kind=kind, reward=reward, E=E, U=U, B=B, w=w, h=h, bs_xy=bs_xy, sh=sh, vel=vel, util=util,
                 req=req, init=init, seed=int(rng.integers(0, 2 ** 31)), base=int(rng.integers(0, 1000)),
                 steps=int(rng.integers(15, 45)), p_noop=float(rng.choice([0.0, 0.5, 0.9])))
 
@@ -65,12 +76,17 @@ def run_case(c, torch):
     from deepcomp_amd.env import BatchedMobileEnv
     from oracle import oracle as orc
     E, U, B, kind, reward = c['E'], c['U'], c['B'], c['kind'], c['reward']
+    arrival = c.get('arrival')
+    L = 1000 if not arrival else 64
     core = BatchedMobileEnv(c['m'], c['bs'], c['ues'], kind, num_envs=E, seed=c['seed'], reward=reward, rng='philox',
-                            rand_episodes=True, env_id_base=c['base'], episode_length=1000)
+                            rand_episodes=True, env_id_base=c['base'], episode_length=L, ue_arrival=arrival)
+    U = core.U                                          # slots per env (max_ues when the list changes)
+    sched = orc.arrival_schedule(L, arrival) if arrival else None
     envs = []
     for e in range(E):
         o = orc.OracleEnv(c['w'], c['h'], c['bs_xy'], c['sh'], c['vel'], kind=orc.MULTI if kind == 'multi' else orc.CENTRAL,
-                          reward_agg={'avg': 0, 'sum': 1, 'min': 2}[reward], ue_util=c['util'], ue_dr_req=c['req'], init_xy=c['init'])
+                          reward_agg={'avg': 0, 'sum': 1, 'min': 2}[reward], ue_util=c['util'], ue_dr_req=c['req'], init_xy=c['init'],
+                          max_ues=U if arrival else None)
         o.set_philox(c['seed'], c['base'] + e)
         envs.append(o)
     ob = orc.OracleBatch(envs)
@@ -81,6 +97,9 @@ def run_case(c, torch):
         if pos_o is not None:
             assert np.array_equal(st['pos'], pos_o), f'{tag}: positions not bit-exact'
             assert np.array_equal(st['conn'], conn_o), f'{tag}: connection masks differ'
+            if arrival:
+                assert core.num_ue == envs[0].num_ue(), f'{tag}: number of UEs'
+                assert np.array_equal(st['uid'], np.stack([o.uids() for o in envs])), f'{tag}: UE ids differ'
         got = core.obs.cpu().numpy()
         want = obs_o if kind == 'multi' else np.concatenate(
             [obs_o[:, :, :B].reshape(E, -1), obs_o[:, :, B:2 * B].reshape(E, -1), obs_o[:, :, 2 * B]], axis=1)
@@ -91,21 +110,29 @@ def run_case(c, torch):
 
     core.reset()
     cmp('reset', ob.reset(), None, None, None)
+    te = 0                                              # env.time inside the episode
     for t in range(c['steps']):
         if t == c['steps'] // 2:
             for o in ob.envs:
                 o.set_episode(1)
             core.reset()
             cmp('reset2', ob.reset(), None, None, None)
+            te = 0
         a = arng.integers(0, B + 1, size=(E, U)).astype(np.uint8)
         a[arng.random((E, U)) < c['p_noop']] = 0
+        if arrival:
+            n_rem, n_add = sched[te]
+            if n_rem or n_add:
+                for o in envs:
+                    o.set_event_counts(n_rem, n_add)
         core.step(torch.from_numpy(a).cuda())
         cmp(f'step {t}', *ob.step(a))
+        te += 1
     core.check()
 
 
 def describe(c):
-    return (f"{c['kind']} U={c['U']} B={c['B']} E={c['E']} map={c['w']}x{c['h']} reward={c['reward']} sharing={sorted(set(c['sh']))} "
+    return (f"{'DYN ' + str(c['arrival']) + ' ' if c.get('arrival') else ''}{c['kind']} U={c['U']} B={c['B']} E={c['E']} map={c['w']}x{c['h']} reward={c['reward']} sharing={sorted(set(c['sh']))} "
             f"seed={c['seed']} base={c['base']} steps={c['steps']} p_noop={c['p_noop']}")
 
 
