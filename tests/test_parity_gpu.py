@@ -287,17 +287,16 @@ def test_random_configurations_slice(torch_cuda):
 
 def test_max_cap_near_tie_goes_to_the_oldest_connection(torch_cuda):
     """station.py:183-187 compares bw*log2(1+snr) in FP64: two UEs whose squared distances to the BS differ in the last
-    bits (here: mirrored positions reached by FP64 movement) have the SAME rate, and the first in connection order is
-    served.  Cases 6 and 102 of the seed-0 fuzz run."""
+    bits (mirrored positions reached by FP64 movement) have the SAME rate, and the first in connection order is served.
+    The two configurations the fuzzer found this with, frozen in tests/golden/fuzz_maxcap_near_ties.json (inputs only;
+    the oracle is the checker)."""
+    import json
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), '..', 'tools'))
     import fuzz_parity
-    rng = np.random.default_rng(0)
-    for i in range(103):
-        c = fuzz_parity.random_case(rng)
-        if i in (6, 102):
-            assert 'max-cap' in c['sh']
-            fuzz_parity.run_case(c, torch_cuda)
+    for spec in json.load(open(os.path.join(GOLDEN, 'fuzz_maxcap_near_ties.json'))):
+        assert 'max-cap' in spec['sh']
+        fuzz_parity.run_case(fuzz_parity.build_case(spec), torch_cuda)
 
 
 @pytest.mark.parametrize('agent_name', ['fullcomp', '3gpp', 'dynamic', 'static'])

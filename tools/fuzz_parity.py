@@ -17,15 +17,14 @@ RTOL_RATE, ATOL_UTIL, ATOL_OBS = 1e-5, 1e-4, 1e-5
 SHARING = ['resource-fair', 'rate-fair', 'max-cap', 'proportional-fair']
 
 
-def random_case(rng):
-    from deepcomp_amd.entities import Basestation, Map, Point, RandomWaypoint, User
+def random_spec(rng):
+    """A random configuration as plain data (JSON-able); build_case() turns it into entity objects."""
     U = int(rng.choice([1, 2, 3, 5, 8, 10, 17, 32, 33, 64, 70, 128, 130]))
     B = int(rng.choice([1, 2, 3, 5, 7, 10, 16, 25, 32]))
     if U * B > 2500:
         U = max(1, 2500 // B)
     E = int(rng.choice([1, 3, 8, 21]))
     w, h = int(rng.integers(60, 500)), int(rng.integers(60, 400))
-    m = Map(w, h)
     style = rng.integers(0, 4)
     if style == 0:
         sh = [SHARING[int(rng.integers(0, 4))]] * B
@@ -36,10 +35,9 @@ def random_case(rng):
     else:
         sh = [SHARING[int(x)] for x in rng.choice([0, 1, 3], B)]
     integer_bs = rng.random() < 0.5
-    bs_xy = [(float(rng.integers(0, w + 1)), float(rng.integers(0, h + 1))) if integer_bs else
-             (float(rng.uniform(0, w)), float(rng.uniform(0, h))) for _ in range(B)]
-    bs = [Basestation(f'B{i}', Point(*xy), s) for i, (xy, s) in enumerate(zip(bs_xy, sh))]
-    ues, vel, util, req, init = [], [], [], [], []
+    bs_xy = [[float(rng.integers(0, w + 1)), float(rng.integers(0, h + 1))] if integer_bs else
+             [float(rng.uniform(0, w)), float(rng.uniform(0, h))] for _ in range(B)]
+    vel, util, req, init = [], [], [], []
     for i in range(U):
         v = [0, 'slow', 'fast', int(rng.integers(1, 30))][int(rng.integers(0, 4))]
         uf = 'step' if rng.random() < 0.25 else 'log'
@@ -52,8 +50,7 @@ def random_case(rng):
             ix, iy = int(rng.integers(0, w + 1)), -1
         else:
             ix, iy = -1, -1
-        ues.append(User(str(i + 1), m, 'random' if ix < 0 else ix, 'random' if iy < 0 else iy, RandomWaypoint(m, v), util_func=uf, dr_req=rq))
-        vel.append(v); util.append(0 if uf == 'log' else 1); req.append(rq); init.append((ix, iy))
+        vel.append(v); util.append(0 if uf == 'log' else 1); req.append(rq); init.append([ix, iy])
     kind = 'multi' if rng.random() < 0.6 else 'central'
     reward = ['avg', 'sum', 'min'][int(rng.integers(0, 3))]
     arrival = None
@@ -67,9 +64,29 @@ def random_case(rng):
                 arrival[t] = n
                 cur += n
         arrival = arrival or None
-    return dict(arrival=arrival, m=m, bs=bs, ues=ues, kind=kind, reward=reward, E=E, U=U, B=B, w=w, h=h, bs_xy=bs_xy, sh=sh, vel=vel, util=util,
-                req=req, init=init, seed=int(rng.integers(0, 2 ** 31)), base=int(rng.integers(0, 1000)),
-                steps=int(rng.integers(15, 45)), p_noop=float(rng.choice([0.0, 0.5, 0.9])))
+    tape = (arrival is None) and rng.random() < 0.35           # reference-exact stdlib-random draws (static UE lists here)
+    return dict(arrival=arrival, tape=bool(tape), rand_episodes=bool(rng.random() < 0.5), kind=kind, reward=reward, E=E, U=U, B=B,
+                w=w, h=h, bs_xy=bs_xy, sh=sh, vel=vel, util=util, req=req, init=init, seed=int(rng.integers(0, 2 ** 31)),
+                base=int(rng.integers(0, 1000)), steps=int(rng.integers(15, 45)), p_noop=float(rng.choice([0.0, 0.5, 0.9])))
+
+
+def build_case(spec):
+    from deepcomp_amd.entities import Basestation, Map, Point, RandomWaypoint, User
+    c = dict(spec)
+    if c.get('arrival'):
+        c['arrival'] = {int(k): int(v) for k, v in c['arrival'].items()}       # JSON keys are strings
+    m = Map(c['w'], c['h'])
+    c['m'] = m
+    c['bs'] = [Basestation(f'B{i}', Point(*xy), s) for i, (xy, s) in enumerate(zip(c['bs_xy'], c['sh']))]
+    c['init'] = [tuple(p) for p in c['init']]
+    c['ues'] = [User(str(i + 1), m, 'random' if ix < 0 else ix, 'random' if iy < 0 else iy, RandomWaypoint(m, v),
+                     util_func='log' if u == 0 else 'step', dr_req=rq)
+                for i, (v, u, rq, (ix, iy)) in enumerate(zip(c['vel'], c['util'], c['req'], c['init']))]
+    return c
+
+
+def random_case(rng):
+    return build_case(random_spec(rng))
 
 
 def run_case(c, torch):
@@ -77,9 +94,12 @@ def run_case(c, torch):
     from oracle import oracle as orc
     E, U, B, kind, reward = c['E'], c['U'], c['B'], c['kind'], c['reward']
     arrival = c.get('arrival')
+    tape = bool(c.get('tape'))
     L = 1000 if not arrival else 64
-    core = BatchedMobileEnv(c['m'], c['bs'], c['ues'], kind, num_envs=E, seed=c['seed'], reward=reward, rng='philox',
-                            rand_episodes=True, env_id_base=c['base'], episode_length=L, ue_arrival=arrival)
+    depth = 48
+    core = BatchedMobileEnv(c['m'], c['bs'], c['ues'], kind, num_envs=E, seed=c['seed'], reward=reward,
+                            rng='reference' if tape else 'philox', rand_episodes=c.get('rand_episodes', True) if tape else True,
+                            env_id_base=c['base'], episode_length=L, ue_arrival=arrival, tape_depth=depth if tape else None)
     U = core.U                                          # slots per env (max_ues when the list changes)
     sched = orc.arrival_schedule(L, arrival) if arrival else None
     envs = []
@@ -87,9 +107,21 @@ def run_case(c, torch):
         o = orc.OracleEnv(c['w'], c['h'], c['bs_xy'], c['sh'], c['vel'], kind=orc.MULTI if kind == 'multi' else orc.CENTRAL,
                           reward_agg={'avg': 0, 'sum': 1, 'min': 2}[reward], ue_util=c['util'], ue_dr_req=c['req'], init_xy=c['init'],
                           max_ues=U if arrival else None)
-        o.set_philox(c['seed'], c['base'] + e)
+        if not tape:
+            o.set_philox(c['seed'], c['base'] + e)
         envs.append(o)
     ob = orc.OracleBatch(envs)
+    tapes = [orc.RefRngTape(int(core.env_seeds[e]), c['w'], c['h'], c['vel'], init_xy=c['init'], depth=depth,
+                            rand_episodes=c.get('rand_episodes', True)) for e in range(E)] if tape else None
+
+    def oracle_reset(first):
+        if tape:                                        # hand every oracle env the reference's own draws for this episode
+            for e, o in enumerate(envs):
+                o.set_tape(*tapes[e].draw_episode(None if first else o.cursors()))
+        elif not first:
+            for o in envs:
+                o.set_episode(1)
+        return ob.reset()
     arng = np.random.default_rng(c['seed'] ^ 0x5bd1e995)
 
     def cmp(tag, obs_o, rew_o, conn_o, pos_o):
@@ -109,14 +141,12 @@ def run_case(c, torch):
             np.testing.assert_allclose(core.reward.cpu().numpy(), rew_o, atol=tol, rtol=0, err_msg=f'{tag}: reward')
 
     core.reset()
-    cmp('reset', ob.reset(), None, None, None)
+    cmp('reset', oracle_reset(True), None, None, None)
     te = 0                                              # env.time inside the episode
     for t in range(c['steps']):
         if t == c['steps'] // 2:
-            for o in ob.envs:
-                o.set_episode(1)
             core.reset()
-            cmp('reset2', ob.reset(), None, None, None)
+            cmp('reset2', oracle_reset(False), None, None, None)
             te = 0
         a = arng.integers(0, B + 1, size=(E, U)).astype(np.uint8)
         a[arng.random((E, U)) < c['p_noop']] = 0
@@ -132,7 +162,7 @@ def run_case(c, torch):
 
 
 def describe(c):
-    return (f"{'DYN ' + str(c['arrival']) + ' ' if c.get('arrival') else ''}{c['kind']} U={c['U']} B={c['B']} E={c['E']} map={c['w']}x{c['h']} reward={c['reward']} sharing={sorted(set(c['sh']))} "
+    return (f"{'TAPE rand_episodes=' + str(c.get('rand_episodes')) + ' ' if c.get('tape') else ''}{'DYN ' + str(c['arrival']) + ' ' if c.get('arrival') else ''}{c['kind']} U={c['U']} B={c['B']} E={c['E']} map={c['w']}x{c['h']} reward={c['reward']} sharing={sorted(set(c['sh']))} "
             f"seed={c['seed']} base={c['base']} steps={c['steps']} p_noop={c['p_noop']}")
 
 
