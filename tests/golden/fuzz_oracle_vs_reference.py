@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Randomised pin of the CPU oracle against the REFERENCE ITSELF (build container only: needs /root/reference).
+
+The committed fixtures pin the oracle on a fixed set of scenarios; this drives the reference's unmodified env classes
+(behind the third-party stand-ins of _ref_shims.py, like gen_golden.py) and oracle/dcomp_oracle.c through random
+configurations -- shapes, BS layouts, sharing models incl. max-cap, utilities, velocities, start positions incl. UEs parked
+on a BS, rewards, agent kinds, fixed and continuing episodes -- with the same action tape, and applies the checks of
+tests/test_oracle_golden.py::test_trajectory to every step: FP64 positions / waypoints / FSM / connection masks and
+connection ORDER bit-exact, rates / utilities / observations / rewards to 1e-9.
+
+    python tests/golden/fuzz_oracle_vs_reference.py [--cases 100] [--seed 0]
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(REPO, 'tools'))
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+
+import gen_golden as G                                    # noqa: E402  (imports the reference behind the shims)
+import fuzz_parity                                        # noqa: E402  (random_spec: plain-data configurations)
+import test_oracle_golden as T                            # noqa: E402  (the oracle-side checks)
+from oracle import oracle as orc                          # noqa: E402
+
+
+def scenario_of(spec):
+    scn = types.SimpleNamespace(width=spec['w'], height=spec['h'], bs_ids=[f'B{i}' for i in range(spec['B'])],
+                                bs_pos=[tuple(p) for p in spec['bs_xy']], bs_sharing=list(spec['sh']))
+    scn.ue_specs = [dict(id=str(i + 1), pos_x='random' if ix < 0 else ix, pos_y='random' if iy < 0 else iy, velocity=v,
+                         util_func='log' if u == 0 else 'step', dr_req=rq)
+                    for i, (v, u, rq, (ix, iy)) in enumerate(zip(spec['vel'], spec['util'], spec['req'], spec['init']))]
+    return scn
+
+
+def run_one(spec):
+    kind = spec['kind']
+    steps = min(spec['steps'], 24)
+    g = G.run_trajectory('fuzz', scenario_of(spec), kind, spec['seed'] % 100000, steps, reward=spec['reward'],
+                         tape_mode='uniform' if spec['p_noop'] == 0.0 else 'sticky', rand_episodes=spec['rand_episodes'],
+                         episodes=2, eps_len=steps, save=False)
+    env, tape, U = T.make_env_from_fixture(g)
+    k = int(g['cfg_kind'])
+    t, consumed = 0, None
+    for ep in range(2):
+        env.set_tape(*tape.draw_episode(consumed))
+        env.reset()
+        T.check_snapshot(env, g, 'reset', ep, k)
+        for _ in range(steps):
+            env.step(g['actions'][t])
+            T.check_snapshot(env, g, 'step', t, k)
+            np.testing.assert_allclose(env.reward(), g['step_reward'][t], rtol=1e-9, atol=1e-12, err_msg=f'reward[{t}]')
+            assert abs(env.sum_utility() - float(g['step_sum_utility'][t])) <= 1e-9 * max(1.0, abs(float(g['step_sum_utility'][t])))
+            t += 1
+        consumed = env.cursors()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cases', type=int, default=100)
+    ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--max-pairs', type=int, default=240, help='U*B cap (the reference needs ~30 us per pair and step)')
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    bad = done = 0
+    while done < a.cases:
+        spec = fuzz_parity.random_spec(rng)
+        if spec['U'] * spec['B'] > a.max_pairs or spec['arrival']:
+            continue
+        done += 1
+        try:
+            run_one(spec)
+        except AssertionError as ex:
+            bad += 1
+            d = {k: spec[k] for k in ('kind', 'U', 'B', 'w', 'h', 'reward', 'seed', 'steps', 'rand_episodes')}
+            print(f'case {done} FAILED: {d} sharing={sorted(set(spec["sh"]))}\n   {str(ex)[:500]}', flush=True)
+    print(f'{a.cases - bad} / {a.cases} random configurations: oracle == reference')
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == '__main__':
+    main()

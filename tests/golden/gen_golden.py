@@ -116,7 +116,7 @@ def snapshot(env, kind, obs, reward=None, info=None):
 
 
 def run_trajectory(name, scn, kind, seed, num_steps, reward='avg', tape_mode='uniform', rand_episodes=False,
-                   episodes=1, eps_len=100, scripted=None):
+                   episodes=1, eps_len=100, scripted=None, save=True):
     """reset() then num_steps x step(); optionally several episodes (reset in between)."""
     m, bs_list, ue_list = build_ref(scn, scn.ue_specs)
     cfg = env_config(m, bs_list, ue_list, seed, eps_len=eps_len, reward=reward, rand_episodes=rand_episodes)
@@ -159,6 +159,8 @@ def run_trajectory(name, scn, kind, seed, num_steps, reward='avg', tape_mode='un
         out['reset_' + k] = np.stack([r[k] for r in resets])
     for k in steps[0]:
         out['step_' + k] = np.stack([s[k] for s in steps])
+    if not save:                      # fuzz_oracle_vs_reference.py: compare in memory
+        return out
     path = os.path.join(HERE, name + '.npz')
     np.savez_compressed(path, **out)
     print(f'{name}: {os.path.getsize(path) / 1024:.0f} KiB  U={U} B={B} steps={num_steps * episodes}')
