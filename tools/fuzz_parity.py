@@ -64,7 +64,7 @@ def random_spec(rng):
                 arrival[t] = n
                 cur += n
         arrival = arrival or None
-    tape = (arrival is None) and rng.random() < 0.35           # reference-exact stdlib-random draws (static UE lists here)
+    tape = rng.random() < 0.35                                  # reference-exact stdlib-random draws (rng='reference')
     return dict(arrival=arrival, tape=bool(tape), rand_episodes=bool(rng.random() < 0.5), kind=kind, reward=reward, E=E, U=U, B=B,
                 w=w, h=h, bs_xy=bs_xy, sh=sh, vel=vel, util=util, req=req, init=init, seed=int(rng.integers(0, 2 ** 31)),
                 base=int(rng.integers(0, 1000)), steps=int(rng.integers(15, 45)), p_noop=float(rng.choice([0.0, 0.5, 0.9])))
@@ -111,11 +111,25 @@ def run_case(c, torch):
             o.set_philox(c['seed'], c['base'] + e)
         envs.append(o)
     ob = orc.OracleBatch(envs)
-    tapes = [orc.RefRngTape(int(core.env_seeds[e]), c['w'], c['h'], c['vel'], init_xy=c['init'], depth=depth,
-                            rand_episodes=c.get('rand_episodes', True)) for e in range(E)] if tape else None
+    re = c.get('rand_episodes', True)
+    tapes = dyn_tapes = None
+    if tape and not arrival:
+        tapes = [orc.RefRngTape(int(core.env_seeds[e]), c['w'], c['h'], c['vel'], init_xy=c['init'], depth=depth, rand_episodes=re)
+                 for e in range(E)]
+    elif tape:                                          # reference draws with a changing UE list (oracle.py: DynRefStreams)
+        max_id = len(c['vel']) + sum(a for _, a in sched)
+        dyn_tapes = [(orc.DynRefStreams(int(core.env_seeds[e]), c['w'], c['h'], c['vel'], depth=depth, rand_episodes=re, init_xy=c['init']),
+                      orc.RefRngTape(int(core.env_seeds[e]), c['w'], c['h'], ['slow'] * max_id, depth=depth),
+                      orc.RefEventDraws(int(core.env_seeds[e]), c['w'], c['h'], rand_episodes=re)) for e in range(E)]
 
     def oracle_reset(first):
-        if tape:                                        # hand every oracle env the reference's own draws for this episode
+        if dyn_tapes:
+            for (init_t, new_t, ev), o in zip(dyn_tapes, envs):
+                p0, t0 = init_t.draw_episode(*((None, None) if first else (o.end_of_episode_list(), o.orig_consumed())))
+                p1, t1 = new_t.draw_episode()
+                o.set_tape_ids(np.concatenate([p0, p1]), np.concatenate([t0, t1]))
+                ev.new_episode()
+        elif tape:                                      # hand every oracle env the reference's own draws for this episode
             for e, o in enumerate(envs):
                 o.set_tape(*tapes[e].draw_episode(None if first else o.cursors()))
         elif not first:
@@ -153,8 +167,11 @@ def run_case(c, torch):
         if arrival:
             n_rem, n_add = sched[te]
             if n_rem or n_add:
-                for o in envs:
-                    o.set_event_counts(n_rem, n_add)
+                for e, o in enumerate(envs):
+                    if dyn_tapes:
+                        o.set_events(dyn_tapes[e][2].departures(n_rem, o.num_ue()), dyn_tapes[e][2].arrivals(n_add))
+                    else:
+                        o.set_event_counts(n_rem, n_add)
         core.step(torch.from_numpy(a).cuda())
         cmp(f'step {t}', *ob.step(a))
         te += 1
