@@ -329,7 +329,7 @@ def gen_estack():
 
 
 def run_dynamic_trajectory(name, scn, kind, seed, num_steps, ue_arrival=None, new_ue_interval=None, episodes=1,
-                           rand_episodes=False, reward='avg'):
+                           rand_episodes=False, reward='avg', save=True):
     """G8: UE arrival / departure (base.py:433-443, 592-618).  Per-UE arrays are padded to max_ues; `num_ue` and
     `ue_ids` say which slots are alive (slot = position in env.ue_list, the order central observations use)."""
     m, bs_list, ue_list = build_ref(scn, scn.ue_specs)
@@ -395,6 +395,8 @@ def run_dynamic_trajectory(name, scn, kind, seed, num_steps, ue_arrival=None, ne
         out['reset_' + k] = np.stack([r[k] for r in resets])
     for k in steps[0]:
         out['step_' + k] = np.stack([s[k] for s in steps])
+    if not save:
+        return out
     path = os.path.join(HERE, name + '.npz')
     np.savez_compressed(path, **out)
     print(f'{name}: {os.path.getsize(path) / 1024:.0f} KiB  max_ues={M} B={B} steps={num_steps * episodes}')
