@@ -87,14 +87,62 @@ def run_one_dynamic(spec):
         consumed, end_list = env.orig_consumed(), env.end_of_episode_list()
 
 
+def has_maxcap_near_tie(spec):
+    """Oracle-only dry run of run_one()'s trajectory: does a max-cap BS ever see its two closest connected UEs at squared
+    distances that differ, but by less than 1e-9 (relative)?  There the FP64 rates of station.py:129-138 coincide and the
+    winner is decided by connection order -- the case worth checking against the reference itself."""
+    steps = 24
+    init = [tuple(p) for p in spec['init']]
+    env = orc.OracleEnv(spec['w'], spec['h'], spec['bs_xy'], spec['sh'], spec['vel'], kind=orc.MULTI if spec['kind'] == 'multi' else orc.CENTRAL,
+                        ue_util=spec['util'], ue_dr_req=spec['req'], init_xy=init)
+    tape = orc.RefRngTape(spec['seed'] % 100000, spec['w'], spec['h'], spec['vel'], init_xy=init, depth=64, rand_episodes=spec['rand_episodes'])
+    acts = G.action_tape(2 * steps, spec['U'], spec['B'], 'sticky')
+    t, consumed = 0, None
+    for _ in range(2):
+        env.set_tape(*tape.draw_episode(consumed))
+        env.reset()
+        for _ in range(steps):
+            env.step(acts[t])
+            t += 1
+            st = env.state()
+            for b in range(spec['B']):
+                us = np.nonzero(st['conn'][:, b])[0]
+                if spec['sh'][b] != 'max-cap' or len(us) < 2:
+                    continue
+                d2 = np.sort(((st['pos'][us] - np.array(spec['bs_xy'][b])) ** 2).sum(1))
+                if d2[0] > 0 and 0 < (d2[1] - d2[0]) / d2[1] < 1e-9:
+                    return True
+        consumed = env.cursors()
+    return False
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--near-ties', type=int, default=0, help='instead: find this many max-cap near-tie configurations with the oracle and check THEM against the reference')
     ap.add_argument('--cases', type=int, default=100)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--max-pairs', type=int, default=240, help='U*B cap (the reference needs ~30 us per pair and step)')
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     bad = done = 0
+    if a.near_ties:
+        tried = 0
+        while done < a.near_ties:
+            spec = fuzz_parity.random_spec(rng)
+            if 'max-cap' not in spec['sh'] or spec['U'] < 30 or spec['arrival']:
+                continue
+            spec.update(p_noop=0.5, steps=24)           # run_one(): sticky action tape, 2 x 24 steps
+            tried += 1
+            if not has_maxcap_near_tie(spec):
+                continue
+            done += 1
+            try:
+                run_one(spec)
+            except AssertionError as ex:
+                bad += 1
+                print(f'near-tie case {done} FAILED: U={spec["U"]} B={spec["B"]} seed={spec["seed"]}\n   {str(ex)[:500]}', flush=True)
+        print(f'{done - bad} / {done} max-cap near-tie configurations (found among {tried} max-cap configurations): oracle == reference')
+        sys.exit(1 if bad else 0)
     while done < a.cases:
         spec = fuzz_parity.random_spec(rng)
         if spec['U'] * spec['B'] > a.max_pairs or (spec['arrival'] and 'max-cap' in spec['sh']):
