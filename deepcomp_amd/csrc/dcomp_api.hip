@@ -145,8 +145,8 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
             kp.pl_c2 = c2;
         }
         kp.half_gamma = (float)(c2 / 20.0);
-        kp.log2k = (float)std::log2(ref_snr(1.0));
-        kp.log2k_s = (float)(std::log2(ref_snr(1.0)) - 12.0 * (c2 / 20.0));
+        kp.log2k = (float)(std::log2(ref_snr(1.0)) + (double)dcomp::L2_OFF);
+        kp.log2k_s = (float)(std::log2(ref_snr(1.0)) + (double)dcomp::L2_OFF - 12.0 * (c2 / 20.0));
         double dt = dcomp_connect_threshold();
         kp.dt2 = dt * dt;
     }

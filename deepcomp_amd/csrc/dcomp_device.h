@@ -101,8 +101,8 @@ struct KParams {
     uint32_t seed_lo, seed_hi, episode;
     uint32_t env_base;         // global id of env 0
     float half_gamma;          // path-loss exponent c2/10, halved (applied to log2 d^2)
-    float log2k;               // log2(K)
-    float log2k_s;             // log2(K) - 12 * half_gamma  (pair_eval scales d^2 by 2^-12)
+    float log2k;               // log2(K) + L2_OFF
+    float log2k_s;             // log2(K) + L2_OFF - 12 * half_gamma  (pair_eval scales d^2 by 2^-12)
     double dt2;                // squared connect-threshold distance
     double bs_x[DCOMP_MAX_BS], bs_y[DCOMP_MAX_BS];
     int32_t bs_mode[DCOMP_MAX_BS];
@@ -202,6 +202,11 @@ __device__ __forceinline__ void wave_lds_fence()
 
 // ---------------------------------------------------------------------------------------------- channel
 constexpr float NEAR_D2 = 1.6f;   // squared distance under which the rare fix-ups run (see eval_pairs)
+// Every `l2` / `l2snr` value in the kernels is log2(snr) + L2_OFF.  log2(snr) of an in-range pair lies in [-25.6, -4]; most
+// connections sit at the far end, where an f32 has an ulp of 1.9e-6 -- the rounding of the final FMA alone would cost
+// 6.6e-7 relative in snr.  Shifted by 24 the same pairs lie in [-1.6, 2] (ulp 2.4e-7).  The shift is free: the host adds it
+// to log2 K, the rate series absorbs 2^-24 in its coefficients, observations only use differences.
+constexpr float L2_OFF = 24.0f;
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32 (1 ulp)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32 (1 ulp)
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32 (1 ulp)
@@ -282,25 +287,27 @@ __device__ __forceinline__ uint32_t eval_pairs(double px, double py, const KPara
 // bw * log2(1 + snr) from log2(snr).  station.py:129-138.  Never forms 1+snr for small snr (1.0f + snr is
 // exactly 1.0f below 6e-8 while the connect threshold is 2e-8): log1p(s)/s = 1 - s/2 + s^2/3 - s^3/4, truncation error
 // s^4/5 < 1.2e-8 for snr < 1/64 (d > 1.24 m).  `needfix` flags the rare larger snr, redone by rate_unshared_any.
-constexpr float RATE_SMALL_L2 = -6.0f;            // log2 of the largest snr the short series takes
+constexpr float RATE_SMALL_L2 = -6.0f + L2_OFF;   // (shifted) log2 of the largest snr the short series takes
 __device__ __forceinline__ float rate_unshared_small(float l2snr, bool &needfix)
 {
     needfix = l2snr > RATE_SMALL_L2;
-    const float s = fast_exp2(min_med3(l2snr, RATE_SMALL_L2));
-    constexpr float K = BW * LOG2E;               // bw / ln 2 folded into the coefficients: one multiply less
-    float t = __builtin_fmaf(s, -0.25f * K, 0.33333334f * K);
-    t = __builtin_fmaf(s, t, -0.5f * K);
-    t = __builtin_fmaf(s, t, K);
-    return s * t;
+    const float z = fast_exp2(min_med3(l2snr, RATE_SMALL_L2));        // z = snr * 2^24
+    // bw/ln2 * s * (1 - s/2 + s^2/3 - s^3/4) with s = z * 2^-24: the powers of 2^-24 live in the coefficients
+    constexpr float K = BW * LOG2E, S1 = 0x1p-24f, S2 = 0x1p-48f, S3 = 0x1p-72f, S4 = 0x1p-96f;
+    float t = __builtin_fmaf(z, -0.25f * K * S4, 0.33333334f * K * S3);
+    t = __builtin_fmaf(z, t, -0.5f * K * S2);
+    t = __builtin_fmaf(z, t, K * S1);
+    return z * t;
 }
 __device__ __forceinline__ float rate_unshared_any(float l2snr)
 {
     // snr >= 1/64.  u = fl(1 + s) loses the low bits of s; log(1+s) = log(u) * s / (u - 1) puts them back (u - 1 is exact),
     // relative error ~2e-7 for any s.  d -> 0 (snr up to 3.5e52): log2(1+s) = log2(s) to f32 precision.
-    const float s = fast_exp2(fminf(l2snr, 100.f));
+    const float l = l2snr - L2_OFF;                                    // exact enough here: |l2snr| < 2^8, l2snr >= 18
+    const float s = fast_exp2(fminf(l, 100.f));
     const float u = 1.0f + s;
-    const float l = fast_log2(u) * (s * fast_rcp(u - 1.0f));
-    return BW * (l2snr > 100.f ? l2snr : l);
+    const float lg = fast_log2(u) * (s * fast_rcp(u - 1.0f));
+    return BW * (l > 100.f ? l : lg);
 }
 // user.py:76-92 -> utility.py:23-54
 __device__ __forceinline__ float ue_utility(float dr, bool step_util, float dr_req)

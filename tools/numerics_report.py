@@ -13,6 +13,8 @@ from deepcomp_amd.env import BatchedMobileEnv
 from oracle import oracle as orc
 
 E, U, B, T = 1024, 32, 10, 60
+if len(sys.argv) > 2:                       # tools/numerics_report.py <envs> <steps>: a larger sample for the tail
+    E, T = int(sys.argv[1]), int(sys.argv[2])
 scn = scenarios.grid_map(B, 'mixed').with_ues(num_static=2, num_slow=22, num_fast=8)
 m, bs, ues = build_from_scenario(scn)
 core = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=E, seed=7, rng='philox')
