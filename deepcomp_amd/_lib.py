@@ -51,7 +51,7 @@ class DcompEvents(ctypes.Structure):
 
 EXPORTS = ['dcomp_create', 'dcomp_destroy', 'dcomp_state_sizes', 'dcomp_obs_dim', 'dcomp_reset', 'dcomp_step',
            'dcomp_step_dyn', 'dcomp_num_ue',
-           'dcomp_rollout', 'dcomp_check', 'dcomp_time', 'dcomp_episode', 'dcomp_set_episode', 'dcomp_mt_draw_tape',
+           'dcomp_rollout', 'dcomp_check', 'dcomp_time', 'dcomp_episode', 'dcomp_set_episode', 'dcomp_get_counters', 'dcomp_set_counters', 'dcomp_mt_draw_tape',
            'dcomp_connect_threshold', 'dcomp_last_error', 'dcomp_version', 'dcomp_selftest']
 
 _lib = None
@@ -88,6 +88,8 @@ def load():
     L.dcomp_episode.argtypes = [vp]
     L.dcomp_episode.restype = i64
     L.dcomp_set_episode.argtypes = [vp, i64]
+    L.dcomp_get_counters.argtypes = [vp, ctypes.POINTER(i64)]
+    L.dcomp_set_counters.argtypes = [vp, ctypes.POINTER(i64)]
     L.dcomp_mt_draw_tape.argtypes = [ctypes.POINTER(DcompCfg), ctypes.POINTER(i64), i32, i32, vp, vp]
     L.dcomp_connect_threshold.restype = ctypes.c_double
     L.dcomp_last_error.restype = ctypes.c_char_p

@@ -354,6 +354,21 @@ extern "C" int dcomp_check(dcomp_env *env, const dcomp_state *st, void *stream)
 
 extern "C" int dcomp_time(const dcomp_env *env) { return env ? env->time : -1; }
 extern "C" int64_t dcomp_episode(const dcomp_env *env) { return env ? env->episode : -1; }
+extern "C" int dcomp_get_counters(const dcomp_env *env, int64_t out[5])
+{
+    if (!env || !out) return fail(DCOMP_EINVAL, "null argument");
+    out[0] = env->time; out[1] = env->episode; out[2] = env->cur_ue; out[3] = env->n_removed; out[4] = env->n_arrived;
+    return DCOMP_OK;
+}
+extern "C" int dcomp_set_counters(dcomp_env *env, const int64_t in[5])
+{
+    if (!env || !in) return fail(DCOMP_EINVAL, "null argument");
+    if (in[0] < 0 || in[1] < -1 || in[2] < 1 || in[2] > env->cap || in[3] < 0 || in[4] < 0) return fail(DCOMP_EINVAL, "counters out of range");
+    if (!env->dyn && (in[2] != env->cfg.num_ue || in[3] || in[4])) return fail(DCOMP_EINVAL, "fixed UE list: num_ue / event counters cannot change");
+    env->time = (int)in[0]; env->episode = in[1]; env->cur_ue = (int)in[2];
+    env->n_removed = (uint32_t)in[3]; env->n_arrived = (uint32_t)in[4];
+    return DCOMP_OK;
+}
 extern "C" int dcomp_set_episode(dcomp_env *env, int64_t episode)
 {
     if (!env) return fail(DCOMP_EINVAL, "null env");

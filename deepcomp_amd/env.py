@@ -306,6 +306,40 @@ class BatchedMobileEnv:
                                              ctypes.byref(self._out), self._stream()))
         return self.obs, self.reward
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def _fingerprint(self):
+        return dict(E=self.E, U=self.U, U0=self.U0, B=self.B, kind=int(self.kind), reward=self.reward_agg, seed=int(self.seed_value),
+                    env_id_base=self.env_id_base, map=(self.map_w, self.map_h), rand_episodes=self.rand_episodes,
+                    bs=self._bs_x.tolist() + self._bs_y.tolist() + self._bs_sh.tolist(), dynamic=self.dynamic)
+
+    def state_dict(self):
+        """Everything needed to continue this env batch bit-identically in another process (the reference never checkpoints
+        env state -- simulation.py:143-147 saves the learner only): the state tensors, the outputs of the last step and the
+        handle's five counters.  Counter-based draws only: the stdlib-`random` streams of rng='reference' are host objects."""
+        if self.rng_mode != _lib.RNG_PHILOX:
+            raise NotImplementedError("state_dict() needs rng='philox' (counter-based draws)")
+        c = (ctypes.c_int64 * 5)()
+        _lib.check(self._L.dcomp_get_counters(self._h, c))
+        torch.cuda.current_stream(self.device).synchronize()
+        sd = {'config': self._fingerprint(), 'counters': list(c), 'outbuf': self._outbuf.detach().cpu().clone()}
+        for k in ('pos', 'mv', 'conn', 'ewma', 'conn_since', 'uid', 'orig_consumed'):
+            t = getattr(self, k)
+            sd[k] = None if t is None else t.detach().cpu().clone()
+        return sd
+
+    def load_state_dict(self, sd):
+        if self.rng_mode != _lib.RNG_PHILOX:
+            raise NotImplementedError("load_state_dict() needs rng='philox' (counter-based draws)")
+        if sd['config'] != self._fingerprint():
+            raise ValueError("checkpoint belongs to a differently configured env batch")
+        for k in ('pos', 'mv', 'conn', 'ewma', 'conn_since', 'uid', 'orig_consumed'):
+            if sd[k] is not None:
+                getattr(self, k).copy_(sd[k])
+        self._outbuf.copy_(sd['outbuf'])
+        self.flags.zero_()
+        c = (ctypes.c_int64 * 5)(*sd['counters'])
+        _lib.check(self._L.dcomp_set_counters(self._h, c))
+
     def info(self):
         """base.py:383-411 as tensors."""
         if not self.log_metrics:

@@ -163,6 +163,12 @@ int dcomp_time(const dcomp_env *env);                 /* env.time (base.py:39) -
 int64_t dcomp_episode(const dcomp_env *env);          /* resets so far - 1 (Philox counter word) */
 int dcomp_set_episode(dcomp_env *env, int64_t episode);
 
+/* Checkpoint / resume of an env batch (the reference never checkpoints env state, simulation.py:143-147 restores the
+ * learner only; with counter-based draws the state tensors plus these five host-side counters are the whole env):
+ * {time, episode, UEs currently listed, departures so far this episode, arrivals so far this episode}. */
+int dcomp_get_counters(const dcomp_env *env, int64_t out[5]);
+int dcomp_set_counters(dcomp_env *env, const int64_t in[5]);
+
 /* Host-side helper for tape mode: CPython-compatible Mersenne Twister draws
  * (random.Random(seed).randint, user.py:94-109 / movement.py:110-130) for UEs
  * [0,U) of `num_envs` envs whose base seeds are seeds[e]; UE i uses seeds[e] + 100*(i+1)

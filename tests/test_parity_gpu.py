@@ -765,3 +765,47 @@ def test_reference_surface_single_env(torch_cuda):
         assert obs['connected'] == g['step_obs_connected'][t].astype(int).reshape(-1).tolist()
     with pytest.raises(AssertionError):
         env.step([4, 0, 0])                          # central.py:61
+
+
+@pytest.mark.parametrize('dyn', [False, True])
+def test_checkpoint_resume_is_bit_identical(torch_cuda, dyn):
+    """state_dict() / load_state_dict(): a second env batch built from the same config continues a checkpoint taken mid-episode
+    bit-identically (state, observations, rewards), across the next reset too -- with UE arrival / departure as well."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    E, L = 257, 40
+    scn = scenarios.large_map('mixed').with_ues(num_static=1, num_slow=4, num_fast=2)
+    m, bs, ues = build_from_scenario(scn)
+    kw = dict(num_envs=E, seed=11, episode_length=L, rng='philox', rand_episodes=True, env_id_base=3,
+              ue_arrival={3: 2, 9: -3, 15: 4, 22: -2, 31: 1} if dyn else None)
+    a = BatchedMobileEnv(m, bs, ues, 'multi', **kw)
+    rng = np.random.default_rng(5)
+    acts = torch.from_numpy(rng.integers(0, a.B + 1, size=(70, E, a.U)).astype(np.uint8)).cuda()
+
+    def run(env, t0, t1, record):
+        for t in range(t0, t1):
+            if t % L == 0:
+                env.reset()
+            env.step(acts[t])
+            if record is not None:
+                record.append((env.obs.cpu().numpy().copy(), env.reward.cpu().numpy().copy()))
+        env.check()
+
+    run(a, 0, 17, None)
+    sd = a.state_dict()
+    want = []
+    run(a, 17, 70, want)                      # crosses the resets at t = 40
+    b = BatchedMobileEnv(m, bs, ues, 'multi', **kw)
+    b.load_state_dict(sd)
+    assert b.time == 17 and b.num_ue == sd['counters'][2]
+    got = []
+    run(b, 17, 70, got)
+    for i, ((o1, r1), (o2, r2)) in enumerate(zip(want, got)):
+        assert np.array_equal(o1, o2) and np.array_equal(r1, r2), f'step {17 + i} differs after resume'
+    sa, sb = a.state_host(), b.state_host()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    with pytest.raises(ValueError):
+        BatchedMobileEnv(m, bs, ues, 'multi', **dict(kw, seed=12)).load_state_dict(sd)
