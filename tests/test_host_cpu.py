@@ -167,3 +167,25 @@ def test_parse_entities_accepts_the_references_own_objects():
     assert e['ue_ids'] == ['1', '2', '3'] and e['ue_util'].tolist() == [0, 1, 0] and e['ue_dr_req'].tolist() == [1.0, 2.0, 1.0]
     assert e['vel_lo'].tolist() == [1, 5, 0] and e['vel_hi'].tolist() == [3, 10, 0]
     assert e['init_xy'] == [(-1, -1), (30, -1), (-1, 7)]
+
+
+def test_fuzz_specs_are_plain_data():
+    """tools/fuzz_parity.py: configurations are JSON-able data; build_case() turns them into entity objects (host only)."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(REPO, 'tools'))
+    import fuzz_parity
+    from deepcomp_amd.env import parse_entities
+    rng = np.random.default_rng(0)
+    kinds = set()
+    for _ in range(60):
+        spec = fuzz_parity.random_spec(rng)
+        c = fuzz_parity.build_case(json.loads(json.dumps(spec)))
+        e = parse_entities(c['m'], c['bs'], c['ues'])
+        assert len(e['ue_ids']) == spec['U'] and e['bs_x'].shape == (spec['B'],) and (e['map_w'], e['map_h']) == (spec['w'], spec['h'])
+        assert e['bs_sharing'].tolist() == [fuzz_parity.SHARING.index(s) for s in spec['sh']]
+        kinds.add((spec['tape'], spec['arrival'] is not None))
+    assert len(kinds) == 4                                  # Philox / reference draws x fixed / changing UE lists all occur
+    frozen = json.load(open(os.path.join(REPO, 'tests', 'golden', 'fuzz_maxcap_near_ties.json')))
+    assert [s['U'] for s in frozen] == [130, 70] and all('max-cap' in s['sh'] for s in frozen)
+    fuzz_parity.build_case(frozen[0])
