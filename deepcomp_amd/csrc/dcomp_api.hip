@@ -96,7 +96,6 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
     const int CAP = cfg->max_ues > 0 ? cfg->max_ues : U;           // slots per env (base.py:79-84)
     if (CAP < U) return fail(DCOMP_EINVAL, "max_ues (%d) < num_ue (%d)", CAP, U);                 // base.py:84
     const bool DYN = cfg->max_ues > 0;                             // departures alone need no extra slots: max_ues == num_ue
-    if (DYN && CAP > 64) return fail(DCOMP_EUNSUPPORTED, "UE arrival/departure needs max_ues <= 64 (got %d)", CAP);
     if ((int64_t)E * CAP > (int64_t)1 << 30) return fail(DCOMP_EINVAL, "num_envs*max_ues too large");
     if (cfg->map_w < 21 || cfg->map_h < 21 || cfg->map_w > 65535 || cfg->map_h > 65535)
         return fail(DCOMP_EINVAL, "map must be 21..65535 in both dimensions (waypoints live in [10, size-10])");
@@ -193,7 +192,6 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
     kp.ue_cfg = env->d_ue_cfg;
     if (env->kern.step_wide && !kp.any_maxcap && !getenv("DCOMP_NO_WIDE")) env->kern.step = env->kern.step_wide;
     if (DYN) {
-        if (kp.any_maxcap) { dcomp_destroy(env); return fail(DCOMP_EUNSUPPORTED, "UE arrival/departure with a max-cap BS is not supported"); }
         if (!env->kern.step_dyn) { dcomp_destroy(env); return fail(DCOMP_EUNSUPPORTED, "no dynamic-UE kernel for this shape"); }
         env->kern.step = env->kern.step_dyn;
     }

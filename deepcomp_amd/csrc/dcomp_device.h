@@ -995,8 +995,7 @@ inline KernelFn wide_or_null()
 template <int B, int UPAD>
 inline KernelFn dyn_or_null()
 {
-    if constexpr (UPAD <= 64) return step_kernel_dyn<B, UPAD>;
-    else return nullptr;
+    return step_kernel_dyn<B, UPAD>;
 }
 
 template <int B, int UPAD>

@@ -10,7 +10,8 @@
 //     velocity 'slow', freshly seeded movement stream (base.py:592-606);
 //   * the number of UEs is the same in every env (the schedule is configuration), so it is a kernel argument; dead
 //     slots write zero rows (the reference zero-pads central observations, central.py:46-55).
-// Envs wider than one wavefront (max_ues > 64) are not supported here.
+// max-cap BSs: the per-slot step-of-connection rows shift with the slots.  Envs wider than one wavefront (max_ues > 64)
+// exchange the slot state through LDS instead.
 #pragma once
 
 namespace dcomp {
@@ -21,13 +22,18 @@ __device__ __forceinline__ T shift_up(bool take, T mine, T next)
     return take ? next : mine;
 }
 
+// Envs wider than a wavefront exchange the slot state through LDS (word-major: conflict-free) instead of __shfl_down.
+template <int UPAD, int NWORDS>
+struct DynExchange { uint32_t w[UPAD > 64 ? NWORDS * DCOMP_BLOCK : 1]; };
+
 template <int B, int UPAD>
 __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel_dyn(const KParams p)
 {
-    static_assert(UPAD <= 64, "dynamic UE lists: one env must fit a wavefront");
     using G = Geo<B, UPAD>;
     constexpr int MP = MP_GENERIC;
+    constexpr int CSW = (B + 1) / 2, XW = 9 + CSW;
     __shared__ BlockSharedT<B, UPAD> sh;
+    __shared__ DynExchange<UPAD, XW> dx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int env_local = tid / UPAD, u = tid % UPAD;
     const int env = blockIdx.x * G::GPB + env_local;
@@ -51,6 +57,22 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel_dyn(const KParams p)
         uidw = p.uid[idx];
     }
 
+    // max-cap BSs: the step-of-connection row of this slot (dcomp_state.conn_since) travels with the UE when slots shift.
+    // Kept in registers (u16 pairs) from here to the write-back before the rates; every lane reads / writes only its own row.
+    uint32_t cs[CSW];
+    const bool mc = p.any_maxcap != 0;                         // uniform
+    if (mc) {
+#pragma unroll
+        for (int j = 0; j < CSW; j++) {
+            uint32_t lo = 0, hi = 0;
+            if (alive) {
+                lo = p.conn_since[(size_t)idx * B + 2 * j];
+                if (2 * j + 1 < B) hi = p.conn_since[(size_t)idx * B + 2 * j + 1];
+            }
+            cs[j] = lo | (hi << 16);
+        }
+    }
+
     // 1./2. pairs at the pre-move position, toggle (base.py:247-263)
     float l2[B];
     uint32_t in_range = eval_pairs<B>(px, py, p, l2);
@@ -58,7 +80,15 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel_dyn(const KParams p)
     if (act > 0) {
         const uint32_t bit = 1u << (act - 1);
         if (conn & bit) conn &= ~bit;
-        else if (in_range & bit) conn |= bit;
+        else if (in_range & bit) {
+            conn |= bit;
+            if (mc && (p.maxcap_mask & bit)) {                  // connection order = (step, slot): see shared_rates
+                const int b = (int)act - 1;
+#pragma unroll
+                for (int j = 0; j < CSW; j++)
+                    if (j == b / 2) cs[j] = (b & 1) ? ((cs[j] & 0x0000FFFFu) | (p.time << 16)) : ((cs[j] & 0xFFFF0000u) | (p.time & 0xFFFFu));
+            }
+        }
     }
 
     // 2b. UE departure / arrival (base.py:433-443), after the actions and before the rates
@@ -74,18 +104,55 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel_dyn(const KParams p)
             if (alive && u == r && !(uidw & UID_BORN) && p.orig_consumed)      // host bookkeeping of the initial UEs' streams
                 p.orig_consumed[(size_t)env * p.U0 + ((uidw & 0x7FFFu) - 1u)] = (uint16_t)(mv >> 48);
             const bool take = u >= r && u + 1 < cur;            // slots behind the leaver move up
-            const double nx = __shfl_down(px, 1, UPAD), ny = __shfl_down(py, 1, UPAD);
-            const unsigned long long nmv = __shfl_down(mv, 1, UPAD);
-            const uint32_t nconn = __shfl_down(conn, 1, UPAD), nuid = __shfl_down(uidw, 1, UPAD);
-            const float newma = __shfl_down(ewma, 1, UPAD);
-            px = shift_up<UPAD>(take, px, nx); py = shift_up<UPAD>(take, py, ny); mv = shift_up<UPAD>(take, mv, nmv);
-            conn = shift_up<UPAD>(take, conn, nconn); uidw = shift_up<UPAD>(take, uidw, nuid); ewma = shift_up<UPAD>(take, ewma, newma);
+            if constexpr (UPAD <= 64) {
+                const double nx = __shfl_down(px, 1, UPAD), ny = __shfl_down(py, 1, UPAD);
+                const unsigned long long nmv = __shfl_down(mv, 1, UPAD);
+                const uint32_t nconn = __shfl_down(conn, 1, UPAD), nuid = __shfl_down(uidw, 1, UPAD);
+                const float newma = __shfl_down(ewma, 1, UPAD);
+                px = shift_up<UPAD>(take, px, nx); py = shift_up<UPAD>(take, py, ny); mv = shift_up<UPAD>(take, mv, nmv);
+                conn = shift_up<UPAD>(take, conn, nconn); uidw = shift_up<UPAD>(take, uidw, nuid); ewma = shift_up<UPAD>(take, ewma, newma);
+                if (mc) {
+#pragma unroll
+                    for (int j = 0; j < CSW; j++) { const uint32_t n = __shfl_down(cs[j], 1, UPAD); cs[j] = take ? n : cs[j]; }
+                }
+            } else {                                            // the env spans several wavefronts of this workgroup
+                uint32_t wd[XW];
+                const unsigned long long bx = (unsigned long long)__double_as_longlong(px), by = (unsigned long long)__double_as_longlong(py);
+                wd[0] = (uint32_t)bx; wd[1] = (uint32_t)(bx >> 32); wd[2] = (uint32_t)by; wd[3] = (uint32_t)(by >> 32);
+                wd[4] = (uint32_t)mv; wd[5] = (uint32_t)(mv >> 32); wd[6] = conn; wd[7] = uidw; wd[8] = __float_as_uint(ewma);
+#pragma unroll
+                for (int j = 0; j < CSW; j++) wd[9 + j] = mc ? cs[j] : 0u;
+#pragma unroll
+                for (int w = 0; w < XW; w++) dx.w[w * DCOMP_BLOCK + tid] = wd[w];
+                __syncthreads();
+                const int src = tid + 1 < DCOMP_BLOCK ? tid + 1 : tid;   // take implies the next slot belongs to the same env
+                if (take) {
+#pragma unroll
+                    for (int w = 0; w < XW; w++) wd[w] = dx.w[w * DCOMP_BLOCK + src];
+                }
+                __syncthreads();
+                px = __longlong_as_double((long long)(((unsigned long long)wd[1] << 32) | wd[0]));
+                py = __longlong_as_double((long long)(((unsigned long long)wd[3] << 32) | wd[2]));
+                mv = ((unsigned long long)wd[5] << 32) | wd[4];
+                conn = wd[6]; uidw = wd[7]; ewma = __uint_as_float(wd[8]);
+                if (mc) {
+#pragma unroll
+                    for (int j = 0; j < CSW; j++) cs[j] = wd[9 + j];
+                }
+            }
             cur -= 1;
-            if (u == cur) { conn = 0; uidw = 0; ewma = 0.f; mv = 0; px = 0.0; py = 0.0; }
+            if (u == cur) { conn = 0; uidw = 0; ewma = 0.f; mv = 0; px = 0.0; py = 0.0; if (mc) { for (int j = 0; j < CSW; j++) cs[j] = 0; } }
             alive = active && u < cur;
         }
         for (int k = 0; k < p.n_add; k++) {                    // base.py:592-606
-            const uint32_t last = __shfl(uidw, gbase + (cur - 1), 64);          // id of ue_list[-1]
+            uint32_t last;                                                       // id of ue_list[-1]
+            if constexpr (UPAD <= 64) last = __shfl(uidw, gbase + (cur - 1), 64);
+            else {
+                dx.w[tid] = uidw;
+                __syncthreads();
+                last = dx.w[env_local * UPAD + (cur - 1)];
+                __syncthreads();
+            }
             if (active && u == cur) {
                 int x, y;
                 if (p.rng_mode == DCOMP_RNG_TAPE) { const size_t t = ((size_t)env * p.n_add + k) * 2; x = p.ev_add_xy[t]; y = p.ev_add_xy[t + 1]; }
@@ -103,11 +170,19 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel_dyn(const KParams p)
                 draw_triple(p, env, uidw, 0u, vel, wx, wy);
                 mv = mv_pack(wx, wy, vel, 0u, 0u, 1u);
                 conn = 0; ewma = 0.f;
+                if (mc) { for (int j = 0; j < CSW; j++) cs[j] = 0; }
             }
             cur += 1;
         }
         alive = active && u < cur;
         in_range = eval_pairs<B>(px, py, p, l2);                // slots changed owners
+    }
+    if (mc && active) {                                         // rows back in place before shared_rates reads its own
+#pragma unroll
+        for (int j = 0; j < CSW; j++) {
+            p.conn_since[(size_t)idx * B + 2 * j] = (uint16_t)(cs[j] & 0xFFFFu);
+            if (2 * j + 1 < B) p.conn_since[(size_t)idx * B + 2 * j + 1] = (uint16_t)(cs[j] >> 16);
+        }
     }
     const uint32_t id0 = (uidw & 0x7FFFu) - 1u;
     bool step_util = false;

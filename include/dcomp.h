@@ -145,7 +145,7 @@ int dcomp_reset(dcomp_env *env, const dcomp_state *st, const dcomp_tape *tape, c
 int dcomp_step(dcomp_env *env, const dcomp_state *st, const uint8_t *action, const dcomp_out *out, void *stream);
 
 /* dcomp_step with this step's UE departures / arrivals (MobileEnv.step incl. base.py:433-443, add_new_ue / remove_ue
- * base.py:592-618).  Needs cfg.max_ues >= cfg.num_ue (> 0), state.uid and max_ues <= 64.  ev may be NULL (no event). */
+ * base.py:592-618).  Needs cfg.max_ues >= cfg.num_ue (> 0) and state.uid.  ev may be NULL (no event). */
 int dcomp_step_dyn(dcomp_env *env, const dcomp_state *st, const uint8_t *action, const dcomp_out *out,
                    const dcomp_events *ev, void *stream);
 int dcomp_num_ue(const dcomp_env *env);               /* UEs currently in every env's list */

@@ -145,7 +145,7 @@ def main():
         sys.exit(1 if bad else 0)
     while done < a.cases:
         spec = fuzz_parity.random_spec(rng)
-        if spec['U'] * spec['B'] > a.max_pairs or (spec['arrival'] and 'max-cap' in spec['sh']):
+        if spec['U'] * spec['B'] > a.max_pairs:
             continue
         done += 1
         try:

@@ -54,12 +54,12 @@ def random_spec(rng):
     kind = 'multi' if rng.random() < 0.6 else 'central'
     reward = ['avg', 'sum', 'min'][int(rng.integers(0, 3))]
     arrival = None
-    if U <= 20 and 'max-cap' not in sh and rng.random() < 0.5:      # UE arrival / departure (base.py:433-443); max_ues <= 64
+    if (U <= 20 or U >= 64) and rng.random() < 0.5:                 # UE arrival / departure (base.py:433-443), also > 1 wavefront
         arrival, cur, steps_max = {}, U, 44
         for t in sorted(set(int(x) for x in rng.integers(1, steps_max, int(rng.integers(1, 9))))):
             n = int(rng.integers(-3, 5))
             n = max(n, 1 - cur)                                      # keep at least one UE in the list
-            n = min(n, 60 - cur)
+            n = min(n, 250 - cur)
             if n:
                 arrival[t] = n
                 cur += n
