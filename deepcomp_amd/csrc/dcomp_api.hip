@@ -230,6 +230,13 @@ extern "C" int dcomp_obs_dim(const dcomp_env *env, int32_t *floats_per_env, int3
     return DCOMP_OK;
 }
 
+static int check_horizon(const dcomp_env *env, int steps)
+{
+    if (env && (int64_t)env->time + steps > 65536)
+        return fail(DCOMP_EUNSUPPORTED, "episodes longer than 65536 steps: conn_since and the draw cursor are 16-bit (reset() first)");
+    return DCOMP_OK;
+}
+
 static int fill_params(dcomp_env *env, const dcomp_state *st, const dcomp_out *out, KParams &kp)
 {
     if (!env || !st || !out) return fail(DCOMP_EINVAL, "null argument");
@@ -278,6 +285,7 @@ extern "C" int dcomp_step(dcomp_env *env, const dcomp_state *st, const uint8_t *
     if (rc) return rc;
     if (!action) return fail(DCOMP_EINVAL, "null action");
     if (env->episode < 0) return fail(DCOMP_EINVAL, "step() before reset()");
+    if ((rc = check_horizon(env, 1))) return rc;
     kp.action = action;
     kp.n_remove = kp.n_add = 0;
     hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
@@ -299,6 +307,7 @@ extern "C" int dcomp_step_dyn(dcomp_env *env, const dcomp_state *st, const uint8
     if (rc) return rc;
     if (!action) return fail(DCOMP_EINVAL, "null action");
     if (env->episode < 0) return fail(DCOMP_EINVAL, "step() before reset()");
+    if ((rc = check_horizon(env, 1))) return rc;
     const int nrem = ev ? ev->n_remove : 0, nadd = ev ? ev->n_add : 0;
     if (nrem < 0 || nadd < 0 || (nrem > 0 && nadd > 0)) return fail(DCOMP_EINVAL, "one step either adds or removes UEs (base.py:436-443)");
     if (env->cur_ue - nrem < 1) return fail(DCOMP_EINVAL, "cannot remove %d of %d UEs", nrem, env->cur_ue);
@@ -325,6 +334,7 @@ extern "C" int dcomp_rollout(dcomp_env *env, const dcomp_state *st, const uint8_
     int rc = fill_params(env, st, out, kp);
     if (rc) return rc;
     if (!actions || num_steps < 1) return fail(DCOMP_EINVAL, "bad action tape");
+    if ((rc = check_horizon(env, num_steps))) return rc;
     if (env->episode < 0) return fail(DCOMP_EINVAL, "rollout() before reset()");
     const size_t stride = (size_t)env->cfg.num_envs * env->cap;
     for (int t = 0; t < num_steps; t++) {

@@ -27,6 +27,7 @@
  *   position in the reference's env.ue_list; uid uint16[E*max_ues] holds the UE ids.
  *   conn_since uint16[E*U][B]   step at which a connection was made -- only when some BS is max-cap (oldest
  *                          connection wins rate ties, station.py:184-186); NULL otherwise
+ *   An episode has at most 65536 steps (16-bit draw cursor and conn_since); dcomp_step returns DCOMP_EUNSUPPORTED beyond.
  */
 #ifndef DCOMP_H
 #define DCOMP_H
