@@ -165,6 +165,7 @@ class BatchedMobileEnv:
         self._dyn_streams = None
         self._ev_keep = None
         self._out = self._make_out(self.obs, self.reward)
+        self._st_ref, self._out_ref = ctypes.byref(self._st), ctypes.byref(self._out)   # per-step ctypes work done once
         self._tape_dev = None
         self._streams = None
         self._fixed_tape = None
@@ -265,14 +266,19 @@ class BatchedMobileEnv:
         on_dev = action.device == self.device or (self.host_io and action.data_ptr() == self.action_host.data_ptr())
         if action.dtype != torch.uint8 or not on_dev or not action.is_contiguous() or action.numel() != self.E * self.U:
             raise ValueError(f"action must be a contiguous uint8 tensor with {self.E}x{self.U} entries on {self.device}")
-        with torch.cuda.device(self.device):
+        if torch.cuda.current_device() == self.device.index:      # the common case: no device switch around the launch
             self._launch_step(action, self._out)
+        else:
+            with torch.cuda.device(self.device):
+                self._launch_step(action, self._out)
         return self.obs, self.reward, None, self.info()
 
     def _launch_step(self, action, out):
         if not self.dynamic:
-            _lib.check(self._L.dcomp_step(self._h, ctypes.byref(self._st), ctypes.c_void_p(action.data_ptr()),
-                                          ctypes.byref(out), self._stream()))
+            rc = self._L.dcomp_step(self._h, self._st_ref, ctypes.c_void_p(action.data_ptr()),
+                                    self._out_ref if out is self._out else ctypes.byref(out), self._stream())
+            if rc:
+                _lib.check(rc)
             return
         t = self.time
         n_rem, n_add = self.schedule[t] if t < len(self.schedule) else (0, 0)      # base.py:433-443
@@ -344,13 +350,16 @@ class BatchedMobileEnv:
         """base.py:383-411 as tensors."""
         if not self.log_metrics:
             return {'time': self.time}
-        return {'time': self.time, 'scalar_metrics': {'sum_utility': self.sum_utility},
-                'vector_metrics': {'dr': self.ue_dr, 'utility': self.ue_utility}}
+        m = self.__dict__.get('_metric_views')
+        if m is None:                                   # the tensors are fixed views of the output buffer: build the dicts once
+            m = self._metric_views = ({'sum_utility': self.sum_utility}, {'dr': self.ue_dr, 'utility': self.ue_utility})
+        return {'time': self.time, 'scalar_metrics': m[0], 'vector_metrics': m[1]}
 
     def enable_reward_before(self):
         """Also write the per-UE pre-move reward clip(utility)/20 (base.py:158-167, 446): the single-agent env's reward."""
         self.want_reward_before = True
         self._out = self._make_out(self.obs, self.reward)
+        self._out_ref = ctypes.byref(self._out)
 
     def outputs_host(self, synced=False):
         """Everything the last reset()/step() produced as a dict of numpy views: ONE device->host copy, or (host_io) the
