@@ -809,3 +809,27 @@ def test_checkpoint_resume_is_bit_identical(torch_cuda, dyn):
         assert np.array_equal(sa[k], sb[k]), k
     with pytest.raises(ValueError):
         BatchedMobileEnv(m, bs, ues, 'multi', **dict(kw, seed=12)).load_state_dict(sd)
+
+
+def test_episode_horizon_guard(torch_cuda):
+    """The draw cursor and conn_since are 16-bit: a step beyond 65536 is refused (NotImplementedError), reset() clears it."""
+    import ctypes as C
+    torch = torch_cuda
+    from deepcomp_amd import _lib, scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    m, bs, ues = build_from_scenario(scenarios.small_map('mixed').with_ues(num_slow=2))
+    env = BatchedMobileEnv(m, bs, ues, 'central', num_envs=4, seed=1, rng='philox', rand_episodes=True, episode_length=10 ** 6)
+    env.reset()
+    a = torch.zeros((4, 2), dtype=torch.uint8, device='cuda')
+    env.step(a)
+    c = (C.c_int64 * 5)()
+    _lib.check(env._L.dcomp_get_counters(env._h, c))
+    c[0] = 65535
+    _lib.check(env._L.dcomp_set_counters(env._h, c))
+    env.step(a)                                        # step 65536 of the episode: the last one allowed
+    with pytest.raises(NotImplementedError):
+        env.step(a)
+    env.reset()
+    env.step(a)
+    env.check()
