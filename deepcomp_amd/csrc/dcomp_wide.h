@@ -59,25 +59,23 @@ __device__ __forceinline__ void wide_xchg(float (&v)[N], SH &sh, int &buf, int w
 template <int B, int NW, int MP, class SH>
 __device__ __forceinline__ void wide_chunk_rates(const KParams &p, SH &sh, int &buf, int c0, const bool (&c)[WIDE_BC],
                                                  const float (&l2)[WIDE_BC], float inv_ewma, int wave, int lane,
-                                                 float (&dr)[WIDE_BC], float (&cnt)[WIDE_BC])
+                                                 float (&dr)[WIDE_BC], float (&cnt)[WIDE_BC], bool near_hint)
 {
+    // near_hint (wave-uniform): some lane of this wave may be within 1.26 m of a BS (pair_eval's flag); only then can a pair
+    // have snr > 1/64, which the short series does not cover (see shared_rates)
     float ex[2 * WIDE_BC];               // [0,BC): counts, [BC,2BC): sums
-    bool fix = false;
 #pragma unroll
     for (int j = 0; j < WIDE_BC; j++) {
         dr[j] = 0.f; ex[j] = 0.f; ex[WIDE_BC + j] = 0.f;
         if (c0 + j < B) {
             const unsigned long long m = __ballot(c[j]);
-            if (m != 0ull) {
-                bool f;
-                const float t = rate_unshared_small(l2[j], f);
-                dr[j] = c[j] ? t : 0.f;
-                fix |= c[j] && f;
-            }
+            bool f;                                            // straight-line: with 64 UEs of one env per wave a station is
+            const float t = rate_unshared_small(l2[j], f);     // rarely empty, and a skip branch per station costs more
+            dr[j] = c[j] ? t : 0.f;
             ex[j] = (float)group_popcount<64>(m, 0);
         }
     }
-    if (__ballot(fix) != 0ull) {
+    if (near_hint) {
 #pragma unroll
         for (int j = 0; j < WIDE_BC; j++) if (c0 + j < B && c[j] && l2[j] > RATE_SMALL_L2) dr[j] = rate_unshared_any(l2[j]);
     }
@@ -154,30 +152,37 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
     // ---- sweep 1: toggle, pre-move rates, drop, stale-rate EWMA term; post-move log2 snr kept in l2n[]
     float *const strow = sh.drst[wave] + lane * (B + 1);      // this lane's row: log2 snr' now, normalised dr later
     uint32_t inr_new = 0;
+    bool near_any = false;                                     // wave-uniform: a lane came within 1.26 m of some BS this step
     float curr = 0.f, stale = 0.f, l2max = -1e30f;
     const float inv_ewma_old = fast_rcp(ewma + EPS);
+    const uint32_t act_bit = act ? 1u << (act - 1u) : 0u;
 #pragma unroll 1
     for (int c0 = 0; c0 < B; c0 += BC) {
         bool c[BC];
         float l2o[BC], l2n[BC], dr[BC], cnt[BC];
         bool anytiny = false;
+        uint32_t inr_old = 0;
 #pragma unroll
         for (int j = 0; j < BC; j++) {
             const int b = c0 + j;
-            c[j] = false; l2o[j] = -30.f;
+            l2o[j] = -30.f;
             if (b < B) {
                 bool inr_o, inr_n, t0, t1;
                 pair_eval(ox, oy, p.bs_x[b], p.bs_y[b], p, inr_o, l2o[j], t0);
                 pair_eval(px, py, p.bs_x[b], p.bs_y[b], p, inr_n, l2n[j], t1);
                 anytiny |= t0 | t1;
                 inr_new |= (uint32_t)inr_n << b;
-                bool cb = (conn >> b) & 1u;
-                if (act == (uint32_t)(b + 1)) cb = cb ? false : inr_o;           // base.py:259-263 -> user.py:190-222
-                c[j] = cb;
-                conn = (conn & ~(1u << b)) | ((uint32_t)cb << b);
+                inr_old |= (uint32_t)inr_o << b;
             }
         }
-        if (__ballot(anytiny) != 0ull) {
+        // toggle of the acted-on station if it is in this chunk, branch-free (base.py:259-263 -> user.py:190-222):
+        // connected -> disconnect; not connected and in range at the pre-move position -> connect
+        conn ^= act_bit & (conn | inr_old) & (((BC >= 32 ? 0u : (1u << BC)) - 1u) << c0);
+#pragma unroll
+        for (int j = 0; j < BC; j++) c[j] = (c0 + j < B) && ((conn >> (c0 + j)) & 1u);
+        const bool near_chunk = __ballot(anytiny) != 0ull;       // a lane within 1.26 m of one of these stations (old or new position)
+        near_any |= near_chunk;
+        if (near_chunk) {
 #pragma unroll
             for (int j = 0; j < BC; j++) {
                 const int b = c0 + j;
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
                 }
             }
         }
-        wide_chunk_rates<B, NW, MP>(p, sh, buf, c0, c, l2o, inv_ewma_old, wave, lane, dr, cnt);
+        wide_chunk_rates<B, NW, MP>(p, sh, buf, c0, c, l2o, inv_ewma_old, wave, lane, dr, cnt, near_chunk);
 #pragma unroll
         for (int j = 0; j < BC; j++) {
             const int b = c0 + j;
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
             c[j] = b < B ? (bool)((conn >> b) & 1u) : false;
             l2c[j] = b < B ? strow[b] : -30.f;
         }
-        wide_chunk_rates<B, NW, MP>(p, sh, buf, c0, c, l2c, inv_ewma, wave, lane, dr, cnt);
+        wide_chunk_rates<B, NW, MP>(p, sh, buf, c0, c, l2c, inv_ewma, wave, lane, dr, cnt, near_any);
 #pragma unroll
         for (int j = 0; j < BC; j++) if (c0 + j < B) curr += dr[j];
     }
