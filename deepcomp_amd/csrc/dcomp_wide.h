@@ -5,7 +5,7 @@
 // (log2 snr, rates, counts, sums: 5 x 32 VGPRs) cap occupancy at 2 waves/SIMD:
 //   * one wavefront holds UEs of ONE env, so everything per (env, BS) -- connected-UE count, sum 1/rate, sum
 //     priority, sum utility -- is wave-uniform: it lives in scalar registers / LDS tables, not in per-lane arrays;
-//   * the BS loop is a real loop over chunks of BC = 8 (not unrolled over B: bounded registers and code size); the
+//   * the BS loop is a real loop over chunks of BC = 3 or 4 stations (not unrolled over B: bounded registers and code size); the
 //     post-move log2 snr of all B stations is parked in the lane's own LDS row, which later becomes the `dr` transpose;
 //   * the move is done FIRST (it does not depend on rates), so one sweep over the BS chunks can evaluate the pre-move
 //     pair, the post-move pair, the toggle, the pre-move rate, the drop and the stale-rate EWMA term of a station
@@ -22,6 +22,10 @@ namespace dcomp {
 #define DCOMP_WIDE_BC 4
 #endif
 constexpr int WIDE_BC = DCOMP_WIDE_BC;   // BSs per chunk: 4 -> ~100 VGPRs (4-5 waves/SIMD), 8 -> ~145 (3 waves/SIMD)
+// The CLI-default 'mixed' pattern cycles resource- / rate- / proportional-fair with the station index: chunks of THREE make the
+// model of every chunk slot a compile-time constant (no scalar mode tests and branches per station): 0.1021 -> 0.0926 ms at config
+// 5's per-GPU share.  The other patterns are faster with 4 (resource-fair 0.077 vs 0.086 ms, generic 0.105 vs 0.115 ms).
+constexpr int wide_bc(int mp) { return mp == MP_MIXED ? 3 : WIDE_BC; }
 
 template <int B, int UPAD>
 struct alignas(16) WideShared {
@@ -56,17 +60,17 @@ __device__ __forceinline__ void wide_xchg(float (&v)[N], SH &sh, int &buf, int w
 
 // Shared rates of one chunk of base stations (station.py:152-220).  c[j]: connected to BS c0+j; l2[j]: log2 snr.
 // Returns the shared rate per station in dr[j] (0 where not connected) and |S_b| in cnt[j].
-template <int B, int NW, int MP, class SH>
-__device__ __forceinline__ void wide_chunk_rates(const KParams &p, SH &sh, int &buf, int c0, const bool (&c)[WIDE_BC],
-                                                 const float (&l2)[WIDE_BC], float inv_ewma, int wave, int lane,
-                                                 float (&dr)[WIDE_BC], float (&cnt)[WIDE_BC], bool near_hint)
+template <int B, int NW, int MP, int BCC, class SH>
+__device__ __forceinline__ void wide_chunk_rates(const KParams &p, SH &sh, int &buf, int c0, const bool (&c)[BCC],
+                                                 const float (&l2)[BCC], float inv_ewma, int wave, int lane,
+                                                 float (&dr)[BCC], float (&cnt)[BCC], bool near_hint)
 {
     // near_hint (wave-uniform): some lane of this wave may be within 1.26 m of a BS (pair_eval's flag); only then can a pair
     // have snr > 1/64, which the short series does not cover (see shared_rates)
-    float ex[2 * WIDE_BC];               // [0,BC): counts, [BC,2BC): sums
+    float ex[2 * BCC];               // [0,BC): counts, [BC,2BC): sums
 #pragma unroll
-    for (int j = 0; j < WIDE_BC; j++) {
-        dr[j] = 0.f; ex[j] = 0.f; ex[WIDE_BC + j] = 0.f;
+    for (int j = 0; j < BCC; j++) {
+        dr[j] = 0.f; ex[j] = 0.f; ex[BCC + j] = 0.f;
         if (c0 + j < B) {
             const unsigned long long m = __ballot(c[j]);
             bool f;                                            // straight-line: with 64 UEs of one env per wave a station is
@@ -77,32 +81,32 @@ __device__ __forceinline__ void wide_chunk_rates(const KParams &p, SH &sh, int &
     }
     if (near_hint) {
 #pragma unroll
-        for (int j = 0; j < WIDE_BC; j++) if (c0 + j < B && c[j] && l2[j] > RATE_SMALL_L2) dr[j] = rate_unshared_any(l2[j]);
+        for (int j = 0; j < BCC; j++) if (c0 + j < B && c[j] && l2[j] > RATE_SMALL_L2) dr[j] = rate_unshared_any(l2[j]);
     }
     bool any_sum = false;
 #pragma unroll
-    for (int j = 0; j < WIDE_BC; j++) {
+    for (int j = 0; j < BCC; j++) {
         if (c0 + j < B) {
             const int mode = bs_mode_of<MP>(p, c0 + j);
-            if (mode == DCOMP_RATE_FAIR) { ex[WIDE_BC + j] = c[j] ? fast_rcp(dr[j]) : 0.f; any_sum = true; }
-            else if (mode == DCOMP_PROP_FAIR) { ex[WIDE_BC + j] = dr[j] * inv_ewma; any_sum = true; }
+            if (mode == DCOMP_RATE_FAIR) { ex[BCC + j] = c[j] ? fast_rcp(dr[j]) : 0.f; any_sum = true; }
+            else if (mode == DCOMP_PROP_FAIR) { ex[BCC + j] = dr[j] * inv_ewma; any_sum = true; }
         }
     }
     if (any_sum) {                       // uniform (modes are uniform)
-        float sv[WIDE_BC];
+        float sv[BCC];
 #pragma unroll
-        for (int j = 0; j < WIDE_BC; j++) sv[j] = ex[WIDE_BC + j];
-        group_reduce_vec<64, OpSum, WIDE_BC>(sv);
+        for (int j = 0; j < BCC; j++) sv[j] = ex[BCC + j];
+        group_reduce_vec<64, OpSum, BCC>(sv);
 #pragma unroll
-        for (int j = 0; j < WIDE_BC; j++) ex[WIDE_BC + j] = sv[j];
+        for (int j = 0; j < BCC; j++) ex[BCC + j] = sv[j];
     }
-    wide_xchg<2 * WIDE_BC, NW, OpSum>(ex, sh, buf, wave, lane);
+    wide_xchg<2 * BCC, NW, OpSum>(ex, sh, buf, wave, lane);
 #pragma unroll
-    for (int j = 0; j < WIDE_BC; j++) {
+    for (int j = 0; j < BCC; j++) {
         cnt[j] = ex[j];
         if (c0 + j < B) {
             const int mode = bs_mode_of<MP>(p, c0 + j);
-            const float dru = dr[j], agg = ex[WIDE_BC + j];
+            const float dru = dr[j], agg = ex[BCC + j];
             float out;
             if (mode == DCOMP_RES_FAIR) out = dru * fast_rcp(fmaxf(cnt[j], 1.f));
             else if (mode == DCOMP_RATE_FAIR) out = fast_rcp(agg);
@@ -116,7 +120,7 @@ template <int B, int UPAD, int MP>
 __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
 {
     static_assert(UPAD >= 64, "wide kernel: one wavefront holds UEs of a single env");
-    constexpr int NW = UPAD / 64, GPB = 256 / UPAD, BC = WIDE_BC, ROW = 4 * B + 1;
+    constexpr int NW = UPAD / 64, GPB = 256 / UPAD, BC = wide_bc(MP), ROW = 4 * B + 1;
     __shared__ WideShared<B, UPAD> sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int env_local = wave / NW, u = (wave % NW) * 64 + lane;
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
                 }
             }
         }
-        wide_chunk_rates<B, NW, MP>(p, sh, buf, c0, c, l2o, inv_ewma_old, wave, lane, dr, cnt, near_chunk);
+        wide_chunk_rates<B, NW, MP, BC>(p, sh, buf, c0, c, l2o, inv_ewma_old, wave, lane, dr, cnt, near_chunk);
 #pragma unroll
         for (int j = 0; j < BC; j++) {
             const int b = c0 + j;
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
             c[j] = b < B ? (bool)((conn >> b) & 1u) : false;
             l2c[j] = b < B ? strow[b] : -30.f;
         }
-        wide_chunk_rates<B, NW, MP>(p, sh, buf, c0, c, l2c, inv_ewma, wave, lane, dr, cnt, near_any);
+        wide_chunk_rates<B, NW, MP, BC>(p, sh, buf, c0, c, l2c, inv_ewma, wave, lane, dr, cnt, near_any);
 #pragma unroll
         for (int j = 0; j < BC; j++) if (c0 + j < B) curr += dr[j];
     }
