@@ -7,7 +7,7 @@
 // wave-uniform: it lives in the kernel-argument segment and is read with scalar loads into SGPRs, the B
 // loop is fully unrolled (B is a template parameter).  No [U,B] intermediate ever reaches HBM: one read
 // and one write of the UE state, one write of the observation row (staged through LDS so that every store
-// instruction covers 1 KiB contiguous, non-temporal).  Variants: dcomp_wide.h (B > 24 with >= 64 lanes per env),
+// instruction covers 1 KiB contiguous, non-temporal).  Variants: dcomp_wide.h (B > 20 with >= 64 lanes per env),
 // dcomp_dyn.h (UE arrival / departure).
 //
 // Numerics: position / movement / connect-drop decisions in FP64 with the reference's operation order
@@ -35,6 +35,10 @@
 #endif
 #ifndef DCOMP_BLOCK
 #define DCOMP_BLOCK 256
+#endif
+#ifndef DCOMP_WIDE_MIN_B
+#define DCOMP_WIDE_MIN_B 20  // envs of >= 64 lanes use the wide kernel (dcomp_wide.h) above this many base stations
+                             // (4 096 x 128 UE: B = 16: narrow 0.046 / wide 0.055 ms; 20: 0.062 / 0.064; 24: 0.102 / 0.070)
 #endif
 #ifndef DCOMP_COMPILER_DIV
 #define DCOMP_COMPILER_DIV 0 // 1 = the compiler's generic FP64 sqrt / division in move_ue (A/B of norm_and_unit)
@@ -987,8 +991,8 @@ template <int B, int UPAD, int MP>
 inline KernelFn wide_or_null()
 {
     // measured on MI355X: the chunked organisation only pays once the unrolled per-BS register arrays of
-    // step_kernel no longer fit (B > 24); below that step_kernel is 1.0-1.7x faster
-    if constexpr (UPAD >= 64 && B > 24) return step_kernel_wide<B, UPAD, MP>;
+    // step_kernel no longer fit (B > DCOMP_WIDE_MIN_B); below that step_kernel is faster
+    if constexpr (UPAD >= 64 && B > DCOMP_WIDE_MIN_B) return step_kernel_wide<B, UPAD, MP>;
     else return nullptr;
 }
 

@@ -222,7 +222,8 @@ def _oracle_batch(scn, kind, reward, E, seed, env_id_base=0):
                                    ('central', 1, 1, 64, 'avg'), ('multi', 1, 2, 64, 'sum'), ('multi', 2, 32, 16, 'min'),
                                    ('multi', 40, 6, 24, 'avg', 'max-cap'), ('multi', 128, 32, 4, 'avg', 'proportional-fair'),
                                    ('multi', 64, 26, 6, 'sum', 'rate-fair'), ('central', 100, 30, 3, 'avg', 'max-cap'),
-                                   ('multi', 32, 10, 64, 'min', 'resource-fair')])
+                                   ('multi', 32, 10, 64, 'min', 'resource-fair'), ('multi', 128, 22, 6, 'avg'), ('central', 70, 21, 5, 'sum'),
+                                   ('multi', 64, 24, 8, 'min', 'rate-fair')])
 def test_oracle_parity_philox(torch_cuda, shape):
     """HIP path vs CPU oracle, same Philox draws, random actions, 60 steps incl. one mid-run reset."""
     torch = torch_cuda
