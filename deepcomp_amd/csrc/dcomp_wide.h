@@ -15,6 +15,7 @@
 //     come from an LDS transpose, `connected` / `utility` of row r are wave-uniform (v_readlane).  Every store
 //     instruction writes 256 contiguous bytes.
 #pragma once
+#include <type_traits>
 
 namespace dcomp {
 
@@ -60,7 +61,7 @@ __device__ __forceinline__ void wide_xchg(float (&v)[N], SH &sh, int &buf, int w
 
 // Shared rates of one chunk of base stations (station.py:152-220).  c[j]: connected to BS c0+j; l2[j]: log2 snr.
 // Returns the shared rate per station in dr[j] (0 where not connected) and |S_b| in cnt[j].
-template <int B, int NW, int MP, int BCC, class SH>
+template <int B, int NW, int MP, int BCC, bool FULL, class SH>
 __device__ __forceinline__ void wide_chunk_rates(const KParams &p, SH &sh, int &buf, int c0, const bool (&c)[BCC],
                                                  const float (&l2)[BCC], float inv_ewma, int wave, int lane,
                                                  float (&dr)[BCC], float (&cnt)[BCC], bool near_hint)
@@ -71,7 +72,7 @@ __device__ __forceinline__ void wide_chunk_rates(const KParams &p, SH &sh, int &
 #pragma unroll
     for (int j = 0; j < BCC; j++) {
         dr[j] = 0.f; ex[j] = 0.f; ex[BCC + j] = 0.f;
-        if (c0 + j < B) {
+        if (FULL || c0 + j < B) {
             const unsigned long long m = __ballot(c[j]);
             bool f;                                            // straight-line: with 64 UEs of one env per wave a station is
             const float t = rate_unshared_small(l2[j], f);     // rarely empty, and a skip branch per station costs more
@@ -81,12 +82,12 @@ __device__ __forceinline__ void wide_chunk_rates(const KParams &p, SH &sh, int &
     }
     if (near_hint) {
 #pragma unroll
-        for (int j = 0; j < BCC; j++) if (c0 + j < B && c[j] && l2[j] > RATE_SMALL_L2) dr[j] = rate_unshared_any(l2[j]);
+        for (int j = 0; j < BCC; j++) if ((FULL || c0 + j < B) && c[j] && l2[j] > RATE_SMALL_L2) dr[j] = rate_unshared_any(l2[j]);
     }
     bool any_sum = false;
 #pragma unroll
     for (int j = 0; j < BCC; j++) {
-        if (c0 + j < B) {
+        if (FULL || c0 + j < B) {
             const int mode = bs_mode_of<MP>(p, c0 + j);
             if (mode == DCOMP_RATE_FAIR) { ex[BCC + j] = c[j] ? fast_rcp(dr[j]) : 0.f; any_sum = true; }
             else if (mode == DCOMP_PROP_FAIR) { ex[BCC + j] = dr[j] * inv_ewma; any_sum = true; }
@@ -104,7 +105,7 @@ __device__ __forceinline__ void wide_chunk_rates(const KParams &p, SH &sh, int &
 #pragma unroll
     for (int j = 0; j < BCC; j++) {
         cnt[j] = ex[j];
-        if (c0 + j < B) {
+        if (FULL || c0 + j < B) {
             const int mode = bs_mode_of<MP>(p, c0 + j);
             const float dru = dr[j], agg = ex[BCC + j];
             float out;
@@ -160,8 +161,8 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
     float curr = 0.f, stale = 0.f, l2max = -1e30f;
     const float inv_ewma_old = fast_rcp(ewma + EPS);
     const uint32_t act_bit = act ? 1u << (act - 1u) : 0u;
-#pragma unroll 1
-    for (int c0 = 0; c0 < B; c0 += BC) {
+    auto sweep1 = [&](const int c0, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;       // every slot of the chunk is a station: no bounds tests
         bool c[BC];
         float l2o[BC], l2n[BC], dr[BC], cnt[BC];
         bool anytiny = false;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
         for (int j = 0; j < BC; j++) {
             const int b = c0 + j;
             l2o[j] = -30.f;
-            if (b < B) {
+            if (FULL || b < B) {
                 bool inr_o, inr_n, t0, t1;
                 pair_eval(ox, oy, p.bs_x[b], p.bs_y[b], p, inr_o, l2o[j], t0);
                 pair_eval(px, py, p.bs_x[b], p.bs_y[b], p, inr_n, l2n[j], t1);
@@ -183,14 +184,14 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
         // connected -> disconnect; not connected and in range at the pre-move position -> connect
         conn ^= act_bit & (conn | inr_old) & (((BC >= 32 ? 0u : (1u << BC)) - 1u) << c0);
 #pragma unroll
-        for (int j = 0; j < BC; j++) c[j] = (c0 + j < B) && ((conn >> (c0 + j)) & 1u);
+        for (int j = 0; j < BC; j++) c[j] = (FULL || c0 + j < B) && ((conn >> (c0 + j)) & 1u);
         const bool near_chunk = __ballot(anytiny) != 0ull;       // a lane within 1.26 m of one of these stations (old or new position)
         near_any |= near_chunk;
         if (near_chunk) {
 #pragma unroll
             for (int j = 0; j < BC; j++) {
                 const int b = c0 + j;
-                if (b < B) {
+                if (FULL || b < B) {
                     double dx = p.bs_x[b] - ox, dy = p.bs_y[b] - oy;
                     if ((float)__builtin_fma(dy, dy, dx * dx) < 1e-20f) l2o[j] = pair_eval_tiny(ox, oy, p.bs_x[b], p.bs_y[b], p);
                     dx = p.bs_x[b] - px; dy = p.bs_y[b] - py;
@@ -198,18 +199,22 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
                 }
             }
         }
-        wide_chunk_rates<B, NW, MP, BC>(p, sh, buf, c0, c, l2o, inv_ewma_old, wave, lane, dr, cnt, near_chunk);
+        wide_chunk_rates<B, NW, MP, BC, FULL>(p, sh, buf, c0, c, l2o, inv_ewma_old, wave, lane, dr, cnt, near_chunk);
 #pragma unroll
         for (int j = 0; j < BC; j++) {
             const int b = c0 + j;
-            if (b < B) {
+            if (FULL || b < B) {
                 curr += dr[j];
                 stale += ((inr_new >> b) & 1u) ? dr[j] : 0.f;                     // dr[j] is 0 unless connected
                 l2max = fmaxf(l2max, l2n[j]);
                 strow[b] = l2n[j];
             }
         }
-    }
+    };
+    constexpr int NFULL = B / BC * BC;
+#pragma unroll 1
+    for (int c0 = 0; c0 < NFULL; c0 += BC) sweep1(c0, std::true_type{});
+    if constexpr (NFULL < B) sweep1(NFULL, std::false_type{});
     const float util_pre = ue_utility(curr, step_util, dr_req);
     const float reward_before = clamp_med3(util_pre, MIN_UTIL, MAX_UTIL) * (1.0f / MAX_UTIL);
     conn &= inr_new;                                                              // user.py:175-188
@@ -218,20 +223,23 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
     // ---- sweep 2: rates after the move (base.py:451)
     curr = 0.f;
     const float inv_ewma = fast_rcp(ewma + EPS);
-#pragma unroll 1
-    for (int c0 = 0; c0 < B; c0 += BC) {
+    auto sweep2 = [&](const int c0, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         bool c[BC];
         float l2c[BC], dr[BC], cnt[BC];
 #pragma unroll
         for (int j = 0; j < BC; j++) {
             const int b = c0 + j;
-            c[j] = b < B ? (bool)((conn >> b) & 1u) : false;
-            l2c[j] = b < B ? strow[b] : -30.f;
+            c[j] = (FULL || b < B) ? (bool)((conn >> b) & 1u) : false;
+            l2c[j] = (FULL || b < B) ? strow[b] : -30.f;
         }
-        wide_chunk_rates<B, NW, MP, BC>(p, sh, buf, c0, c, l2c, inv_ewma, wave, lane, dr, cnt, near_any);
+        wide_chunk_rates<B, NW, MP, BC, FULL>(p, sh, buf, c0, c, l2c, inv_ewma, wave, lane, dr, cnt, near_any);
 #pragma unroll
-        for (int j = 0; j < BC; j++) if (c0 + j < B) curr += dr[j];
-    }
+        for (int j = 0; j < BC; j++) if (FULL || c0 + j < B) curr += dr[j];
+    };
+#pragma unroll 1
+    for (int c0 = 0; c0 < NFULL; c0 += BC) sweep2(c0, std::true_type{});
+    if constexpr (NFULL < B) sweep2(NFULL, std::false_type{});
     const float util = ue_utility(curr, step_util, dr_req);
     if (active) {
         p.pos[idx] = make_double2(px, py);
