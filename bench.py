@@ -78,32 +78,61 @@ def cpu_baseline(scn, kind, U, B, budget_s=15.0):
             'sample': f'{E} envs x {steps} steps ({U} UE x {B} BS, {kind}), oracle/dcomp_oracle.c with OpenMP over envs, {dt:.1f} s'}
 
 
-def measure_small(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev, steps=2000):
-    """BASELINE config 2 (4 096 envs x 10 UE x 5 BS, central obs): launch-latency-bound; stepped through dcomp_rollout in
-    chunks of 50 (one host call per chunk).  Secondary figure, not the headline."""
-    E, U, B, L, T = 4096, 10, 5, 100, 50
+def measure_rollout(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev, E, U, B, kind, T, L=100, steps=2000, launches_too=False):
+    """Fused rollout (dcomp_rollout_ex): T steps per launch with the UE state in registers, EVERY step's observations /
+    rewards / info written into [T, ...] fragment buffers, reset at the horizon inside the kernel.  Secondary figures, not
+    the headline (the headline is one step() per launch, policy in the loop)."""
     scn = scenarios.grid_map(B, 'mixed').with_ues(num_slow=U)
     m, bs, ues = build_from_scenario(scn)
-    env = BatchedMobileEnv(m, bs, ues, 'central', num_envs=E, seed=42, episode_length=L, rng='philox', rand_episodes=True, device=dev)
+    env = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=42, episode_length=L, rng='philox', rand_episodes=True, device=dev)
     g = torch.Generator(device=dev).manual_seed(7)
-    tape = torch.randint(0, B + 1, (4, T, E, U), generator=g, device=dev, dtype=torch.uint8)
+    tape = torch.randint(0, B + 1, (2, T, E, U), generator=g, device=dev, dtype=torch.uint8)
+    frag = {'obs': torch.empty((T,) + tuple(env.obs.shape), device=dev), 'reward': torch.empty((T,) + tuple(env.reward.shape), device=dev),
+            'sum_utility': torch.empty((T, E), device=dev), 'ue_dr': torch.empty((T, E, U), device=dev),
+            'ue_utility': torch.empty((T, E, U), device=dev)}
+    n_calls = max(1, steps // T)
+    env.reset()
 
     def run(n):
-        t = 0
-        for i in range(n // T):
-            if t % L == 0:
-                env.reset()
-            env.rollout(tape[i & 3])
-            t += T
-    run(200)
+        for i in range(n):
+            env.rollout(tape[i & 1], out=frag, horizon=L)
+    run(max(2, n_calls // 10))
     torch.cuda.synchronize(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    run(steps)
+    a.record()
+    run(n_calls)
+    b.record()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     env.check()
-    return {'value': E * steps / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps,
-            'bytes_per_env_step': bytes_per_env_step(U, B, 'central')}
+    n = n_calls * T
+    bpe = survey_bytes_per_env_step(U, B, kind)
+    # the fused kernel reads / writes the UE state once per LAUNCH, not per step: its own traffic per env-step
+    state_b = U * (33 + 32 - 1)
+    fused_bpe = bytes_per_env_step(U, B, kind) - state_b + state_b / T
+    out = {'value': E * n / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / n * 1e3, 'steps': n, 'steps_per_launch': T,
+           'fused_one_launch': bool(env.fused_rollout), 'kernel_ms_per_launch': a.elapsed_time(b) / n_calls,
+           'algorithmic_bytes_per_env_step': bpe, 'achieved_GBps_algorithmic': bpe * E * n / (a.elapsed_time(b) * 1e-3) / 1e9,
+           'kernel_bytes_per_env_step': fused_bpe, 'achieved_GBps_kernel_traffic': fused_bpe * E * n / (a.elapsed_time(b) * 1e-3) / 1e9,
+           'outputs': 'every step ([T, ...] fragment buffers), reset at the horizon inside the kernel'}
+    if launches_too:                                # the same workload as one launch per step (what round 1 measured)
+        acts = tape[0]
+        k_total = max(T, steps)
+
+        def loop(n, k=0):
+            for i in range(n):
+                if k % L == 0:
+                    env.reset()
+                env.step(acts[k % T])
+                k += 1
+        loop(200)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        loop(k_total)
+        torch.cuda.synchronize(dev)
+        out['one_launch_per_step_env_steps_per_s'] = E * k_total / (time.perf_counter() - t0)
+    return out
 
 
 def stream_ceiling(torch, dev, write_bytes, rw_bytes, iters=100):
@@ -144,6 +173,11 @@ def main():
     ap.add_argument('--force-dist', action='store_true', help='initialise torch.distributed even with one rank (exercises the RCCL path on one GPU)')
     ap.add_argument('--same-device', action='store_true', help='dry run: every rank uses cuda:0')
     ap.add_argument('--no-gather', action='store_true', help='N>1: skip the per-episode all-gather of the rollout summary')
+    ap.add_argument('--gather', default='summary', choices=['summary', 'obs'],
+                    help="learner hand-off inside the timed region (N>1 or --force-dist): 'summary' = end-of-episode rewards + utility once per "
+                         "episode (default); 'obs' = every fragment of --fragment steps of observations + rewards, all-gathered on a side stream "
+                         "while the next fragment is being stepped")
+    ap.add_argument('--fragment', type=int, default=4, help='steps per rollout fragment for --gather obs and for the post-run obs hand-off probe')
     ap.add_argument('--no-also', action='store_true', help='skip the secondary BASELINE config 2 measurement')
     ap.add_argument('--no-stream', action='store_true', help='skip the measured fill/copy bandwidth (roofline.measured_stream)')
     ap.add_argument('--no-check', action='store_true', help='skip the device error-flag check (ablation builds)')
@@ -209,6 +243,41 @@ def main():
         from deepcomp_amd.sharded import RolloutGather
         gather = RolloutGather(use_side_stream=(args.backend == 'nccl'))
 
+    # --gather obs: the rollout hand-off north_star describes.  Steps write into a fragment buffer [F, E, U, 4B+1] (two of
+    # them, alternating); a finished fragment is all-gathered on the side stream while the next one is being stepped.
+    F = args.fragment
+    frag_bufs, frag_pending, gather_stats = None, [None, None], {'wait_s': 0.0, 'fragments': 0}
+    if gather is not None and args.gather == 'obs':
+        assert L % F == 0 and K % F == 0 and W % F == 0, "--fragment must divide the episode length, steps and warmup"
+        frag_bufs = [{'obs': torch.empty((F,) + tuple(env.obs.shape), device=dev), 'reward': torch.empty((F,) + tuple(env.reward.shape), device=dev)}
+                     for _ in range(2)]
+
+    def timed_wait(h):
+        """h.wait() makes the compute stream wait for the collective; the HIP events around it time that stall on the GPU
+        (0 when the gather had finished long before), the host clock what the host itself blocked."""
+        t0 = time.perf_counter()
+        if dev.type == 'cuda' and args.backend == 'nccl':
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            h.wait()
+            b.record()
+            gather_stats.setdefault('stall_events', []).append((a, b))
+        else:
+            h.wait()
+        gather_stats['wait_s'] += time.perf_counter() - t0
+
+    def step_into_fragment(t):
+        """One step whose outputs land in the current fragment buffer; hands the fragment over when it is full."""
+        k, f = (t // F) & 1, t % F
+        if f == 0 and frag_pending[k] is not None:      # about to overwrite a buffer: its gather must have read it
+            timed_wait(frag_pending[k])
+            frag_pending[k] = None
+        env.step_into(pool[t & 15], frag_bufs[k]['obs'][f], frag_bufs[k]['reward'][f])
+        if f == F - 1:
+            frag = frag_bufs[k] if args.backend == 'nccl' else {n: v.cpu() for n, v in frag_bufs[k].items()}
+            frag_pending[k] = gather.all_gather_async(frag)
+            gather_stats['fragments'] += 1
+
     def end_of_episode():
         if gather is None:
             return
@@ -219,22 +288,50 @@ def main():
         if len(pending) > 2:
             pending.pop(0).wait()
 
-    def run(nsteps, t_start):
+    def run(nsteps, t_start, spans=None):
+        """spans: list that receives one HIP-event pair per run of back-to-back step launches between two resets -- the
+        events sit on torch's current stream, the stream dcomp_step enqueues on, so a pair brackets pure step-kernel time."""
         t = t_start
+        open_span = None
+
+        def close():
+            nonlocal open_span
+            if open_span is not None:
+                b = torch.cuda.Event(enable_timing=True)
+                b.record()
+                spans.append((open_span[0], b, t - open_span[1]))
+                open_span = None
+
+        def begin():
+            nonlocal open_span
+            if spans is not None and open_span is None:
+                a = torch.cuda.Event(enable_timing=True)
+                a.record()
+                open_span = (a, t)
         if T:
             for i in range(nsteps // T):
                 if t % L == 0:
+                    close()
                     env.reset()
+                begin()
                 env.rollout(tape[i & 3])
                 t += T
+            close()
             return t
         for i in range(nsteps):
             if t % L == 0:
+                close()
                 env.reset()
-            env.step(pool[t & 15])
+            begin()
+            if frag_bufs is not None:
+                step_into_fragment(t)
+            else:
+                env.step(pool[t & 15])
             t += 1
-            if gather is not None and t % L == 0:
+            if gather is not None and frag_bufs is None and t % L == 0:
+                close()
                 end_of_episode()
+        close()
         return t
 
     def fence():
@@ -243,13 +340,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def drain():
+        for h in pending + [h for h in frag_pending if h is not None]:
+            timed_wait(h)
+        pending.clear()
+        frag_pending[0] = frag_pending[1] = None
+
     t_env = run(W, 0)
+    drain()
     fence()
+    gather_stats.update(wait_s=0.0, fragments=0, stall_events=[])
+    spans = []
     t0 = time.perf_counter()
-    t_env = run(K, t_env)
-    for h in pending:
-        h.wait()
-    pending.clear()
+    t_env = run(K, t_env, spans)
+    drain()
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -258,31 +362,85 @@ def main():
         elapsed = float(tt.item())
     if not args.no_check:
         env.check()
-
-    # Duration of one step-kernel launch: ONE HIP-event pair around each run of back-to-back launches between two resets
-    # (events on torch's current stream = the stream dcomp_step enqueues on).  The queue stays full inside a run, so the
-    # pair brackets pure kernel time; an event pair per launch would also time the launch latency of an empty queue
-    # (round 1's kernel_ms > ms_per_step).  Independent of --steps: always >= 200 launches.
-    n_ev = max(200, min(K, 400))
-    spans, t, left = [], t_env, n_ev
-    while left > 0:
-        if t % L == 0:
-            env.reset()
-        n = min(left, L - t % L)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        if T and n % T == 0:
-            for i in range(n // T):
-                env.rollout(tape[i & 3])
+    handoff = None
+    if gather is not None:
+        torch.cuda.synchronize(dev)
+        stall_ms = sum(a.elapsed_time(b) for a, b in gather_stats.get('stall_events', []))
+        per_frag = F * (env.obs.numel() + env.reward.numel()) * 4
+        handoff = {'mode': args.gather, 'backend': 'rccl' if args.backend == 'nccl' else args.backend, 'rccl_ranks': dist.get_world_size(),
+                   'overlapped_on_side_stream': args.backend == 'nccl',
+                   'compute_stream_stall_ms_total': stall_ms, 'host_blocked_ms_total': gather_stats['wait_s'] * 1e3}
+        if args.gather == 'obs':
+            handoff.update(fragment_steps=F, fragments=gather_stats['fragments'], bytes_sent_per_rank_per_fragment=per_frag,
+                           bytes_received_per_rank_per_fragment=per_frag * world,
+                           compute_stream_stall_ms_per_fragment=stall_ms / max(1, gather_stats['fragments']))
         else:
-            for i in range(n):
-                env.step(pool[(t + i) & 15])
-        b.record()
-        spans.append((a, b, n))
-        t += n
-        left -= n
+            handoff.update(what=f'end-of-episode reward + sum_utility of every env, once per {L} steps',
+                           bytes_sent_per_rank=4 * (env.reward.numel() + E))
+
+    def probe_obs_handoff(nfrag=4):
+        """The rollout hand-off north_star names, measured next to the headline (never part of `value`): fragments of F steps
+        of observations + rewards all-gathered over RCCL on a side stream while the next fragment is stepped."""
+        from deepcomp_amd.sharded import RolloutGather
+        g2 = gather if gather is not None else RolloutGather(use_side_stream=(args.backend == 'nccl'))
+        bufs = [{'obs': torch.empty((F,) + tuple(env.obs.shape), device=dev), 'reward': torch.empty((F,) + tuple(env.reward.shape), device=dev)}
+                for _ in range(2)]
+        env.reset()
+
+        def steps(k):
+            for f in range(F):
+                env.step_into(pool[f & 15], bufs[k]['obs'][f], bufs[k]['reward'][f])
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        steps(0); steps(1)                                   # warm
+        fence()
+        ev[0].record()
+        for i in range(nfrag):
+            steps(i & 1)
+        ev[1].record()                                       # stepping alone
+        fence()
+        hs = [None, None]
+        t0 = time.perf_counter()
+        ev[2].record()
+        for i in range(nfrag):
+            k = i & 1
+            if hs[k] is not None:
+                hs[k].wait()
+            steps(k)
+            hs[k] = g2.all_gather_async(bufs[k] if args.backend == 'nccl' else {n: v.cpu() for n, v in bufs[k].items()})
+        for h in hs:
+            if h is not None:
+                h.wait()
+        ev[3].record()
+        fence()
+        wall = time.perf_counter() - t0
+        per = F * (env.obs.numel() + env.reward.numel()) * 4
+        step_ms, both_ms = ev[0].elapsed_time(ev[1]) / nfrag, ev[2].elapsed_time(ev[3]) / nfrag
+        return {'fragment_steps': F, 'fragments': nfrag, 'rccl_ranks': dist.get_world_size(), 'backend': 'rccl' if args.backend == 'nccl' else args.backend,
+                'bytes_sent_per_rank_per_fragment': per, 'bytes_received_per_rank_per_fragment': per * world,
+                'ms_per_fragment_stepping_only': step_ms, 'ms_per_fragment_with_overlapped_all_gather': both_ms,
+                'exposed_handoff_ms_per_fragment': max(0.0, both_ms - step_ms), 'wall_s': wall,
+                'all_gather_GBps_per_rank_ingress': per * max(world - 1, 1) / max(both_ms, 1e-9) / 1e6,
+                'env_steps_per_s_with_obs_handoff': world * E * F / (both_ms * 1e-3)}
+
+    obs_probe = None
+    if use_dist and args.gather != 'obs' and not args.no_gather:
+        obs_probe = probe_obs_handoff()
+
+    # Duration of one step-kernel launch, over the TIMED region itself: the event pairs run() recorded around each run of
+    # back-to-back launches between two resets (an event pair per launch would also time the launch latency of an empty
+    # queue: round 1's kernel_ms > ms_per_step).
     torch.cuda.synchronize(dev)
-    kern_ms = sum(a.elapsed_time(b) for a, b, _ in spans) / sum(n for _, _, n in spans)
+    kern_ms = sum(a.elapsed_time(b) for a, b, _ in spans) / max(1, sum(n for _, _, n in spans))
+    # The first few hundred launches after idle run 5-15 % slower (clock / power management settling: 91 -> 115 -> 82 us per
+    # launch over 300 launches on a cold MI355X, tools/kprobe.py): with the driver's --steps 20 the timed region lies inside
+    # that transient.  The steady state is reported NEXT to it, never instead of it: >= 300 further launches untimed, then 200 timed.
+    steady_ms = None
+    if world == 1 and not T and frag_bufs is None:
+        t = run(max(0, 300 - K), t_env)
+        sp2 = []
+        run(200, t, sp2)
+        torch.cuda.synchronize(dev)
+        steady_ms = sum(a.elapsed_time(b) for a, b, _ in sp2) / sum(n for _, _, n in sp2)
     resets_timed = sum(1 for s in range(t_env - K, t_env) if s % L == 0)
 
     if rank == 0:
@@ -298,15 +456,25 @@ def main():
                                    f'log utility, reward avg, episode {L} ({resets_timed} reset launch(es) inside the timed {K} steps), random actions' + (f', rollout chunks of {T}' if T else ''),
                        'envs_per_gpu': E, 'num_ue': U, 'num_bs': B, 'pair_steps_per_s': world * E * K / elapsed * U * B,
                        'parallelism': f'env-shard x{world}',
-                       'collective': (f'all-gather of end-of-episode rewards + sum_utility ({4 * E * (env.reward.numel() // E + 1) * world / 1e6:.1f} MB) every {L} steps, async'
-                                      if gather is not None else 'none on the data path')},
+                       'collective': ('none on the data path' if gather is None else
+                                      f'all-gather of {F}-step observation + reward fragments ({F * (env.obs.numel() + env.reward.numel()) * 4 * world / 1e6:.0f} MB received per rank), side stream, overlapped'
+                                      if args.gather == 'obs' else
+                                      f'all-gather of end-of-episode rewards + sum_utility ({4 * E * (env.reward.numel() // E + 1) * world / 1e6:.1f} MB) every {L} steps, async')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,
                          'traffic': args.traffic_bytes, 'kernel': 'dcomp::step_kernel', 'kernel_ms': kern_ms,
-                         'kernel_ms_how': f'HIP events around {sum(n for _, _, n in spans)} back-to-back launches in {len(spans)} run(s) between resets',
-                         'launch_bound': bool(kern_ms > 1.02 * elapsed / K * 1e3) or kern_ms < 0.02,
+                         'kernel_ms_how': f'HIP events over the timed region: {sum(n for _, _, n in spans)} launches in {len(spans)} back-to-back run(s) between resets',
+                         'launch_bound': kern_ms < 0.02,
                          'algorithmic_bytes_per_env_step': sbpe, 'layout_bytes_per_env_step': bpe},
         }
+        if handoff is not None:
+            out['handoff'] = handoff
+        if obs_probe is not None:
+            out.setdefault('also', {})['obs_handoff_probe'] = obs_probe
+        if steady_ms is not None:
+            out['roofline']['steady_state'] = {'kernel_ms': steady_ms, 'achieved': sbpe * E / (steady_ms * 1e-3) / 1e9,
+                                               'frac': sbpe * E / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                               'how': f'200 launches timed after {max(300, K)} untimed ones (same HIP-event method)'}
         default_workload = (E, U, B, args.kind, args.sharing) == (65536, 32, 10, 'multi', 'mixed')
         if args.traffic_bytes is None and default_workload:
             # PMC pass of this exact workload (profiles/r01g_final_step_kernel_summary.txt): FETCH_SIZE 33 938 KB x2 (gfx950
@@ -320,7 +488,8 @@ def main():
             sc['frac_of_fill'] = achieved / sc['fill_GBps']
             out['roofline']['measured_stream'] = sc
         if world == 1 and not args.no_also and default_workload:
-            out['also'] = {'config2_4096x10x5_central': measure_small(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev)}
+            mk = (torch, BatchedMobileEnv, scenarios, build_from_scenario, dev)
+            out.setdefault('also', {}).update({'config2_4096x10x5_central_fused_rollout': measure_rollout(*mk, 4096, 10, 5, 'central', T=100, steps=4000, launches_too=True)})
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(scn, args.kind, U, B)
     if use_dist:

@@ -44,6 +44,11 @@ class DcompTape(ctypes.Structure):
     _fields_ = [('pos0', ctypes.c_void_p), ('triples', ctypes.c_void_p), ('num_ids', ctypes.c_int32)]
 
 
+class DcompRolloutOpts(ctypes.Structure):
+    _fields_ = [('every_step', ctypes.c_int32), ('horizon', ctypes.c_int32), ('new_episode_draws', ctypes.c_int32),
+                ('reserved', ctypes.c_int32)]
+
+
 class DcompEvents(ctypes.Structure):
     _fields_ = [('n_remove', ctypes.c_int32), ('n_add', ctypes.c_int32), ('remove_idx', ctypes.c_void_p),
                 ('add_xy', ctypes.c_void_p)]
@@ -51,7 +56,7 @@ class DcompEvents(ctypes.Structure):
 
 EXPORTS = ['dcomp_create', 'dcomp_destroy', 'dcomp_state_sizes', 'dcomp_obs_dim', 'dcomp_reset', 'dcomp_step',
            'dcomp_step_dyn', 'dcomp_num_ue',
-           'dcomp_rollout', 'dcomp_check', 'dcomp_time', 'dcomp_episode', 'dcomp_set_episode', 'dcomp_get_counters', 'dcomp_set_counters', 'dcomp_mt_draw_tape',
+           'dcomp_rollout', 'dcomp_rollout_ex', 'dcomp_rollout_is_fused', 'dcomp_check', 'dcomp_time', 'dcomp_episode', 'dcomp_set_episode', 'dcomp_set_seed', 'dcomp_set_tape', 'dcomp_get_counters', 'dcomp_set_counters', 'dcomp_mt_draw_tape',
            'dcomp_connect_threshold', 'dcomp_last_error', 'dcomp_version', 'dcomp_selftest']
 
 _lib = None
@@ -83,11 +88,20 @@ def load():
     L.dcomp_step_dyn.argtypes = [vp, ctypes.POINTER(DcompState), vp, ctypes.POINTER(DcompOut), ctypes.POINTER(DcompEvents), vp]
     L.dcomp_num_ue.argtypes = [vp]
     L.dcomp_rollout.argtypes = [vp, ctypes.POINTER(DcompState), vp, i32, ctypes.POINTER(DcompOut), vp]
+    if os.environ.get('DCOMP_LIB') and not hasattr(L, 'dcomp_rollout_ex'):     # a timing variant built from older sources
+        EXPORTS[:] = [n for n in EXPORTS if hasattr(L, n)]
+        L.dcomp_rollout_ex = L.dcomp_rollout_is_fused = lambda *a: EUNSUPPORTED
+    else:
+        L.dcomp_rollout_ex.argtypes = [vp, ctypes.POINTER(DcompState), vp, i32, ctypes.POINTER(DcompOut), ctypes.POINTER(DcompRolloutOpts), vp]
+        L.dcomp_rollout_is_fused.argtypes = [vp]
     L.dcomp_check.argtypes = [vp, ctypes.POINTER(DcompState), vp]
     L.dcomp_time.argtypes = [vp]
     L.dcomp_episode.argtypes = [vp]
     L.dcomp_episode.restype = i64
     L.dcomp_set_episode.argtypes = [vp, i64]
+    if hasattr(L, 'dcomp_set_seed'):
+        L.dcomp_set_seed.argtypes = [vp, ctypes.c_uint64]
+        L.dcomp_set_tape.argtypes = [vp, ctypes.POINTER(DcompTape), i32]
     L.dcomp_get_counters.argtypes = [vp, ctypes.POINTER(i64)]
     L.dcomp_set_counters.argtypes = [vp, ctypes.POINTER(i64)]
     L.dcomp_mt_draw_tape.argtypes = [ctypes.POINTER(DcompCfg), ctypes.POINTER(i64), i32, i32, vp, vp]

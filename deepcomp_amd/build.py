@@ -25,6 +25,8 @@ CXXFLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contra
 
 
 def b_list():
+    if os.environ.get('DCOMP_BUILD_B'):        # development builds: only these base-station counts (e.g. "5,10,32")
+        return [int(x) for x in os.environ['DCOMP_BUILD_B'].split(',')]
     txt = open(os.path.join(CSRC, 'dcomp_blist.h')).read()
     line = re.search(r'#define DCOMP_B_LIST\(X\)((?:.*\\\n)*.*)', txt).group(1)
     return [int(x) for x in re.findall(r'X\((\d+)\)', line)]
@@ -33,6 +35,13 @@ def b_list():
 def _sources():
     return [os.path.join(CSRC, f) for f in ('dcomp_device.h', 'dcomp_wide.h', 'dcomp_dyn.h', 'dcomp_blist.h', 'dcomp_inst.hip', 'dcomp_api.hip')] + \
         [os.path.join(os.path.dirname(HERE), 'include', 'dcomp.h')]
+
+
+def _dev_flags():
+    if not os.environ.get('DCOMP_BUILD_B'):
+        return []
+    bl = b_list()
+    return ['-DDCOMP_B_LIST(X)=' + ' '.join(f'X({b})' for b in bl), '-DDCOMP_B_LIST_STR="' + ','.join(map(str, bl)) + ' (development build)"']
 
 
 STAMP = LIB + '.stamp'
@@ -50,6 +59,7 @@ def _fingerprint(extra_flags=()):
 
 
 def up_to_date(extra_flags=()):
+    extra_flags = [f for f in extra_flags if f not in _dev_flags()] + _dev_flags()
     if not (os.path.exists(LIB) and os.path.exists(STAMP)):
         return False
     return open(STAMP).read().strip() == _fingerprint(extra_flags)
@@ -63,6 +73,7 @@ def _run(cmd):
 
 
 def build(force=False, jobs=None, extra_flags=()):
+    extra_flags = [f for f in extra_flags if f not in _dev_flags()] + _dev_flags()
     if not force and up_to_date(extra_flags):
         return LIB
     hipcc = os.environ.get('HIPCC', 'hipcc')

@@ -24,7 +24,7 @@ static KernelPair lookup_kernels(int B, int upad, int mp)
 #define DCOMP_CASE(n) case n: return kernels_b##n(upad, mp);
         DCOMP_B_LIST(DCOMP_CASE)
 #undef DCOMP_CASE
-    default: return KernelPair{nullptr, nullptr, nullptr};
+    default: return KernelPair{nullptr, nullptr, nullptr, nullptr, nullptr};
     }
 }
 }  // namespace dcomp
@@ -53,6 +53,7 @@ struct dcomp_env {
     dcomp::KernelPair kern;
     UeCfg *d_ue_cfg;
     bool dyn;                  // UE list changes during an episode (cfg.max_ues > 0)
+    bool fused;                // kern.step is step_kernel: T steps in one launch (the wide / dynamic kernels step once per launch)
     int upad, grid;
     int cap, cur_ue;            // slots per env; UEs currently listed
     uint32_t n_removed, n_arrived;   // this episode (Philox draw words)
@@ -195,6 +196,16 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
         if (!env->kern.step_dyn) { dcomp_destroy(env); return fail(DCOMP_EUNSUPPORTED, "no dynamic-UE kernel for this shape"); }
         env->kern.step = env->kern.step_dyn;
     }
+    {
+        // The fused rollout kernel is the LATENCY-optimised variant (state in registers, no LDS staging, no kernel boundaries):
+        // it wins while the grid leaves the SIMDs under-occupied (4 096 x 10 x 5: one wave per SIMD, 2.2 vs 5.3 us per step).  A
+        // grid of many waves per SIMD is throughput-bound: there the plain step kernel (fewer registers, coalesced staged
+        // stores) launched once per step is faster and launch latency hides behind the running kernel.
+        long max_waves = 4 * 1024;                                   // 4 waves per SIMD of the 256 CUs
+        if (const char *e = getenv("DCOMP_FUSE_MAX_WAVES")) max_waves = atol(e);
+        const long waves = (long)env->grid * (DCOMP_BLOCK / 64);
+        env->fused = !DYN && env->kern.step != env->kern.step_wide && env->kern.rollout != nullptr && waves <= max_waves;
+    }
     *out = env;
     return DCOMP_OK;
 }
@@ -253,6 +264,7 @@ static int fill_params(dcomp_env *env, const dcomp_state *st, const dcomp_out *o
     kp.pos = (double2 *)st->pos; kp.mv = (unsigned long long *)st->mv; kp.conn = st->conn; kp.ewma = st->ewma; kp.flags = st->flags;
     kp.obs = out->obs; kp.reward = out->reward; kp.sum_util = out->sum_utility; kp.ue_dr = out->ue_dr; kp.ue_util = out->ue_utility; kp.rb_out = out->reward_before;
     kp.episode = (uint32_t)(env->episode < 0 ? 0 : env->episode);
+    kp.num_steps = 1; kp.out_every_step = 0; kp.horizon = 0; kp.episode_inc = 0;
     return DCOMP_OK;
 }
 
@@ -327,25 +339,74 @@ extern "C" int dcomp_step_dyn(dcomp_env *env, const dcomp_state *st, const uint8
 }
 extern "C" int dcomp_num_ue(const dcomp_env *env) { return env ? env->cur_ue : -1; }
 
-extern "C" int dcomp_rollout(dcomp_env *env, const dcomp_state *st, const uint8_t *actions, int32_t num_steps, const dcomp_out *out,
-                             void *stream)
+// T consecutive steps.  step_kernel runs them in ONE launch (state in registers in between); the wide and the dynamic-UE
+// kernels are launched once per step.  Same results either way, and the same as T dcomp_step calls (+ dcomp_reset calls
+// at the horizon).
+static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *actions, int32_t T, const dcomp_out *out,
+                        const dcomp_rollout_opts *opts, void *stream)
 {
     KParams kp;
     int rc = fill_params(env, st, out, kp);
     if (rc) return rc;
-    if (!actions || num_steps < 1) return fail(DCOMP_EINVAL, "bad action tape");
-    if ((rc = check_horizon(env, num_steps))) return rc;
+    if (!actions || T < 1) return fail(DCOMP_EINVAL, "bad action tape");
     if (env->episode < 0) return fail(DCOMP_EINVAL, "rollout() before reset()");
-    const size_t stride = (size_t)env->cfg.num_envs * env->cap;
-    for (int t = 0; t < num_steps; t++) {
-        kp.action = actions + stride * t;
-        kp.time = (uint32_t)(env->time + t);
-        hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
+    const int L = opts ? opts->horizon : 0, every = opts ? (opts->every_step != 0) : 0;
+    const uint32_t inc = (opts && opts->new_episode_draws) ? 1u : 0u;
+    if (L < 0 || L > 65536) return fail(DCOMP_EINVAL, "horizon must be 0 (none) .. 65536");
+    if (L > 0) {
+        if (env->dyn) return fail(DCOMP_EUNSUPPORTED, "in-rollout reset: not with UE arrival / departure (the event schedule is fed per step)");
+        if (env->time > L) return fail(DCOMP_EINVAL, "env.time %d is already beyond the horizon %d", env->time, L);
+        if (env->cfg.rng_mode == DCOMP_RNG_TAPE && inc) return fail(DCOMP_EINVAL, "tape mode replays the borrowed tape: only fixed episodes can reset inside a rollout");
+    } else if ((rc = check_horizon(env, T))) return rc;
+    if (env->dyn && every) return fail(DCOMP_EUNSUPPORTED, "every_step: not with UE arrival / departure");
+    const size_t EU = (size_t)env->cfg.num_envs * env->cap, E = (size_t)env->cfg.num_envs;
+    const bool multi = env->cfg.env_kind == DCOMP_MULTI;
+    const size_t obs_step = EU * (size_t)(multi ? 4 * env->cfg.num_bs + 1 : 2 * env->cfg.num_bs + 1);
+    if (env->fused) {
+        kp.action = actions; kp.num_steps = T; kp.out_every_step = every; kp.horizon = L; kp.episode_inc = inc;
+        hipLaunchKernelGGL(env->kern.rollout, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
+    }
+    int time = env->time;
+    int64_t episode = env->episode;
+    for (int t = 0; t < T; t++) {
+        const bool do_reset = L > 0 && time == L;
+        if (do_reset) { time = 0; episode += inc; }
+        if (!env->fused) {
+            if (every) {
+                kp.obs = out->obs + obs_step * t;
+                if (out->reward) kp.reward = out->reward + (multi ? EU : E) * t;
+                if (out->sum_utility) kp.sum_util = out->sum_utility + E * t;
+                if (out->ue_dr) kp.ue_dr = out->ue_dr + EU * t;
+                if (out->ue_utility) kp.ue_util = out->ue_utility + EU * t;
+                if (out->reward_before) kp.rb_out = out->reward_before + EU * t;
+            }
+            kp.episode = (uint32_t)episode;
+            if (do_reset) hipLaunchKernelGGL(env->kern.reset, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
+            kp.action = actions + EU * t;
+            kp.time = (uint32_t)time;
+            hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
+        }
+        time += 1;
     }
     HIP_TRY(hipGetLastError());
-    env->time += num_steps;
+    env->time = time;
+    env->episode = episode;
     return DCOMP_OK;
 }
+
+extern "C" int dcomp_rollout(dcomp_env *env, const dcomp_state *st, const uint8_t *actions, int32_t num_steps, const dcomp_out *out,
+                             void *stream)
+{
+    return rollout_impl(env, st, actions, num_steps, out, nullptr, stream);
+}
+
+extern "C" int dcomp_rollout_ex(dcomp_env *env, const dcomp_state *st, const uint8_t *actions, int32_t num_steps, const dcomp_out *out,
+                                const dcomp_rollout_opts *opts, void *stream)
+{
+    return rollout_impl(env, st, actions, num_steps, out, opts, stream);
+}
+
+extern "C" int dcomp_rollout_is_fused(const dcomp_env *env) { return env ? (env->fused ? 1 : 0) : -1; }
 
 extern "C" int dcomp_check(dcomp_env *env, const dcomp_state *st, void *stream)
 {
@@ -375,6 +436,27 @@ extern "C" int dcomp_set_counters(dcomp_env *env, const int64_t in[5])
     if (!env->dyn && (in[2] != env->cfg.num_ue || in[3] || in[4])) return fail(DCOMP_EINVAL, "fixed UE list: num_ue / event counters cannot change");
     env->time = (int)in[0]; env->episode = in[1]; env->cur_ue = (int)in[2];
     env->n_removed = (uint32_t)in[3]; env->n_arrived = (uint32_t)in[4];
+    return DCOMP_OK;
+}
+extern "C" int dcomp_set_seed(dcomp_env *env, uint64_t seed)
+{
+    if (!env) return fail(DCOMP_EINVAL, "null env");
+    env->cfg.seed = seed;
+    env->kp.seed_lo = (uint32_t)seed; env->kp.seed_hi = (uint32_t)(seed >> 32);
+    return DCOMP_OK;
+}
+extern "C" int dcomp_set_tape(dcomp_env *env, const dcomp_tape *tape, int32_t depth)
+{
+    if (!env || !tape || !tape->pos0 || !tape->triples) return fail(DCOMP_EINVAL, "null argument");
+    if (env->cfg.rng_mode != DCOMP_RNG_TAPE) return fail(DCOMP_EINVAL, "handle draws with Philox: it has no tape");
+    if (depth < env->cfg.tape_depth) return fail(DCOMP_EINVAL, "the replacement tape (depth %d) must contain the current one (depth %d)", depth, env->cfg.tape_depth);
+    const int ids = tape->num_ids > 0 ? tape->num_ids : env->cfg.num_ue;
+    if (env->episode >= 0 && ids != env->kp.tape_ids) return fail(DCOMP_EINVAL, "tape has %d streams per env, the episode was started with %d", ids, env->kp.tape_ids);
+    env->cfg.tape_depth = depth;
+    env->kp.tape_depth = depth;
+    env->kp.tape_pos0 = tape->pos0;
+    env->kp.tape_triples = (const ushort4 *)tape->triples;
+    env->kp.tape_ids = ids;
     return DCOMP_OK;
 }
 extern "C" int dcomp_set_episode(dcomp_env *env, int64_t episode)

@@ -46,6 +46,15 @@
 #ifndef DCOMP_LOG2_MODE
 #define DCOMP_LOG2_MODE 2    // log2(d^2): 0 = plain v_log_f32, 1 = frexp range reduction, 2 = 2^-12 prescale (default)
 #endif
+#ifndef DCOMP_CENTRAL_STAGED
+#define DCOMP_CENTRAL_STAGED 1  // 0: central observation rows are stored straight from registers (round 1; A/B only)
+#endif
+#ifndef DCOMP_BS_VOLATILE
+#define DCOMP_BS_VOLATILE 0    // experiment: re-read the BS table from the kernel-argument segment at every use (no hoisting out of the step loop)
+#endif
+#ifndef DCOMP_FORCE_KIND
+#define DCOMP_FORCE_KIND -1     // experiment: compile write_outputs for one env kind only (register-pressure bisection)
+#endif
 #ifndef DCOMP_NT_STATE
 #define DCOMP_NT_STATE 0     // experiment: bit 0 non-temporal state loads, bit 1 non-temporal state stores
 #endif
@@ -101,6 +110,12 @@ struct KParams {
     uint32_t maxcap_mask;      // bit b: BS b is max-cap
     double pl_c1, pl_c2;       // Okumura-Hata constants of station.py:110-116 (FP64, for the max-cap rate key)
     uint32_t time;             // env.time before this step (base.py:39)
+    // fused rollout (step_kernel only): T steps per launch with the UE state in registers in between
+    int32_t num_steps;         // T >= 1; actions[T][E][U]
+    int32_t out_every_step;    // 1: the outputs of step t go to out + t * (one step's size), i.e. [T][...] buffers; 0: last step only
+    int32_t horizon;           // > 0: reset inside the kernel when env.time reaches it (RLlib's horizon = episode_length,
+                               //      env_setup.py:281) -- the same sequence as `if time == L: reset()` before every step
+    uint32_t episode_inc;      // Philox episode-word increment per in-kernel reset (0: rand_episodes = False, base.py:171-173)
     uint32_t any_sum_mode;     // some BS is rate-fair or proportional-fair (needs a sum over its UEs)
     uint32_t seed_lo, seed_hi, episode;
     uint32_t env_base;         // global id of env 0
@@ -258,8 +273,13 @@ __shared__ double g_bs_lds[2 * DCOMP_MAX_BS];
 #define DCOMP_BSX(b) (*(volatile double *)&g_bs_lds[b])
 #define DCOMP_BSY(b) (*(volatile double *)&g_bs_lds[DCOMP_MAX_BS + (b)])
 #else
+#if DCOMP_BS_VOLATILE
+#define DCOMP_BSX(b) (*(const volatile double *)&p.bs_x[b])
+#define DCOMP_BSY(b) (*(const volatile double *)&p.bs_y[b])
+#else
 #define DCOMP_BSX(b) p.bs_x[b]
 #define DCOMP_BSY(b) p.bs_y[b]
+#endif
 #endif
 // `near_wave` (optional, wave-uniform): some lane of this wave is within NEAR_D2^(1/2) = 1.26 m of a BS.  That one test
 // triggers both rare fix-ups: the exact d + 1e-16 of a UE sitting ON a BS (here) and, in shared_rates, the rate of a pair
@@ -348,8 +368,11 @@ __device__ __forceinline__ unsigned long long mv_pack(uint32_t wx, uint32_t wy, 
 // uidw = UE id (1-based) | UID_BORN for UEs that arrived during the episode (base.py:592-606: always 'slow', freshly
 // seeded).  Draws are keyed by the id, not by the slot: slots shift when a UE leaves.
 constexpr uint32_t UID_BORN = 0x8000u;
-__device__ __forceinline__ void draw_triple(const KParams &p, int env, uint32_t uidw, uint32_t k, uint32_t &vel, uint32_t &wx,
-                                            uint32_t &wy)
+// vrange: the UE's velocity draw range (lo | hi << 8) when the caller already holds it (fixed UE lists load it once per
+// kernel, next to the state: a load here sits in the middle of the move and, in the fused rollout, waits behind the
+// previous step's stores); < 0: read it from the per-UE config.
+__device__ __forceinline__ void draw_triple(const KParams &p, int env, uint32_t uidw, uint32_t k, uint32_t episode, uint32_t &vel,
+                                            uint32_t &wx, uint32_t &wy, int vrange = -1)
 {
     const uint32_t id0 = (uidw & 0x7FFFu) - 1u;
     const bool born = (uidw & UID_BORN) != 0u;
@@ -360,9 +383,12 @@ __device__ __forceinline__ void draw_triple(const KParams &p, int env, uint32_t 
         vel = t.x; wx = t.y; wy = t.z;
     } else {
         uint32_t r[4] = {0x12345678u + k * 977u, 0x9abcdef0u ^ uidw * 2654435761u, 0x0fedcba9u + (uint32_t)env * 40503u, 0u};
-        if (!(DCOMP_ABLATE & 128)) philox4x32_10(p.env_base + (uint32_t)env, id0 | (born ? UID_BORN : 0u), p.episode, k + 1, p.seed_lo, p.seed_hi, r);
+        if (!(DCOMP_ABLATE & 128)) philox4x32_10(p.env_base + (uint32_t)env, id0 | (born ? UID_BORN : 0u), episode, k + 1, p.seed_lo, p.seed_hi, r);
         uint32_t vlo = 1u, vhi = 3u;
-        if (!born) { UeCfg c = p.ue_cfg[id0]; vlo = c.vel_lo; vhi = c.vel_hi; }
+        if (!born) {
+            if (vrange >= 0) { vlo = (uint32_t)vrange & 0xFFu; vhi = (uint32_t)vrange >> 8; }
+            else { UeCfg c = p.ue_cfg[id0]; vlo = c.vel_lo; vhi = c.vel_hi; }
+        }
         vel = vlo + __umulhi(r[0], vhi - vlo + 1u);
         wx = 10u + __umulhi(r[1], (uint32_t)(p.map_w - 20 + 1));
         wy = 10u + __umulhi(r[2], (uint32_t)(p.map_h - 20 + 1));
@@ -400,7 +426,8 @@ __device__ __forceinline__ void norm_and_unit(double vx, double vy, double &nrm,
 
 // One RandomWaypoint step in FP64, in the reference's operation order.  movement.py:132-181.
 // Contraction is off: the only fused op is the explicit fma of the 2-element dot product (numpy).
-__device__ __forceinline__ void move_ue(const KParams &p, int env, uint32_t uidw, double &px, double &py, unsigned long long &mv)
+__device__ __forceinline__ void move_ue(const KParams &p, int env, uint32_t uidw, uint32_t episode, double &px, double &py,
+                                        unsigned long long &mv, int vrange = -1)
 {
 #pragma clang fp contract(off)
     uint32_t wxi = (uint32_t)(mv & 0xFFFF), wyi = (uint32_t)((mv >> 16) & 0xFFFF), vel = (uint32_t)((mv >> 32) & 0xFF);
@@ -412,7 +439,7 @@ __device__ __forceinline__ void move_ue(const KParams &p, int env, uint32_t uidw
     if (pausing) {
         if (cp < 2) { cp += 1; stay = true; }                       // movement.py:172-175 (pause_duration = 2)
         else {                                                      // movement.py:176 -> reset()
-            draw_triple(p, env, uidw, cursor, vel, wxi, wyi);
+            draw_triple(p, env, uidw, cursor, episode, vel, wxi, wyi, vrange);
             cursor += 1; pausing = 0; cp = 0;
             wx = (double)wxi; wy = (double)wyi;
         }
@@ -477,7 +504,11 @@ struct StageGeo {
     static constexpr int ROW = 4 * B + 1;
     static constexpr int NPASS = (64 * ROW * 4 <= 6144) ? 1 : (32 * ROW * 4 <= 6144) ? 2 : (16 * ROW * 4 <= 6144) ? 4 : 8;
     static constexpr int RPP = 64 / NPASS;                  // rows per pass
-    static constexpr int WORDS = RPP * ROW + 4;             // + alignment phase
+    // Central observations (connected[U*B] | dr[U*B] | utility[U] per env, central.py:147-151) of the <= 64 rows of a wave are
+    // 64 * (2B+1) contiguous floats: staged in ONE window when that fits ~6 KB (B <= 11), else in windows of the multi size.
+    static constexpr int CENTRAL_ONE = 64 * (2 * B + 1) + 4;
+    static constexpr int MULTI_WORDS = RPP * ROW + 4;       // + alignment phase
+    static constexpr int WORDS = (CENTRAL_ONE <= 1540 && CENTRAL_ONE > MULTI_WORDS) ? CENTRAL_ONE : MULTI_WORDS;
 };
 
 template <int B, int UPAD>
@@ -660,8 +691,12 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
 // l2 / cnt are consumed (overwritten with the observation entries).
 // `active`: this lane owns a slot (row) of the env; `alive`: a UE currently sits in that slot (always the same unless
 // UEs arrive / depart, then dead slots produce zero rows: central.py:46-55); n_eff = UEs currently in the env.
-template <int B, int UPAD, bool RESET, bool DYN = false>
-__device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, UPAD> &sh, bool active, int env, int env_local, int u, int idx,
+struct Outs { float *obs, *reward, *sum_util, *ue_dr, *ue_util, *rb_out; };   // where this step's outputs go
+// STAGED: observation rows go through LDS and leave as linear 16-byte stores (1 KiB contiguous per store instruction) -- what
+// a bandwidth-bound launch needs.  false: straight from registers; the fused rollout kernel, used for small batches with
+// one or two waves per SIMD, is latency-bound and the LDS round trips cost it 0.7 us per step (2.88 -> 2.21 us at 4 096 x 10 x 5).
+template <int B, int UPAD, bool RESET, bool DYN = false, bool STAGED = true>
+__device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, BlockSharedT<B, UPAD> &sh, bool active, int env, int env_local, int u, int idx,
                                               int wave, int lane, int gbase, uint32_t conn, uint32_t in_range,
                                               float (&l2)[B], float (&cnt)[B], float util, float curr_dr,
                                               float reward_before, bool alive, int n_eff)
@@ -669,6 +704,7 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
     using G = Geo<B, UPAD>;
     using SG = StageGeo<B>;
     const int U = p.U;
+    const int kind = DCOMP_FORCE_KIND >= 0 ? DCOMP_FORCE_KIND : p.kind;
     // per-BS utility aggregates over connected UEs (station.py:63-83)
     float tsum[B];
 #pragma unroll
@@ -683,7 +719,7 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
 
     // ---- reward
     float reward = 0.f;
-    if (p.kind == DCOMP_CENTRAL) {
+    if (kind == DCOMP_CENTRAL) {
         float r[1];
         if (p.reward_agg == DCOMP_REWARD_MIN) {
             r[0] = group_reduce<G::WG, OpMin>(alive ? reward_before : 1.f);
@@ -729,16 +765,16 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
     }
 
     // ---- info (base.py:383-411)
-    if (p.sum_util) {
+    if (o.sum_util) {
         float s[1];
         s[0] = group_reduce<G::WG, OpSum>(alive ? util : 0.f);
         xwave_reduce_<1, G::NW, OpSum>(s, sh, wave, lane);
-        if (active && u == 0) p.sum_util[env] = s[0];
+        if (active && u == 0) o.sum_util[env] = s[0];
     }
     if (active) {
-        if (p.ue_dr) stream_store(&p.ue_dr[idx], alive ? curr_dr : 0.f);
-        if (p.ue_util) stream_store(&p.ue_util[idx], alive ? util : 0.f);
-        if (p.rb_out) stream_store(&p.rb_out[idx], alive ? reward_before : 0.f);
+        if (o.ue_dr) stream_store(&o.ue_dr[idx], alive ? curr_dr : 0.f);
+        if (o.ue_util) stream_store(&o.ue_util[idx], alive ? util : 0.f);
+        if (o.rb_out) stream_store(&o.rb_out[idx], alive ? reward_before : 0.f);
     }
 
     // ---- observation entries (in place): l2 -> snr_b / max snr, tsum -> avg utility at BS, cnt -> UEs at BS / U
@@ -755,16 +791,29 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
         tsum[b] = live ? avg : 0.f;
         cnt[b] = live ? cnt[b] * inv_u : 0.f;                                                   // variants.py:296
     }
-    if ((DCOMP_ABLATE & 8) && p.kind == DCOMP_MULTI) {
+    if ((DCOMP_ABLATE & 8) && kind == DCOMP_MULTI) {
         float acc = util_n + reward;
         for (int b = 0; b < B; b++) acc += l2[b] + cnt[b] + tsum[b];
-        if (active && acc == 123456.f) p.obs[idx] = acc;         // keeps the producers alive, writes nothing
-    } else if (p.kind == DCOMP_MULTI) {
-        if (active && p.reward) stream_store(&p.reward[idx], alive ? reward : 0.f);
+        if (active && acc == 123456.f) o.obs[idx] = acc;         // keeps the producers alive, writes nothing
+    } else if (kind == DCOMP_MULTI && !STAGED) {
+        if (active) {
+            if (o.reward) o.reward[idx] = alive ? reward : 0.f;
+            float *row = o.obs + (size_t)idx * SG::ROW;
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                row[b] = (float)((conn >> b) & 1u);
+                row[B + b] = l2[b];
+                row[2 * B + b] = cnt[b];
+                row[3 * B + b] = tsum[b];
+            }
+            row[4 * B] = util_n;
+        }
+    } else if (kind == DCOMP_MULTI) {
+        if (active && o.reward) stream_store(&o.reward[idx], alive ? reward : 0.f);
         // rows of this wave are contiguous in memory: [row0, row0 + nrows)
         const unsigned long long am = __ballot(active);
         const int nrows = group_popcount<64>(am, 0);
-        const int row0 = __shfl(idx, am ? __ffsll((long long)am) - 1 : 0, 64);
+        const int row0 = __builtin_amdgcn_readlane(idx, am ? __ffsll((long long)am) - 1 : 0);   // uniform source lane: no LDS round trip
         const int r = idx - row0;
         float *st = sh.stage[wave];
 #pragma unroll 1
@@ -773,7 +822,7 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
             if (rbase >= nrows) break;
             const int rows = min(SG::RPP, nrows - rbase);
             const size_t g0 = (size_t)(row0 + rbase) * SG::ROW;            // first float of this pass in obs
-            const int ph = (int)((((size_t)p.obs >> 2) + g0) & 3);         // 16-byte phase of that address
+            const int ph = (int)((((size_t)o.obs >> 2) + g0) & 3);         // 16-byte phase of that address
             if (active && r >= rbase && r < rbase + rows) {
                 float *row = st + ph + (r - rbase) * SG::ROW;              // word stride 4B+1 is odd: conflict-free
 #pragma unroll
@@ -787,7 +836,7 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
             }
             wave_lds_fence();
             const int n_end = ph + rows * SG::ROW;                         // staged floats live in st[ph, n_end)
-            float *gbase_ptr = p.obs + g0 - ph;                            // 16-byte aligned
+            float *gbase_ptr = o.obs + g0 - ph;                            // 16-byte aligned
             for (int j = lane * 4; j < n_end; j += 256) {
                 if (j >= ph && j + 4 <= n_end) {
 #if DCOMP_NT_OBS
@@ -803,9 +852,58 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
             }
             wave_lds_fence();
         }
-    } else if (active) {
-        if (p.reward && u == 0) p.reward[env] = reward;
-        float *base = p.obs + (size_t)env * U * (2 * B + 1);
+    } else if (G::NW == 1 && STAGED && DCOMP_CENTRAL_STAGED) {
+        // Central layout: the records of the envs of one wave are contiguous in memory (REC floats each), so the wave stages
+        // them in LDS exactly as they lie in memory and copies them out linearly -- every store instruction covers 1 KiB
+        // instead of 64 scattered 4-byte pieces (round 1: 41 % of the HBM peak at 65 536 x 10 x 5).  Lane u owns B
+        // consecutive floats of the `connected` and of the `dr` block (LDS word stride B between lanes: conflict-free for
+        // odd B, 2-way -- free for ds_write_b32 -- for B = 2 mod 4).  Regions larger than the staging buffer go in windows.
+        if (active && o.reward && u == 0) o.reward[env] = reward;
+        const unsigned long long am = __ballot(active);
+        if (am != 0ull) {
+            const int REC = U * (2 * B + 1);
+            const int env0 = __builtin_amdgcn_readlane(env, __ffsll((long long)am) - 1);
+            const int envl = __builtin_amdgcn_readlane(env, 63 - __clzll((long long)am));
+            const int n = (envl - env0 + 1) * REC;                             // floats this wave produces
+            const size_t g0 = (size_t)env0 * REC;
+            const int ph = (int)((((size_t)o.obs >> 2) + g0) & 3);             // 16-byte phase of the region start
+            float *st = sh.stage[wave];
+            constexpr int CH = (SG::WORDS - 4) & ~3;                           // window size (multiple of 4: constant phase)
+            const int o_conn = (env - env0) * REC + u * B, o_dr = o_conn + U * B, o_ut = (env - env0) * REC + 2 * U * B + u;
+#pragma unroll 1
+            for (int w0 = 0; w0 < n; w0 += CH) {
+                const int cnt = min(CH, n - w0);
+                if (active) {
+                    float *row = st + ph - w0;
+                    const bool one = n <= CH;                                  // the usual case: everything in one window
+#pragma unroll
+                    for (int b = 0; b < B; b++) {
+                        if (one || (unsigned)(o_conn + b - w0) < (unsigned)cnt) row[o_conn + b] = (float)((conn >> b) & 1u);
+                        if (one || (unsigned)(o_dr + b - w0) < (unsigned)cnt) row[o_dr + b] = l2[b];
+                    }
+                    if (one || (unsigned)(o_ut - w0) < (unsigned)cnt) row[o_ut] = util_n;
+                }
+                wave_lds_fence();
+                const int n_end = ph + cnt;
+                float *gbase_ptr = o.obs + g0 + w0 - ph;                       // 16-byte aligned
+                for (int j = lane * 4; j < n_end; j += 256) {
+                    if (j >= ph && j + 4 <= n_end) {
+#if DCOMP_NT_OBS
+                        typedef float f4v __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(*reinterpret_cast<const f4v *>(st + j), reinterpret_cast<f4v *>(gbase_ptr + j));
+#else
+                        *reinterpret_cast<float4 *>(gbase_ptr + j) = *reinterpret_cast<const float4 *>(st + j);
+#endif
+                    } else {
+                        for (int k = max(j, ph); k < min(j + 4, n_end); k++) gbase_ptr[k] = st[k];
+                    }
+                }
+                wave_lds_fence();
+            }
+        }
+    } else if (active) {                                                       // envs wider than a wavefront: direct stores
+        if (o.reward && u == 0) o.reward[env] = reward;
+        float *base = o.obs + (size_t)env * U * (2 * B + 1);
 #pragma unroll
         for (int b = 0; b < B; b++) {
             base[u * B + b] = (float)((conn >> b) & 1u);
@@ -815,11 +913,113 @@ __device__ __forceinline__ void write_outputs(const KParams &p, BlockSharedT<B, 
     }
 }
 
-template <int B, int UPAD, int MP>
-__global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel(const KParams p)
+// Start position and first movement draw of the UE in slot u (user.py:98-116, movement.py:110-122): what MobileEnv.reset
+// (base.py:169-189) does per UE.  Used by reset_kernel and by step_kernel's in-kernel reset at the horizon.
+__device__ __forceinline__ void reset_ue(const KParams &p, int env, int u, uint32_t episode, double &px, double &py, unsigned long long &mv)
+{
+    const UeCfg c = p.ue_cfg[u];
+    int x, y;
+    if (p.rng_mode == DCOMP_RNG_TAPE) { const size_t t = (size_t)env * p.U0 + u; x = p.tape_pos0[2 * t]; y = p.tape_pos0[2 * t + 1]; }
+    else {
+        uint32_t r[4];
+        philox4x32_10(p.env_base + (uint32_t)env, (uint32_t)u, episode, 0u, p.seed_lo, p.seed_hi, r);
+        x = (int)__umulhi(r[0], (uint32_t)p.map_w + 1u);
+        y = (int)__umulhi(r[1], (uint32_t)p.map_h + 1u);
+    }
+    if (c.init_x >= 0) x = c.init_x;
+    if (c.init_y >= 0) y = c.init_y;
+    px = (double)x; py = (double)y;
+    uint32_t vel, wx, wy;
+    draw_triple(p, env, (uint32_t)u + 1u, 0u, episode, vel, wx, wy, (int)c.vel_lo | ((int)c.vel_hi << 8));
+    mv = mv_pack(wx, wy, vel, 0u, 0u, 1u);
+}
+
+__device__ __forceinline__ void store_state(const KParams &p, int idx, double px, double py, unsigned long long mv, uint32_t conn, float ewma)
+{
+#if DCOMP_NT_STATE & 2
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    d2v q; q.x = px; q.y = py;
+    __builtin_nontemporal_store(q, reinterpret_cast<d2v *>(p.pos) + idx);
+    __builtin_nontemporal_store(mv, p.mv + idx);
+    __builtin_nontemporal_store(conn, p.conn + idx);
+    __builtin_nontemporal_store(ewma, p.ewma + idx);
+#else
+    p.pos[idx] = make_double2(px, py);
+    p.mv[idx] = mv;
+    p.conn[idx] = conn;
+    p.ewma[idx] = ewma;
+#endif
+}
+
+// One MobileEnv.step (base.py:413-466) of the UE in this lane: toggle -> rates -> move -> drop -> EWMA -> rates -> outputs.
+// The UE state is passed by reference and stays in registers; `emit` (uniform): write observation / reward / info to `o`.
+// STORE: write the state back BEFORE the outputs (plain step) -- position, movement word and EWMA are then dead while the
+// observation rows are staged, which is worth a wave per SIMD (73 vs 92 VGPRs at B = 10).
+template <int B, int UPAD, int MP, bool STORE>
+__device__ __forceinline__ void step_once(const KParams &p, BlockSharedT<B, UPAD> &sh, const Outs &o, bool emit, bool active, int env,
+                                          int env_local, int u, int idx, int wave, int lane, int gbase, uint32_t act, uint32_t time,
+                                          uint32_t episode, bool step_util, float dr_req, int vrange, double &px, double &py,
+                                          unsigned long long &mv, uint32_t &conn, float &ewma)
+{
+    // 1. pairs at the pre-move position
+    float l2[B];
+    uint32_t in_range = B >= 32 ? 0xFFFFFFFFu : ((1u << (B & 31)) - 1u);
+    bool near_pre = false, near_post = false;
+    if (!(DCOMP_ABLATE & 32)) in_range = eval_pairs<B>(px, py, p, l2, &near_pre);
+    else { for (int b = 0; b < B; b++) l2[b] = -20.f; }
+    // 2. toggle (base.py:247-263 -> user.py:190-222)
+    if (act > (uint32_t)B) { atomicOr(p.flags, DCOMP_FLAG_BAD_ACTION); act = 0; }
+    if (act > 0) {
+        const uint32_t bit = 1u << (act - 1);
+        if (conn & bit) conn &= ~bit;
+        else if (in_range & bit) {
+            conn |= bit;
+            if (MP == MP_GENERIC && (p.maxcap_mask & bit)) p.conn_since[(size_t)idx * B + (act - 1)] = (uint16_t)time;
+        }
+    }
+    // 3. rates before the move (base.py:446) -> reward_before (base.py:158-167)
+    float dr[B], cnt[B];
+    if (!(DCOMP_ABLATE & 1)) shared_rates<B, UPAD, MP>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, (int)near_pre);
+    else { for (int b = 0; b < B; b++) { dr[b] = 1.f; cnt[b] = 1.f; } }
+    float curr = 0.f;
+#pragma unroll
+    for (int b = 0; b < B; b++) curr += dr[b];
+    const float util_pre = ue_utility(curr, step_util, dr_req);
+    const float reward_before = clamp_med3(util_pre, MIN_UTIL, MAX_UTIL) * (1.0f / MAX_UTIL);
+    // 4. move (base.py:447 -> user.py:159-173)
+    if (active && !(DCOMP_ABLATE & 2)) {
+        move_ue(p, env, (uint32_t)u + 1u, episode, px, py, mv, vrange);
+        if (px < 0.0 || py < 0.0 || px > (double)p.map_w || py > (double)p.map_h) atomicOr(p.flags, DCOMP_FLAG_OUTSIDE_MAP);
+    }
+    // 5. pairs at the new position; drop lost connections (user.py:175-188); EWMA from the stale rates (user.py:148-157)
+    if (!(DCOMP_ABLATE & 64)) in_range = eval_pairs<B>(px, py, p, l2, &near_post);
+    conn &= in_range;
+    float stale = 0.f;
+#pragma unroll
+    for (int b = 0; b < B; b++) stale += ((conn >> b) & 1u) ? dr[b] : 0.f;
+    ewma = 0.9f * stale + 0.1f * ewma;
+    // 6. rates after the move (base.py:451)
+    if (!(DCOMP_ABLATE & 4)) shared_rates<B, UPAD, MP>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, (int)near_post);
+    curr = 0.f;
+#pragma unroll
+    for (int b = 0; b < B; b++) curr += dr[b];
+    const float util = ue_utility(curr, step_util, dr_req);
+    if (STORE && active) store_state(p, idx, px, py, mv, conn, ewma);
+    // 7. observation, reward, info
+    if (emit)
+        write_outputs<B, UPAD, false, false, STORE>(p, o, sh, active, env, env_local, u, idx, wave, lane, gbase, conn, in_range, l2, cnt,
+                                                    util, curr, reward_before, active, p.U);
+}
+
+// MobileEnv.step for all envs: one launch = one step.  ROLLOUT = true is the fused rollout: p.num_steps consecutive steps
+// in ONE launch, the UE state (position, movement word, connections, EWMA) staying in registers in between -- no kernel
+// boundary, no state round trip through HBM, no host launch per step (the loop this replaces: simulation.py:512-541).
+// Two instantiations on purpose: with the step loop around it the compiler hoists the kernel-argument loads (BS table) out
+// of the loop and spills them (73 -> 163 VGPRs, 0.081 -> 0.099 ms at config 3), so the plain step keeps its loop-free code.
+template <int B, int UPAD, int MP, bool ROLLOUT>
+__device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<B, UPAD> &sh)
 {
     using G = Geo<B, UPAD>;
-    __shared__ BlockSharedT<B, UPAD> sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int env_local = tid / UPAD, u = tid % UPAD;
     const int env = blockIdx.x * G::GPB + env_local;
@@ -838,6 +1038,7 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel(const KParams p)
     float ewma = 0.f;
     bool step_util = false;
     float dr_req = 1.f;
+    int vrange = -1;
     if (active) {
 #if DCOMP_NT_STATE & 1
         typedef double d2v __attribute__((ext_vector_type(2)));
@@ -846,80 +1047,89 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel(const KParams p)
         mv = __builtin_nontemporal_load(p.mv + idx);
         conn = __builtin_nontemporal_load(p.conn + idx);
         ewma = __builtin_nontemporal_load(p.ewma + idx);
-        act = __builtin_nontemporal_load(p.action + idx);
 #else
         double2 q = p.pos[idx];
         px = q.x; py = q.y;
         mv = p.mv[idx];
         conn = p.conn[idx];
         ewma = p.ewma[idx];
-        act = p.action[idx];
 #endif
-        if (!p.all_log_util) { UeCfg c = p.ue_cfg[u]; step_util = c.util == DCOMP_UTIL_STEP; dr_req = c.dr_req; }
-    }
-
-    // 1. pairs at the pre-move position
-    float l2[B];
-    uint32_t in_range = B >= 32 ? 0xFFFFFFFFu : ((1u << (B & 31)) - 1u);
-    bool near_pre = false, near_post = false;
-    if (!(DCOMP_ABLATE & 32)) in_range = eval_pairs<B>(px, py, p, l2, &near_pre);
-    else { for (int b = 0; b < B; b++) l2[b] = -20.f; }
-    // 2. toggle (base.py:247-263 -> user.py:190-222)
-    if (act > (uint32_t)B) { atomicOr(p.flags, DCOMP_FLAG_BAD_ACTION); act = 0; }
-    if (act > 0) {
-        const uint32_t bit = 1u << (act - 1);
-        if (conn & bit) conn &= ~bit;
-        else if (in_range & bit) {
-            conn |= bit;
-            if (MP == MP_GENERIC && (p.maxcap_mask & bit)) p.conn_since[(size_t)idx * B + (act - 1)] = (uint16_t)p.time;
+        if (!ROLLOUT) act = p.action[idx];
+        if (p.rng_mode != DCOMP_RNG_TAPE || !p.all_log_util) {
+            const UeCfg c = p.ue_cfg[u];
+            step_util = c.util == DCOMP_UTIL_STEP; dr_req = c.dr_req;
+            vrange = (int)c.vel_lo | ((int)c.vel_hi << 8);
         }
     }
-    // 3. rates before the move (base.py:446) -> reward_before (base.py:158-167)
-    float dr[B], cnt[B];
-    if (!(DCOMP_ABLATE & 1)) shared_rates<B, UPAD, MP>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, (int)near_pre);
-    else { for (int b = 0; b < B; b++) { dr[b] = 1.f; cnt[b] = 1.f; } }
-    float curr = 0.f;
+    Outs o{p.obs, p.reward, p.sum_util, p.ue_dr, p.ue_util, p.rb_out};
+    if (!ROLLOUT) {
+        step_once<B, UPAD, MP, true>(p, sh, o, true, active, env, env_local, u, idx, wave, lane, gbase, act, p.time, p.episode, step_util, dr_req,
+                               vrange, px, py, mv, conn, ewma);
+    } else {
+        const int T = p.num_steps;
+        const size_t EU = (size_t)p.E * p.U;
+        uint32_t time = p.time, episode = p.episode;
+        // Actions: 8 steps' bytes per lane are fetched at a time, one chunk ahead.  A load per step would make every step
+        // wait for its own HBM round trip -- and, vmcnt being one in-order counter for loads and stores, for the previous
+        // step's observation stores to drain.
+        const uint8_t *actp = p.action + (active ? idx : 0);      // idle lanes read a valid byte, masked below: no exec-masked blocks
+        uint32_t nb[8];                                            // the NEXT chunk's bytes, still in flight
+        auto load_chunk = [&](int t0) {                            // 8 independent loads (steps past T re-read the last one)
 #pragma unroll
-    for (int b = 0; b < B; b++) curr += dr[b];
-    const float util_pre = ue_utility(curr, step_util, dr_req);
-    const float reward_before = clamp_med3(util_pre, MIN_UTIL, MAX_UTIL) * (1.0f / MAX_UTIL);
-    // 4. move (base.py:447 -> user.py:159-173)
-    if (active && !(DCOMP_ABLATE & 2)) {
-        move_ue(p, env, (uint32_t)u + 1u, px, py, mv);
-        if (px < 0.0 || py < 0.0 || px > (double)p.map_w || py > (double)p.map_h) atomicOr(p.flags, DCOMP_FLAG_OUTSIDE_MAP);
+            for (int j = 0; j < 8; j++) nb[j] = (uint32_t)actp[(size_t)min(t0 + j, T - 1) * EU];
+        };
+        load_chunk(0);
+        unsigned long long act_cur = 0ull;
+#pragma unroll 1
+        for (int t = 0; t < T; t++) {
+            if (p.horizon > 0 && time == (uint32_t)p.horizon) {    // RLlib's horizon (env_setup.py:281): reset(), then step
+                episode += p.episode_inc;
+                time = 0;
+                conn = 0u; ewma = 0.f;
+                if (active) reset_ue(p, env, u, episode, px, py, mv);
+            }
+            if ((t & 7) == 0) {                                    // first use of the bytes requested 8 steps ago; request the next 8
+                const uint32_t lo = nb[0] | (nb[1] << 8) | (nb[2] << 16) | (nb[3] << 24), hi = nb[4] | (nb[5] << 8) | (nb[6] << 16) | (nb[7] << 24);
+                act_cur = ((unsigned long long)hi << 32) | lo;
+                load_chunk(t + 8);
+            }
+            act = active ? (uint32_t)(act_cur >> (8 * (t & 7))) & 0xFFu : 0u;
+            step_once<B, UPAD, MP, false>(p, sh, o, p.out_every_step || t == T - 1, active, env, env_local, u, idx, wave, lane, gbase, act, time,
+                                   episode, step_util, dr_req, vrange, px, py, mv, conn, ewma);
+            time += 1;
+            if (p.out_every_step) {                                  // outputs of step t -> [T][...] buffers
+                const bool multi = p.kind == DCOMP_MULTI;
+                o.obs += EU * (size_t)(multi ? 4 * B + 1 : 2 * B + 1);
+                if (o.reward) o.reward += multi ? EU : (size_t)p.E;
+                if (o.sum_util) o.sum_util += p.E;
+                if (o.ue_dr) o.ue_dr += EU;
+                if (o.ue_util) o.ue_util += EU;
+                if (o.rb_out) o.rb_out += EU;
+            }
+            // the max-cap and 'sum'-reward scratch of the next step aliases the observation staging other waves may still be copying out
+            if ((MP == MP_GENERIC && p.any_maxcap) || (p.kind == DCOMP_MULTI && p.reward_agg == DCOMP_REWARD_SUM)) __syncthreads();
+        }
     }
-    // 5. pairs at the new position; drop lost connections (user.py:175-188); EWMA from the stale rates (user.py:148-157)
-    if (!(DCOMP_ABLATE & 64)) in_range = eval_pairs<B>(px, py, p, l2, &near_post);
-    conn &= in_range;
-    float stale = 0.f;
-#pragma unroll
-    for (int b = 0; b < B; b++) stale += ((conn >> b) & 1u) ? dr[b] : 0.f;
-    ewma = 0.9f * stale + 0.1f * ewma;
-    // 6. rates after the move (base.py:451)
-    if (!(DCOMP_ABLATE & 4)) shared_rates<B, UPAD, MP>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, (int)near_post);
-    curr = 0.f;
-#pragma unroll
-    for (int b = 0; b < B; b++) curr += dr[b];
-    const float util = ue_utility(curr, step_util, dr_req);
-    // 7. state write-back
-    if (active) {
-#if DCOMP_NT_STATE & 2
-        typedef double d2v __attribute__((ext_vector_type(2)));
-        d2v q; q.x = px; q.y = py;
-        __builtin_nontemporal_store(q, reinterpret_cast<d2v *>(p.pos) + idx);
-        __builtin_nontemporal_store(mv, p.mv + idx);
-        __builtin_nontemporal_store(conn, p.conn + idx);
-        __builtin_nontemporal_store(ewma, p.ewma + idx);
+    if (ROLLOUT && active) store_state(p, idx, px, py, mv, conn, ewma);
+}
+
+#ifdef DCOMP_MINW
+#define DCOMP_STEP_BOUNDS __launch_bounds__(DCOMP_BLOCK, DCOMP_MINW)
 #else
-        p.pos[idx] = make_double2(px, py);
-        p.mv[idx] = mv;
-        p.conn[idx] = conn;
-        p.ewma[idx] = ewma;
+#define DCOMP_STEP_BOUNDS __launch_bounds__(DCOMP_BLOCK)
 #endif
-    }
-    // 8. observation, reward, info
-    write_outputs<B, UPAD, false>(p, sh, active, env, env_local, u, idx, wave, lane, gbase, conn, in_range, l2, cnt, util, curr,
-                                  reward_before, active, p.U);
+template <int B, int UPAD, int MP>
+__global__ DCOMP_STEP_BOUNDS void step_kernel(const KParams p)
+{
+    __shared__ BlockSharedT<B, UPAD> sh;
+    step_kernel_body<B, UPAD, MP, false>(p, sh);
+}
+
+template <int B, int UPAD, int MP>
+__global__ __launch_bounds__(DCOMP_BLOCK) void rollout_kernel(const KParams p)
+{
+    __shared__ BlockSharedT<B, UPAD> sh;
+    step_kernel_body<B, UPAD, MP, true>(p, sh);
 }
 
 // MobileEnv.reset (base.py:169-189): user.py:98-116 + movement.py:110-122 + first observation.
@@ -942,21 +1152,10 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void reset_kernel(const KParams p)
     if (alive) {
         UeCfg c = p.ue_cfg[u];
         step_util = c.util == DCOMP_UTIL_STEP; dr_req = c.dr_req;
-        int x, y;
-        if (p.rng_mode == DCOMP_RNG_TAPE) { const size_t t = (size_t)env * p.U0 + u; x = p.tape_pos0[2 * t]; y = p.tape_pos0[2 * t + 1]; }
-        else {
-            uint32_t r[4];
-            philox4x32_10(p.env_base + (uint32_t)env, (uint32_t)u, p.episode, 0u, p.seed_lo, p.seed_hi, r);
-            x = (int)__umulhi(r[0], (uint32_t)p.map_w + 1u);
-            y = (int)__umulhi(r[1], (uint32_t)p.map_h + 1u);
-        }
-        if (c.init_x >= 0) x = c.init_x;
-        if (c.init_y >= 0) y = c.init_y;
-        px = (double)x; py = (double)y;
-        uint32_t vel, wx, wy;
-        draw_triple(p, env, (uint32_t)u + 1u, 0u, vel, wx, wy);
+        unsigned long long mv;
+        reset_ue(p, env, u, p.episode, px, py, mv);
         p.pos[idx] = make_double2(px, py);
-        p.mv[idx] = mv_pack(wx, wy, vel, 0u, 0u, 1u);
+        p.mv[idx] = mv;
         p.conn[idx] = 0u;
         p.ewma[idx] = 0.f;
         if (p.uid) p.uid[idx] = (uint16_t)(u + 1);
@@ -973,7 +1172,8 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void reset_kernel(const KParams p)
 #pragma unroll
     for (int b = 0; b < B; b++) cnt[b] = 0.f;
     const float util = ue_utility(0.f, step_util, dr_req);
-    write_outputs<B, UPAD, true, true>(p, sh, active, env, env_local, u, idx, wave, lane, gbase, 0u, in_range, l2, cnt, util, 0.f, 0.f, alive,
+    const Outs o{p.obs, p.reward, p.sum_util, p.ue_dr, p.ue_util, p.rb_out};
+    write_outputs<B, UPAD, true, true>(p, o, sh, active, env, env_local, u, idx, wave, lane, gbase, 0u, in_range, l2, cnt, util, 0.f, 0.f, alive,
                                  p.U0);
 }
 
@@ -985,7 +1185,7 @@ namespace dcomp {
 using KernelFn = void (*)(const KParams);
 // step_wide: organisation for envs of >= 64 lanes (dcomp_wide.h); nullptr for narrower envs.  It has no max-cap
 // path, the host falls back to `step` when a BS is max-cap.
-struct KernelPair { KernelFn step, reset, step_wide, step_dyn; };   // step_dyn: UEs arrive / depart (dcomp_dyn.h), UPAD <= 64
+struct KernelPair { KernelFn step, reset, step_wide, step_dyn, rollout; };   // step_dyn: UEs arrive / depart (dcomp_dyn.h), UPAD <= 64
 
 template <int B, int UPAD, int MP>
 inline KernelFn wide_or_null()
@@ -994,6 +1194,14 @@ inline KernelFn wide_or_null()
     // step_kernel no longer fit (B > DCOMP_WIDE_MIN_B); below that step_kernel is faster
     if constexpr (UPAD >= 64 && B > DCOMP_WIDE_MIN_B) return step_kernel_wide<B, UPAD, MP>;
     else return nullptr;
+}
+
+template <int B, int UPAD, int MP>
+inline KernelFn rollout_or_null()
+{
+    // shapes the wide kernel takes over never reach the fused rollout (and their instantiations are the costly ones to build)
+    if constexpr (UPAD >= 64 && B > DCOMP_WIDE_MIN_B) return nullptr;
+    else return rollout_kernel<B, UPAD, MP>;
 }
 
 template <int B, int UPAD>
@@ -1005,9 +1213,9 @@ inline KernelFn dyn_or_null()
 template <int B, int UPAD>
 inline KernelPair make_pair_(int mp)
 {
-    if (mp == MP_RES_FAIR) return KernelPair{step_kernel<B, UPAD, MP_RES_FAIR>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_RES_FAIR>(), dyn_or_null<B, UPAD>()};
-    if (mp == MP_MIXED) return KernelPair{step_kernel<B, UPAD, MP_MIXED>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_MIXED>(), dyn_or_null<B, UPAD>()};
-    return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_GENERIC>(), dyn_or_null<B, UPAD>()};
+    if (mp == MP_RES_FAIR) return KernelPair{step_kernel<B, UPAD, MP_RES_FAIR>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_RES_FAIR>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_RES_FAIR>()};
+    if (mp == MP_MIXED) return KernelPair{step_kernel<B, UPAD, MP_MIXED>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_MIXED>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_MIXED>()};
+    return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_GENERIC>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_GENERIC>()};
 }
 
 // One translation unit per B instantiates all UPAD widths (dcomp_inst_bXX.hip).
@@ -1022,7 +1230,7 @@ inline KernelPair kernels_for_upad(int upad, int mp)
     case 64: return make_pair_<B, 64>(mp);
     case 128: return make_pair_<B, 128>(mp);
     case 256: return make_pair_<B, 256>(mp);
-    default: return KernelPair{nullptr, nullptr, nullptr, nullptr};
+    default: return KernelPair{nullptr, nullptr, nullptr, nullptr, nullptr};
     }
 }
 

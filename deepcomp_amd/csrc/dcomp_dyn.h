@@ -167,7 +167,7 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel_dyn(const KParams p)
                 uidw = ((last & 0x7FFFu) + 1u) | UID_BORN;
                 px = (double)x; py = (double)y;
                 uint32_t vel, wx, wy;
-                draw_triple(p, env, uidw, 0u, vel, wx, wy);
+                draw_triple(p, env, uidw, 0u, p.episode, vel, wx, wy);
                 mv = mv_pack(wx, wy, vel, 0u, 0u, 1u);
                 conn = 0; ewma = 0.f;
                 if (mc) { for (int j = 0; j < CSW; j++) cs[j] = 0; }
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel_dyn(const KParams p)
     const float reward_before = clamp_med3(util_pre, MIN_UTIL, MAX_UTIL) * (1.0f / MAX_UTIL);
     // 4. move
     if (alive) {
-        move_ue(p, env, uidw, px, py, mv);
+        move_ue(p, env, uidw, p.episode, px, py, mv);
         if (px < 0.0 || py < 0.0 || px > (double)p.map_w || py > (double)p.map_h) atomicOr(p.flags, DCOMP_FLAG_OUTSIDE_MAP);
     }
     // 5. drop + EWMA
@@ -224,7 +224,8 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel_dyn(const KParams p)
         p.uid[idx] = alive ? (uint16_t)uidw : (uint16_t)0;
     }
     // 8. observation, reward, info
-    write_outputs<B, UPAD, false, true>(p, sh, active, env, env_local, u, idx, wave, lane, gbase, alive ? conn : 0u, in_range, l2, cnt, util,
+    const Outs o{p.obs, p.reward, p.sum_util, p.ue_dr, p.ue_util, p.rb_out};
+    write_outputs<B, UPAD, false, true>(p, o, sh, active, env, env_local, u, idx, wave, lane, gbase, alive ? conn : 0u, in_range, l2, cnt, util,
                                   curr, reward_before, alive, cur);
 }
 

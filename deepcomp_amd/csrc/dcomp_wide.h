@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
     float ewma = 0.f;
     bool step_util = false;
     float dr_req = 1.f;
+    int vrange = -1;
     if (active) {
         double2 q = p.pos[idx];
         px = q.x; py = q.y;
@@ -143,14 +144,18 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
         conn = p.conn[idx];
         ewma = p.ewma[idx];
         act = p.action[idx];
-        if (!p.all_log_util) { UeCfg c = p.ue_cfg[u]; step_util = c.util == DCOMP_UTIL_STEP; dr_req = c.dr_req; }
+        if (p.rng_mode != DCOMP_RNG_TAPE || !p.all_log_util) {       // loaded here, next to the state, not in the middle of the move
+            const UeCfg c = p.ue_cfg[u];
+            step_util = c.util == DCOMP_UTIL_STEP; dr_req = c.dr_req;
+            vrange = (int)c.vel_lo | ((int)c.vel_hi << 8);
+        }
     }
     if (act > (uint32_t)B) { atomicOr(p.flags, DCOMP_FLAG_BAD_ACTION); act = 0; }
 
     // move first (base.py:447 -> user.py:159-173); keep the old position for the pre-move pairs
     const double ox = px, oy = py;
     if (active) {
-        move_ue(p, env, (uint32_t)u + 1u, px, py, mv);
+        move_ue(p, env, (uint32_t)u + 1u, p.episode, px, py, mv, vrange);
         if (px < 0.0 || py < 0.0 || px > (double)p.map_w || py > (double)p.map_h) atomicOr(p.flags, DCOMP_FLAG_OUTSIDE_MAP);
     }
 

@@ -19,6 +19,40 @@ import torch
 
 from . import _lib, rng as _rng, spaces
 
+# The reference's classes ARE gym / RLlib classes (single_ue/base.py:20 `class MobileEnv(gym.Env)`, multi_ue/multi_agent.py:6
+# `class MultiAgentMobileEnv(RelNormEnv, MultiAgentEnv)`), and its callers dispatch on that: `MultiAgentEnv in
+# env_class.__mro__` (util/env_setup.py:289, util/simulation.py:46) decides whether RLlib gets a policy map, and RLlib's own
+# BaseEnv conversion tests isinstance(env, MultiAgentEnv).  So the drop-in classes derive from the REAL base classes whenever
+# gym / ray are importable; without them (this build image has neither) neutral stand-ins keep the module importable.
+try:                                            # pragma: no cover - gym is absent in the build image
+    from gym import Env as _GymEnv
+    HAVE_GYM = True
+except Exception:                               # noqa: BLE001
+    HAVE_GYM = False
+
+    class _GymEnv:                              # attribute surface of gym.Env that callers read
+        metadata = {'render.modes': []}
+        reward_range = (-float('inf'), float('inf'))
+        spec = None
+        action_space = None
+        observation_space = None
+
+        def close(self):
+            pass
+
+        @property
+        def unwrapped(self):
+            return self
+
+try:                                            # pragma: no cover - ray is absent in the build image
+    from ray.rllib.env.multi_agent_env import MultiAgentEnv as _MultiAgentEnv
+    HAVE_RAY = True
+except Exception:                               # noqa: BLE001
+    HAVE_RAY = False
+
+    class _MultiAgentEnv:                       # RLlib's MultiAgentEnv has no __init__ either (multi_agent.py:14)
+        pass
+
 SNR_THRESHOLD = 2e-8          # station.py:10
 MIN_UTILITY, MAX_UTILITY = -20, 20   # constants.py:40-41
 
@@ -37,6 +71,14 @@ def parse_entities(map, bs_list, ue_list):
     for ue in ue_list:
         if ue.util_func not in _lib.UTILITY:
             raise NotImplementedError(f"Utility function {ue.util_func} not implemented!")   # user.py:92
+    for ue in ue_list:                       # movement.py:87-104: the kernels implement the defaults of RandomWaypoint
+        mvt = ue.movement
+        if getattr(mvt, 'pause_duration', 2) != 2 or getattr(mvt, 'border_buffer', 10) != 10:
+            raise NotImplementedError(f"UE {ue.id}: pause_duration={getattr(mvt, 'pause_duration', 2)} / border_buffer="
+                                      f"{getattr(mvt, 'border_buffer', 10)}: only the reference defaults (2, 10) are implemented")
+        v = mvt.init_velocity
+        if not isinstance(v, str) and float(v) != int(v):
+            raise NotImplementedError(f"UE {ue.id}: velocity {v} is not an integer (the movement word stores velocities as integers)")
     vel_specs = [ue.movement.init_velocity for ue in ue_list]
     vr = [_rng.vel_range(v) for v in vel_specs]
     init_xy = [(_coord(ue.init_pos_x), _coord(ue.init_pos_y)) for ue in ue_list]
@@ -101,8 +143,11 @@ class BatchedMobileEnv:
         self.seed_value = seed if seed is not None else int(np.random.SeedSequence().generate_state(1)[0])
         self.env_id_base = int(env_id_base)
         # env e of a batch gets base seed `seed + 20000*e` (UE i adds 100*(i+1), base.py:138-143)
+        # (UE offsets reach 100*U: with more than 199 UEs a stride of 20000 would make env e's UE i+200 replay env e+1's UE i)
+        self._seed_stride = max(20000, 100 * (len(ue_list) + 1))
+        self._reseeded = False
         self.env_seeds = (np.asarray(env_seeds, dtype=np.int64) if env_seeds is not None
-                          else self.seed_value + 20000 * (self.env_id_base + np.arange(self.E, dtype=np.int64)))
+                          else self.seed_value + self._seed_stride * (self.env_id_base + np.arange(self.E, dtype=np.int64)))
 
         U, B = self.U, self.B          # U: slots per env
         ent = parse_entities(map, bs_list, ue_list)
@@ -198,14 +243,18 @@ class BatchedMobileEnv:
         return self._L.dcomp_episode(self._h)
 
     def seed(self, seed=None):
-        """base.py:132-143 (None leaves the generator state alone)."""
+        """MobileEnv.seed (base.py:132-143); None leaves the generators alone.  The new seed governs every draw from the
+        next reset() on (the gym convention `env.seed(s); env.reset()`); the reference also re-seeds the streams of the
+        episode in progress, whose remaining draws here still come from the tape / key the episode started with."""
         if seed is None:
             return
-        self.seed_value = int(seed)
-        self.env_seeds = self.seed_value + 20000 * (self.env_id_base + np.arange(self.E, dtype=np.int64))
-        self._streams, self._fixed_tape = None, None
-        if self.rng_mode == _lib.RNG_PHILOX:
-            raise NotImplementedError("re-seeding a Philox env: create a new env with the new seed")
+        seed = int(seed)
+        if self.rng_mode == _lib.RNG_PHILOX:          # may fail: nothing below is changed before it succeeded
+            _lib.check(self._L.dcomp_set_seed(self._h, ctypes.c_uint64(seed & 0xFFFFFFFFFFFFFFFF)))
+        self.seed_value = seed
+        self.env_seeds = self.seed_value + self._seed_stride * (self.env_id_base + np.arange(self.E, dtype=np.int64))
+        self._streams, self._fixed_tape, self._dyn_streams = None, None, None
+        self._reseeded = True                         # reset() starts the new key's episode 0
 
     def _draw_tape_dynamic(self):
         """Reference-exact draws with UE arrival: see rng.DynamicStdlibStreams (initial UEs keep their generators)."""
@@ -245,6 +294,35 @@ class BatchedMobileEnv:
             self._fixed_tape = _rng.mt_tape(self._cfg, self.env_seeds, self.tape_depth)
         return self._fixed_tape
 
+    def _upload_tape(self, pos0, trip):
+        self._tape_dev = (torch.from_numpy(pos0).to(self.device), torch.from_numpy(trip.view(np.int16)).to(self.device))
+        self._tape_depth_now = int(trip.shape[1])
+        return _lib.DcompTape(self._tape_dev[0].data_ptr(), self._tape_dev[1].data_ptr(), self.U0 + self.max_id if self.dynamic else 0)
+
+    def _ensure_tape(self, steps=1):
+        """rng='reference': the episode's draw tape must cover the next `steps` steps.  A UE redraws at most every third step
+        (arrive, pause two steps: movement.py:158-181), so step t needs at most t // 3 + 2 triples.  Episodes that outlive
+        the tape -- the reference's done() is always None and --cont-train never resets (main.py:48-51) -- get a longer
+        one: the same draws, continued."""
+        if self.rng_mode != _lib.RNG_TAPE or self._tape_dev is None:
+            return
+        need = (self.time + steps) // 3 + 3
+        if need <= self._tape_depth_now:
+            return
+        depth = max(need, 2 * self._tape_depth_now)
+        if self.dynamic:
+            pos0, trip = self._dyn_streams.extend(depth)
+        elif self.rand_episodes:
+            pos0, trip = self._streams.extend(depth)
+        else:
+            pos0, trip = self._fixed_tape = _rng.mt_tape(self._cfg, self.env_seeds, depth)     # stateless: same prefix, longer
+        torch.cuda.current_stream(self.device).synchronize()       # steps in flight still read the old tape
+        old = self._tape_dev
+        tape = self._upload_tape(pos0, trip)
+        _lib.check(self._L.dcomp_set_tape(self._h, ctypes.byref(tape), depth))
+        self.tape_depth = depth
+        del old
+
     # ------------------------------------------------------------------ gym-like batched API
     def reset(self):
         """MobileEnv.reset (base.py:169-189) for all envs -> first observation tensor."""
@@ -252,11 +330,10 @@ class BatchedMobileEnv:
             tape = None
             if self.rng_mode == _lib.RNG_TAPE:
                 pos0, trip = self._draw_tape()
-                self._tape_dev = (torch.from_numpy(pos0).to(self.device), torch.from_numpy(trip.view(np.int16)).to(self.device))
-                tape = _lib.DcompTape(self._tape_dev[0].data_ptr(), self._tape_dev[1].data_ptr(),
-                                      self.U0 + self.max_id if self.dynamic else 0)
-            elif not self.rand_episodes:
+                tape = self._upload_tape(pos0, trip)
+            elif not self.rand_episodes or self._reseeded:
                 self._L.dcomp_set_episode(self._h, 0)     # fixed episodes: same Philox counter word every reset
+            self._reseeded = False
             _lib.check(self._L.dcomp_reset(self._h, ctypes.byref(self._st), ctypes.byref(tape) if tape else None,
                                            ctypes.byref(self._out), self._stream()))
         return self.obs
@@ -274,6 +351,8 @@ class BatchedMobileEnv:
         return self.obs, self.reward, None, self.info()
 
     def _launch_step(self, action, out):
+        if self.rng_mode == _lib.RNG_TAPE:
+            self._ensure_tape(1)
         if not self.dynamic:
             rc = self._L.dcomp_step(self._h, self._st_ref, ctypes.c_void_p(action.data_ptr()),
                                     self._out_ref if out is self._out else ctypes.byref(out), self._stream())
@@ -296,21 +375,66 @@ class BatchedMobileEnv:
         """UEs currently in every env's list (the arrival schedule is configuration, identical for all envs)."""
         return self._L.dcomp_num_ue(self._h)
 
+    def _require(self, t, dtype, numel, what):
+        """The kernels get raw pointers: a wrong dtype / device / size would read or write out of bounds on the device."""
+        if not isinstance(t, torch.Tensor) or t.dtype != dtype or t.device != self.device or not t.is_contiguous() or t.numel() != numel:
+            raise ValueError(f"{what} must be a contiguous {dtype} tensor with {numel} elements on {self.device}")
+
     def step_into(self, action, obs, reward):
         """Like step() but writes observation / reward into caller-provided tensors (rollout buffers)."""
+        self._require(action, torch.uint8, self.E * self.U, 'action')
+        self._require(obs, torch.float32, self.obs.numel(), 'obs')
+        self._require(reward, torch.float32, self.reward.numel(), 'reward')
         out = self._make_out(obs, reward)
         with torch.cuda.device(self.device):
             self._launch_step(action, out)
 
-    def rollout(self, actions):
-        """T steps from an action tape [T, E, U] (uint8); outputs of the last step."""
-        T = actions.shape[0]
+    def rollout(self, actions, out=None, horizon=None, new_episode_draws=None):
+        """T consecutive steps from an action tape [T, E, U] (uint8) in ONE host call -- and, for the narrow kernel
+        (``fused_rollout``), ONE kernel launch with the UE state in registers in between (replaces the per-step loop of
+        simulation.py:512-541).
+
+        out: None -> the outputs of the last step land in self.obs / self.reward / info tensors; or a dict with 'obs'
+        [T, *obs.shape] and 'reward' [T, *reward.shape] (optionally 'sum_utility' [T, E], 'ue_dr' / 'ue_utility' [T, E, U]):
+        the outputs of EVERY step (a rollout fragment).  horizon: reset the envs inside the rollout whenever env.time has
+        reached it (RLlib's horizon = episode_length, env_setup.py:281); same sequence as `if time == L: reset()` before
+        every step."""
         if self.dynamic:
             raise NotImplementedError("rollout() has no event feed; step an env with UE arrival one step at a time")
+        if actions.dim() != 3:
+            raise ValueError("actions must be [T, E, U]")
+        T = int(actions.shape[0])
+        self._require(actions, torch.uint8, T * self.E * self.U, 'actions')
+        L = int(horizon or 0)
+        if new_episode_draws is None:
+            new_episode_draws = self.rand_episodes
+        if L and self.rng_mode == _lib.RNG_TAPE and (self.rand_episodes or new_episode_draws):
+            raise NotImplementedError("rng='reference' with rand_episodes: every episode needs a fresh host-drawn tape; "
+                                      "reset() between rollouts instead of passing horizon")
+        o = self._out
+        if out is not None:
+            self._require(out['obs'], torch.float32, T * self.obs.numel(), "out['obs']")
+            self._require(out['reward'], torch.float32, T * self.reward.numel(), "out['reward']")
+            ptr = {}
+            for k, n in (('sum_utility', self.E), ('ue_dr', self.E * self.U), ('ue_utility', self.E * self.U),
+                         ('reward_before', self.E * self.U)):
+                if out.get(k) is not None:
+                    self._require(out[k], torch.float32, T * n, f"out['{k}']")
+                    ptr[k] = out[k].data_ptr()
+            o = _lib.DcompOut(out['obs'].data_ptr(), out['reward'].data_ptr(), ptr.get('sum_utility'), ptr.get('ue_dr'),
+                              ptr.get('ue_utility'), ptr.get('reward_before'))
+        if self.rng_mode == _lib.RNG_TAPE:
+            self._ensure_tape(min(T, L - self.time) if L else T)
+        opts = _lib.DcompRolloutOpts(1 if out is not None else 0, L, 1 if new_episode_draws else 0, 0)
         with torch.cuda.device(self.device):
-            _lib.check(self._L.dcomp_rollout(self._h, ctypes.byref(self._st), ctypes.c_void_p(actions.data_ptr()), T,
-                                             ctypes.byref(self._out), self._stream()))
-        return self.obs, self.reward
+            _lib.check(self._L.dcomp_rollout_ex(self._h, self._st_ref, ctypes.c_void_p(actions.data_ptr()), T, ctypes.byref(o),
+                                                ctypes.byref(opts), self._stream()))
+        return (self.obs, self.reward) if out is None else (out['obs'], out['reward'])
+
+    @property
+    def fused_rollout(self):
+        """True when rollout() runs its T steps in one kernel launch."""
+        return self._L.dcomp_rollout_is_fused(self._h) == 1
 
     # ------------------------------------------------------------------ checkpoint / resume
     def _fingerprint(self):
@@ -411,8 +535,9 @@ class BatchedMobileEnv:
 
 
 # ====================================================================================================
-class _RefSurfaceEnv:
-    """Shared implementation of the reference-named classes (MobileEnv surface, base.py:20-466)."""
+class _RefSurfaceEnv(_GymEnv):
+    """Shared implementation of the reference-named classes (MobileEnv surface, base.py:20-466); a gym.Env like the
+    reference's MobileEnv (base.py:20) whenever gym is importable."""
     KIND = None
     metadata = {'render.modes': ['human']}
 
@@ -491,6 +616,20 @@ class _RefSurfaceEnv:
 
     def done(self):
         return None                                                                   # base.py:371-381
+
+    def get_max_num_ue(self):
+        """base.py:191-209: most UEs listed at the same time within an episode."""
+        return _rng.max_num_ue(len(self.original_ue_list), self.episode_length, self.ue_arrival, self.new_ue_interval)
+
+    def get_num_diff_ues(self):
+        """base.py:211-225: number of DIFFERENT UEs over an episode (env_setup.py:295 sizes the policy map of
+        --separate-agent-nns with it): departures do not free an id."""
+        if self.ue_arrival is None:
+            return self.get_max_num_ue()
+        return len(self.original_ue_list) + sum(a for a in self.ue_arrival.values() if a > 0)
+
+    def render(self, mode='human'):
+        raise NotImplementedError("rendering is not part of the device path (SURVEY.md section 2: out of scope)")
 
     def _refresh_ue_list(self):
         """Mirror env 0's UE list (base.py:592-618): original objects for the initial UEs, new config holders for UEs
@@ -592,8 +731,10 @@ class CentralRelNormEnv(_RefSurfaceEnv):
         return self._info_dict()
 
 
-class MultiAgentMobileEnv(_RefSurfaceEnv):
-    """Multi-agent env (DD-CoMP / D3-CoMP): multi_ue/multi_agent.py:6-107 on top of variants.py:244-305."""
+class MultiAgentMobileEnv(_RefSurfaceEnv, _MultiAgentEnv):
+    """Multi-agent env (DD-CoMP / D3-CoMP): multi_ue/multi_agent.py:6-107 on top of variants.py:244-305.  Derives from RLlib's
+    MultiAgentEnv like the reference (multi_agent.py:6), so `MultiAgentEnv in env_class.__mro__` (env_setup.py:289,
+    simulation.py:46) and RLlib's isinstance dispatch see a multi-agent env."""
     KIND = 'multi'
 
     def _define_spaces(self):

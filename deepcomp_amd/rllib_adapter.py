@@ -1,16 +1,26 @@
 """RLlib-facing batched adapters.
 
 RLlib 1.4 (the reference's pinned version, setup.py:14) steps several env copies per rollout worker through its
-``VectorEnv`` protocol -- ``vector_reset() / reset_at(i) / vector_step(actions) / get_unwrapped()`` -- and
-multi-agent envs through ``BaseEnv.poll() / send_actions()``.  ``CentralVectorEnv`` and ``MultiAgentBaseEnv`` expose ONE
-``BatchedMobileEnv`` (E envs, one kernel launch per step) through those protocols: one device->host copy of the packed
+``VectorEnv`` protocol -- ``vector_reset() / reset_at(i) / vector_step(actions) / get_unwrapped()`` -- and multi-agent
+envs through ``BaseEnv.poll() / send_actions() / try_reset()``.  ``CentralVectorEnv`` and ``MultiAgentBaseEnv`` expose
+ONE ``BatchedMobileEnv`` (E envs, one kernel launch per step) through those protocols: one device->host copy of the packed
 observation tensor per step, then per-env *views* (no per-env device work).  The observation dicts have the keys and
-shapes of the reference's spaces (central.py:147-151, variants.py:255-269), so the untouched PPO config's preprocessor
-flattens them in the same sorted-key order the packed tensor already uses.
+shapes of the reference's spaces (central.py:147-151, variants.py:255-269); the packed tensor already IS RLlib's
+flattening of them (DictFlatteningPreprocessor concatenates the sub-spaces in gym's sorted-key order: connected, dr,
+[ues_at_bs, util_at_bs,] utility) -- ``flatten_obs`` spells that order out and the tests hold the two against each other
+and against the reference-run fixtures.
+
+Caller contract kept (deepcomp/util/env_setup.py:262-316, deepcomp/util/simulation.py:143): ``observation_space``,
+``action_space``, agent ids = ``ue.id`` strings, ``horizon`` = episode_length -> all envs of a batch reach it in the same step.
+
+Two ways to consume a batch:
+* the protocol methods (per-env Python dicts; what an unmodified RLlib sampler calls) -- E bounded by Python, fine for the
+  handful of envs per worker RLlib uses;
+* ``poll_tensors() / send_action_tensor()`` -- the same data as device tensors ``[E, U, 4B+1]`` / ``[E, U(2B+1)]`` with no
+  host copy and no per-env objects: what a learner on the same GPU (or a custom sampler) uses at E = 65 536.
 
 ``ray`` is not installed in the build image: the classes derive from RLlib's base classes when importable and are plain
-duck-typed classes otherwise; tests/test_parity_gpu.py checks them against E independent single-env instances.
-All envs of a batch run in lock step (shared ``time``), which is how RLlib drives a VectorEnv with a fixed horizon.
+duck-typed classes otherwise.  All envs of a batch run in lock step (shared ``time``).
 """
 import numpy as np
 import torch
@@ -29,16 +39,43 @@ except Exception:                               # noqa: BLE001
     class _BaseEnvBase:
         pass
 
+CENTRAL_KEYS = ('connected', 'dr', 'utility')                                   # sorted: gym.spaces.Dict order
+MULTI_KEYS = ('connected', 'dr', 'ues_at_bs', 'util_at_bs', 'utility')
+
+
+def flatten_obs(obs):
+    """What RLlib's DictFlatteningPreprocessor makes of one observation dict: sub-spaces in sorted-key order, each raveled."""
+    return np.concatenate([np.asarray(obs[k], dtype=np.float32).ravel() for k in sorted(obs)])
+
 
 def _core_from_config(env_config, kind):
     return BatchedMobileEnv(env_config['map'], env_config['bs_list'], env_config['ue_list'], kind,
                             num_envs=int(env_config.get('num_envs', 1)), seed=env_config['seed'],
                             episode_length=env_config['episode_length'], reward=env_config['reward'],
                             rand_episodes=env_config['rand_episodes'], rng=env_config.get('rng', 'philox'),
-                            device=env_config.get('device', 'cuda'), env_id_base=env_config.get('env_id_base', 0))
+                            device=env_config.get('device', 'cuda'), env_id_base=env_config.get('env_id_base', 0),
+                            env_seeds=env_config.get('env_seeds'))
 
 
-class CentralVectorEnv(_VectorEnvBase):
+class _LockStepResets:
+    """RLlib resets env copies one by one (`reset_at(i)` / `try_reset(i)`, in whatever order its sampler walks them) when
+    they hit the horizon; the batch can only reset as a whole.  The FIRST reset request after a step (or a repeated request
+    for an index already served) resets the batch; the other indices are then served from that same reset."""
+
+    def _init_resets(self):
+        self._served = set()
+        self._stepped = True             # nothing has been reset yet
+
+    def _reset_for(self, index):
+        if self._stepped or index in self._served:
+            self.core.reset()
+            self._after_core_reset()
+            self._served = set()
+            self._stepped = False
+        self._served.add(index)
+
+
+class CentralVectorEnv(_VectorEnvBase, _LockStepResets):
     """VectorEnv over E central (DeepCoMP) envs.  Actions: list of E int vectors (central.py:28)."""
 
     def __init__(self, env_config):
@@ -46,42 +83,59 @@ class CentralVectorEnv(_VectorEnvBase):
         U, B = self.core.U, self.core.B
         obs_space = spaces.Dict({'connected': spaces.MultiBinary(U * B), 'dr': spaces.Box(low=0, high=1, shape=(U * B,)),
                                  'utility': spaces.Box(low=-1, high=1, shape=(U,))})
-        super().__init__(obs_space, spaces.MultiDiscrete([B + 1] * U), self.core.E)
-        self._host = None
+        _VectorEnvBase.__init__(self, obs_space, spaces.MultiDiscrete([B + 1] * U), self.core.E)
+        self._all = None
+        self._obs = None
+        self._init_resets()
 
     def _obs_list(self):
         U, B = self.core.U, self.core.B
         self._all = self.core.outputs_host()                           # ONE D2H copy of obs + reward + info; below are views
-        self._host = self._all['obs']
-        return [{'connected': row[:U * B], 'dr': row[U * B:2 * U * B], 'utility': row[2 * U * B:]} for row in self._host]
+        host = self._all['obs']
+        self._obs = [{'connected': row[:U * B], 'dr': row[U * B:2 * U * B], 'utility': row[2 * U * B:]} for row in host]
+        return self._obs
+
+    def _after_core_reset(self):
+        self._obs_list()
 
     def vector_reset(self):
-        self.core.reset()
-        return self._obs_list()
+        self._reset_for(None)
+        self._served = set()
+        return self._obs
 
     def reset_at(self, index=None):
-        """Lock-step batch: resetting one env resets the episode of all (RLlib calls this at the shared horizon)."""
-        if index in (None, 0):
-            self.core.reset()
-            self._obs_cache = self._obs_list()
-        return self._obs_cache[index or 0]
+        index = 0 if index is None else int(index)
+        self._reset_for(index)
+        return self._obs[index]
 
     def vector_step(self, actions):
         a = torch.from_numpy(np.ascontiguousarray(np.asarray(actions, dtype=np.uint8).reshape(self.core.E, self.core.U)))
         self.core.step(a.to(self.core.device))
         self.core.check()
+        self._stepped = True
         obs = self._obs_list()
         rew, su = self._all['reward'].tolist(), self._all['sum_utility'].tolist()
         t = self.core.time
         infos = [{'time': t, 'scalar_metrics': {'sum_utility': su[e]}} for e in range(self.core.E)]
         return obs, rew, [False] * self.core.E, infos
 
+    # ---- zero-copy path
+    def poll_tensors(self):
+        """(obs [E, U(2B+1)], reward [E]) device tensors of the last reset / step -- rows are flatten_obs() of the dicts."""
+        return self.core.obs, self.core.reward
+
+    def send_action_tensor(self, actions):
+        """actions: uint8 [E, U] on the env's device."""
+        self.core.step(actions)
+        self._stepped = True
+
     def get_unwrapped(self):
         return [self.core]
 
 
-class MultiAgentBaseEnv(_BaseEnvBase):
-    """BaseEnv (poll / send_actions) over E multi-agent (DD-/D3-CoMP) envs; agent ids '1'..'U' (env_setup.py:145-161)."""
+class MultiAgentBaseEnv(_BaseEnvBase, _LockStepResets):
+    """BaseEnv (poll / send_actions / try_reset) over E multi-agent (DD-/D3-CoMP) envs; agent ids = the UE ids of the
+    env_config ('1'..'U', env_setup.py:145-161)."""
 
     def __init__(self, env_config):
         self.core = _core_from_config(env_config, 'multi')
@@ -92,9 +146,12 @@ class MultiAgentBaseEnv(_BaseEnvBase):
                                               'utility': spaces.Box(low=-1, high=1, shape=(1,)),
                                               'ues_at_bs': spaces.Box(low=0, high=1, shape=(B,)),
                                               'util_at_bs': spaces.Box(low=-1, high=1, shape=(B,))})
-        self._pending = None
+        self._all = None
+        self._reset_obs = None
         self._fresh = True
-        self.core.reset()
+        self._init_resets()
+        self._reset_for(None)
+        self._served = set()
 
     def _views(self):
         B = self.core.B
@@ -104,14 +161,17 @@ class MultiAgentBaseEnv(_BaseEnvBase):
                           'util_at_bs': host[e, i, 3 * B:4 * B], 'utility': host[e, i, 4 * B:4 * B + 1]}
                     for i, aid in enumerate(self.agent_ids)} for e in range(self.core.E)}
 
+    def _after_core_reset(self):
+        self._reset_obs = self._views()
+
     def poll(self):
-        obs = self._views()
         E = self.core.E
-        if self._fresh:
+        if self._fresh:                                                 # right after a reset: observations only
             self._fresh = False
             zeros = {e: {a: 0.0 for a in self.agent_ids} for e in range(E)}
             dones = {e: {'__all__': False} for e in range(E)}
-            return obs, zeros, dones, {e: {} for e in range(E)}, {}
+            return self._reset_obs, zeros, dones, {e: {} for e in range(E)}, {}
+        obs = self._views()
         rew = self._all['reward'].tolist()
         rewards = {e: dict(zip(self.agent_ids, rew[e])) for e in range(E)}
         dones = {e: {'__all__': False} for e in range(E)}
@@ -126,12 +186,23 @@ class MultiAgentBaseEnv(_BaseEnvBase):
                     a[e, i] = int(acts[aid])
         self.core.step(torch.from_numpy(a).to(self.core.device))
         self.core.check()
+        self._stepped = True
 
     def try_reset(self, env_id=None):
-        if env_id in (None, 0):
-            self.core.reset()
-            self._reset_views = self._views()
-        return self._reset_views[env_id or 0]
+        env_id = 0 if env_id is None else int(env_id)
+        self._reset_for(env_id)
+        return self._reset_obs[env_id]
+
+    # ---- zero-copy path
+    def poll_tensors(self):
+        """(obs [E, U, 4B+1], reward [E, U]) device tensors of the last reset / step; obs[e, i] is flatten_obs() of agent
+        agent_ids[i]'s dict in env e."""
+        return self.core.obs, self.core.reward
+
+    def send_action_tensor(self, actions):
+        """actions: uint8 [E, U] on the env's device, column i = agent agent_ids[i]."""
+        self.core.step(actions)
+        self._stepped = True
 
     def get_unwrapped(self):
         return [self.core]

@@ -86,7 +86,26 @@ class StdlibStreams:
                     st.append(mr.getstate())
                 st_e.append(st)
             self._states.append(st_e)
+        self._pos0, self._trip = pos0, trip
         return pos0, trip
+
+    def extend(self, new_depth):
+        """Continue every movement stream beyond the tape drawn by draw_episode (an episode that runs longer than the
+        tape was sized for: --cont-train never resets, main.py:48-51).  The generators still stand where the tape ended."""
+        E, U, D = len(self.seeds), self.U, self.depth
+        trip = np.zeros((E * U, new_depth, 4), dtype=np.uint16)
+        trip[:, :D] = self._trip
+        for e in range(E):
+            for i in range(U):
+                mr, st = self.mov_rng[e][i], self._states[e][i]
+                lo, hi = self.vel[i]
+                for k in range(D, new_depth):
+                    trip[e * U + i, k, 0] = mr.randint(lo, hi) if lo != hi else lo
+                    trip[e * U + i, k, 1] = mr.randint(10, self.w - 10)
+                    trip[e * U + i, k, 2] = mr.randint(10, self.h - 10)
+                    st.append(mr.getstate())
+        self.depth, self._trip = new_depth, trip
+        return self._pos0, trip
 
 
 def arrival_schedule(episode_length, ue_arrival=None, new_ue_interval=None):
@@ -181,7 +200,29 @@ class DynamicStdlibStreams:
                 mr = random.Random(s + 100 * (j + 1))
                 for k in range(D):
                     trip[e * ids + U0 + j, k, :3] = (mr.randint(1, 3), mr.randint(10, self.w - 10), mr.randint(10, self.h - 10))
+        self._pos0, self._trip = pos0, trip
         return pos0, trip
+
+    def extend(self, new_depth):
+        """As StdlibStreams.extend: initial UEs continue their generators, the (stateless) tapes of arriving ids are redrawn."""
+        E, U0, D = len(self.seeds), self.U0, self.depth
+        ids = U0 + self.max_id
+        trip = np.zeros((E * ids, new_depth, 4), dtype=np.uint16)
+        trip[:, :D] = self._trip
+        for e, s in enumerate(self.seeds):
+            for i in range(U0):
+                mr, st = self.mov_rng[e][i], self._states[e][i]
+                lo, hi = self.vel[i]
+                for k in range(D, new_depth):
+                    trip[e * ids + i, k, :3] = (mr.randint(lo, hi) if lo != hi else lo, mr.randint(10, self.w - 10),
+                                                mr.randint(10, self.h - 10))
+                    st.append(mr.getstate())
+            for j in range(self.max_id):
+                mr = random.Random(s + 100 * (j + 1))
+                for k in range(new_depth):
+                    trip[e * ids + U0 + j, k, :3] = (mr.randint(1, 3), mr.randint(10, self.w - 10), mr.randint(10, self.h - 10))
+        self.depth, self._trip = new_depth, trip
+        return self._pos0, trip
 
     def departures(self, n_remove, num_ue):
         out = np.zeros((len(self.seeds), n_remove), dtype=np.int32)

@@ -151,10 +151,31 @@ int dcomp_step_dyn(dcomp_env *env, const dcomp_state *st, const uint8_t *action,
                    const dcomp_events *ev, void *stream);
 int dcomp_num_ue(const dcomp_env *env);               /* UEs currently in every env's list */
 
-/* T consecutive steps from an action tape actions[T][E][U] (one launch per step, no host work in
- * between); outputs of the last step only.  Used for launch-overhead-free measurement. */
+/* T consecutive steps from an action tape actions[T][E][U] with no host work in between; outputs of the LAST step only.
+ * Replaces the per-step Python loop of simulation.py:512-541.  The narrow kernel (dcomp_rollout_is_fused() == 1) runs all T
+ * steps in ONE launch with the UE state in registers in between; envs of >= 64 lanes with more than 20 BSs and envs with UE
+ * arrival / departure are launched once per step.  Results are identical to T dcomp_step calls either way. */
 int dcomp_rollout(dcomp_env *env, const dcomp_state *st, const uint8_t *actions, int32_t num_steps,
                   const dcomp_out *out, void *stream);
+
+/* dcomp_rollout with options.
+ *   every_step          1: out->obs, out->reward and the info tensors are [T][...] buffers that receive the outputs of
+ *                       every step (a rollout fragment for the learner); 0: outputs of the last step only
+ *   horizon             > 0: whenever env.time has reached it the envs are reset before the next step, inside the rollout --
+ *                       what RLlib does at its `horizon` = episode_length (env_setup.py:281); the first observation of
+ *                       the new episode is not emitted.  0: never (then an episode has at most 65536 steps)
+ *   new_episode_draws   Philox mode: 1 = every such reset starts the next episode's draws (rand_episodes = True),
+ *                       0 = the same episode again (the reference re-seeds at reset, base.py:171-173).  Tape mode replays the
+ *                       tape handed to the last dcomp_reset, so it must be 0 there. */
+typedef struct dcomp_rollout_opts {
+    int32_t every_step;
+    int32_t horizon;
+    int32_t new_episode_draws;
+    int32_t reserved;
+} dcomp_rollout_opts;
+int dcomp_rollout_ex(dcomp_env *env, const dcomp_state *st, const uint8_t *actions, int32_t num_steps,
+                     const dcomp_out *out, const dcomp_rollout_opts *opts, void *stream);
+int dcomp_rollout_is_fused(const dcomp_env *env);      /* 1: T steps = one launch */
 
 /* Synchronises `stream`, reads the sticky flags and maps them to DCOMP_EACTION / DCOMP_ETAPE /
  * DCOMP_EPOS (the reference raises AssertionError in these cases).  Clears the flags. */
@@ -163,6 +184,16 @@ int dcomp_check(dcomp_env *env, const dcomp_state *st, void *stream);
 int dcomp_time(const dcomp_env *env);                 /* env.time (base.py:39) -- lock-step over the batch */
 int64_t dcomp_episode(const dcomp_env *env);          /* resets so far - 1 (Philox counter word) */
 int dcomp_set_episode(dcomp_env *env, int64_t episode);
+
+/* MobileEnv.seed (base.py:132-143) for counter-based draws: a new Philox key.  Takes effect with the next draw; callers
+ * normally follow it with dcomp_set_episode(env, 0) + dcomp_reset (the gym convention env.seed(s); env.reset()). */
+int dcomp_set_seed(dcomp_env *env, uint64_t seed);
+
+/* Tape mode: replace the borrowed draw tape of the episode in progress by a LONGER one holding the same draws (first
+ * `depth_old` triples of every stream identical) -- for episodes that outlive the tape they were started with: the
+ * reference's done() is always None (base.py:371-381) and --cont-train never resets (main.py:48-51).  The caller
+ * synchronises the stream first (steps in flight read the old tape). */
+int dcomp_set_tape(dcomp_env *env, const dcomp_tape *tape, int32_t depth);
 
 /* Checkpoint / resume of an env batch (the reference never checkpoints env state, simulation.py:143-147 restores the
  * learner only; with counter-based draws the state tensors plus these five host-side counters are the whole env):

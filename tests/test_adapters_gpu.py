@@ -1,0 +1,132 @@
+"""GPU tests of the RLlib-protocol adapters against the REFERENCE-RUN fixtures -- not against
+other instances of the same HIP path: tests/golden/estack_* hold 8 reference runs (seeds 42 + 20000 e) of the 10 x 5 central
+and the 32 x 10 multi-agent env under one action tape each.  Caller contract: deepcomp/util/env_setup.py:262-316 (observation /
+action spaces, agent ids = ue.id, horizon = episode_length), deepcomp/util/simulation.py:143."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.test_parity_gpu import ATOL_OBS, ATOL_UTIL, GOLDEN, RTOL_RATE, _entities_from_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def _load(stack):
+    return [np.load(os.path.join(GOLDEN, f'{stack}_e{e}.npz')) for e in range(8)]
+
+
+def _env_config(g, num_envs):
+    m, bs, ues = _entities_from_fixture(g)
+    return {'map': m, 'bs_list': bs, 'ue_list': ues, 'seed': int(g['cfg_seed']), 'episode_length': int(g['cfg_eps_len']),
+            'reward': {0: 'avg', 1: 'sum', 2: 'min'}[int(g['cfg_reward'])], 'rand_episodes': bool(g['cfg_rand_episodes']),
+            'num_envs': num_envs, 'rng': 'reference'}
+
+
+def _check_central(obs, g, prefix, i, U, B):
+    assert obs['connected'].shape == (U * B,) and obs['dr'].shape == (U * B,) and obs['utility'].shape == (U,)
+    assert np.array_equal(obs['connected'], g[f'{prefix}_obs_connected'][i].ravel())          # central.py:36-44: UE-major
+    np.testing.assert_allclose(obs['dr'], g[f'{prefix}_obs_dr'][i].ravel(), rtol=RTOL_RATE, atol=1e-30)
+    np.testing.assert_allclose(obs['utility'], g[f'{prefix}_obs_utility'][i], atol=ATOL_OBS, rtol=0)
+
+
+def test_central_vector_env_against_reference_runs(torch_cuda):
+    torch = torch_cuda
+    from deepcomp_amd.rllib_adapter import CENTRAL_KEYS, CentralVectorEnv, flatten_obs
+    gs = _load('estack_grid10x5_central')
+    U, B = 10, 5
+    vec = CentralVectorEnv(_env_config(gs[0], 8))
+    assert vec.num_envs == 8 and tuple(sorted(vec.observation_space.spaces)) == CENTRAL_KEYS
+    assert list(vec.observation_space.spaces) == list(CENTRAL_KEYS)                      # gym's sorted-key order = RLlib's flatten order
+    assert list(vec.action_space.nvec) == [B + 1] * U                                    # central.py:28
+    obs = vec.vector_reset()
+    for e in range(8):
+        _check_central(obs[e], gs[e], 'reset', 0, U, B)
+        assert np.array_equal(flatten_obs(obs[e]), vec.poll_tensors()[0][e].cpu().numpy())   # packed row == RLlib's flattening
+    T = gs[0]['actions'].shape[0]
+    for t in range(T):
+        obs, rew, dones, infos = vec.vector_step([g['actions'][t].tolist() for g in gs])
+        assert dones == [False] * 8
+        for e in range(8):
+            _check_central(obs[e], gs[e], 'step', t, U, B)
+            assert rew[e] == pytest.approx(float(gs[e]['step_reward'][t, 0]), abs=ATOL_OBS)
+            assert infos[e]['time'] == int(gs[e]['step_time'][t])
+            assert infos[e]['scalar_metrics']['sum_utility'] == pytest.approx(float(gs[e]['step_sum_utility'][t]), abs=ATOL_UTIL * U)
+            assert np.array_equal(flatten_obs(obs[e]), vec.poll_tensors()[0][e].cpu().numpy())
+    # the horizon: RLlib resets the copies one by one, in its own order; every one must get ITS first observation
+    order = [5, 2, 7, 0, 1, 3, 4, 6]
+    time_before = vec.core.time
+    for k, e in enumerate(order):
+        _check_central(vec.reset_at(e), gs[e], 'reset', 0, U, B)
+        assert vec.core.time == 0 and (k > 0 or time_before > 0)
+    episodes = vec.core.episode
+    _check_central(vec.reset_at(3), gs[3], 'reset', 0, U, B)              # a second request for a served index: a new reset
+    assert vec.core.episode == episodes + 1
+    obs, rew, _, _ = vec.vector_step([g['actions'][0].tolist() for g in gs])
+    for e in range(8):
+        _check_central(obs[e], gs[e], 'step', 0, U, B)                    # fixed episodes (base.py:171-173): the same episode again
+    # zero-copy path == protocol path
+    vec.reset_at(0)
+    a = torch.from_numpy(np.stack([g['actions'][0] for g in gs]).astype(np.uint8)).cuda()
+    vec.send_action_tensor(a)
+    o, r = vec.poll_tensors()
+    for e in range(8):
+        assert np.array_equal(o[e].cpu().numpy(), flatten_obs(obs[e])) and float(r[e]) == pytest.approx(rew[e], abs=1e-7)
+
+
+def _check_agent(obs, g, prefix, i, u, B):
+    assert set(obs) == {'connected', 'dr', 'utility', 'ues_at_bs', 'util_at_bs'}                # variants.py:302-303
+    assert np.array_equal(obs['connected'], g[f'{prefix}_obs_connected'][i][u])
+    np.testing.assert_allclose(obs['dr'], g[f'{prefix}_obs_dr'][i][u], rtol=RTOL_RATE, atol=1e-30)
+    np.testing.assert_allclose(obs['utility'], [g[f'{prefix}_obs_utility'][i][u]], atol=ATOL_OBS, rtol=0)
+    np.testing.assert_allclose(obs['ues_at_bs'], g[f'{prefix}_obs_ues_at_bs'][i][u], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(obs['util_at_bs'], g[f'{prefix}_obs_util_at_bs'][i][u], atol=ATOL_OBS, rtol=0)
+
+
+def test_multi_agent_base_env_against_reference_runs(torch_cuda):
+    torch = torch_cuda
+    from deepcomp_amd.rllib_adapter import MULTI_KEYS, MultiAgentBaseEnv, flatten_obs
+    gs = _load('estack_grid32x10_multi')
+    U, B = 32, 10
+    base = MultiAgentBaseEnv(_env_config(gs[0], 8))
+    assert base.agent_ids == [str(i + 1) for i in range(U)]                             # ue.id strings (env_setup.py:304-309)
+    assert list(base.observation_space.spaces) == list(MULTI_KEYS) and base.action_space.n == B + 1
+    obs, rew, dones, infos, off = base.poll()
+    assert sorted(obs) == list(range(8)) and off == {}
+    for e in range(8):
+        assert list(obs[e]) == base.agent_ids and dones[e] == {'__all__': False}
+        for u in (0, 7, 31):
+            _check_agent(obs[e][str(u + 1)], gs[e], 'reset', 0, u, B)
+            assert np.array_equal(flatten_obs(obs[e][str(u + 1)]), base.poll_tensors()[0][e, u].cpu().numpy())
+    T = min(12, gs[0]['actions'].shape[0])
+    for t in range(T):
+        acts = {e: {str(u + 1): int(gs[e]['actions'][t][u]) for u in range(U) if gs[e]['actions'][t][u] or u % 2}
+                for e in range(8)}                                                      # some no-op agents left out (multi_agent.py:30)
+        base.send_actions(acts)
+        obs, rew, dones, infos, _ = base.poll()
+        for e in range(8):
+            for u in range(U):
+                _check_agent(obs[e][str(u + 1)], gs[e], 'step', t, u, B)
+                assert rew[e][str(u + 1)] == pytest.approx(float(gs[e]['step_reward'][t][u]), abs=ATOL_UTIL)
+            assert infos[e]['1']['time'] == t + 1 and dones[e] == {'__all__': False}
+    for e in (6, 0, 3, 7, 1, 2, 5, 4):                                                  # try_reset in any order
+        o = base.try_reset(e)
+        for u in (0, 13, 31):
+            _check_agent(o[str(u + 1)], gs[e], 'reset', 0, u, B)
+    assert base.core.time == 0
+    # zero-copy path: one more step through tensors == the fixtures' first step
+    a = torch.from_numpy(np.stack([g['actions'][0] for g in gs]).astype(np.uint8)).cuda()
+    base.send_action_tensor(a)
+    o, r = base.poll_tensors()
+    base.core.check()
+    oh = o.cpu().numpy()
+    for e in range(8):
+        assert np.array_equal(oh[e, :, :B], gs[e]['step_obs_connected'][0])
+        np.testing.assert_allclose(r[e].cpu().numpy(), gs[e]['step_reward'][0], atol=ATOL_UTIL, rtol=0)

@@ -61,7 +61,7 @@ def _compare(core, g, prefix, i, e=0, with_reward=False):
     assert np.array_equal(st['curr_pause'][e], g[f'{prefix}_curr_pause'][i]), f'{prefix}[{i}] curr_pause'
     conn = ((st['conn'][e][:, None] >> np.arange(B)[None, :]) & 1).astype(np.uint8)
     assert np.array_equal(conn, g[f'{prefix}_conn'][i]), f'{prefix}[{i}] connection mask'
-    np.testing.assert_allclose(st['ewma'][e], g[f'{prefix}_ewma'][i], rtol=RTOL_RATE, atol=1e-30, err_msg=f'{prefix}[{i}] ewma')
+    np.testing.assert_allclose(st['ewma'][e], g[f'{prefix}_ewma'][i], rtol=RTOL_RATE, atol=1e-30, err_msg=f"{prefix}[{i}] ewma")
     v = {k: t.cpu().numpy()[e] for k, t in core.obs_views().items()}
     assert np.array_equal(v['connected'].reshape(U, B), g[f'{prefix}_obs_connected'][i])
     np.testing.assert_allclose(v['dr'].reshape(U, B), g[f'{prefix}_obs_dr'][i], rtol=RTOL_RATE, atol=1e-30, err_msg=f'{prefix}[{i}] obs dr')
@@ -663,7 +663,7 @@ def test_long_horizon_soak(torch_cuda):
         assert np.array_equal(st['pos'], o_pos) and np.array_equal(st['conn'], o_conn), f'episode {ep}'
         np.testing.assert_allclose(core.obs.cpu().numpy(), o_obs, rtol=RTOL_RATE, atol=ATOL_OBS)
         np.testing.assert_allclose(core.ewma.cpu().numpy().reshape(E, U), np.stack([o.state()['ewma'] for o in ob.envs]),
-                                   rtol=2e-5, atol=1e-12)
+                                   rtol=RTOL_RATE, atol=1e-30)
     core.check()
 
 
@@ -694,12 +694,69 @@ def test_tape_exhaustion_is_reported(torch_cuda):
     scn = scenarios.small_map('mixed').with_ues(num_fast=6)
     m, bs, ues = build_from_scenario(scn)
     core = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=4, seed=1, rng='reference', tape_depth=1, episode_length=400)
+    core._ensure_tape = lambda steps=1: None            # the env extends its tape on demand; without that the device flag is the net
     core.reset()
     a = torch.zeros((4, 6), dtype=torch.uint8, device='cuda')
     for _ in range(200):
         core.step(a)
     with pytest.raises(_lib.DcompError, match='tape'):
         core.check()
+
+
+@pytest.mark.parametrize('rand_episodes,dyn', [(False, False), (True, False), (True, True)])
+def test_tape_is_extended_for_episodes_that_outlive_it(torch_cuda, rand_episodes, dyn):
+    """rng='reference' past the horizon the tape was sized for (the reference's done() is always None, --cont-train never
+    resets: main.py:48-51): the env continues the SAME stdlib streams -- identical to an env whose tape was long enough from
+    the start, over two episodes (so the generator states handed to the next episode line up too)."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    scn = scenarios.small_map('mixed').with_ues(num_fast=4, num_slow=2)
+    m, bs, ues = build_from_scenario(scn)
+    kw = dict(num_envs=3, seed=5, rng='reference', rand_episodes=rand_episodes, episode_length=20)
+    if dyn:
+        kw.update(ue_arrival={3: 1, 9: -2, 15: 1})
+    short = BatchedMobileEnv(m, bs, ues, 'multi', tape_depth=2, **kw)
+    long_ = BatchedMobileEnv(m, bs, ues, 'multi', tape_depth=200, **kw)
+    g = torch.Generator(device='cuda').manual_seed(1)
+    for ep in range(2):
+        short.reset(); long_.reset()
+        assert torch.equal(short.obs, long_.obs)
+        for t in range(150 if not dyn else 19):
+            a = torch.randint(0, len(bs) + 1, (3, short.U), generator=g, device='cuda', dtype=torch.uint8)
+            short.step(a); long_.step(a)
+        short.check(); long_.check()
+        assert torch.equal(short.pos, long_.pos) and torch.equal(short.mv, long_.mv) and torch.equal(short.obs, long_.obs)
+    assert short.tape_depth > 2
+
+
+def test_seed_on_a_live_env(torch_cuda):
+    """MobileEnv.seed (base.py:132-143) on an existing env, counter-based and tape draws: after seed(s); reset() the env is
+    indistinguishable from one constructed with seed s (round 1 raised NotImplementedError for Philox envs)."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    scn = scenarios.medium_map('mixed').with_ues(num_slow=3, num_fast=2)
+    m, bs, ues = build_from_scenario(scn)
+    acts = torch.randint(0, len(bs) + 1, (12, 16, 5), device='cuda', dtype=torch.uint8)
+    for rng, rand in (('philox', True), ('philox', False), ('reference', False), ('reference', True)):
+        a = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=16, seed=11, rng=rng, rand_episodes=rand, episode_length=6)
+        a.reset()
+        for t in range(4):
+            a.step(acts[t])
+        a.seed(None)                                     # no-op (base.py:133)
+        assert a.seed_value == 11
+        a.seed(977)
+        b = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=16, seed=977, rng=rng, rand_episodes=rand, episode_length=6)
+        for ep in range(2):
+            a.reset(); b.reset()
+            assert torch.equal(a.obs, b.obs), (rng, rand, ep)
+            for t in range(6):
+                a.step(acts[t + ep]); b.step(acts[t + ep])
+            assert torch.equal(a.pos, b.pos) and torch.equal(a.mv, b.mv) and torch.equal(a.obs, b.obs), (rng, rand, ep)
+        assert a._fingerprint() == b._fingerprint()
 
 
 def test_rollout_buffer_and_unaligned_outputs(torch_cuda):
@@ -834,3 +891,20 @@ def test_episode_horizon_guard(torch_cuda):
     env.reset()
     env.step(a)
     env.check()
+
+
+def test_policy_map_helpers(torch_cuda):
+    """get_max_num_ue / get_num_diff_ues (base.py:191-225): env_setup.py:295 sizes the --separate-agent-nns policy map with them."""
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import make_env_config
+    from deepcomp_amd.env import CentralRelNormEnv, MultiAgentMobileEnv
+    scn = scenarios.medium_map('mixed').with_ues(num_slow=3)
+    env = MultiAgentMobileEnv(make_env_config(scn, episode_length=12, ue_arrival={'2': 1, '5': -1, '8': 2}))
+    assert env.get_max_num_ue() == 5 and env.max_ues == 5          # 3 -> 4 -> 3 -> 5
+    assert env.get_num_diff_ues() == 6                             # 3 + 1 + 2: a departure does not free an id
+    env2 = CentralRelNormEnv(make_env_config(scn, episode_length=11, new_ue_interval=4))
+    assert env2.get_max_num_ue() == 3 + int(10 / 4) == env2.get_num_diff_ues()
+    env3 = MultiAgentMobileEnv(make_env_config(scn))
+    assert env3.get_max_num_ue() == env3.get_num_diff_ues() == 3
+    with pytest.raises(NotImplementedError):
+        env3.render()

@@ -1,0 +1,191 @@
+"""GPU tests of the fused T-step rollout (dcomp_rollout / dcomp_rollout_ex, one launch for T steps) and of the LDS-staged
+central observation stores.  Bar: BIT-IDENTICAL to the same steps issued one dcomp_step at a time (which the parity
+suite ties to the reference fixtures and the oracle); one case also runs against the CPU oracle directly.
+
+Replaces the per-step evaluation loop of deepcomp/util/simulation.py:512-541 and RLlib's reset at the horizon
+(deepcomp/util/env_setup.py:281)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def _make(kind, U, B, E, reward='avg', sharing='mixed', seed=77, rand_episodes=True, L=100, rng='philox'):
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    scn = scenarios.grid_map(B, sharing).with_ues(num_static=U // 8, num_slow=U - U // 8 - U // 4, num_fast=U // 4)
+    m, bs, ues = build_from_scenario(scn)
+    return BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=seed, reward=reward, rng=rng, rand_episodes=rand_episodes,
+                            episode_length=L, env_id_base=3)
+
+
+def _state(env):
+    return {k: getattr(env, k).clone() for k in ('pos', 'mv', 'conn', 'ewma')}
+
+
+def _same_state(a, b):
+    import torch
+    return all(torch.equal(a[k], b[k]) for k in a)
+
+
+SHAPES = [('multi', 32, 10, 200, 'avg', 'mixed'), ('central', 10, 5, 333, 'avg', 'mixed'), ('multi', 7, 4, 129, 'sum', 'mixed'),
+          ('multi', 20, 6, 64, 'min', 'max-cap'), ('central', 16, 9, 50, 'sum', 'rate-fair'), ('multi', 3, 3, 700, 'avg', 'resource-fair'),
+          ('central', 32, 10, 65, 'min', 'mixed'), ('multi', 100, 12, 9, 'avg', 'mixed'), ('central', 12, 16, 40, 'avg', 'proportional-fair'),
+          ('central', 64, 15, 11, 'avg', 'mixed'), ('central', 5, 32, 77, 'avg', 'mixed'), ('multi', 128, 32, 3, 'avg', 'mixed'),
+          ('central', 130, 6, 5, 'avg', 'mixed'), ('central', 40, 20, 7, 'sum', 'max-cap')]
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+def test_fused_rollout_equals_single_steps(torch_cuda, shape):
+    """rollout(T) -- last-step outputs and [T, ...] fragments -- against T step() calls: every tensor bit-identical."""
+    torch = torch_cuda
+    kind, U, B, E, reward, sharing = shape
+    T = 23
+    g = torch.Generator(device='cuda').manual_seed(11)
+    acts = torch.randint(0, B + 1, (T, E, U), generator=g, device='cuda', dtype=torch.uint8)
+    acts[torch.rand((T, E, U), generator=g, device='cuda') < 0.4] = 0
+
+    ref = _make(kind, U, B, E, reward, sharing)
+    ref.reset()
+    want = {k: [] for k in ('obs', 'reward', 'sum_utility', 'ue_dr', 'ue_utility')}
+    for t in range(T):
+        ref.step(acts[t])
+        for k in want:
+            want[k].append(getattr(ref, k).clone())
+    ref.check()
+    want = {k: torch.stack(v) for k, v in want.items()}
+
+    a = _make(kind, U, B, E, reward, sharing)
+    a.reset()
+    o, r = a.rollout(acts)                                   # outputs of the last step only
+    a.check()
+    assert a.time == T
+    assert torch.equal(o, want['obs'][-1]) and torch.equal(r, want['reward'][-1])
+    assert torch.equal(a.sum_utility, want['sum_utility'][-1]) and torch.equal(a.ue_dr, want['ue_dr'][-1])
+    assert _same_state(_state(a), _state(ref))
+
+    b = _make(kind, U, B, E, reward, sharing)
+    b.reset()
+    out = {k: torch.full_like(v, float('nan')) for k, v in want.items()}
+    b.rollout(acts[:10], out={k: v[:10] for k, v in out.items()})          # two fragments: the state carries over
+    b.rollout(acts[10:], out={k: v[10:] for k, v in out.items()})
+    b.check()
+    for k in want:
+        assert torch.equal(out[k], want[k]), k
+    assert _same_state(_state(b), _state(ref))
+
+
+@pytest.mark.parametrize('kind,U,B,E,rand', [('multi', 32, 10, 96, True), ('central', 10, 5, 200, True), ('multi', 9, 7, 40, False),
+                                             ('multi', 128, 32, 3, True)])
+def test_rollout_resets_at_the_horizon(torch_cuda, kind, U, B, E, rand):
+    """horizon=L inside rollout() == `if time == L: reset()` before every step (RLlib's horizon, env_setup.py:281)."""
+    torch = torch_cuda
+    L, T = 8, 29
+    g = torch.Generator(device='cuda').manual_seed(3)
+    acts = torch.randint(0, B + 1, (T, E, U), generator=g, device='cuda', dtype=torch.uint8)
+    ref = _make(kind, U, B, E, rand_episodes=rand, L=L)
+    ref.reset()
+    want_obs, want_rew = [], []
+    for t in range(T):
+        if ref.time == L:
+            ref.reset()
+        ref.step(acts[t])
+        want_obs.append(ref.obs.clone()); want_rew.append(ref.reward.clone())
+    env = _make(kind, U, B, E, rand_episodes=rand, L=L)
+    env.reset()
+    out = {'obs': torch.empty((T,) + tuple(env.obs.shape), device='cuda'), 'reward': torch.empty((T,) + tuple(env.reward.shape), device='cuda')}
+    env.rollout(acts, out=out, horizon=L)
+    env.check()
+    assert torch.equal(out['obs'], torch.stack(want_obs)) and torch.equal(out['reward'], torch.stack(want_rew))
+    assert env.time == ref.time and env.episode == ref.episode
+    assert _same_state(_state(env), _state(ref))
+    env.step(acts[0]); ref.step(acts[0])                     # and the handles agree on what comes next
+    assert torch.equal(env.obs, ref.obs)
+
+
+def test_rollout_reference_tape_fixed_episodes(torch_cuda):
+    """rng='reference' with the reference's default (re-seeded at every reset, base.py:171-173): the borrowed tape is replayed."""
+    torch = torch_cuda
+    L, T, U, B, E = 6, 20, 5, 4, 9
+    acts = torch.randint(0, B + 1, (T, E, U), device='cuda', dtype=torch.uint8)
+    ref = _make('multi', U, B, E, rand_episodes=False, L=L, rng='reference')
+    env = _make('multi', U, B, E, rand_episodes=False, L=L, rng='reference')
+    ref.reset(); env.reset()
+    for t in range(T):
+        if ref.time == L:
+            ref.reset()
+        ref.step(acts[t])
+    env.rollout(acts, horizon=L)
+    env.check()
+    assert torch.equal(env.obs, ref.obs) and _same_state(_state(env), _state(ref))
+    bad = _make('multi', U, B, E, rand_episodes=True, L=L, rng='reference')
+    bad.reset()
+    with pytest.raises(NotImplementedError):
+        bad.rollout(acts, horizon=L)
+
+
+def test_fused_rollout_against_the_oracle(torch_cuda):
+    """The fused kernel directly against the CPU oracle (not only against single steps): 4 096 x 10 x 5 central -- BASELINE
+    config 2 -- 40 steps with a reset at the horizon, every step's observation and reward compared."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    from oracle import oracle as orc
+    E, U, B, L, T = 4096, 10, 5, 25, 40
+    scn = scenarios.grid_map(B, 'mixed').with_ues(num_slow=U)
+    m, bs, ues = build_from_scenario(scn)
+    env = BatchedMobileEnv(m, bs, ues, 'central', num_envs=E, seed=42, rng='philox', rand_episodes=True, episode_length=L)
+    assert env.fused_rollout
+    oenvs = []
+    for e in range(E):
+        o = orc.OracleEnv(int(scn.width), int(scn.height), scn.bs_pos, scn.bs_sharing, ['slow'] * U, kind=orc.CENTRAL)
+        o.set_philox(42, e)
+        oenvs.append(o)
+    ob = orc.OracleBatch(oenvs)
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, B + 1, size=(T, E, U)).astype(np.uint8)
+    env.reset(); ob.reset()
+    out = {'obs': torch.empty((T, E, U * (2 * B + 1)), device='cuda'), 'reward': torch.empty((T, E), device='cuda')}
+    env.rollout(torch.from_numpy(a).cuda(), out=out, horizon=L)
+    env.check()
+    got_obs, got_rew = out['obs'].cpu().numpy(), out['reward'].cpu().numpy()
+    episode = 0
+    for t in range(T):
+        if t and t % L == 0:
+            episode += 1
+            for o in ob.envs:
+                o.set_episode(episode)
+            ob.reset()
+        o_obs, o_rew, o_conn, o_pos = ob.step(a[t])
+        want = np.concatenate([o_obs[:, :, :B].reshape(E, -1), o_obs[:, :, B:2 * B].reshape(E, -1), o_obs[:, :, 2 * B]], axis=1)
+        np.testing.assert_allclose(got_obs[t], want, rtol=1e-5, atol=1e-5, err_msg=f'step {t}')
+        np.testing.assert_allclose(got_rew[t], o_rew, rtol=0, atol=1e-5, err_msg=f'step {t}')
+    st = env.state_host()
+    assert np.array_equal(st['pos'], o_pos) and np.array_equal(st['conn'], o_conn)
+
+
+def test_rollout_argument_validation(torch_cuda):
+    """Raw pointers cross the ABI: wrong dtype / device / size must be refused on the host."""
+    torch = torch_cuda
+    env = _make('multi', 4, 3, 8)
+    env.reset()
+    good = torch.zeros((5, 8, 4), dtype=torch.uint8, device='cuda')
+    env.rollout(good)
+    for bad in (good.to(torch.int32), good.cpu(), good[:, :, :3], good[:, ::2]):
+        with pytest.raises(ValueError):
+            env.rollout(bad)
+    with pytest.raises(ValueError):
+        env.rollout(good, out={'obs': torch.zeros((4, 8, 4, 13), device='cuda'), 'reward': torch.zeros((5, 8, 4), device='cuda')})
+    with pytest.raises(ValueError):
+        env.step_into(good[0], torch.zeros((8, 4, 12), device='cuda'), torch.zeros((8, 4), device='cuda'))
+    with pytest.raises(ValueError):
+        env.step_into(good[0].to(torch.int64), env.obs, env.reward)
