@@ -22,20 +22,27 @@ namespace dcomp {
 #ifndef DCOMP_WIDE_BC
 #define DCOMP_WIDE_BC 4
 #endif
-constexpr int WIDE_BC = DCOMP_WIDE_BC;   // BSs per chunk: 4 -> ~100 VGPRs (4-5 waves/SIMD), 8 -> ~145 (3 waves/SIMD)
+#ifndef DCOMP_WIDE_BC_MIXED
+#define DCOMP_WIDE_BC_MIXED 6
+#endif
+constexpr int WIDE_BC = DCOMP_WIDE_BC;
+constexpr int WIDE_BC_MAX = DCOMP_WIDE_BC_MIXED > DCOMP_WIDE_BC ? DCOMP_WIDE_BC_MIXED : DCOMP_WIDE_BC;   // BSs per chunk: 4 -> ~100 VGPRs (4-5 waves/SIMD), 8 -> ~145 (3 waves/SIMD)
 // The CLI-default 'mixed' pattern cycles resource- / rate- / proportional-fair with the station index: chunks of THREE make the
 // model of every chunk slot a compile-time constant (no scalar mode tests and branches per station): 0.1021 -> 0.0926 ms at config
 // 5's per-GPU share.  The other patterns are faster with 4 (resource-fair 0.077 vs 0.086 ms, generic 0.105 vs 0.115 ms).
-constexpr int wide_bc(int mp) { return mp == MP_MIXED ? 3 : WIDE_BC; }
+constexpr int wide_bc(int mp) { return mp == MP_MIXED ? DCOMP_WIDE_BC_MIXED : WIDE_BC; }
 
 template <int B, int UPAD>
 struct alignas(16) WideShared {
     float drst[4][64 * (B + 1)];          // per-wave transpose of the per-UE `dr` observation (row stride B+1: conflict-free)
-    float xw[2][4][2 * WIDE_BC];          // double-buffered per-wave partials of the cross-wave exchange
-    float tab_cnt[4][B];                  // per env in this block: |S_b| / U          (variants.py:296)
-    float tab_ub[4][B];                   //                        avg utility at b / 20 (variants.py:299)
-    uint32_t nb_conn[256];                // 'sum' reward: conn' and reward_before of the block's UEs
-    float nb_rb[256];
+    float xw[2][4][2 * WIDE_BC_MAX];          // double-buffered per-wave partials of the cross-wave exchange
+    // (sized to the shape: 4 workgroups of this kernel must keep fitting into the CU's 160 KB of LDS)
+    float4 tab[256 / UPAD][32];           // per env in this block and station: {|S_b|, sum utility, min utility, sum of all utilities}
+    float4 part[UPAD > 64 ? 4 : 1][32];   // the same per wave (cross-wave combine when an env spans several waves)
+    double2 bs[32];                       // BS positions, indexed PER LANE in the sparse pre-move pass
+    uint32_t nb_conn[256];                // conn' of the block's UEs (column sums below; 'sum' reward)
+    float nb_util[256];                   // utility of the block's UEs
+    float nb_rb[256];                     // 'sum' reward: reward_before of the block's UEs
 };
 
 // Combine N wave-uniform partials over the NW waves of an env; one barrier per call (buffers alternate).
@@ -61,7 +68,8 @@ __device__ __forceinline__ void wide_xchg(float (&v)[N], SH &sh, int &buf, int w
 
 // Shared rates of one chunk of base stations (station.py:152-220).  c[j]: connected to BS c0+j; l2[j]: log2 snr.
 // Returns the shared rate per station in dr[j] (0 where not connected) and |S_b| in cnt[j].
-template <int B, int NW, int MP, int BCC, bool FULL, class SH>
+// PRE: l2[j] already holds the UNSHARED rate of the connected pairs (the sparse pre-move pass of step_kernel_wide).
+template <int B, int NW, int MP, int BCC, bool FULL, bool PRE = false, class SH>
 __device__ __forceinline__ void wide_chunk_rates(const KParams &p, SH &sh, int &buf, int c0, const bool (&c)[BCC],
                                                  const float (&l2)[BCC], float inv_ewma, int wave, int lane,
                                                  float (&dr)[BCC], float (&cnt)[BCC], bool near_hint)
@@ -74,13 +82,13 @@ __device__ __forceinline__ void wide_chunk_rates(const KParams &p, SH &sh, int &
         dr[j] = 0.f; ex[j] = 0.f; ex[BCC + j] = 0.f;
         if (FULL || c0 + j < B) {
             const unsigned long long m = __ballot(c[j]);
-            bool f;                                            // straight-line: with 64 UEs of one env per wave a station is
-            const float t = rate_unshared_small(l2[j], f);     // rarely empty, and a skip branch per station costs more
+            bool f = false;                                    // straight-line: with 64 UEs of one env per wave a station is
+            const float t = PRE ? l2[j] : rate_unshared_small(l2[j], f);   // rarely empty, and a skip branch per station costs more
             dr[j] = c[j] ? t : 0.f;
             ex[j] = (float)group_popcount<64>(m, 0);
         }
     }
-    if (near_hint) {
+    if (!PRE && near_hint) {
 #pragma unroll
         for (int j = 0; j < BCC; j++) if ((FULL || c0 + j < B) && c[j] && l2[j] > RATE_SMALL_L2) dr[j] = rate_unshared_any(l2[j]);
     }
@@ -93,7 +101,16 @@ __device__ __forceinline__ void wide_chunk_rates(const KParams &p, SH &sh, int &
             else if (mode == DCOMP_PROP_FAIR) { ex[BCC + j] = dr[j] * inv_ewma; any_sum = true; }
         }
     }
-    if (any_sum) {                       // uniform (modes are uniform)
+    if (MP == MP_MIXED && BCC % 3 == 0) {
+        // chunks start at a multiple of 3: slots 0, 3, ... are resource-fair (bs_mode_of) and need no sum over the UEs
+        constexpr int NS = BCC - BCC / 3;
+        float sv[NS];
+#pragma unroll
+        for (int j = 0, k = 0; j < BCC; j++) if (j % 3 != 0) sv[k++] = ex[BCC + j];
+        group_reduce_vec<64, OpSum, NS>(sv);
+#pragma unroll
+        for (int j = 0, k = 0; j < BCC; j++) if (j % 3 != 0) ex[BCC + j] = sv[k++];
+    } else if (any_sum) {                // uniform (modes are uniform)
         float sv[BCC];
 #pragma unroll
         for (int j = 0; j < BCC; j++) sv[j] = ex[BCC + j];
@@ -129,6 +146,7 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
     const bool active = (env < p.E) && (u < p.U);
     const int idx = env * p.U + u;
     int buf = 0;
+    if (tid < B) sh.bs[tid] = make_double2(p.bs_x[tid], p.bs_y[tid]);          // for the per-lane station index of the sparse pass
 
     double px = 0.0, py = 0.0;
     unsigned long long mv = 0;
@@ -152,59 +170,83 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
     }
     if (act > (uint32_t)B) { atomicOr(p.flags, DCOMP_FLAG_BAD_ACTION); act = 0; }
 
-    // move first (base.py:447 -> user.py:159-173); keep the old position for the pre-move pairs
-    const double ox = px, oy = py;
+    __syncthreads();                                                              // BS table
+
+    // ---- pre-move pass, SPARSE: the pre-move position only matters where this UE is connected (its rate before the move:
+    // base.py:446, and the stale-rate EWMA term) and at the station it acts on (in range -> may connect, user.py:203-222):
+    // typically 1-4 of the B stations.  Each lane walks ITS OWN set bits -- per-lane station index, BS position from the LDS
+    // table -- and parks the unshared rate of station b in strow[b]; the station sweep below picks it up where the UE is
+    // connected (other entries are never read) before it overwrites strow[b] with the post-move log2 snr.  The trip count is
+    // the largest need-set in the wave (~5) instead of B = 32 dense evaluations of pair, log2 and rate series per lane.
+    float *const strow = sh.drst[wave] + lane * (B + 1);      // this lane's row: pre-move rates -> log2 snr' -> normalised dr
+    const uint32_t act_bit = act ? 1u << (act - 1u) : 0u;
+    uint32_t inr_old = 0;                                      // in range at the OLD position (only bits of `need` are set)
+    {
+        uint32_t need = active ? (conn | act_bit) : 0u;
+        while (__ballot(need != 0u) != 0ull) {
+            if (need != 0u) {
+                const int b = __ffs((int)need) - 1;
+                need &= need - 1u;
+                const double2 bp = sh.bs[b];
+                bool ir, near;
+                float l2;
+                pair_eval(px, py, bp.x, bp.y, p, ir, l2, near);
+                if (near) {                                        // rare, per lane: within 1.26 m of the station
+                    const double dx = bp.x - px, dy = bp.y - py;
+                    if ((float)__builtin_fma(dy, dy, dx * dx) < 1e-20f) l2 = pair_eval_tiny(px, py, bp.x, bp.y, p);
+                }
+                inr_old |= (uint32_t)ir << b;
+                bool big;
+                float dru = rate_unshared_small(l2, big);
+                if (big) dru = rate_unshared_any(l2);              // rare: snr > 1/64
+                strow[b] = dru;
+            }
+        }
+    }
+    // toggle (base.py:259-263 -> user.py:190-222): connected -> disconnect; not connected and in range at the pre-move position -> connect
+    conn ^= act_bit & (conn | inr_old);
+    // move (base.py:447 -> user.py:159-173)
     if (active) {
         move_ue(p, env, (uint32_t)u + 1u, p.episode, px, py, mv, vrange);
         if (px < 0.0 || py < 0.0 || px > (double)p.map_w || py > (double)p.map_h) atomicOr(p.flags, DCOMP_FLAG_OUTSIDE_MAP);
     }
 
-    // ---- sweep 1: toggle, pre-move rates, drop, stale-rate EWMA term; post-move log2 snr kept in l2n[]
-    float *const strow = sh.drst[wave] + lane * (B + 1);      // this lane's row: log2 snr' now, normalised dr later
+    // ---- sweep 1: pre-move shared rates, post-move pairs, drop, stale-rate EWMA term; post-move log2 snr parked in strow[]
     uint32_t inr_new = 0;
-    bool near_any = false;                                     // wave-uniform: a lane came within 1.26 m of some BS this step
+    bool near_any = false;                                     // wave-uniform: a lane is within 1.26 m of some BS at the NEW position
     float curr = 0.f, stale = 0.f, l2max = -1e30f;
     const float inv_ewma_old = fast_rcp(ewma + EPS);
-    const uint32_t act_bit = act ? 1u << (act - 1u) : 0u;
     auto sweep1 = [&](const int c0, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;       // every slot of the chunk is a station: no bounds tests
         bool c[BC];
-        float l2o[BC], l2n[BC], dr[BC], cnt[BC];
+        float dru[BC], l2n[BC], dr[BC], cnt[BC];
         bool anytiny = false;
-        uint32_t inr_old = 0;
 #pragma unroll
         for (int j = 0; j < BC; j++) {
             const int b = c0 + j;
-            l2o[j] = -30.f;
+            c[j] = (FULL || b < B) && ((conn >> b) & 1u);
+            dru[j] = 0.f; l2n[j] = -30.f;
             if (FULL || b < B) {
-                bool inr_o, inr_n, t0, t1;
-                pair_eval(ox, oy, p.bs_x[b], p.bs_y[b], p, inr_o, l2o[j], t0);
+                bool inr_n, t1;
                 pair_eval(px, py, p.bs_x[b], p.bs_y[b], p, inr_n, l2n[j], t1);
-                anytiny |= t0 | t1;
+                anytiny |= t1;
                 inr_new |= (uint32_t)inr_n << b;
-                inr_old |= (uint32_t)inr_o << b;
+                dru[j] = strow[b];                             // the sparse pass's rate where connected; unused otherwise
             }
         }
-        // toggle of the acted-on station if it is in this chunk, branch-free (base.py:259-263 -> user.py:190-222):
-        // connected -> disconnect; not connected and in range at the pre-move position -> connect
-        conn ^= act_bit & (conn | inr_old) & (((BC >= 32 ? 0u : (1u << BC)) - 1u) << c0);
-#pragma unroll
-        for (int j = 0; j < BC; j++) c[j] = (FULL || c0 + j < B) && ((conn >> (c0 + j)) & 1u);
-        const bool near_chunk = __ballot(anytiny) != 0ull;       // a lane within 1.26 m of one of these stations (old or new position)
+        const bool near_chunk = __ballot(anytiny) != 0ull;       // a lane within 1.26 m of one of these stations (new position)
         near_any |= near_chunk;
         if (near_chunk) {
 #pragma unroll
             for (int j = 0; j < BC; j++) {
                 const int b = c0 + j;
                 if (FULL || b < B) {
-                    double dx = p.bs_x[b] - ox, dy = p.bs_y[b] - oy;
-                    if ((float)__builtin_fma(dy, dy, dx * dx) < 1e-20f) l2o[j] = pair_eval_tiny(ox, oy, p.bs_x[b], p.bs_y[b], p);
-                    dx = p.bs_x[b] - px; dy = p.bs_y[b] - py;
+                    const double dx = p.bs_x[b] - px, dy = p.bs_y[b] - py;
                     if ((float)__builtin_fma(dy, dy, dx * dx) < 1e-20f) l2n[j] = pair_eval_tiny(px, py, p.bs_x[b], p.bs_y[b], p);
                 }
             }
         }
-        wide_chunk_rates<B, NW, MP, BC, FULL>(p, sh, buf, c0, c, l2o, inv_ewma_old, wave, lane, dr, cnt, near_chunk);
+        wide_chunk_rates<B, NW, MP, BC, FULL, true>(p, sh, buf, c0, c, dru, inv_ewma_old, wave, lane, dr, cnt, false);
 #pragma unroll
         for (int j = 0; j < BC; j++) {
             const int b = c0 + j;
@@ -254,44 +296,65 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
     }
 
     // ---- sweep 3: per-BS utility aggregates (station.py:63-83), reward, per-env observation tables
+    // Transposed: what a station needs -- |S_b|, sum and min of the utilities of its UEs -- is a function of just TWO words
+    // per UE (connection mask, utility).  Every lane parks those two words in LDS; lane l then owns station l & 31 and adds up
+    // the 32 UEs of its own half-wave (rows it reads are broadcast within the half), the two halves and the env's waves are
+    // combined, and the totals go to a per-env table.  ~5 VALU per (station, UE-row) pair of a half-wave instead of a 64-lane
+    // butterfly per station and sum kind, and 2 workgroup barriers per step instead of one or two per chunk of stations.
     const bool multi = p.kind == DCOMP_MULTI;
-    const bool need_min = multi && p.reward_agg == DCOMP_REWARD_MIN;
+    sh.nb_conn[tid] = active ? conn : 0u;
+    sh.nb_util[tid] = active ? util : 0.f;
+    wave_lds_fence();
+    {
+        const int sb = lane & 31;                                 // my station (B <= 32)
+        const int r0 = tid & ~31;                                 // first UE row of my half-wave
+        float n = 0.f, t = 0.f, mn = MAX_UTIL, ta = 0.f;          // ta: sum of ALL utilities (info sum_utility, base.py:383-411)
+        if (multi && p.reward_agg == DCOMP_REWARD_MIN) {          // the minimum is only needed by the 'min' reward (multi_agent.py:81-85)
+#pragma unroll 8
+            for (int r = 0; r < 32; r++) {
+                const uint32_t cj = sh.nb_conn[r0 + r];
+                const float uj = sh.nb_util[r0 + r];
+                const bool bit = (cj >> sb) & 1u;
+                n += bit ? 1.f : 0.f;
+                t += bit ? uj : 0.f;
+                mn = bit ? min_med3(mn, uj) : mn;
+                ta += uj;
+            }
+        } else {
+#pragma unroll 8
+            for (int r = 0; r < 32; r++) {
+                const uint32_t cj = sh.nb_conn[r0 + r];
+                const float uj = sh.nb_util[r0 + r];
+                const bool bit = (cj >> sb) & 1u;
+                n += bit ? 1.f : 0.f;
+                t += bit ? uj : 0.f;
+                ta += uj;
+            }
+        }
+        n += __shfl_xor(n, 32, 64); t += __shfl_xor(t, 32, 64); mn = min_med3(mn, __shfl_xor(mn, 32, 64)); ta += __shfl_xor(ta, 32, 64);
+        if (NW > 1) {
+            if (lane < 32) sh.part[wave][sb] = make_float4(n, t, mn, ta);
+            __syncthreads();
+            const int w0 = (wave / NW) * NW;
+            float4 a = sh.part[w0][sb];
+#pragma unroll
+            for (int k = 1; k < NW; k++) { const float4 q = sh.part[w0 + k][sb]; a.x += q.x; a.y += q.y; a.z = min_med3(a.z, q.z); a.w += q.w; }
+            n = a.x; t = a.y; mn = a.z; ta = a.w;
+        }
+        if ((wave % NW) == 0 && lane < 32) sh.tab[env_local][sb] = make_float4(n, t, mn, ta);
+    }
+    __syncthreads();                                                              // tables (and nb_*) visible to the block
     float rn = 0.f, rt = 0.f, rmin = util;
     const float inv_u = 1.0f / (float)p.U;
-#pragma unroll 1
-    for (int c0 = 0; c0 < B; c0 += BC) {
-        float ex[2 * BC], mn[BC];
-#pragma unroll
-        for (int j = 0; j < BC; j++) {
-            const int b = c0 + j;
-            const bool cb = b < B ? (bool)((conn >> b) & 1u) : false;
-            ex[j] = b < B ? (float)group_popcount<64>(__ballot(cb), 0) : 0.f;
-            ex[BC + j] = cb ? util : 0.f;
-            mn[j] = cb ? util : MAX_UTIL;
-        }
-        {
-            float sv[BC];
-#pragma unroll
-            for (int j = 0; j < BC; j++) sv[j] = ex[BC + j];
-            group_reduce_vec<64, OpSum, BC>(sv);
-#pragma unroll
-            for (int j = 0; j < BC; j++) ex[BC + j] = sv[j];
-        }
-        wide_xchg<2 * BC, NW, OpSum>(ex, sh, buf, wave, lane);
-        if (need_min) {
-            group_reduce_vec<64, OpMin, BC>(mn);
-            wide_xchg<BC, NW, OpMin>(mn, sh, buf, wave, lane);
-        }
-#pragma unroll
-        for (int j = 0; j < BC; j++) {
-            const int b = c0 + j;
-            if (b < B) {
-                const float n = ex[j], t = ex[BC + j];
-                if ((inr_new >> b) & 1u) { rn += n; rt += t; rmin = fminf(rmin, n > 0.f ? mn[j] : MAX_UTIL); }
-                if (lane == 0 && (wave % NW) == 0) {
-                    sh.tab_cnt[env_local][b] = n * inv_u;
-                    sh.tab_ub[env_local][b] = n > 0.f ? t * fast_rcp(n) * (1.0f / MAX_UTIL) : 0.f;
-                }
+    if (multi && p.reward_agg != DCOMP_REWARD_SUM) {                              // multi_agent.py:60-71, 81-85
+        // over the stations in range of this UE (1-2 of the B on the grid layouts): sparse again, per-lane station index
+        uint32_t todo = active ? inr_new : 0u;
+        while (__ballot(todo != 0u) != 0ull) {
+            if (todo != 0u) {
+                const int b = __ffs((int)todo) - 1;
+                todo &= todo - 1u;
+                const float4 q = sh.tab[env_local][b];
+                rn += q.x; rt += q.y; rmin = fminf(rmin, q.x > 0.f ? q.z : MAX_UTIL);
             }
         }
     }
@@ -310,8 +373,7 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
     } else {                                                                      // multi_agent.py:39-95
         reward = util;
         if (p.reward_agg == DCOMP_REWARD_SUM) {
-            sh.nb_conn[tid] = active ? conn : 0u;
-            sh.nb_rb[tid] = reward_before;
+            sh.nb_rb[tid] = reward_before;                                        // (nb_conn was written in sweep 3)
             __syncthreads();
             if (inr_new != 0) {
                 float s = 0.f;
@@ -325,12 +387,7 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
             reward = rmin;
         }
     }
-    if (p.sum_util) {                                                             // base.py:383-411
-        float s[1];
-        s[0] = group_reduce<64, OpSum>(active ? util : 0.f);
-        wide_xchg<1, NW, OpSum>(s, sh, buf, wave, lane);
-        if (active && u == 0) p.sum_util[env] = s[0];
-    }
+    if (p.sum_util && active && u == 0) p.sum_util[env] = sh.tab[env_local][0].w;  // base.py:383-411
     if (active) {
         if (p.ue_dr) p.ue_dr[idx] = curr;
         if (p.ue_util) p.ue_util[idx] = util;
@@ -356,35 +413,48 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
     float *st = sh.drst[wave];
 #pragma unroll 4
     for (int b = 0; b < B; b++) strow[b] = fast_exp2(strow[b] - l2max);                       // variants.py:276-284
-    __syncthreads();                                                              // tables of sweep 3 + staging visible
+    wave_lds_fence();                                                             // the rows are this wave's own; the tables were fenced above
     // column slots of this lane: c = lane + 64 k.  Row layout: connected[B] | dr[B] | ues_at_bs[B] | util_at_bs[B] | utility
-    constexpr int NSLOT = (ROW + 63) / 64;
+    constexpr int NSLOT = (4 * B + 63) / 64;                                      // the utility column (4B) goes separately, below
     float pre[NSLOT];
 #pragma unroll
     for (int k = 0; k < NSLOT; k++) {
         const int c = lane + 64 * k;
         pre[k] = 0.f;
-        if (c >= 2 * B && c < 3 * B) pre[k] = sh.tab_cnt[env_local][c - 2 * B];
-        else if (c >= 3 * B && c < 4 * B) pre[k] = sh.tab_ub[env_local][c - 3 * B];
+        if (c >= 2 * B && c < 3 * B) pre[k] = sh.tab[env_local][c - 2 * B].x * inv_u;                    // variants.py:296
+        else if (c >= 3 * B && c < 4 * B) {                                                                 // variants.py:299
+            const float4 q = sh.tab[env_local][c - 3 * B];
+            pre[k] = q.x > 0.f ? q.y * fast_rcp(q.x) * (1.0f / MAX_UTIL) : 0.f;
+        }
     }
     const unsigned long long am = __ballot(active);
     const int nrows = group_popcount<64>(am, 0);                                              // active lanes are lanes [0, nrows)
     const size_t row0 = (size_t)env * p.U + (size_t)(wave % NW) * 64;
-    for (int r = 0; r < ((DCOMP_ABLATE & 8) ? 0 : nrows); r++) {
-        const uint32_t conn_r = (uint32_t)__builtin_amdgcn_readlane((int)conn, r);
-        const float util_r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(util_n), r));
-        float *orow = p.obs + (row0 + r) * ROW;
+    // Rows go out four at a time; the utility column (one float per row, the row's last) is stored by lanes 0-3 right
+    // behind its rows: one store instruction per four rows instead of a single-lane store per row -- and close in time to
+    // the rest of the row.  (All 64 utility entries in ONE scattered store after the loop is faster while the observation
+    // buffer fits the 256 MB Infinity Cache -- 4 096 envs -- and 45 % slower beyond: lines leave L2 partially written.)
+    for (int r0 = 0; r0 < ((DCOMP_ABLATE & 8) ? 0 : nrows); r0 += 4) {
 #pragma unroll
-        for (int k = 0; k < NSLOT; k++) {
-            const int c = lane + 64 * k;
-            if (c < ROW) {
-                float v = pre[k];
-                if (c < B) v = (float)((conn_r >> c) & 1u);
-                else if (c < 2 * B) v = st[r * (B + 1) + (c - B)];
-                else if (c == 4 * B) v = util_r;
-                orow[c] = v;                 // plain store: non-temporal 4-byte stores bypass L2 write-combining (measured slower)
+        for (int k4 = 0; k4 < 4; k4++) {
+            const int r = r0 + k4;
+            if (r < nrows) {
+                const uint32_t conn_r = (uint32_t)__builtin_amdgcn_readlane((int)conn, r);
+                float *orow = p.obs + (row0 + r) * ROW;
+#pragma unroll
+                for (int k = 0; k < NSLOT; k++) {
+                    const int c = lane + 64 * k;
+                    if (c < 4 * B) {
+                        float v = pre[k];
+                        if (c < B) v = (float)((conn_r >> c) & 1u);
+                        else if (c < 2 * B) v = st[r * (B + 1) + (c - B)];
+                        orow[c] = v;         // plain store: non-temporal 4-byte stores bypass L2 write-combining (measured slower)
+                    }
+                }
             }
         }
+        if (lane < 4 && r0 + lane < nrows)
+            p.obs[(row0 + r0 + lane) * ROW + 4 * B] = sh.nb_util[wave * 64 + r0 + lane] * (1.0f / MAX_UTIL);
     }
 }
 

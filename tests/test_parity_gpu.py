@@ -635,6 +635,43 @@ def test_full_size_oracle_parity(torch_cuda):
     core.check()
 
 
+@pytest.mark.parametrize('E,U,B,steps,seed_base', [(4096, 128, 32, 4, 3 * 4096), (32768, 32, 10, 5, 5 * 32768)])
+def test_per_gpu_shares_oracle_parity(torch_cuda, E, U, B, steps, seed_base):
+    """One GPU's share of BASELINE config 5 (4 096 x 128 UE x 32 BS: the wide kernel with its sparse pre-move pass and
+    transposed per-station sums) and of config 4 (32 768 x 32 x 10), at FULL size against the CPU oracle, as the rank that
+    owns global envs [seed_base, seed_base + E): masks and FP64 positions bit-exact, every observation entry and reward
+    within tolerance.  Actions are biased towards in-range stations so that many UEs hold several connections at once."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    scn = scenarios.grid_map(B, 'mixed').with_ues(num_static=U // 16, num_slow=U - U // 16 - U // 4, num_fast=U // 4)
+    m, bs, ues = build_from_scenario(scn)
+    core = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=E, seed=42, rng='philox', env_id_base=seed_base)
+    ob = _oracle_batch(scn, 'multi', 'avg', E, 42, env_id_base=seed_base)
+    rng = np.random.default_rng(5)
+    obs = core.reset()
+    np.testing.assert_allclose(obs.cpu().numpy(), ob.reset(), rtol=RTOL_RATE, atol=ATOL_OBS)
+    bsx = np.array([q[0] for q in scn.bs_pos]); bsy = np.array([q[1] for q in scn.bs_pos])
+    nconn = 0
+    for t in range(steps):
+        pos = core.state_host()['pos']
+        d2 = (pos[:, :, 0:1] - bsx[None, None, :]) ** 2 + (pos[:, :, 1:2] - bsy[None, None, :]) ** 2
+        near = np.argsort(d2, axis=2)[:, :, :3]                                     # the three closest stations
+        pick = np.take_along_axis(near, rng.integers(0, 3, size=(E, U, 1)), axis=2)[:, :, 0] + 1
+        a = np.where(rng.random((E, U)) < 0.7, pick, rng.integers(0, B + 1, size=(E, U))).astype(np.uint8)
+        core.step(torch.from_numpy(a).cuda())
+        o_obs, o_rew, o_conn, o_pos = ob.step(a)
+        st = core.state_host()
+        assert np.array_equal(st['conn'], o_conn), f'step {t}: connection masks differ'
+        assert np.array_equal(st['pos'], o_pos), f'step {t}: positions differ'
+        np.testing.assert_allclose(core.obs.cpu().numpy(), o_obs, rtol=RTOL_RATE, atol=ATOL_OBS)
+        np.testing.assert_allclose(core.reward.cpu().numpy(), o_rew, atol=ATOL_UTIL, rtol=0)
+        nconn = int(np.unpackbits(o_conn.view(np.uint8)).sum())
+    assert nconn > E * U // 4, 'the action bias should leave many connections in place'
+    core.check()
+
+
 def test_long_horizon_soak(torch_cuda):
     """3 000 steps (30 episodes, resets in between) of 64 envs against the oracle: FP64 positions and masks must
     still be bit-identical at the end -- no drift, no error flag (UE outside the map, bad action)."""
