@@ -98,8 +98,17 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
     if (CAP < U) return fail(DCOMP_EINVAL, "max_ues (%d) < num_ue (%d)", CAP, U);                 // base.py:84
     const bool DYN = cfg->max_ues > 0;                             // departures alone need no extra slots: max_ues == num_ue
     if ((int64_t)E * CAP > (int64_t)1 << 30) return fail(DCOMP_EINVAL, "num_envs*max_ues too large");
-    if (cfg->map_w < 21 || cfg->map_h < 21 || cfg->map_w > 65535 || cfg->map_h > 65535)
-        return fail(DCOMP_EINVAL, "map must be 21..65535 in both dimensions (waypoints live in [10, size-10])");
+    if (cfg->map_w < 3 || cfg->map_h < 3 || cfg->map_w > 65535 || cfg->map_h > 65535)
+        return fail(DCOMP_EINVAL, "map must be 3..65535 in both dimensions");
+    for (int u = 0; u < U; u++) {                                  // RandomWaypoint(pause_duration, border_buffer), movement.py:87-104
+        const int pd = cfg->ue_pause_duration ? cfg->ue_pause_duration[u] : 2, bb = cfg->ue_border_buffer ? cfg->ue_border_buffer[u] : 10;
+        if (pd < 0 || pd > 127) return fail(DCOMP_EINVAL, "ue %d: pause_duration %d outside 0..127 (7 bits of the movement word)", u, pd);
+        if (bb < 1 || bb > 255) return fail(DCOMP_EINVAL, "ue %d: border_buffer %d outside 1..255 (movement.py:103 asserts > 0)", u, bb);
+        if (cfg->map_w < 2 * bb + 1 || cfg->map_h < 2 * bb + 1)
+            return fail(DCOMP_EINVAL, "ue %d: map %dx%d leaves no waypoint inside a border buffer of %d", u, cfg->map_w, cfg->map_h, bb);
+    }
+    if (cfg->max_ues > 0 && (cfg->map_w < 21 || cfg->map_h < 21))
+        return fail(DCOMP_EINVAL, "UE arrival needs a map of at least 21x21 (arriving UEs use border_buffer 10, base.py:597-599)");
     if (cfg->env_kind != DCOMP_CENTRAL && cfg->env_kind != DCOMP_MULTI) return fail(DCOMP_EINVAL, "bad env_kind");
     if (cfg->reward_agg < 0 || cfg->reward_agg > 2) return fail(DCOMP_EINVAL, "bad reward_agg");
     if (cfg->rng_mode != DCOMP_RNG_TAPE && cfg->rng_mode != DCOMP_RNG_PHILOX) return fail(DCOMP_EINVAL, "bad rng_mode");
@@ -110,6 +119,7 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
     dcomp_env *env = new dcomp_env();
     env->cfg = *cfg;
     env->cfg.bs_x = env->cfg.bs_y = nullptr;   // host arrays are not retained
+    env->cfg.ue_pause_duration = env->cfg.ue_border_buffer = nullptr;
     env->cap = CAP; env->dyn = DYN; env->cur_ue = U; env->n_removed = env->n_arrived = 0;
     env->upad = next_pow2(CAP) < 4 ? 4 : next_pow2(CAP);
     int mp = dcomp::MP_RES_FAIR;            // sharing pattern -> specialised kernel (dcomp_device.h bs_mode_of)
@@ -184,6 +194,8 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
         if (c.util > DCOMP_UTIL_STEP) { delete env; return fail(DCOMP_EUNSUPPORTED, "ue %d: utility %d not implemented", u, (int)c.util); }   // user.py:92
         if (c.util != DCOMP_UTIL_LOG) kp.all_log_util = 0;
         c.dr_req = cfg->ue_dr_req ? cfg->ue_dr_req[u] : 1.0f;
+        c.pause = (uint8_t)(cfg->ue_pause_duration ? cfg->ue_pause_duration[u] : 2);
+        c.border = (uint8_t)(cfg->ue_border_buffer ? cfg->ue_border_buffer[u] : 10);
         uc[u] = c;
     }
     hipError_t e = hipSetDevice(cfg->device);
@@ -546,8 +558,9 @@ extern "C" int dcomp_mt_draw_tape(const dcomp_cfg *cfg, const int64_t *seeds, in
                 const int lo = cfg->ue_vel_lo[u], hi = cfg->ue_vel_hi[u];
                 uint16_t *t = triples + (idx * depth + k) * 4;
                 t[0] = (uint16_t)(lo != hi ? mov_rng.randint(lo, hi) : lo);      // movement.py:112-117
-                t[1] = (uint16_t)mov_rng.randint(10, W - 10);                    // movement.py:126
-                t[2] = (uint16_t)mov_rng.randint(10, H - 10);                    // movement.py:127
+                const int bb = cfg->ue_border_buffer ? cfg->ue_border_buffer[u] : 10;
+                t[1] = (uint16_t)mov_rng.randint(bb, W - bb);                    // movement.py:126
+                t[2] = (uint16_t)mov_rng.randint(bb, H - bb);                    // movement.py:127
                 t[3] = 0;
             }
         }

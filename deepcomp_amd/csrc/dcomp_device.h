@@ -73,10 +73,17 @@ struct UeCfg {          // per-UE immutable config (same in every env), 16 B
     int16_t init_x, init_y;   // -1 = random
     uint8_t vel_lo, vel_hi;   // inclusive draw range
     uint8_t util;             // DCOMP_UTIL_*
-    uint8_t pad;
+    uint8_t pause;            // RandomWaypoint.pause_duration (movement.py:87), 0..127
     float dr_req;
-    uint32_t pad2;
+    uint8_t border;           // RandomWaypoint.border_buffer, 1..255
+    uint8_t pad[3];
 };
+// Movement parameters of a UE packed into one non-negative int: velocity range lo:8 | hi:8, pause_duration:7, border_buffer:8.
+__device__ __forceinline__ int mv_cfg_pack(uint32_t lo, uint32_t hi, uint32_t pause, uint32_t border)
+{
+    return (int)(lo | (hi << 8) | (pause << 16) | (border << 23));
+}
+constexpr int MV_CFG_ARRIVED = 1 | (3 << 8) | (2 << 16) | (10 << 23);   // RandomWaypoint(map, velocity='slow') of an arriving UE (base.py:597-599)
 
 struct KParams {
     // state (device)
@@ -356,23 +363,23 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// packed movement word: wx:16 | wy:16 | vel:8 | pause:8 (bit2 pausing, bits0-1 curr_pause) | cursor:16
+// packed movement word: wx:16 | wy:16 | vel:8 | pause:8 (bit 7 pausing, bits 0-6 curr_pause) | cursor:16
 __device__ __forceinline__ unsigned long long mv_pack(uint32_t wx, uint32_t wy, uint32_t vel, uint32_t pausing, uint32_t cp,
                                                       uint32_t cursor)
 {
     return (unsigned long long)(wx & 0xFFFF) | ((unsigned long long)(wy & 0xFFFF) << 16) | ((unsigned long long)(vel & 0xFF) << 32) |
-           ((unsigned long long)((pausing << 2) | (cp & 3)) << 40) | ((unsigned long long)(cursor & 0xFFFF) << 48);
+           ((unsigned long long)((pausing << 7) | (cp & 0x7Fu)) << 40) | ((unsigned long long)(cursor & 0xFFFF) << 48);
 }
 
 // movement.py:110-130 (RandomWaypoint.reset): k-th movement triple of this UE in this episode.
 // uidw = UE id (1-based) | UID_BORN for UEs that arrived during the episode (base.py:592-606: always 'slow', freshly
 // seeded).  Draws are keyed by the id, not by the slot: slots shift when a UE leaves.
 constexpr uint32_t UID_BORN = 0x8000u;
-// vrange: the UE's velocity draw range (lo | hi << 8) when the caller already holds it (fixed UE lists load it once per
-// kernel, next to the state: a load here sits in the middle of the move and, in the fused rollout, waits behind the
-// previous step's stores); < 0: read it from the per-UE config.
+// mcfg: the UE's movement parameters (mv_cfg_pack) -- velocity draw range, border buffer.  Fixed UE lists load them once per
+// kernel, next to the state: a load here would sit in the middle of the move and, in the fused rollout, wait behind the
+// previous step's stores.
 __device__ __forceinline__ void draw_triple(const KParams &p, int env, uint32_t uidw, uint32_t k, uint32_t episode, uint32_t &vel,
-                                            uint32_t &wx, uint32_t &wy, int vrange = -1)
+                                            uint32_t &wx, uint32_t &wy, int mcfg)
 {
     const uint32_t id0 = (uidw & 0x7FFFu) - 1u;
     const bool born = (uidw & UID_BORN) != 0u;
@@ -384,15 +391,18 @@ __device__ __forceinline__ void draw_triple(const KParams &p, int env, uint32_t 
     } else {
         uint32_t r[4] = {0x12345678u + k * 977u, 0x9abcdef0u ^ uidw * 2654435761u, 0x0fedcba9u + (uint32_t)env * 40503u, 0u};
         if (!(DCOMP_ABLATE & 128)) philox4x32_10(p.env_base + (uint32_t)env, id0 | (born ? UID_BORN : 0u), episode, k + 1, p.seed_lo, p.seed_hi, r);
-        uint32_t vlo = 1u, vhi = 3u;
-        if (!born) {
-            if (vrange >= 0) { vlo = (uint32_t)vrange & 0xFFu; vhi = (uint32_t)vrange >> 8; }
-            else { UeCfg c = p.ue_cfg[id0]; vlo = c.vel_lo; vhi = c.vel_hi; }
-        }
-        vel = vlo + __umulhi(r[0], vhi - vlo + 1u);
-        wx = 10u + __umulhi(r[1], (uint32_t)(p.map_w - 20 + 1));
-        wy = 10u + __umulhi(r[2], (uint32_t)(p.map_h - 20 + 1));
+        const uint32_t vlo = (uint32_t)mcfg & 0xFFu, vhi = ((uint32_t)mcfg >> 8) & 0xFFu, bb = ((uint32_t)mcfg >> 23) & 0xFFu;
+        vel = vlo + __umulhi(r[0], vhi - vlo + 1u);                                   // movement.py:112-117
+        wx = bb + __umulhi(r[1], (uint32_t)(p.map_w - 2 * (int)bb + 1));              // movement.py:126-127
+        wy = bb + __umulhi(r[2], (uint32_t)(p.map_h - 2 * (int)bb + 1));
     }
+}
+// Movement parameters of the UE with id word uidw when the caller does not hold them (UE lists that change: dcomp_dyn.h).
+__device__ __forceinline__ int load_mv_cfg(const KParams &p, uint32_t uidw)
+{
+    if (uidw & UID_BORN) return MV_CFG_ARRIVED;
+    const UeCfg c = p.ue_cfg[(uidw & 0x7FFFu) - 1u];
+    return mv_cfg_pack(c.vel_lo, c.vel_hi, c.pause, c.border);
 }
 
 // nrm = sqrt(vy*vy + vx*vx), nx = vx / nrm, ny = vy / nrm, correctly rounded: the compiler's own FP64 sqrt and division
@@ -427,19 +437,20 @@ __device__ __forceinline__ void norm_and_unit(double vx, double vy, double &nrm,
 // One RandomWaypoint step in FP64, in the reference's operation order.  movement.py:132-181.
 // Contraction is off: the only fused op is the explicit fma of the 2-element dot product (numpy).
 __device__ __forceinline__ void move_ue(const KParams &p, int env, uint32_t uidw, uint32_t episode, double &px, double &py,
-                                        unsigned long long &mv, int vrange = -1)
+                                        unsigned long long &mv, int mcfg)
 {
 #pragma clang fp contract(off)
     uint32_t wxi = (uint32_t)(mv & 0xFFFF), wyi = (uint32_t)((mv >> 16) & 0xFFFF), vel = (uint32_t)((mv >> 32) & 0xFF);
     uint32_t pz = (uint32_t)((mv >> 40) & 0xFF), cursor = (uint32_t)(mv >> 48);
-    uint32_t pausing = (pz >> 2) & 1, cp = pz & 3;
+    uint32_t pausing = (pz >> 7) & 1, cp = pz & 0x7Fu;
+    const uint32_t pause_dur = ((uint32_t)mcfg >> 16) & 0x7Fu;
     double wx = (double)wxi, wy = (double)wyi;
     if (px == wx && py == wy) pausing = 1;                          // movement.py:169-170
     bool stay = false;
     if (pausing) {
-        if (cp < 2) { cp += 1; stay = true; }                       // movement.py:172-175 (pause_duration = 2)
+        if (cp < pause_dur) { cp += 1; stay = true; }               // movement.py:172-175
         else {                                                      // movement.py:176 -> reset()
-            draw_triple(p, env, uidw, cursor, episode, vel, wxi, wyi, vrange);
+            draw_triple(p, env, uidw, cursor, episode, vel, wxi, wyi, mcfg);
             cursor += 1; pausing = 0; cp = 0;
             wx = (double)wxi; wy = (double)wyi;
         }
@@ -930,7 +941,7 @@ __device__ __forceinline__ void reset_ue(const KParams &p, int env, int u, uint3
     if (c.init_y >= 0) y = c.init_y;
     px = (double)x; py = (double)y;
     uint32_t vel, wx, wy;
-    draw_triple(p, env, (uint32_t)u + 1u, 0u, episode, vel, wx, wy, (int)c.vel_lo | ((int)c.vel_hi << 8));
+    draw_triple(p, env, (uint32_t)u + 1u, 0u, episode, vel, wx, wy, mv_cfg_pack(c.vel_lo, c.vel_hi, c.pause, c.border));
     mv = mv_pack(wx, wy, vel, 0u, 0u, 1u);
 }
 
@@ -997,7 +1008,7 @@ __device__ __forceinline__ void step_once(const KParams &p, BlockSharedT<B, UPAD
     float stale = 0.f;
 #pragma unroll
     for (int b = 0; b < B; b++) stale += ((conn >> b) & 1u) ? dr[b] : 0.f;
-    ewma = 0.9f * stale + 0.1f * ewma;
+    ewma = __builtin_fmaf(0.9f, stale, 0.1f * ewma);   // one explicit contraction: every kernel variant rounds alike
     // 6. rates after the move (base.py:451)
     if (!(DCOMP_ABLATE & 4)) shared_rates<B, UPAD, MP>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, (int)near_post);
     curr = 0.f;
@@ -1038,7 +1049,7 @@ __device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<
     float ewma = 0.f;
     bool step_util = false;
     float dr_req = 1.f;
-    int vrange = -1;
+    int vrange = MV_CFG_ARRIVED;
     if (active) {
 #if DCOMP_NT_STATE & 1
         typedef double d2v __attribute__((ext_vector_type(2)));
@@ -1055,10 +1066,10 @@ __device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<
         ewma = p.ewma[idx];
 #endif
         if (!ROLLOUT) act = p.action[idx];
-        if (p.rng_mode != DCOMP_RNG_TAPE || !p.all_log_util) {
-            const UeCfg c = p.ue_cfg[u];
+        {
+            const UeCfg c = p.ue_cfg[u];                                           // loaded here, next to the state
             step_util = c.util == DCOMP_UTIL_STEP; dr_req = c.dr_req;
-            vrange = (int)c.vel_lo | ((int)c.vel_hi << 8);
+            vrange = mv_cfg_pack(c.vel_lo, c.vel_hi, c.pause, c.border);
         }
     }
     Outs o{p.obs, p.reward, p.sum_util, p.ue_dr, p.ue_util, p.rb_out};

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel_dyn(const KParams p)
                 uidw = ((last & 0x7FFFu) + 1u) | UID_BORN;
                 px = (double)x; py = (double)y;
                 uint32_t vel, wx, wy;
-                draw_triple(p, env, uidw, 0u, p.episode, vel, wx, wy);
+                draw_triple(p, env, uidw, 0u, p.episode, vel, wx, wy, load_mv_cfg(p, uidw));
                 mv = mv_pack(wx, wy, vel, 0u, 0u, 1u);
                 conn = 0; ewma = 0.f;
                 if (mc) { for (int j = 0; j < CSW; j++) cs[j] = 0; }
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel_dyn(const KParams p)
     const float reward_before = clamp_med3(util_pre, MIN_UTIL, MAX_UTIL) * (1.0f / MAX_UTIL);
     // 4. move
     if (alive) {
-        move_ue(p, env, uidw, p.episode, px, py, mv);
+        move_ue(p, env, uidw, p.episode, px, py, mv, load_mv_cfg(p, uidw));
         if (px < 0.0 || py < 0.0 || px > (double)p.map_w || py > (double)p.map_h) atomicOr(p.flags, DCOMP_FLAG_OUTSIDE_MAP);
     }
     // 5. drop + EWMA
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel_dyn(const KParams p)
     float stale = 0.f;
 #pragma unroll
     for (int b = 0; b < B; b++) stale += ((conn >> b) & 1u) ? dr[b] : 0.f;
-    ewma = 0.9f * stale + 0.1f * ewma;
+    ewma = __builtin_fmaf(0.9f, stale, 0.1f * ewma);   // one explicit contraction: every kernel variant rounds alike
     // 6. rates after the move
     shared_rates<B, UPAD, MP>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt);
     curr = 0.f;

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
     float ewma = 0.f;
     bool step_util = false;
     float dr_req = 1.f;
-    int vrange = -1;
+    int vrange = MV_CFG_ARRIVED;
     if (active) {
         double2 q = p.pos[idx];
         px = q.x; py = q.y;
@@ -162,10 +162,10 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
         conn = p.conn[idx];
         ewma = p.ewma[idx];
         act = p.action[idx];
-        if (p.rng_mode != DCOMP_RNG_TAPE || !p.all_log_util) {       // loaded here, next to the state, not in the middle of the move
+        {                                                            // loaded here, next to the state, not in the middle of the move
             const UeCfg c = p.ue_cfg[u];
             step_util = c.util == DCOMP_UTIL_STEP; dr_req = c.dr_req;
-            vrange = (int)c.vel_lo | ((int)c.vel_hi << 8);
+            vrange = mv_cfg_pack(c.vel_lo, c.vel_hi, c.pause, c.border);
         }
     }
     if (act > (uint32_t)B) { atomicOr(p.flags, DCOMP_FLAG_BAD_ACTION); act = 0; }
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
     const float util_pre = ue_utility(curr, step_util, dr_req);
     const float reward_before = clamp_med3(util_pre, MIN_UTIL, MAX_UTIL) * (1.0f / MAX_UTIL);
     conn &= inr_new;                                                              // user.py:175-188
-    ewma = 0.9f * stale + 0.1f * ewma;                                            // user.py:148-157
+    ewma = __builtin_fmaf(0.9f, stale, 0.1f * ewma);   // one explicit contraction: every kernel variant rounds alike                                            // user.py:148-157
 
     // ---- sweep 2: rates after the move (base.py:451)
     curr = 0.f;

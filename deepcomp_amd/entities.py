@@ -43,10 +43,11 @@ class RandomWaypoint:
     """movement.py:86-104: velocity is a number or 'slow' (1..3) / 'fast' (5..10)."""
 
     def __init__(self, map, velocity, pause_duration=2, border_buffer=10):
-        if pause_duration != 2 or border_buffer != 10:
-            raise NotImplementedError("device kernels implement the reference defaults pause_duration=2, border_buffer=10")
+        assert border_buffer > 0, "Border Buffer must be >0 to avoid placing waypoints on or outside map borders."   # movement.py:103
         self.map = map
         self.init_velocity = velocity
+        self.pause_duration = pause_duration
+        self.border_buffer = border_buffer
 
     def __str__(self):
         return f"RandomWaypoint({self.init_velocity})"
@@ -121,7 +122,9 @@ def build_from_scenario(scn: scenarios.Scenario):
     """Scenario table -> (Map, [Basestation], [User]) exactly as env_setup.get_env would hand to env_config."""
     m = Map(scn.width, scn.height)
     bs_list = [Basestation(i, Point(x, y), s) for i, (x, y), s in zip(scn.bs_ids, scn.bs_pos, scn.bs_sharing)]
-    ue_list = [User(s['id'], m, s['pos_x'], s['pos_y'], RandomWaypoint(m, velocity=s['velocity']),
+    ue_list = [User(s['id'], m, s['pos_x'], s['pos_y'],
+                    RandomWaypoint(m, velocity=s['velocity'], pause_duration=s.get('pause_duration', 2),
+                                   border_buffer=s.get('border_buffer', 10)),
                     util_func=s['util_func'], dr_req=s['dr_req']) for s in scn.ue_specs]
     return m, bs_list, ue_list
 

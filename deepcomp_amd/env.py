@@ -71,14 +71,16 @@ def parse_entities(map, bs_list, ue_list):
     for ue in ue_list:
         if ue.util_func not in _lib.UTILITY:
             raise NotImplementedError(f"Utility function {ue.util_func} not implemented!")   # user.py:92
-    for ue in ue_list:                       # movement.py:87-104: the kernels implement the defaults of RandomWaypoint
+    pause, border = [], []
+    for ue in ue_list:                       # RandomWaypoint(map, velocity, pause_duration=2, border_buffer=10), movement.py:87-104
         mvt = ue.movement
-        if getattr(mvt, 'pause_duration', 2) != 2 or getattr(mvt, 'border_buffer', 10) != 10:
-            raise NotImplementedError(f"UE {ue.id}: pause_duration={getattr(mvt, 'pause_duration', 2)} / border_buffer="
-                                      f"{getattr(mvt, 'border_buffer', 10)}: only the reference defaults (2, 10) are implemented")
+        pd, bb = getattr(mvt, 'pause_duration', 2), getattr(mvt, 'border_buffer', 10)
         v = mvt.init_velocity
         if not isinstance(v, str) and float(v) != int(v):
             raise NotImplementedError(f"UE {ue.id}: velocity {v} is not an integer (the movement word stores velocities as integers)")
+        if int(pd) != pd or int(bb) != bb or not 0 <= pd <= 127 or not 1 <= bb <= 255:
+            raise NotImplementedError(f"UE {ue.id}: pause_duration={pd} / border_buffer={bb}: integers in 0..127 / 1..255 are implemented")
+        pause.append(int(pd)); border.append(int(bb))
     vel_specs = [ue.movement.init_velocity for ue in ue_list]
     vr = [_rng.vel_range(v) for v in vel_specs]
     init_xy = [(_coord(ue.init_pos_x), _coord(ue.init_pos_y)) for ue in ue_list]
@@ -94,6 +96,7 @@ def parse_entities(map, bs_list, ue_list):
         'vel_lo': np.array([r[0] for r in vr], dtype=np.int32), 'vel_hi': np.array([r[1] for r in vr], dtype=np.int32),
         'init_xy': init_xy,
         'init_x': np.array([p[0] for p in init_xy], dtype=np.int32), 'init_y': np.array([p[1] for p in init_xy], dtype=np.int32),
+        'pause': np.array(pause, dtype=np.int32), 'border': np.array(border, dtype=np.int32),
     }
 
 
@@ -155,6 +158,7 @@ class BatchedMobileEnv:
         self._ue_util, self._ue_req = ent['ue_util'], ent['ue_dr_req']
         self.vel_specs, self._vlo, self._vhi = ent['vel_specs'], ent['vel_lo'], ent['vel_hi']
         self.init_xy, self._ix, self._iy = ent['init_xy'], ent['init_x'], ent['init_y']
+        self._pause, self._border = ent['pause'], ent['border']
 
         c = _lib.DcompCfg()
         c.num_envs, c.num_ue, c.num_bs = self.E, self.U0, B
@@ -171,6 +175,7 @@ class BatchedMobileEnv:
         c.ue_util, c.ue_dr_req = self._ue_util.ctypes.data_as(ip), self._ue_req.ctypes.data_as(fp)
         c.ue_vel_lo, c.ue_vel_hi = self._vlo.ctypes.data_as(ip), self._vhi.ctypes.data_as(ip)
         c.ue_init_x, c.ue_init_y = self._ix.ctypes.data_as(ip), self._iy.ctypes.data_as(ip)
+        c.ue_pause_duration, c.ue_border_buffer = self._pause.ctypes.data_as(ip), self._border.ctypes.data_as(ip)
         self._cfg = c
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
@@ -261,7 +266,7 @@ class BatchedMobileEnv:
         first = self._dyn_streams is None
         if first:
             self._dyn_streams = _rng.DynamicStdlibStreams(self.env_seeds, self.map_w, self.map_h, self.vel_specs, self.init_xy,
-                                                         self.tape_depth, self.rand_episodes, self.max_id)
+                                                         self.tape_depth, self.rand_episodes, self.max_id, border=self._border)
             return self._dyn_streams.draw_episode()
         E, U, U0 = self.E, self.U, self.U0
         uid = self.uid.cpu().numpy().astype(np.uint16).reshape(E, U)
@@ -285,7 +290,7 @@ class BatchedMobileEnv:
         if self.rand_episodes:
             if self._streams is None:
                 self._streams = _rng.StdlibStreams(self.env_seeds, self.map_w, self.map_h, self.vel_specs, self.init_xy,
-                                                   self.tape_depth)
+                                                   self.tape_depth, border=self._border)
                 consumed = None
             else:
                 consumed = ((self.mv >> 48) & 0xFFFF).cpu().numpy()
@@ -440,7 +445,8 @@ class BatchedMobileEnv:
     def _fingerprint(self):
         return dict(E=self.E, U=self.U, U0=self.U0, B=self.B, kind=int(self.kind), reward=self.reward_agg, seed=int(self.seed_value),
                     env_id_base=self.env_id_base, map=(self.map_w, self.map_h), rand_episodes=self.rand_episodes,
-                    bs=self._bs_x.tolist() + self._bs_y.tolist() + self._bs_sh.tolist(), dynamic=self.dynamic)
+                    bs=self._bs_x.tolist() + self._bs_y.tolist() + self._bs_sh.tolist(), dynamic=self.dynamic,
+                    movement=self._pause.tolist() + self._border.tolist(), state_layout=2)
 
     def state_dict(self):
         """Everything needed to continue this env batch bit-identically in another process (the reference never checkpoints
@@ -524,8 +530,8 @@ class BatchedMobileEnv:
             'pos': self.pos.cpu().numpy().reshape(E, U, 2),
             'wp': np.stack([(mv & 0xFFFF).astype(np.float64), ((mv >> 16) & 0xFFFF).astype(np.float64)], -1).reshape(E, U, 2),
             'vel': ((mv >> 32) & 0xFF).astype(np.float64).reshape(E, U),
-            'pausing': ((mv >> 42) & 1).astype(np.int32).reshape(E, U),
-            'curr_pause': ((mv >> 40) & 3).astype(np.int32).reshape(E, U),
+            'pausing': ((mv >> 47) & 1).astype(np.int32).reshape(E, U),
+            'curr_pause': ((mv >> 40) & 0x7F).astype(np.int32).reshape(E, U),
             'cursor': ((mv >> 48) & 0xFFFF).astype(np.int32).reshape(E, U),
             'conn': self.conn.cpu().numpy().astype(np.uint32).reshape(E, U),
             'ewma': self.ewma.cpu().numpy().reshape(E, U),

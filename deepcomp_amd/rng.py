@@ -43,7 +43,8 @@ def mt_tape(cfg_struct, seeds, depth):
 class StdlibStreams:
     """Per-UE stdlib ``random.Random`` pairs for E envs; supports continuing streams across episodes."""
 
-    def __init__(self, seeds, map_w, map_h, vel_specs, init_xy, depth):
+    def __init__(self, seeds, map_w, map_h, vel_specs, init_xy, depth, border=None):
+        self.border = [10] * len(vel_specs) if border is None else [int(b) for b in border]      # movement.py:87,126-127
         self.seeds = [int(s) for s in seeds]
         self.w, self.h, self.depth = int(map_w), int(map_h), int(depth)
         self.vel = [vel_range(v) for v in vel_specs]
@@ -81,8 +82,8 @@ class StdlibStreams:
                 for k in range(D):
                     v = mr.randint(lo, hi) if lo != hi else lo
                     trip[e * U + i, k, 0] = v
-                    trip[e * U + i, k, 1] = mr.randint(10, self.w - 10)
-                    trip[e * U + i, k, 2] = mr.randint(10, self.h - 10)
+                    trip[e * U + i, k, 1] = mr.randint(self.border[i], self.w - self.border[i])
+                    trip[e * U + i, k, 2] = mr.randint(self.border[i], self.h - self.border[i])
                     st.append(mr.getstate())
                 st_e.append(st)
             self._states.append(st_e)
@@ -101,8 +102,8 @@ class StdlibStreams:
                 lo, hi = self.vel[i]
                 for k in range(D, new_depth):
                     trip[e * U + i, k, 0] = mr.randint(lo, hi) if lo != hi else lo
-                    trip[e * U + i, k, 1] = mr.randint(10, self.w - 10)
-                    trip[e * U + i, k, 2] = mr.randint(10, self.h - 10)
+                    trip[e * U + i, k, 1] = mr.randint(self.border[i], self.w - self.border[i])
+                    trip[e * U + i, k, 2] = mr.randint(self.border[i], self.h - self.border[i])
                     st.append(mr.getstate())
         self.depth, self._trip = new_depth, trip
         return self._pos0, trip
@@ -149,7 +150,8 @@ class DynamicStdlibStreams:
       ``map.rand_border_point()`` (map.py:52-65); both seeded with the env seed by MobileEnv.seed (base.py:132-136).
     """
 
-    def __init__(self, seeds, map_w, map_h, vel_specs, init_xy, depth, rand_episodes, max_id):
+    def __init__(self, seeds, map_w, map_h, vel_specs, init_xy, depth, rand_episodes, max_id, border=None):
+        self.border = [10] * len(vel_specs) if border is None else [int(b) for b in border]      # initial UEs; arriving ones: 10
         self.seeds = [int(s) for s in seeds]
         self.w, self.h, self.depth, self.rand_episodes = int(map_w), int(map_h), int(depth), bool(rand_episodes)
         self.vel = [vel_range(v) for v in vel_specs]
@@ -191,8 +193,8 @@ class DynamicStdlibStreams:
                 lo, hi = self.vel[i]
                 st = [mr.getstate()]
                 for k in range(D):
-                    trip[e * ids + i, k, :3] = (mr.randint(lo, hi) if lo != hi else lo, mr.randint(10, self.w - 10),
-                                                mr.randint(10, self.h - 10))
+                    trip[e * ids + i, k, :3] = (mr.randint(lo, hi) if lo != hi else lo, mr.randint(self.border[i], self.w - self.border[i]),
+                                                mr.randint(self.border[i], self.h - self.border[i]))
                     st.append(mr.getstate())
                 st_e.append(st)
             self._states.append(st_e)
@@ -214,8 +216,8 @@ class DynamicStdlibStreams:
                 mr, st = self.mov_rng[e][i], self._states[e][i]
                 lo, hi = self.vel[i]
                 for k in range(D, new_depth):
-                    trip[e * ids + i, k, :3] = (mr.randint(lo, hi) if lo != hi else lo, mr.randint(10, self.w - 10),
-                                                mr.randint(10, self.h - 10))
+                    trip[e * ids + i, k, :3] = (mr.randint(lo, hi) if lo != hi else lo, mr.randint(self.border[i], self.w - self.border[i]),
+                                                mr.randint(self.border[i], self.h - self.border[i]))
                     st.append(mr.getstate())
             for j in range(self.max_id):
                 mr = random.Random(s + 100 * (j + 1))

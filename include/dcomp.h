@@ -19,7 +19,7 @@
  *
  * Lane/data layout (E envs, U UEs, B base stations; idx = env*U + ue):
  *   pos   double[E*U][2]   UE position x,y (FP64: connect/drop decisions are bit-exact vs the reference)
- *   mv    uint64[E*U]      waypoint x:16 | y:16 | velocity:8 | pausing:1+curr_pause:2 (8 bits) | draw cursor:16
+ *   mv    uint64[E*U]      waypoint x:16 | y:16 | velocity:8 | pausing:1 (bit 47) + curr_pause:7 (bits 40-46) | draw cursor:16
  *   conn  uint32[E*U]      bit b set <=> UE connected to BS b                  (user.py:34 bs_dr keys)
  *   ewma  float [E*U]      exponentially weighted average rate                 (user.py:148-157)
  *   flags uint32[4]        sticky device-side error bits, read by dcomp_check()
@@ -80,6 +80,9 @@ typedef struct dcomp_cfg {
     const float *ue_dr_req;      /* host [U] or NULL (= 1) -- step utility only (user.py:33) */
     const int32_t *ue_vel_lo, *ue_vel_hi;  /* host [U] inclusive velocity draw range; lo==hi: fixed (movement.py:112-117) */
     const int32_t *ue_init_x, *ue_init_y;  /* host [U] fixed start coordinate or -1 = 'random' (user.py:98-109); NULL = random */
+    const int32_t *ue_pause_duration;      /* host [U] RandomWaypoint.pause_duration, 0..127 (movement.py:87,172-176); NULL = 2 */
+    const int32_t *ue_border_buffer;       /* host [U] RandomWaypoint.border_buffer, 1..255 (movement.py:87,126-127); NULL = 10.
+                                            * UEs that arrive during an episode always get the defaults (base.py:597-599). */
 } dcomp_cfg;
 
 typedef struct dcomp_state {     /* device, caller-allocated; sizes via dcomp_state_sizes() */

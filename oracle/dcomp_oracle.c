@@ -27,7 +27,7 @@
 #define BS_TX_POWER 30.0
 #define BS_HEIGHT 50.0
 #define UE_HEIGHT 1.5
-#define PAUSE_DURATION 2
+#define PAUSE_DURATION 2    /* movement.py:87 defaults; per-UE values via orc_set_movement */
 #define BORDER_BUFFER 10
 
 struct orc_env {
@@ -43,6 +43,7 @@ struct orc_env {
     int32_t *orig_consumed;   /* [U] movement triples an initial UE had consumed when it was removed (-1: still listed) */
     double *bs_x, *bs_y;
     int32_t *bs_sharing, *ue_util, *vel_lo, *vel_hi, *init_x, *init_y;
+    int32_t *pause_dur, *border;   /* per configured UE: RandomWaypoint(pause_duration, border_buffer), movement.py:87-104 */
     double *ue_dr_req;
     /* UE state: user.py:27-46, movement.py:96-104 */
     double *px, *py, *wx, *wy, *vel, *ewma;
@@ -75,6 +76,9 @@ static int ue_util_kind(const orc_env *e, int u) { return ue_born(e, u) ? ORC_UT
 static double ue_req(const orc_env *e, int u) { return ue_born(e, u) ? 1.0 : e->ue_dr_req[ue_idnum(e, u) - 1]; }
 static int ue_vlo(const orc_env *e, int u) { return ue_born(e, u) ? 1 : e->vel_lo[ue_idnum(e, u) - 1]; }
 static int ue_vhi(const orc_env *e, int u) { return ue_born(e, u) ? 3 : e->vel_hi[ue_idnum(e, u) - 1]; }
+/* arriving UEs get RandomWaypoint(map, velocity='slow') with the default pause / border (base.py:597-599) */
+static int ue_pause(const orc_env *e, int u) { return ue_born(e, u) ? PAUSE_DURATION : e->pause_dur[ue_idnum(e, u) - 1]; }
+static int ue_border(const orc_env *e, int u) { return ue_born(e, u) ? BORDER_BUFFER : e->border[ue_idnum(e, u) - 1]; }
 
 /* ------------------------------------------------------------------ channel: station.py:110-138,222-226 */
 static double path_loss(double distance)
@@ -245,8 +249,9 @@ static void movement_reset(orc_env *e, int u)
     } else {
         uint32_t r[4]; philox_draw(e, u, (uint32_t)k + 1, r);
         e->vel[u] = ue_vlo(e, u) + (int)mulhi32(r[0], (uint32_t)(ue_vhi(e, u) - ue_vlo(e, u) + 1));
-        e->wx[u] = BORDER_BUFFER + (int)mulhi32(r[1], (uint32_t)(e->map_w - 2 * BORDER_BUFFER + 1));
-        e->wy[u] = BORDER_BUFFER + (int)mulhi32(r[2], (uint32_t)(e->map_h - 2 * BORDER_BUFFER + 1));
+        const int bb = ue_border(e, u);
+        e->wx[u] = bb + (int)mulhi32(r[1], (uint32_t)(e->map_w - 2 * bb + 1));
+        e->wy[u] = bb + (int)mulhi32(r[2], (uint32_t)(e->map_h - 2 * bb + 1));
     }
     e->pausing[u] = 0;
     e->curr_pause[u] = 0;
@@ -267,7 +272,7 @@ static void movement_step(orc_env *e, int u)
 {   /* movement.py:158-181 */
     if (e->px[u] == e->wx[u] && e->py[u] == e->wy[u]) e->pausing[u] = 1;
     if (e->pausing[u]) {
-        if (e->curr_pause[u] < PAUSE_DURATION) { e->curr_pause[u] += 1; return; }
+        if (e->curr_pause[u] < ue_pause(e, u)) { e->curr_pause[u] += 1; return; }
         movement_reset(e, u);
     }
     move_towards(e, u);
@@ -405,6 +410,19 @@ void orc_set_events(orc_env *e, int n_remove, const int32_t *remove_idx, int n_a
     for (int k = 0; k < 2 * n_add && add_xy; k++) e->ev_add_xy[k] = add_xy[k];
 }
 void orc_set_initial_ues(orc_env *e, int num_initial) { e->U0 = num_initial; }
+/* Test hook: Basestation.data_rate(ue) (station.py:204-220) in the CURRENT state, optionally with the UEs' EWMA rates
+ * replaced first -- lets the sharing-model table of the reference (tests/golden/sharing.npz: connected and not-yet-connected
+ * askers, with and without EWMA history) be checked row by row, proportional-fair included. */
+double orc_probe_data_rate(orc_env *e, int b, int u, const double *ewma)
+{
+    if (ewma) for (int k = 0; k < e->nU; k++) e->ewma[k] = ewma[k];
+    return bs_data_rate(e, b, u);
+}
+/* RandomWaypoint(pause_duration, border_buffer) of the first n configured UEs (movement.py:87-104) */
+void orc_set_movement(orc_env *e, int n, const int32_t *pause_duration, const int32_t *border_buffer)
+{
+    for (int u = 0; u < n && u < e->U; u++) { e->pause_dur[u] = pause_duration[u]; e->border[u] = border_buffer[u]; }
+}
 int orc_num_ue(const orc_env *e) { return e->nU; }
 /* per initial UE: movement triples consumed this episode (at removal, or so far if still listed) */
 void orc_get_orig_consumed(const orc_env *e, int32_t *out)
@@ -531,6 +549,8 @@ orc_env *orc_create(int U, int B, int map_w, int map_h, int kind, int reward_agg
     e->ue_util = dup_mem(ue_util, sizeof(int32_t) * U);
     e->ue_dr_req = dup_mem(ue_dr_req, sizeof(double) * U);
     e->vel_lo = dup_mem(vel_lo, sizeof(int32_t) * U); e->vel_hi = dup_mem(vel_hi, sizeof(int32_t) * U);
+    e->pause_dur = dup_mem(NULL, sizeof(int32_t) * U); e->border = dup_mem(NULL, sizeof(int32_t) * U);
+    for (int u = 0; u < U; u++) { e->pause_dur[u] = PAUSE_DURATION; e->border[u] = BORDER_BUFFER; }
     e->init_x = dup_mem(init_x, sizeof(int32_t) * U); e->init_y = dup_mem(init_y, sizeof(int32_t) * U);
     if (!ue_dr_req) for (int u = 0; u < U; u++) e->ue_dr_req[u] = 1.0;
     if (!init_x) for (int u = 0; u < U; u++) e->init_x[u] = -1;
@@ -553,6 +573,7 @@ void orc_destroy(orc_env *e)
 {
     if (!e) return;
     free(e->bs_x); free(e->bs_y); free(e->bs_sharing); free(e->ue_util); free(e->ue_dr_req); free(e->vel_lo); free(e->vel_hi);
+    free(e->pause_dur); free(e->border);
     free(e->init_x); free(e->init_y); free(e->px); free(e->py); free(e->wx); free(e->wy); free(e->vel); free(e->ewma);
     free(e->reward_before); free(e->reward); free(e->pausing); free(e->curr_pause); free(e->cursor); free(e->ue_nbs);
     free(e->ue_bs); free(e->ue_dr); free(e->bs_ues); free(e->bs_nues); free(e->tape_pos0); free(e->tape_triples); free(e->uid); free(e->orig_consumed);

@@ -76,6 +76,9 @@ def lib():
         L.orc_connect_threshold_distance.restype = ctypes.c_double
         L.orc_philox4x32_10.argtypes = [_c_u32p, _c_u32p, _c_u32p]
         L.orc_set_initial_ues.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_set_movement.argtypes = [ctypes.c_void_p, ctypes.c_int, _c_ip, _c_ip]
+        L.orc_probe_data_rate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _c_dp]
+        L.orc_probe_data_rate.restype = ctypes.c_double
         L.orc_set_events.argtypes = [ctypes.c_void_p, ctypes.c_int, _c_ip, ctypes.c_int, _c_ip]
         L.orc_set_tape_ids.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _c_ip, _c_ip]
         L.orc_num_ue.argtypes = [ctypes.c_void_p]
@@ -111,10 +114,11 @@ class RefRngTape:
     (base.py:171-173); ``True`` lets the streams continue, which needs the number of triples the
     previous episode consumed (``consumed``)."""
 
-    def __init__(self, seed, map_w, map_h, vel_specs, init_xy=None, depth=48, rand_episodes=False):
+    def __init__(self, seed, map_w, map_h, vel_specs, init_xy=None, depth=48, rand_episodes=False, border=None):
         self.seed, self.w, self.h, self.depth, self.rand_episodes = seed, int(map_w), int(map_h), depth, rand_episodes
         self.vel_specs = list(vel_specs)
         self.U = len(self.vel_specs)
+        self.border = [10] * self.U if border is None else [int(b) for b in border]      # movement.py:87,126-127
         self.init_xy = init_xy if init_xy is not None else [(-1, -1)] * self.U
         self._seed_streams()
         self._states = None
@@ -127,8 +131,9 @@ class RefRngTape:
         r, v = self.mov_rng[i], self.vel_specs[i]
         lo, hi = vel_range(v)
         vel = r.randint(lo, hi) if lo != hi else lo      # only 'slow'/'fast' consume a draw
-        wx = r.randint(10, int(self.w - 10))
-        wy = r.randint(10, int(self.h - 10))
+        bb = self.border[i]
+        wx = r.randint(bb, int(self.w - bb))
+        wy = r.randint(bb, int(self.h - bb))
         return vel, wx, wy
 
     def draw_episode(self, consumed=None):
@@ -158,7 +163,7 @@ class OracleEnv:
     """One env instance of the oracle."""
 
     def __init__(self, map_w, map_h, bs_pos, bs_sharing, vel_specs, kind=MULTI, reward_agg=AVG, ue_util=None,
-                 ue_dr_req=None, init_xy=None, max_ues=None):
+                 ue_dr_req=None, init_xy=None, max_ues=None, pause=None, border=None):
         L = lib()
         self.U0 = len(vel_specs)                      # UEs in the configured ue_list
         self.U, self.B = max(max_ues or 0, self.U0), len(bs_pos)     # capacity (max_ues, base.py:79-84)
@@ -188,6 +193,15 @@ class OracleEnv:
         self.h = ctypes.c_void_p(self.h)
         if pad:
             L.orc_set_initial_ues(self.h, self.U0)
+        if pause is not None or border is not None:                 # RandomWaypoint(pause_duration, border_buffer), movement.py:87-104
+            self._pause = np.asarray([2] * self.U0 if pause is None else pause, dtype=np.int32)
+            self._border = np.asarray([10] * self.U0 if border is None else border, dtype=np.int32)
+            L.orc_set_movement(self.h, self.U0, _p(self._pause, _c_ip), _p(self._border, _c_ip))
+
+    def probe_data_rate(self, b, u, ewma=None):
+        """Basestation.data_rate(ue) (station.py:204-220) in the current state; ewma: replace the UEs' EWMA rates first."""
+        e = None if ewma is None else np.ascontiguousarray(ewma, dtype=np.float64)
+        return float(lib().orc_probe_data_rate(self.h, int(b), int(u), _p(e, _c_dp) if e is not None else None))
 
     def set_events(self, remove_idx=(), add_xy=()):
         """Arrival / departure of the NEXT step (base.py:433-443).  Lists: tape mode (reference draws)."""

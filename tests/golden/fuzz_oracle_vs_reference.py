@@ -121,12 +121,13 @@ def main():
     ap.add_argument('--near-ties', type=int, default=0, help='instead: find this many max-cap near-tie configurations with the oracle and check THEM against the reference')
     ap.add_argument('--cases', type=int, default=100)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--dump', default=None, help='--near-ties: write the configurations the reference confirmed to this JSON file (inputs only)')
     ap.add_argument('--max-pairs', type=int, default=240, help='U*B cap (the reference needs ~30 us per pair and step)')
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     bad = done = 0
     if a.near_ties:
-        tried = 0
+        tried, confirmed = 0, []
         while done < a.near_ties:
             spec = fuzz_parity.random_spec(rng)
             if 'max-cap' not in spec['sh'] or spec['U'] < 30 or spec['arrival']:
@@ -138,9 +139,14 @@ def main():
             done += 1
             try:
                 run_one(spec)
+                confirmed.append({k: (v.tolist() if hasattr(v, 'tolist') else v) for k, v in spec.items()})
             except AssertionError as ex:
                 bad += 1
                 print(f'near-tie case {done} FAILED: U={spec["U"]} B={spec["B"]} seed={spec["seed"]}\n   {str(ex)[:500]}', flush=True)
+        if a.dump:
+            import json
+            with open(a.dump, 'w') as f:
+                json.dump(confirmed, f, default=lambda o: o.tolist() if hasattr(o, 'tolist') else int(o))
         print(f'{done - bad} / {done} max-cap near-tie configurations (found among {tried} max-cap configurations): oracle == reference')
         sys.exit(1 if bad else 0)
     while done < a.cases:

@@ -51,7 +51,9 @@ def build_ref(scn, ue_specs):
     """Turn a geometry table into reference Map / Basestation / User objects."""
     m = Map(scn.width, scn.height)
     bs_list = [Basestation(i, Point(x, y), s) for i, (x, y), s in zip(scn.bs_ids, scn.bs_pos, scn.bs_sharing)]
-    ue_list = [User(s['id'], m, s['pos_x'], s['pos_y'], RandomWaypoint(m, velocity=s['velocity']),
+    ue_list = [User(s['id'], m, s['pos_x'], s['pos_y'],
+                    RandomWaypoint(m, velocity=s['velocity'], pause_duration=s.get('pause_duration', 2),
+                                   border_buffer=s.get('border_buffer', 10)),          # movement.py:87
                     util_func=s['util_func'], dr_req=s['dr_req']) for s in ue_specs]
     return m, bs_list, ue_list
 
@@ -155,6 +157,9 @@ def run_trajectory(name, scn, kind, seed, num_steps, reward='avg', tape_mode='un
         'cfg_eps_len': np.array(eps_len, dtype=np.int32),
         'actions': tape,
     }
+    if any('pause_duration' in s or 'border_buffer' in s for s in scn.ue_specs):      # non-default RandomWaypoint parameters
+        out['cfg_ue_pause'] = np.array([s.get('pause_duration', 2) for s in scn.ue_specs], dtype=np.int32)
+        out['cfg_ue_border'] = np.array([s.get('border_buffer', 10) for s in scn.ue_specs], dtype=np.int32)
     for k in resets[0]:
         out['reset_' + k] = np.stack([r[k] for r in resets])
     for k in steps[0]:
@@ -318,6 +323,19 @@ def gen_trajectories():
                    'multi', 42, 12, tape_mode='sticky')
 
 
+def gen_movement_params():
+    """RandomWaypoint(pause_duration, border_buffer) away from the defaults 2 / 10 (movement.py:87-104), per UE."""
+    scn = scenarios.custom_map('mixed').with_ues(num_slow=2, num_fast=4)
+    for spec, (pd, bb) in zip(scn.ue_specs, [(0, 5), (1, 10), (3, 20), (5, 30), (2, 12), (7, 1)]):
+        spec['pause_duration'], spec['border_buffer'] = pd, bb
+    run_trajectory('traj_custom6x4_multi_pause_border_s42', scn, 'multi', 42, 120, tape_mode='sticky', eps_len=120)
+    scn = scenarios.medium_map('mixed').with_ues(num_fast=3)
+    for spec, (pd, bb) in zip(scn.ue_specs, [(0, 3), (4, 25), (1, 40)]):
+        spec['pause_duration'], spec['border_buffer'] = pd, bb
+    run_trajectory('traj_medium3x3_central_pause_border_2eps_rand_s43', scn, 'central', 43, 60, episodes=2, eps_len=60,
+                   rand_episodes=True)
+
+
 def gen_estack():
     """E-axis parity: env e uses base seed 42 + 20000*e."""
     for e in range(8):
@@ -391,6 +409,9 @@ def run_dynamic_trajectory(name, scn, kind, seed, num_steps, ue_arrival=None, ne
         'cfg_arrival_n': np.array([arr[k] for k in sorted(arr.keys())], dtype=np.int32),
         'actions': tape,
     }
+    if any('pause_duration' in s or 'border_buffer' in s for s in scn.ue_specs):      # non-default RandomWaypoint parameters
+        out['cfg_ue_pause'] = np.array([s.get('pause_duration', 2) for s in scn.ue_specs], dtype=np.int32)
+        out['cfg_ue_border'] = np.array([s.get('border_buffer', 10) for s in scn.ue_specs], dtype=np.int32)
     for k in resets[0]:
         out['reset_' + k] = np.stack([r[k] for r in resets])
     for k in steps[0]:
@@ -474,11 +495,16 @@ def gen_heuristics():
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1:                     # e.g. `gen_golden.py gen_movement_params`: only these generators
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     gen_channel()
     gen_sharing()
     gen_utility()
     gen_movement()
     gen_trajectories()
+    gen_movement_params()
     gen_estack()
     gen_heuristics()
     gen_dynamic()

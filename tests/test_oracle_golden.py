@@ -56,30 +56,24 @@ def _connect_in_order(env, n_connected):
 
 
 def test_sharing_table():
-    """1 BS at the origin, static UEs on the x axis (integer distances), connected oldest-first."""
+    """Every row of the reference's sharing-model table (all four models incl. proportional-fair, with and without EWMA
+    history): 1 BS at the origin, static UEs on the x axis, connected oldest-first.  `dr_last_unconnected`: all but the last UE
+    connected and everyone asked -- the last one takes the temporarily-appended path of station.py:164-168;
+    `dr_all_connected`: everyone connected."""
     g = load('sharing')
     checked = 0
     for i in range(len(g['model'])):
         n, model = int(g['n'][i]), int(g['model'][i])
         dist, ewma = g['dist'][i][:n], g['ewma'][i][:n]
-        if np.any(ewma != 0):
-            continue     # ewma-dependent rates are pinned through the proportional-fair trajectories
-        env = orc.OracleEnv(400, 400, [(0, 0)], [model], [0] * n, kind=orc.MULTI,
-                            init_xy=[(int(d), 0) for d in dist])
-        env.set_tape(np.zeros((n, 2), np.int32), np.tile(np.array([0, 200, 200], np.int32), (n, 4, 1)))
-        env.reset()
-        _connect_in_order(env, n)
-        st = env.state()
-        want = g['dr_all_connected'][i][:n]
-        if model == orc.PROP_FAIR:
-            # after the connect steps ewma is no longer 0; recompute the closed form (station.py:192-195)
-            dru = np.array([orc.dr_unshared(d) for d in dist])
-            # the state's rates were computed with the ewma of the step before; check self-consistency instead
-            assert np.all(st['dr'][:, 0] > 0) and st['dr'][:, 0].sum() <= dru.max() * 1.0000001
-        else:
-            np.testing.assert_allclose(st['dr'][:, 0], want, rtol=1e-9)
-        checked += 1
-    assert checked >= 15
+        for column, k_conn in (('dr_last_unconnected', n - 1), ('dr_all_connected', n)):
+            env = orc.OracleEnv(400, 400, [(0, 0)], [model], [0] * n, kind=orc.MULTI, init_xy=[(int(d), 0) for d in dist])
+            env.set_tape(np.zeros((n, 2), np.int32), np.tile(np.array([0, 200, 200], np.int32), (n, 4, 1)))
+            env.reset()
+            _connect_in_order(env, k_conn)
+            got = [env.probe_data_rate(0, u, ewma) for u in range(n)]              # the stepping above moved the EWMAs: reseed them
+            np.testing.assert_allclose(got, g[column][i][:n], rtol=1e-9, atol=0, err_msg=f'row {i} {column} model {model}')
+            checked += 1
+    assert checked == 2 * len(g['model']) >= 60
 
 
 # ------------------------------------------------------------------ G4 movement traces
@@ -113,10 +107,13 @@ def make_env_from_fixture(g, depth=64):
     w, h = (int(x) for x in g['cfg_map_wh'])
     vel = [int(v) for v in g['cfg_ue_vel']]
     init = [tuple(int(v) for v in xy) for xy in g['cfg_ue_init_xy']]
+    pause = [int(v) for v in g['cfg_ue_pause']] if 'cfg_ue_pause' in (g.files if hasattr(g, 'files') else g) else None      # RandomWaypoint parameters away
+    border = [int(v) for v in g['cfg_ue_border']] if 'cfg_ue_border' in (g.files if hasattr(g, 'files') else g) else None   # from the defaults (movement.py:87)
     env = orc.OracleEnv(w, h, g['cfg_bs_pos'], list(g['cfg_bs_sharing']), vel, kind=int(g['cfg_kind']),
-                        reward_agg=int(g['cfg_reward']), ue_util=g['cfg_ue_util'], ue_dr_req=g['cfg_ue_dr_req'], init_xy=init)
+                        reward_agg=int(g['cfg_reward']), ue_util=g['cfg_ue_util'], ue_dr_req=g['cfg_ue_dr_req'], init_xy=init,
+                        pause=pause, border=border)
     tape = orc.RefRngTape(int(g['cfg_seed']), w, h, vel, init_xy=init, depth=depth,
-                          rand_episodes=bool(g['cfg_rand_episodes']))
+                          rand_episodes=bool(g['cfg_rand_episodes']), border=border)
     return env, tape, U
 
 

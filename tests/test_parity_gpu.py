@@ -36,7 +36,11 @@ def _entities_from_fixture(g):
     bs = [Basestation(chr(65 + i), Point(x, y), inv_sh[int(s)]) for i, ((x, y), s) in enumerate(zip(g['cfg_bs_pos'], g['cfg_bs_sharing']))]
     vel = {-1: 'slow', -2: 'fast'}
     xy = [['random' if int(c) < 0 else int(c) for c in p] for p in g['cfg_ue_init_xy']]
-    ues = [User(str(i + 1), m, xy[i][0], xy[i][1], RandomWaypoint(m, vel.get(int(v), int(v))),
+    U = len(g['cfg_ue_vel'])
+    pause = [int(v) for v in g['cfg_ue_pause']] if 'cfg_ue_pause' in g.files else [2] * U           # movement.py:87 defaults
+    border = [int(v) for v in g['cfg_ue_border']] if 'cfg_ue_border' in g.files else [10] * U
+    ues = [User(str(i + 1), m, xy[i][0], xy[i][1],
+                RandomWaypoint(m, vel.get(int(v), int(v)), pause_duration=pause[i], border_buffer=border[i]),
                 util_func='log' if int(u) == 0 else 'step', dr_req=float(r))
            for i, (v, u, r) in enumerate(zip(g['cfg_ue_vel'], g['cfg_ue_util'], g['cfg_ue_dr_req']))]
     return m, bs, ues
@@ -206,7 +210,9 @@ def _oracle_batch(scn, kind, reward, E, seed, env_id_base=0):
     envs = []
     for e in range(E):
         o = orc.OracleEnv(int(scn.width), int(scn.height), scn.bs_pos, scn.bs_sharing, vel,
-                          kind=orc.MULTI if kind == 'multi' else orc.CENTRAL, reward_agg={'avg': 0, 'sum': 1, 'min': 2}[reward])
+                          kind=orc.MULTI if kind == 'multi' else orc.CENTRAL, reward_agg={'avg': 0, 'sum': 1, 'min': 2}[reward],
+                          pause=[s.get('pause_duration', 2) for s in scn.ue_specs],
+                          border=[s.get('border_buffer', 10) for s in scn.ue_specs])
         o.set_philox(seed, env_id_base + e)
         envs.append(o)
     return orc.OracleBatch(envs)
@@ -270,6 +276,43 @@ def test_oracle_parity_philox(torch_cuda, shape):
     core.check()
 
 
+@pytest.mark.parametrize('kind,U,B,E', [('multi', 32, 10, 256), ('central', 10, 5, 300), ('multi', 128, 32, 6), ('multi', 70, 9, 20)])
+def test_movement_parameters_philox(torch_cuda, kind, U, B, E):
+    """RandomWaypoint(pause_duration, border_buffer) per UE away from the defaults 2 / 10 (movement.py:87-104; round 1 refused
+    them): counter-based draws against the oracle, 90 steps incl. a reset, through step() and through the fused rollout.
+    (The reference-run fixtures traj_*pause_border* pin the same parameters in tape mode.)"""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    scn = scenarios.grid_map(B, 'mixed').with_ues(num_slow=U - U // 2, num_fast=U // 2)
+    for i, spec in enumerate(scn.ue_specs):
+        spec['pause_duration'], spec['border_buffer'] = (0, 1, 2, 5, 9, 30, 127)[i % 7], (1, 10, 25, 49, 3)[i % 5]
+    m, bs, ues = build_from_scenario(scn)
+    core = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=99, rng='philox', rand_episodes=True, episode_length=45)
+    roll = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=99, rng='philox', rand_episodes=True, episode_length=45)
+    ob = _oracle_batch(scn, kind, 'avg', E, 99)
+    rng = np.random.default_rng(3)
+    acts = rng.integers(0, B + 1, size=(90, E, U)).astype(np.uint8)
+    dev = torch.from_numpy(acts).cuda()
+    core.reset(); roll.reset(); ob.reset()
+    for t in range(90):
+        if t == 45:
+            for o in ob.envs:
+                o.set_episode(1)
+            core.reset(); ob.reset()
+        core.step(dev[t])
+        o_obs, o_rew, o_conn, o_pos = ob.step(acts[t])
+        st = core.state_host()
+        assert np.array_equal(st['pos'], o_pos) and np.array_equal(st['conn'], o_conn), f'step {t}'
+    want = o_obs if kind == 'multi' else np.concatenate([o_obs[:, :, :B].reshape(E, -1), o_obs[:, :, B:2 * B].reshape(E, -1), o_obs[:, :, 2 * B]], axis=1)
+    np.testing.assert_allclose(core.obs.cpu().numpy(), want, rtol=RTOL_RATE, atol=ATOL_OBS)
+    assert int(st['curr_pause'].max()) > 3                      # pauses longer than the default were exercised
+    roll.rollout(dev, horizon=45)
+    assert torch.equal(roll.pos, core.pos) and torch.equal(roll.mv, core.mv) and torch.equal(roll.obs, core.obs)
+    core.check(); roll.check()
+
+
 def test_random_configurations_slice(torch_cuda):
     """A fixed-seed slice of tools/fuzz_parity.py: random shapes, BS layouts, sharing models (incl. max-cap), utilities,
     velocities, start positions (incl. UEs parked ON a BS), rewards and agent kinds against the oracle.  (The full
@@ -298,6 +341,24 @@ def test_max_cap_near_tie_goes_to_the_oldest_connection(torch_cuda):
     for spec in json.load(open(os.path.join(GOLDEN, 'fuzz_maxcap_near_ties.json'))):
         assert 'max-cap' in spec['sh']
         fuzz_parity.run_case(fuzz_parity.build_case(spec), torch_cuda)
+
+
+def test_max_cap_near_ties_the_reference_confirmed(torch_cuda):
+    """The 28 configurations in which a max-cap BS sees its two closest UEs at squared distances a few ulps apart AND the
+    reference itself was run against the oracle on them (tests/golden/fuzz_oracle_vs_reference.py --near-ties 28 --seed 0
+    --dump ...: 28 / 28 agree; inputs only are stored): the HIP path must agree with the oracle on every one."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), '..', 'tools'))
+    import fuzz_parity
+    specs = json.load(open(os.path.join(GOLDEN, 'fuzz_maxcap_near_ties_reference_confirmed.json')))
+    assert len(specs) == 28
+    for i, spec in enumerate(specs):
+        assert 'max-cap' in spec['sh'] and spec['U'] >= 30
+        try:
+            fuzz_parity.run_case(fuzz_parity.build_case(spec), torch_cuda)
+        except AssertionError as ex:
+            raise AssertionError(f'near-tie configuration {i}: {ex}') from None
 
 
 @pytest.mark.parametrize('agent_name', ['fullcomp', '3gpp', 'dynamic', 'static'])
