@@ -424,7 +424,11 @@ def main():
 
     obs_probe = None
     if use_dist and args.gather != 'obs' and not args.no_gather:
-        obs_probe = probe_obs_handoff()
+        try:                                   # a side measurement: it must never cost the headline line
+            obs_probe = probe_obs_handoff()
+        except Exception as ex:                # noqa: BLE001
+            obs_probe = {'error': f'{type(ex).__name__}: {ex}'[:300]}
+            torch.cuda.synchronize(dev)
 
     # Duration of one step-kernel launch, over the TIMED region itself: the event pairs run() recorded around each run of
     # back-to-back launches between two resets (an event pair per launch would also time the launch latency of an empty

@@ -1210,8 +1210,10 @@ inline KernelFn wide_or_null()
 template <int B, int UPAD, int MP>
 inline KernelFn rollout_or_null()
 {
-    // shapes the wide kernel takes over never reach the fused rollout (and their instantiations are the costly ones to build)
-    if constexpr (UPAD >= 64 && B > DCOMP_WIDE_MIN_B) return nullptr;
+    // The fused rollout serves small batches (dcomp_create: <= 4 waves per SIMD).  Not instantiated where it is never or hardly
+    // ever picked -- shapes the wide kernel takes over, envs of more than one wavefront -- those are also the costly ones to
+    // build; dcomp_rollout then launches the step kernel once per step (same results).
+    if constexpr (UPAD > 64 || (UPAD >= 64 && B > DCOMP_WIDE_MIN_B)) return nullptr;
     else return rollout_kernel<B, UPAD, MP>;
 }
 

@@ -34,6 +34,9 @@ def scenario_of(spec):
     scn.ue_specs = [dict(id=str(i + 1), pos_x='random' if ix < 0 else ix, pos_y='random' if iy < 0 else iy, velocity=v,
                          util_func='log' if u == 0 else 'step', dr_req=rq)
                     for i, (v, u, rq, (ix, iy)) in enumerate(zip(spec['vel'], spec['util'], spec['req'], spec['init']))]
+    if spec.get('pause'):                                 # RandomWaypoint(pause_duration, border_buffer), movement.py:87-104
+        for s, pd, bb in zip(scn.ue_specs, spec['pause'], spec['border']):
+            s['pause_duration'], s['border_buffer'] = pd, bb
     return scn
 
 

@@ -65,9 +65,24 @@ def random_spec(rng):
                 cur += n
         arrival = arrival or None
     tape = rng.random() < 0.35                                  # reference-exact stdlib-random draws (rng='reference')
-    return dict(arrival=arrival, tape=bool(tape), rand_episodes=bool(rng.random() < 0.5), kind=kind, reward=reward, E=E, U=U, B=B,
-                w=w, h=h, bs_xy=bs_xy, sh=sh, vel=vel, util=util, req=req, init=init, seed=int(rng.integers(0, 2 ** 31)),
-                base=int(rng.integers(0, 1000)), steps=int(rng.integers(15, 45)), p_noop=float(rng.choice([0.0, 0.5, 0.9])))
+    seed = int(rng.integers(0, 2 ** 31))
+    # round-2 features, drawn from a stream of their own so that the specs above stay what they were for a given seed:
+    # RandomWaypoint(pause_duration, border_buffer) per UE (movement.py:87-104; fixed UE lists only) and stepping the HIP
+    # path through the fused rollout kernel in fragments of 1-3 steps
+    r2 = np.random.default_rng(seed ^ 0x2F0B5EED)
+    pause = border = None
+    if arrival is None and r2.random() < 0.4:
+        bmax = max(1, min(255, (min(w, h) - 1) // 2))
+        pause = [int(r2.choice([0, 1, 2, 3, 6, 20])) for _ in range(U)]
+        border = [int(r2.integers(1, bmax + 1)) if r2.random() < 0.7 else min(10, bmax) for _ in range(U)]
+    rollout = int(r2.integers(1, 4)) if (arrival is None and r2.random() < 0.35) else 0
+    return dict(pause=pause, border=border, rollout=rollout, **_spec_rest(arrival=arrival, tape=bool(tape), rand_episodes=bool(rng.random() < 0.5), kind=kind, reward=reward, E=E, U=U, B=B,
+                w=w, h=h, bs_xy=bs_xy, sh=sh, vel=vel, util=util, req=req, init=init, seed=seed,
+                base=int(rng.integers(0, 1000)), steps=int(rng.integers(15, 45)), p_noop=float(rng.choice([0.0, 0.5, 0.9]))))
+
+
+def _spec_rest(**kw):
+    return kw
 
 
 def build_case(spec):
@@ -79,7 +94,9 @@ def build_case(spec):
     c['m'] = m
     c['bs'] = [Basestation(f'B{i}', Point(*xy), s) for i, (xy, s) in enumerate(zip(c['bs_xy'], c['sh']))]
     c['init'] = [tuple(p) for p in c['init']]
-    c['ues'] = [User(str(i + 1), m, 'random' if ix < 0 else ix, 'random' if iy < 0 else iy, RandomWaypoint(m, v),
+    pause, border = c.get('pause') or [2] * c['U'], c.get('border') or [10] * c['U']
+    c['ues'] = [User(str(i + 1), m, 'random' if ix < 0 else ix, 'random' if iy < 0 else iy,
+                     RandomWaypoint(m, v, pause_duration=pause[i], border_buffer=border[i]),
                      util_func='log' if u == 0 else 'step', dr_req=rq)
                 for i, (v, u, rq, (ix, iy)) in enumerate(zip(c['vel'], c['util'], c['req'], c['init']))]
     return c
@@ -106,7 +123,7 @@ def run_case(c, torch):
     for e in range(E):
         o = orc.OracleEnv(c['w'], c['h'], c['bs_xy'], c['sh'], c['vel'], kind=orc.MULTI if kind == 'multi' else orc.CENTRAL,
                           reward_agg={'avg': 0, 'sum': 1, 'min': 2}[reward], ue_util=c['util'], ue_dr_req=c['req'], init_xy=c['init'],
-                          max_ues=U if arrival else None)
+                          max_ues=U if arrival else None, pause=c.get('pause'), border=c.get('border'))
         if not tape:
             o.set_philox(c['seed'], c['base'] + e)
         envs.append(o)
@@ -114,7 +131,8 @@ def run_case(c, torch):
     re = c.get('rand_episodes', True)
     tapes = dyn_tapes = None
     if tape and not arrival:
-        tapes = [orc.RefRngTape(int(core.env_seeds[e]), c['w'], c['h'], c['vel'], init_xy=c['init'], depth=depth, rand_episodes=re)
+        tapes = [orc.RefRngTape(int(core.env_seeds[e]), c['w'], c['h'], c['vel'], init_xy=c['init'], depth=depth, rand_episodes=re,
+                                border=c.get('border'))
                  for e in range(E)]
     elif tape:                                          # reference draws with a changing UE list (oracle.py: DynRefStreams)
         max_id = len(c['vel']) + sum(a for _, a in sched)
@@ -157,13 +175,26 @@ def run_case(c, torch):
     core.reset()
     cmp('reset', oracle_reset(True), None, None, None)
     te = 0                                              # env.time inside the episode
+    frag = int(c.get('rollout') or 0)                   # > 0: the HIP path goes through the fused rollout, `frag` steps per call
+    pend = []
     for t in range(c['steps']):
         if t == c['steps'] // 2:
+            if pend:
+                core.rollout(torch.from_numpy(np.stack(pend)).cuda()); pend = []
             core.reset()
             cmp('reset2', oracle_reset(False), None, None, None)
             te = 0
         a = arng.integers(0, B + 1, size=(E, U)).astype(np.uint8)
         a[arng.random((E, U)) < c['p_noop']] = 0
+        if frag and not arrival:
+            pend.append(a)
+            res = ob.step(a)
+            te += 1
+            if len(pend) == frag or t == c['steps'] - 1 or t + 1 == c['steps'] // 2:
+                core.rollout(torch.from_numpy(np.stack(pend)).cuda())
+                pend = []
+                cmp(f'step {t} (rollout x{frag})', *res)
+            continue
         if arrival:
             n_rem, n_add = sched[te]
             if n_rem or n_add:
@@ -179,7 +210,7 @@ def run_case(c, torch):
 
 
 def describe(c):
-    return (f"{'TAPE rand_episodes=' + str(c.get('rand_episodes')) + ' ' if c.get('tape') else ''}{'DYN ' + str(c['arrival']) + ' ' if c.get('arrival') else ''}{c['kind']} U={c['U']} B={c['B']} E={c['E']} map={c['w']}x{c['h']} reward={c['reward']} sharing={sorted(set(c['sh']))} "
+    return (f"{'ROLLOUT x' + str(c['rollout']) + ' ' if c.get('rollout') else ''}{'PAUSE/BORDER ' if c.get('pause') else ''}{'TAPE rand_episodes=' + str(c.get('rand_episodes')) + ' ' if c.get('tape') else ''}{'DYN ' + str(c['arrival']) + ' ' if c.get('arrival') else ''}{c['kind']} U={c['U']} B={c['B']} E={c['E']} map={c['w']}x{c['h']} reward={c['reward']} sharing={sorted(set(c['sh']))} "
             f"seed={c['seed']} base={c['base']} steps={c['steps']} p_noop={c['p_noop']}")
 
 
