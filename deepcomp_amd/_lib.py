@@ -56,7 +56,7 @@ class DcompEvents(ctypes.Structure):
 
 EXPORTS = ['dcomp_create', 'dcomp_destroy', 'dcomp_state_sizes', 'dcomp_obs_dim', 'dcomp_reset', 'dcomp_step',
            'dcomp_step_dyn', 'dcomp_num_ue',
-           'dcomp_rollout', 'dcomp_rollout_ex', 'dcomp_rollout_is_fused', 'dcomp_check', 'dcomp_time', 'dcomp_episode', 'dcomp_set_episode', 'dcomp_set_seed', 'dcomp_set_tape', 'dcomp_get_counters', 'dcomp_set_counters', 'dcomp_mt_draw_tape',
+           'dcomp_rollout', 'dcomp_rollout_ex', 'dcomp_rollout_is_fused', 'dcomp_lanes_per_env', 'dcomp_check', 'dcomp_time', 'dcomp_episode', 'dcomp_set_episode', 'dcomp_set_seed', 'dcomp_set_tape', 'dcomp_get_counters', 'dcomp_set_counters', 'dcomp_mt_draw_tape',
            'dcomp_connect_threshold', 'dcomp_last_error', 'dcomp_version', 'dcomp_selftest']
 
 _lib = None
@@ -94,6 +94,8 @@ def load():
     else:
         L.dcomp_rollout_ex.argtypes = [vp, ctypes.POINTER(DcompState), vp, i32, ctypes.POINTER(DcompOut), ctypes.POINTER(DcompRolloutOpts), vp]
         L.dcomp_rollout_is_fused.argtypes = [vp]
+        if hasattr(L, 'dcomp_lanes_per_env'):
+            L.dcomp_lanes_per_env.argtypes = [vp]
     L.dcomp_check.argtypes = [vp, ctypes.POINTER(DcompState), vp]
     L.dcomp_time.argtypes = [vp]
     L.dcomp_episode.argtypes = [vp]

@@ -24,7 +24,7 @@ static KernelPair lookup_kernels(int B, int upad, int mp)
 #define DCOMP_CASE(n) case n: return kernels_b##n(upad, mp);
         DCOMP_B_LIST(DCOMP_CASE)
 #undef DCOMP_CASE
-    default: return KernelPair{nullptr, nullptr, nullptr, nullptr, nullptr};
+    default: return KernelPair{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     }
 }
 }  // namespace dcomp
@@ -55,6 +55,7 @@ struct dcomp_env {
     bool dyn;                  // UE list changes during an episode (cfg.max_ues > 0)
     bool fused;                // kern.step is step_kernel: T steps in one launch (the wide / dynamic kernels step once per launch)
     int upad, grid;
+    int tight_g, tight_gpw, tight_magic, tight_grid;   // step_kernel's tight packing of non-power-of-two UE lists (0 = off)
     int cap, cur_ue;            // slots per env; UEs currently listed
     uint32_t n_removed, n_arrived;   // this episode (Philox draw words)
     int time;
@@ -217,6 +218,29 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
         if (const char *e = getenv("DCOMP_FUSE_MAX_WAVES")) max_waves = atol(e);
         const long waves = (long)env->grid * (DCOMP_BLOCK / 64);
         env->fused = !DYN && env->kern.step != env->kern.step_wide && env->kern.rollout != nullptr && waves <= max_waves;
+        // Tight packing of UE lists whose length is not a power of two (dcomp_device.h, struct Seg): G = U lanes per env,
+        // 64 / G envs per wavefront, segmented ds_bpermute reductions (~13 instead of 4 instructions each).  It pays where the
+        // launch is throughput-bound and the padding wastes many lanes: >= 4 padded waves per SIMD and >= 1.4x the lanes in use
+        // (U = 5, 9, 10, 17-21; measured: 10 x 5 central +10 %, 20 x 10 multi +8 %, 5 x 3 central +14 %, but 12 x 7 multi -2 % at 1.25x).
+        // Not with max-cap BSs (their LDS scratch is indexed by padded env slots), not for UE lists that change.
+        env->tight_g = 0;
+        const int U1 = CAP;
+        if (!DYN && env->kern.step_tight && U1 >= 3 && (U1 & (U1 - 1)) != 0 && !kp.any_maxcap && env->kern.step != env->kern.step_wide) {
+            const int gpw = 64 / U1;
+            const double padded_use = (double)U1 / env->upad, tight_use = (double)(gpw * U1) / 64.0;
+            int want = waves >= 4 * 1024 && tight_use >= 1.4 * padded_use;
+            if (const char *e = getenv("DCOMP_TIGHT")) want = atoi(e) != 0;       // tests / A-B: force on or off
+            if (want) {
+                const int magic = 65536 / U1 + 1;
+                bool ok = true;
+                for (int l = 0; l < 64; l++) if (((l * magic) >> 16) != l / U1) ok = false;
+                if (ok) {
+                    env->tight_g = U1; env->tight_gpw = gpw; env->tight_magic = magic;
+                    const int epb = gpw * (DCOMP_BLOCK / 64);
+                    env->tight_grid = (E + epb - 1) / epb;
+                }
+            }
+        }
     }
     *out = env;
     return DCOMP_OK;
@@ -253,6 +277,17 @@ extern "C" int dcomp_obs_dim(const dcomp_env *env, int32_t *floats_per_env, int3
     return DCOMP_OK;
 }
 
+// One launch of the step kernel (plain step; also the per-step launches of a rollout that is not fused).
+static void launch_step(dcomp_env *env, KParams &kp, void *stream)
+{
+    if (env->tight_g) {
+        kp.tight_g = env->tight_g; kp.tight_gpw = env->tight_gpw; kp.tight_magic = env->tight_magic;
+        hipLaunchKernelGGL(env->kern.step_tight, dim3(env->tight_grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
+        return;
+    }
+    hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
+}
+
 static int check_horizon(const dcomp_env *env, int steps)
 {
     if (env && (int64_t)env->time + steps > 65536)
@@ -277,6 +312,7 @@ static int fill_params(dcomp_env *env, const dcomp_state *st, const dcomp_out *o
     kp.obs = out->obs; kp.reward = out->reward; kp.sum_util = out->sum_utility; kp.ue_dr = out->ue_dr; kp.ue_util = out->ue_utility; kp.rb_out = out->reward_before;
     kp.episode = (uint32_t)(env->episode < 0 ? 0 : env->episode);
     kp.num_steps = 1; kp.out_every_step = 0; kp.horizon = 0; kp.episode_inc = 0;
+    kp.tight_g = 0; kp.tight_gpw = 0; kp.tight_magic = 0;
     return DCOMP_OK;
 }
 
@@ -312,7 +348,7 @@ extern "C" int dcomp_step(dcomp_env *env, const dcomp_state *st, const uint8_t *
     if ((rc = check_horizon(env, 1))) return rc;
     kp.action = action;
     kp.n_remove = kp.n_add = 0;
-    hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
+    launch_step(env, kp, stream);
     HIP_TRY(hipGetLastError());
     env->time += 1;
     return DCOMP_OK;
@@ -396,7 +432,7 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
             if (do_reset) hipLaunchKernelGGL(env->kern.reset, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
             kp.action = actions + EU * t;
             kp.time = (uint32_t)time;
-            hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
+            launch_step(env, kp, stream);
         }
         time += 1;
     }
@@ -419,6 +455,7 @@ extern "C" int dcomp_rollout_ex(dcomp_env *env, const dcomp_state *st, const uin
 }
 
 extern "C" int dcomp_rollout_is_fused(const dcomp_env *env) { return env ? (env->fused ? 1 : 0) : -1; }
+extern "C" int dcomp_lanes_per_env(const dcomp_env *env) { return env ? (env->tight_g ? env->tight_g : env->upad) : -1; }
 
 extern "C" int dcomp_check(dcomp_env *env, const dcomp_state *st, void *stream)
 {

@@ -122,6 +122,9 @@ struct KParams {
     int32_t out_every_step;    // 1: the outputs of step t go to out + t * (one step's size), i.e. [T][...] buffers; 0: last step only
     int32_t horizon;           // > 0: reset inside the kernel when env.time reaches it (RLlib's horizon = episode_length,
                                //      env_setup.py:281) -- the same sequence as `if time == L: reset()` before every step
+    int32_t tight_g;           // > 0: step_kernel packs envs tightly, G = U lanes each (see Seg); 0: padded power-of-two groups
+    int32_t tight_gpw;         //      envs per wavefront = 64 / G
+    int32_t tight_magic;       //      lane / G == (lane * magic) >> 16 for lane < 64
     uint32_t episode_inc;      // Philox episode-word increment per in-kernel reset (0: rand_episodes = False, base.py:171-173)
     uint32_t any_sum_mode;     // some BS is rate-fair or proportional-fair (needs a sum over its UEs)
     uint32_t seed_lo, seed_hi, episode;
@@ -210,6 +213,53 @@ __device__ __forceinline__ void group_reduce_vec(float (&v)[N])
 #undef DCOMP_STAGE
 #endif
 }
+// ---- tight packing of UE lists whose length is not a power of two (step_kernel_tight only)
+// Padded groups waste lanes: U = 10 sits in groups of 16 (37.5 % idle), U = 5 in 8, U = 20 in 32.  In tight mode an env takes
+// exactly G = U lanes and a wavefront holds floor(64 / G) envs (U = 10: six instead of four).  The per-env reductions then run
+// over lane segments that are neither aligned nor a power of two wide, which DPP butterflies cannot do: an inclusive
+// Hillis-Steele scan with ds_bpermute (ceil(log2 G) steps, restricted to the segment) and a broadcast of the segment's last
+// lane -- every lane of an env still ends with the bit-identical total.  ~13 instead of 4 instructions per reduction, paid
+// back by a third fewer wavefronts wherever the kernel is throughput-bound (dcomp_create decides).
+template <bool TIGHT>
+struct SegT {
+    static constexpr bool tight = TIGHT;   // compile-time: the padded kernels carry none of the segmented code
+    int g;                  // lanes per env
+    int u;                  // my position inside the segment
+    int last_addr;          // ds_bpermute address (4 * lane) of the segment's last lane
+    uint32_t mlo, mhi;      // ballot mask of my segment's lanes
+};
+using SegPadded = SegT<false>;
+template <int W, class S>
+__device__ __forceinline__ int seg_popcount(unsigned long long m, int gbase, const S &sg)
+{
+    if constexpr (S::tight) return __builtin_popcount((uint32_t)m & sg.mlo) + __builtin_popcount((uint32_t)(m >> 32) & sg.mhi);
+    else return group_popcount<W>(m, gbase);
+}
+template <int W, class Op, int N, class S>
+__device__ __forceinline__ void seg_reduce_vec(float (&v)[N], const S &sg, int lane)
+{
+    if constexpr (S::tight) {
+        for (int d = 1; d < sg.g; d <<= 1) {                    // uniform trip count
+            const int addr = (lane - d) * 4;
+            const bool take = sg.u >= d;
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const float t = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v[i])));
+                v[i] = take ? Op::f(v[i], t) : v[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(sg.last_addr, __float_as_int(v[i])));
+    } else group_reduce_vec<W, Op, N>(v);
+}
+template <int W, class Op, class S>
+__device__ __forceinline__ float seg_reduce(float x, const S &sg, int lane)
+{
+    float v[1] = {x};
+    seg_reduce_vec<W, Op, 1>(v, sg, lane);
+    return v[0];
+}
+
 template <class T>
 __device__ __forceinline__ void stream_store(T *ptr, T v)
 {
@@ -578,10 +628,10 @@ __device__ __noinline__ unsigned long long maxcap_rate_key(double pl_c1, double 
 // Shared data rates of this UE at every BS.  station.py:152-220 with S_b = {u : conn[u,b]}.
 //   in : conn mask, l2snr[b], ewma, (px,py) for the max-cap arg-min
 //   out: dr[b] (0 where not connected), cnt[b] = |S_b|
-template <int B, int UPAD, int MP>
+template <int B, int UPAD, int MP, class S = SegPadded>
 __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, UPAD> &sh, uint32_t conn, const float (&l2)[B], float ewma,
                                              double px, double py, int u, int idx, int env_local, int wave, int lane, int gbase,
-                                             float (&dr)[B], float (&cnt)[B], int near_hint = -1)
+                                             float (&dr)[B], float (&cnt)[B], int near_hint = -1, const S &sg = S{})
 {
     // near_hint (wave-uniform): eval_pairs' "a lane of this wave is within 1.26 m of a BS" for the position l2 belongs to
     // (1 / 0), or -1 = unknown, then the per-pair snr > 1/64 test is made here.
@@ -601,7 +651,7 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
             if (near_hint < 0) fix |= c && f;
         }
         dr[b] = dru;
-        cnt[b] = (float)group_popcount<G::WG>(m, gbase);
+        cnt[b] = (float)seg_popcount<G::WG>(m, gbase, sg);
     }
     if (near_hint < 0 ? (__ballot(fix) != 0ull) : (near_hint != 0)) {   // rare: a connected UE closer than 1.24 m to its BS (snr > 1/64)
 #pragma unroll
@@ -624,11 +674,11 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
             float sv[NS > 0 ? NS : 1];
 #pragma unroll
             for (int b = 0, k = 0; b < B; b++) if (b % 3 != 0) sv[k++] = agg[b];
-            group_reduce_vec<G::WG, OpSum, (NS > 0 ? NS : 1)>(sv);
+            seg_reduce_vec<G::WG, OpSum, (NS > 0 ? NS : 1)>(sv, sg, lane);
 #pragma unroll
             for (int b = 0, k = 0; b < B; b++) if (b % 3 != 0) agg[b] = sv[k++];
         }
-    } else if (MP == MP_GENERIC && p.any_sum_mode) group_reduce_vec<G::WG, OpSum, B>(agg);
+    } else if (MP == MP_GENERIC && p.any_sum_mode) seg_reduce_vec<G::WG, OpSum, B>(agg, sg, lane);
     if (G::NW > 1) {
         xwave_reduce_<B, G::NW, OpSum>(cnt, sh, wave, lane);
         if (MP == MP_MIXED || (MP == MP_GENERIC && p.any_sum_mode)) xwave_reduce_<B, G::NW, OpSum>(agg, sh, wave, lane);
@@ -706,11 +756,11 @@ struct Outs { float *obs, *reward, *sum_util, *ue_dr, *ue_util, *rb_out; };   //
 // STAGED: observation rows go through LDS and leave as linear 16-byte stores (1 KiB contiguous per store instruction) -- what
 // a bandwidth-bound launch needs.  false: straight from registers; the fused rollout kernel, used for small batches with
 // one or two waves per SIMD, is latency-bound and the LDS round trips cost it 0.7 us per step (2.88 -> 2.21 us at 4 096 x 10 x 5).
-template <int B, int UPAD, bool RESET, bool DYN = false, bool STAGED = true>
+template <int B, int UPAD, bool RESET, bool DYN = false, bool STAGED = true, class S = SegPadded>
 __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, BlockSharedT<B, UPAD> &sh, bool active, int env, int env_local, int u, int idx,
                                               int wave, int lane, int gbase, uint32_t conn, uint32_t in_range,
                                               float (&l2)[B], float (&cnt)[B], float util, float curr_dr,
-                                              float reward_before, bool alive, int n_eff)
+                                              float reward_before, bool alive, int n_eff, const S &sg = S{})
 {
     using G = Geo<B, UPAD>;
     using SG = StageGeo<B>;
@@ -720,8 +770,8 @@ __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, B
     float tsum[B];
 #pragma unroll
     for (int b = 0; b < B; b++) tsum[b] = ((conn >> b) & 1u) ? util : 0.f;
-    if (!RESET && !(DCOMP_ABLATE & 16)) {
-        group_reduce_vec<G::WG, OpSum, B>(tsum);
+    if (!RESET && kind == DCOMP_MULTI && !(DCOMP_ABLATE & 16)) {     // central observations carry no per-station utilities
+        seg_reduce_vec<G::WG, OpSum, B>(tsum, sg, lane);
         if (G::NW > 1) xwave_reduce_<B, G::NW, OpSum>(tsum, sh, wave, lane);
     }
     float l2max = l2[0];
@@ -733,10 +783,10 @@ __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, B
     if (kind == DCOMP_CENTRAL) {
         float r[1];
         if (p.reward_agg == DCOMP_REWARD_MIN) {
-            r[0] = group_reduce<G::WG, OpMin>(alive ? reward_before : 1.f);
+            r[0] = seg_reduce<G::WG, OpMin>(alive ? reward_before : 1.f, sg, lane);
             xwave_reduce_<1, G::NW, OpMin>(r, sh, wave, lane);
         } else {
-            r[0] = group_reduce<G::WG, OpSum>(alive ? reward_before : 0.f);
+            r[0] = seg_reduce<G::WG, OpSum>(alive ? reward_before : 0.f, sg, lane);
             xwave_reduce_<1, G::NW, OpSum>(r, sh, wave, lane);
             if (p.reward_agg == DCOMP_REWARD_AVG) r[0] = r[0] / (float)n_eff;
         }
@@ -750,7 +800,7 @@ __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, B
             __syncthreads();
             if (in_range != 0) {
                 float s = 0.f;
-                const int base = env_local * UPAD;
+                const int base = (int)threadIdx.x - u;               // first lane of my env (padded and tight groups alike)
                 for (int v = 0; v < U; v++) if (sh.nb_conn[base + v] & conn) s += sh.nb_rb[base + v];
                 reward = s;
             }
@@ -765,7 +815,7 @@ __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, B
                 float tmin[B];
 #pragma unroll
                 for (int b = 0; b < B; b++) tmin[b] = ((conn >> b) & 1u) ? util : MAX_UTIL;
-                group_reduce_vec<G::WG, OpMin, B>(tmin);
+                seg_reduce_vec<G::WG, OpMin, B>(tmin, sg, lane);
                 if (G::NW > 1) xwave_reduce_<B, G::NW, OpMin>(tmin, sh, wave, lane);
                 float m = util;
 #pragma unroll
@@ -778,7 +828,7 @@ __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, B
     // ---- info (base.py:383-411)
     if (o.sum_util) {
         float s[1];
-        s[0] = group_reduce<G::WG, OpSum>(alive ? util : 0.f);
+        s[0] = seg_reduce<G::WG, OpSum>(alive ? util : 0.f, sg, lane);
         xwave_reduce_<1, G::NW, OpSum>(s, sh, wave, lane);
         if (active && u == 0) o.sum_util[env] = s[0];
     }
@@ -966,11 +1016,11 @@ __device__ __forceinline__ void store_state(const KParams &p, int idx, double px
 // The UE state is passed by reference and stays in registers; `emit` (uniform): write observation / reward / info to `o`.
 // STORE: write the state back BEFORE the outputs (plain step) -- position, movement word and EWMA are then dead while the
 // observation rows are staged, which is worth a wave per SIMD (73 vs 92 VGPRs at B = 10).
-template <int B, int UPAD, int MP, bool STORE>
+template <int B, int UPAD, int MP, bool STORE, class S>
 __device__ __forceinline__ void step_once(const KParams &p, BlockSharedT<B, UPAD> &sh, const Outs &o, bool emit, bool active, int env,
                                           int env_local, int u, int idx, int wave, int lane, int gbase, uint32_t act, uint32_t time,
                                           uint32_t episode, bool step_util, float dr_req, int vrange, double &px, double &py,
-                                          unsigned long long &mv, uint32_t &conn, float &ewma)
+                                          unsigned long long &mv, uint32_t &conn, float &ewma, const S &sg)
 {
     // 1. pairs at the pre-move position
     float l2[B];
@@ -990,7 +1040,7 @@ __device__ __forceinline__ void step_once(const KParams &p, BlockSharedT<B, UPAD
     }
     // 3. rates before the move (base.py:446) -> reward_before (base.py:158-167)
     float dr[B], cnt[B];
-    if (!(DCOMP_ABLATE & 1)) shared_rates<B, UPAD, MP>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, (int)near_pre);
+    if (!(DCOMP_ABLATE & 1)) shared_rates<B, UPAD, MP, S>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, (int)near_pre, sg);
     else { for (int b = 0; b < B; b++) { dr[b] = 1.f; cnt[b] = 1.f; } }
     float curr = 0.f;
 #pragma unroll
@@ -1010,7 +1060,7 @@ __device__ __forceinline__ void step_once(const KParams &p, BlockSharedT<B, UPAD
     for (int b = 0; b < B; b++) stale += ((conn >> b) & 1u) ? dr[b] : 0.f;
     ewma = __builtin_fmaf(0.9f, stale, 0.1f * ewma);   // one explicit contraction: every kernel variant rounds alike
     // 6. rates after the move (base.py:451)
-    if (!(DCOMP_ABLATE & 4)) shared_rates<B, UPAD, MP>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, (int)near_post);
+    if (!(DCOMP_ABLATE & 4)) shared_rates<B, UPAD, MP, S>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, (int)near_post, sg);
     curr = 0.f;
 #pragma unroll
     for (int b = 0; b < B; b++) curr += dr[b];
@@ -1018,8 +1068,8 @@ __device__ __forceinline__ void step_once(const KParams &p, BlockSharedT<B, UPAD
     if (STORE && active) store_state(p, idx, px, py, mv, conn, ewma);
     // 7. observation, reward, info
     if (emit)
-        write_outputs<B, UPAD, false, false, STORE>(p, o, sh, active, env, env_local, u, idx, wave, lane, gbase, conn, in_range, l2, cnt,
-                                                    util, curr, reward_before, active, p.U);
+        write_outputs<B, UPAD, false, false, STORE, S>(p, o, sh, active, env, env_local, u, idx, wave, lane, gbase, conn, in_range, l2, cnt,
+                                                    util, curr, reward_before, active, p.U, sg);
 }
 
 // MobileEnv.step for all envs: one launch = one step.  ROLLOUT = true is the fused rollout: p.num_steps consecutive steps
@@ -1027,16 +1077,28 @@ __device__ __forceinline__ void step_once(const KParams &p, BlockSharedT<B, UPAD
 // boundary, no state round trip through HBM, no host launch per step (the loop this replaces: simulation.py:512-541).
 // Two instantiations on purpose: with the step loop around it the compiler hoists the kernel-argument loads (BS table) out
 // of the loop and spills them (73 -> 163 VGPRs, 0.081 -> 0.099 ms at config 3), so the plain step keeps its loop-free code.
-template <int B, int UPAD, int MP, bool ROLLOUT>
+template <int B, int UPAD, int MP, bool ROLLOUT, bool TIGHT = false>
 __device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<B, UPAD> &sh)
 {
     using G = Geo<B, UPAD>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int env_local = tid / UPAD, u = tid % UPAD;
-    const int env = blockIdx.x * G::GPB + env_local;
-    const bool active = (env < p.E) && (u < p.U);
+    int env_local = tid / UPAD, u = tid % UPAD;
+    int env = blockIdx.x * G::GPB + env_local;
+    bool active = (env < p.E) && (u < p.U);
+    int gbase = lane & ~(G::WG - 1);
+    using S = SegT<TIGHT>;
+    S sg{};
+    if constexpr (TIGHT) {                                         // tight packing: G = U lanes per env, 64 / G envs per wavefront
+        const int g = p.tight_g, gi = (lane * p.tight_magic) >> 16; // gi = lane / g
+        u = lane - gi * g;
+        env_local = wave * p.tight_gpw + gi;
+        env = (blockIdx.x * (DCOMP_BLOCK / 64) + wave) * p.tight_gpw + gi;
+        active = gi < p.tight_gpw && env < p.E;
+        gbase = gi * g;
+        const unsigned long long m = gi < p.tight_gpw ? ((1ull << g) - 1ull) << gbase : 0ull;
+        sg = S{g, u, (gbase + g - 1) * 4, (uint32_t)m, (uint32_t)(m >> 32)};
+    }
     const int idx = env * p.U + u;
-    const int gbase = lane & ~(G::WG - 1);
 
 #if DCOMP_BS_IN_LDS
 #pragma unroll
@@ -1075,7 +1137,7 @@ __device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<
     Outs o{p.obs, p.reward, p.sum_util, p.ue_dr, p.ue_util, p.rb_out};
     if (!ROLLOUT) {
         step_once<B, UPAD, MP, true>(p, sh, o, true, active, env, env_local, u, idx, wave, lane, gbase, act, p.time, p.episode, step_util, dr_req,
-                               vrange, px, py, mv, conn, ewma);
+                               vrange, px, py, mv, conn, ewma, sg);
     } else {
         const int T = p.num_steps;
         const size_t EU = (size_t)p.E * p.U;
@@ -1105,8 +1167,8 @@ __device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<
                 load_chunk(t + 8);
             }
             act = active ? (uint32_t)(act_cur >> (8 * (t & 7))) & 0xFFu : 0u;
-            step_once<B, UPAD, MP, false>(p, sh, o, p.out_every_step || t == T - 1, active, env, env_local, u, idx, wave, lane, gbase, act, time,
-                                   episode, step_util, dr_req, vrange, px, py, mv, conn, ewma);
+            step_once<B, UPAD, MP, false, S>(p, sh, o, p.out_every_step || t == T - 1, active, env, env_local, u, idx, wave, lane, gbase, act, time,
+                                   episode, step_util, dr_req, vrange, px, py, mv, conn, ewma, sg);
             time += 1;
             if (p.out_every_step) {                                  // outputs of step t -> [T][...] buffers
                 const bool multi = p.kind == DCOMP_MULTI;
@@ -1134,6 +1196,14 @@ __global__ DCOMP_STEP_BOUNDS void step_kernel(const KParams p)
 {
     __shared__ BlockSharedT<B, UPAD> sh;
     step_kernel_body<B, UPAD, MP, false>(p, sh);
+}
+
+// step_kernel with envs packed tightly (see SegT): only where dcomp_create ever picks it -- UE lists of 5, 9, 10, 17-21.
+template <int B, int UPAD, int MP>
+__global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel_tight(const KParams p)
+{
+    __shared__ BlockSharedT<B, UPAD> sh;
+    step_kernel_body<B, UPAD, MP, false, true>(p, sh);
 }
 
 template <int B, int UPAD, int MP>
@@ -1196,7 +1266,7 @@ namespace dcomp {
 using KernelFn = void (*)(const KParams);
 // step_wide: organisation for envs of >= 64 lanes (dcomp_wide.h); nullptr for narrower envs.  It has no max-cap
 // path, the host falls back to `step` when a BS is max-cap.
-struct KernelPair { KernelFn step, reset, step_wide, step_dyn, rollout; };   // step_dyn: UEs arrive / depart (dcomp_dyn.h), UPAD <= 64
+struct KernelPair { KernelFn step, reset, step_wide, step_dyn, rollout, step_tight; };   // step_dyn: UEs arrive / depart (dcomp_dyn.h), UPAD <= 64
 
 template <int B, int UPAD, int MP>
 inline KernelFn wide_or_null()
@@ -1217,6 +1287,13 @@ inline KernelFn rollout_or_null()
     else return rollout_kernel<B, UPAD, MP>;
 }
 
+template <int B, int UPAD, int MP>
+inline KernelFn tight_or_null()
+{
+    if constexpr (UPAD == 8 || UPAD == 16 || UPAD == 32) return step_kernel_tight<B, UPAD, MP>;
+    else return nullptr;
+}
+
 template <int B, int UPAD>
 inline KernelFn dyn_or_null()
 {
@@ -1226,9 +1303,9 @@ inline KernelFn dyn_or_null()
 template <int B, int UPAD>
 inline KernelPair make_pair_(int mp)
 {
-    if (mp == MP_RES_FAIR) return KernelPair{step_kernel<B, UPAD, MP_RES_FAIR>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_RES_FAIR>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_RES_FAIR>()};
-    if (mp == MP_MIXED) return KernelPair{step_kernel<B, UPAD, MP_MIXED>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_MIXED>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_MIXED>()};
-    return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_GENERIC>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_GENERIC>()};
+    if (mp == MP_RES_FAIR) return KernelPair{step_kernel<B, UPAD, MP_RES_FAIR>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_RES_FAIR>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_RES_FAIR>(), tight_or_null<B, UPAD, MP_RES_FAIR>()};
+    if (mp == MP_MIXED) return KernelPair{step_kernel<B, UPAD, MP_MIXED>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_MIXED>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_MIXED>(), tight_or_null<B, UPAD, MP_MIXED>()};
+    return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_GENERIC>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_GENERIC>(), tight_or_null<B, UPAD, MP_GENERIC>()};
 }
 
 // One translation unit per B instantiates all UPAD widths (dcomp_inst_bXX.hip).
@@ -1243,7 +1320,7 @@ inline KernelPair kernels_for_upad(int upad, int mp)
     case 64: return make_pair_<B, 64>(mp);
     case 128: return make_pair_<B, 128>(mp);
     case 256: return make_pair_<B, 256>(mp);
-    default: return KernelPair{nullptr, nullptr, nullptr, nullptr, nullptr};
+    default: return KernelPair{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     }
 }
 

@@ -437,6 +437,11 @@ class BatchedMobileEnv:
         return (self.obs, self.reward) if out is None else (out['obs'], out['reward'])
 
     @property
+    def lanes_per_env(self):
+        """Lanes an env occupies in step(): next power of two >= U, or U itself when the batch is packed tightly."""
+        return self._L.dcomp_lanes_per_env(self._h)
+
+    @property
     def fused_rollout(self):
         """True when rollout() runs its T steps in one kernel launch."""
         return self._L.dcomp_rollout_is_fused(self._h) == 1

@@ -179,6 +179,9 @@ typedef struct dcomp_rollout_opts {
 int dcomp_rollout_ex(dcomp_env *env, const dcomp_state *st, const uint8_t *actions, int32_t num_steps,
                      const dcomp_out *out, const dcomp_rollout_opts *opts, void *stream);
 int dcomp_rollout_is_fused(const dcomp_env *env);      /* 1: T steps = one launch */
+int dcomp_lanes_per_env(const dcomp_env *env);         /* lanes an env occupies in dcomp_step: next power of two >= num_ue, or
+                                                         * num_ue itself when envs are packed tightly (throughput-bound batches of
+                                                         * UE lists that are not a power of two long; DCOMP_TIGHT=0/1 overrides) */
 
 /* Synchronises `stream`, reads the sticky flags and maps them to DCOMP_EACTION / DCOMP_ETAPE /
  * DCOMP_EPOS (the reference raises AssertionError in these cases).  Clears the flags. */

@@ -276,6 +276,43 @@ def test_oracle_parity_philox(torch_cuda, shape):
     core.check()
 
 
+TIGHT_SHAPES = [('multi', 10, 5, 333, 'avg'), ('central', 10, 5, 1000, 'avg'), ('multi', 20, 10, 77, 'sum'), ('multi', 5, 3, 700, 'min'),
+                ('central', 12, 9, 50, 'min'), ('multi', 17, 6, 41, 'avg'), ('multi', 7, 4, 129, 'avg', 'proportional-fair'),
+                ('central', 5, 32, 77, 'sum'), ('multi', 24, 11, 30, 'min', 'rate-fair'), ('multi', 31, 2, 19, 'avg'),
+                ('central', 6, 7, 300, 'avg', 'resource-fair')]
+
+
+@pytest.mark.parametrize('shape', TIGHT_SHAPES)
+def test_tight_packing_oracle_parity(torch_cuda, shape, monkeypatch):
+    """UE lists whose length is not a power of two, packed tightly (U lanes per env, 64 // U envs per wavefront, segmented
+    ds_bpermute reductions) -- forced on with DCOMP_TIGHT=1 (dcomp_create picks it by itself only for throughput-bound
+    batches): the same oracle-parity run as test_oracle_parity_philox, batch sizes that leave partial wavefronts; and bit-identical
+    positions / masks against the padded kernel."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    kind, U, B, E, reward = shape[:5]
+    sharing = shape[5] if len(shape) > 5 else 'mixed'
+    monkeypatch.setenv('DCOMP_TIGHT', '1')
+    test_oracle_parity_philox(torch, shape)
+    scn = scenarios.grid_map(B, sharing).with_ues(num_static=U // 8, num_slow=U - U // 8 - U // 4, num_fast=U // 4)
+    m, bs, ues = build_from_scenario(scn)
+    tight = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=5, reward=reward, rng='philox')
+    monkeypatch.setenv('DCOMP_TIGHT', '0')
+    padded = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=5, reward=reward, rng='philox')
+    assert tight.lanes_per_env == U and padded.lanes_per_env == 1 << (U - 1).bit_length()
+    tight.reset(); padded.reset()
+    g = torch.Generator(device='cuda').manual_seed(9)
+    for t in range(25):
+        a = torch.randint(0, B + 1, (E, U), generator=g, device='cuda', dtype=torch.uint8)
+        tight.step(a); padded.step(a)
+        assert torch.equal(tight.pos, padded.pos) and torch.equal(tight.conn, padded.conn) and torch.equal(tight.mv, padded.mv), f'step {t}'
+        torch.testing.assert_close(tight.obs, padded.obs, rtol=2e-6, atol=2e-6)          # sums in scan order vs butterfly order
+        torch.testing.assert_close(tight.reward, padded.reward, rtol=0, atol=2e-5 * (U if reward == 'sum' else 1))
+    tight.check(); padded.check()
+
+
 @pytest.mark.parametrize('kind,U,B,E', [('multi', 32, 10, 256), ('central', 10, 5, 300), ('multi', 128, 32, 6), ('multi', 70, 9, 20)])
 def test_movement_parameters_philox(torch_cuda, kind, U, B, E):
     """RandomWaypoint(pause_duration, border_buffer) per UE away from the defaults 2 / 10 (movement.py:87-104; round 1 refused

@@ -76,7 +76,8 @@ def random_spec(rng):
         pause = [int(r2.choice([0, 1, 2, 3, 6, 20])) for _ in range(U)]
         border = [int(r2.integers(1, bmax + 1)) if r2.random() < 0.7 else min(10, bmax) for _ in range(U)]
     rollout = int(r2.integers(1, 4)) if (arrival is None and r2.random() < 0.35) else 0
-    return dict(pause=pause, border=border, rollout=rollout, **_spec_rest(arrival=arrival, tape=bool(tape), rand_episodes=bool(rng.random() < 0.5), kind=kind, reward=reward, E=E, U=U, B=B,
+    tight = bool(r2.random() < 0.5)                              # DCOMP_TIGHT: U lanes per env where eligible (U not a power of two, <= 32)
+    return dict(pause=pause, border=border, rollout=rollout, tight=tight, **_spec_rest(arrival=arrival, tape=bool(tape), rand_episodes=bool(rng.random() < 0.5), kind=kind, reward=reward, E=E, U=U, B=B,
                 w=w, h=h, bs_xy=bs_xy, sh=sh, vel=vel, util=util, req=req, init=init, seed=seed,
                 base=int(rng.integers(0, 1000)), steps=int(rng.integers(15, 45)), p_noop=float(rng.choice([0.0, 0.5, 0.9]))))
 
@@ -114,9 +115,13 @@ def run_case(c, torch):
     tape = bool(c.get('tape'))
     L = 1000 if not arrival else 64
     depth = 48
-    core = BatchedMobileEnv(c['m'], c['bs'], c['ues'], kind, num_envs=E, seed=c['seed'], reward=reward,
-                            rng='reference' if tape else 'philox', rand_episodes=c.get('rand_episodes', True) if tape else True,
-                            env_id_base=c['base'], episode_length=L, ue_arrival=arrival, tape_depth=depth if tape else None)
+    os.environ['DCOMP_TIGHT'] = '1' if c.get('tight') else '0'
+    try:
+        core = BatchedMobileEnv(c['m'], c['bs'], c['ues'], kind, num_envs=E, seed=c['seed'], reward=reward,
+                                rng='reference' if tape else 'philox', rand_episodes=c.get('rand_episodes', True) if tape else True,
+                                env_id_base=c['base'], episode_length=L, ue_arrival=arrival, tape_depth=depth if tape else None)
+    finally:
+        os.environ.pop('DCOMP_TIGHT', None)
     U = core.U                                          # slots per env (max_ues when the list changes)
     sched = orc.arrival_schedule(L, arrival) if arrival else None
     envs = []
@@ -210,7 +215,7 @@ def run_case(c, torch):
 
 
 def describe(c):
-    return (f"{'ROLLOUT x' + str(c['rollout']) + ' ' if c.get('rollout') else ''}{'PAUSE/BORDER ' if c.get('pause') else ''}{'TAPE rand_episodes=' + str(c.get('rand_episodes')) + ' ' if c.get('tape') else ''}{'DYN ' + str(c['arrival']) + ' ' if c.get('arrival') else ''}{c['kind']} U={c['U']} B={c['B']} E={c['E']} map={c['w']}x{c['h']} reward={c['reward']} sharing={sorted(set(c['sh']))} "
+    return (f"{'TIGHT ' if c.get('tight') else ''}{'ROLLOUT x' + str(c['rollout']) + ' ' if c.get('rollout') else ''}{'PAUSE/BORDER ' if c.get('pause') else ''}{'TAPE rand_episodes=' + str(c.get('rand_episodes')) + ' ' if c.get('tape') else ''}{'DYN ' + str(c['arrival']) + ' ' if c.get('arrival') else ''}{c['kind']} U={c['U']} B={c['B']} E={c['E']} map={c['w']}x{c['h']} reward={c['reward']} sharing={sorted(set(c['sh']))} "
             f"seed={c['seed']} base={c['base']} steps={c['steps']} p_noop={c['p_noop']}")
 
 
