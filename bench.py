@@ -135,6 +135,38 @@ def measure_rollout(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev
     return out
 
 
+def measure_steps(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev, E, U, B, kind, steps=300, L=100):
+    """One launch per step on another shape (secondary figures): HIP events around back-to-back launches after 300 untimed
+    ones (steady state), SURVEY 8(d) bytes / launch duration."""
+    scn = scenarios.grid_map(B, 'mixed').with_ues(num_slow=U)
+    m, bs, ues = build_from_scenario(scn)
+    env = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=42, episode_length=L, rng='philox', rand_episodes=True, device=dev)
+    g = torch.Generator(device=dev).manual_seed(7)
+    pool = torch.randint(0, B + 1, (4, E, U), generator=g, device=dev, dtype=torch.uint8)
+    ms, n = 0.0, 0
+    for phase, count in (('warm', 300), ('timed', steps)):
+        t = 0
+        while t < count:
+            env.reset()
+            k = min(L, count - t)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for i in range(k):
+                env.step(pool[i & 3])
+            b.record()
+            torch.cuda.synchronize(dev)
+            if phase == 'timed':
+                ms += a.elapsed_time(b)
+                n += k
+            t += k
+    env.check()
+    kms = ms / n
+    bpe = survey_bytes_per_env_step(U, B, kind)
+    return {'kernel_ms': kms, 'env_steps_per_s_kernel_only': E / (kms * 1e-3), 'algorithmic_bytes_per_env_step': bpe,
+            'achieved_GBps': bpe * E / (kms * 1e-3) / 1e9, 'frac_of_hbm_peak': bpe * E / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            'lanes_per_env': env.lanes_per_env, 'how': f'{n} back-to-back launches after 300 untimed ones, HIP events'}
+
+
 def stream_ceiling(torch, dev, write_bytes, rw_bytes, iters=100):
     """"also report against a measured device-copy bandwidth on the box".  torch's own elementwise kernels
     (fill = write-only, out-of-place add = read + write) on buffers of the step kernel's traffic, HIP-event timed."""
@@ -493,7 +525,11 @@ def main():
             out['roofline']['measured_stream'] = sc
         if world == 1 and not args.no_also and default_workload:
             mk = (torch, BatchedMobileEnv, scenarios, build_from_scenario, dev)
-            out.setdefault('also', {}).update({'config2_4096x10x5_central_fused_rollout': measure_rollout(*mk, 4096, 10, 5, 'central', T=100, steps=4000, launches_too=True)})
+            out.setdefault('also', {}).update({
+                'config2_4096x10x5_central_fused_rollout': measure_rollout(*mk, 4096, 10, 5, 'central', T=100, steps=4000, launches_too=True),
+                'config5_share_4096x128x32_multi': measure_steps(*mk, 4096, 128, 32, 'multi'),
+                'config4_share_32768x32x10_multi': measure_steps(*mk, 32768, 32, 10, 'multi'),
+                'central_65536x10x5': measure_steps(*mk, 65536, 10, 5, 'central')})
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(scn, args.kind, U, B)
     if use_dist:

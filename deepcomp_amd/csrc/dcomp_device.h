@@ -1303,15 +1303,26 @@ inline KernelFn dyn_or_null()
 template <int B, int UPAD>
 inline KernelPair make_pair_(int mp)
 {
-    if (mp == MP_RES_FAIR) return KernelPair{step_kernel<B, UPAD, MP_RES_FAIR>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_RES_FAIR>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_RES_FAIR>(), tight_or_null<B, UPAD, MP_RES_FAIR>()};
+    // Envs of >= 64 lanes with more than DCOMP_WIDE_MIN_B stations run the wide kernel; the narrow step kernel only serves them
+    // when a BS is max-cap (the wide kernel has no max-cap path) -- always the generic sharing pattern.  The two specialised
+    // narrow variants would never be launched there and are the most expensive instantiations of the build: left out.
+    if constexpr (UPAD >= 64 && B > DCOMP_WIDE_MIN_B) {
+        const KernelFn w = mp == MP_RES_FAIR ? wide_or_null<B, UPAD, MP_RES_FAIR>() : mp == MP_MIXED ? wide_or_null<B, UPAD, MP_MIXED>() : wide_or_null<B, UPAD, MP_GENERIC>();
+        return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, w, dyn_or_null<B, UPAD>(), nullptr, nullptr};
+    } else {
+    if (mp == MP_RES_FAIR) return KernelPair{step_kernel<B, UPAD, MP_RES_FAIR>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_RES_FAIR>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_GENERIC>(), tight_or_null<B, UPAD, MP_GENERIC>()};   // (all-resource-fair: the generic variants, run-time modes, serve the fused rollout and the tight packing -- build time)
     if (mp == MP_MIXED) return KernelPair{step_kernel<B, UPAD, MP_MIXED>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_MIXED>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_MIXED>(), tight_or_null<B, UPAD, MP_MIXED>()};
     return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_GENERIC>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_GENERIC>(), tight_or_null<B, UPAD, MP_GENERIC>()};
+    }
 }
 
 // One translation unit per B instantiates all UPAD widths (dcomp_inst_bXX.hip).
 template <int B>
 inline KernelPair kernels_for_upad(int upad, int mp)
 {
+#ifdef DCOMP_ONLY_UPAD
+    return make_pair_<B, DCOMP_ONLY_UPAD>(mp);      // build-time probe
+#else
     switch (upad) {
     case 1: case 2: case 4: return make_pair_<B, 4>(mp);
     case 8: return make_pair_<B, 8>(mp);
@@ -1322,6 +1333,7 @@ inline KernelPair kernels_for_upad(int upad, int mp)
     case 256: return make_pair_<B, 256>(mp);
     default: return KernelPair{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     }
+#endif
 }
 
 }  // namespace dcomp
