@@ -267,26 +267,64 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
     conn &= inr_new;                                                              // user.py:175-188
     ewma = __builtin_fmaf(0.9f, stale, 0.1f * ewma);   // one explicit contraction: every kernel variant rounds alike                                            // user.py:148-157
 
-    // ---- sweep 2: rates after the move (base.py:451)
+    // ---- sweep 2: rates after the move (base.py:451).  The unshared rate is only needed where the UE is (still) connected:
+    // a sparse pass like the pre-move one computes it for the lane's own set bits and puts it into strow[b]; the log2 snr it
+    // displaces there (needed again for the `dr` observation) waits in four registers and is put back after the sweep.  A
+    // wavefront in which some UE holds more than four connections takes the dense path (rate series for every station).
     curr = 0.f;
     const float inv_ewma = fast_rcp(ewma + EPS);
-    auto sweep2 = [&](const int c0, auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
+    const uint32_t conn_post = active ? conn : 0u;
+    const bool dense2 = __ballot(__builtin_popcount(conn_post) > 4) != 0ull;      // wave-uniform, rare
+    float sv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!dense2) {
+        uint32_t todo = conn_post;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (__ballot(todo != 0u) == 0ull) break;
+            if (todo != 0u) {
+                const int b = __ffs((int)todo) - 1;
+                todo &= todo - 1u;
+                const float l2 = strow[b];
+                sv[k] = l2;
+                bool big;
+                float dru = rate_unshared_small(l2, big);
+                if (big) dru = rate_unshared_any(l2);              // rare: snr > 1/64
+                strow[b] = dru;
+            }
+        }
+    }
+    auto sweep2 = [&](const int c0, auto full_tag, auto pre_tag) {
+        constexpr bool FULL = decltype(full_tag)::value, PRE = decltype(pre_tag)::value;
         bool c[BC];
         float l2c[BC], dr[BC], cnt[BC];
 #pragma unroll
         for (int j = 0; j < BC; j++) {
             const int b = c0 + j;
             c[j] = (FULL || b < B) ? (bool)((conn >> b) & 1u) : false;
-            l2c[j] = (FULL || b < B) ? strow[b] : -30.f;
+            l2c[j] = (FULL || b < B) ? strow[b] : -30.f;           // PRE: the unshared rate where connected (unused elsewhere)
         }
-        wide_chunk_rates<B, NW, MP, BC, FULL>(p, sh, buf, c0, c, l2c, inv_ewma, wave, lane, dr, cnt, near_any);
+        wide_chunk_rates<B, NW, MP, BC, FULL, PRE>(p, sh, buf, c0, c, l2c, inv_ewma, wave, lane, dr, cnt, near_any);
 #pragma unroll
         for (int j = 0; j < BC; j++) if (FULL || c0 + j < B) curr += dr[j];
     };
+    if (!dense2) {
 #pragma unroll 1
-    for (int c0 = 0; c0 < NFULL; c0 += BC) sweep2(c0, std::true_type{});
-    if constexpr (NFULL < B) sweep2(NFULL, std::false_type{});
+        for (int c0 = 0; c0 < NFULL; c0 += BC) sweep2(c0, std::true_type{}, std::true_type{});
+        if constexpr (NFULL < B) sweep2(NFULL, std::false_type{}, std::true_type{});
+        uint32_t todo = conn_post;                                 // put the log2 snr back
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (todo != 0u) {
+                const int b = __ffs((int)todo) - 1;
+                todo &= todo - 1u;
+                strow[b] = sv[k];
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int c0 = 0; c0 < NFULL; c0 += BC) sweep2(c0, std::true_type{}, std::false_type{});
+        if constexpr (NFULL < B) sweep2(NFULL, std::false_type{}, std::false_type{});
+    }
     const float util = ue_utility(curr, step_util, dr_req);
     if (active) {
         p.pos[idx] = make_double2(px, py);

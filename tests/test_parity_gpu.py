@@ -770,6 +770,38 @@ def test_per_gpu_shares_oracle_parity(torch_cuda, E, U, B, steps, seed_base):
     core.check()
 
 
+@pytest.mark.parametrize('kind,U,B,E,reward,sharing', [('multi', 128, 32, 6, 'avg', 'mixed'), ('multi', 64, 24, 9, 'min', 'proportional-fair'),
+                                                       ('central', 100, 29, 4, 'sum', 'mixed'), ('multi', 32, 10, 40, 'sum', 'rate-fair')])
+def test_dense_cells_many_connections(torch_cuda, kind, U, B, E, reward, sharing):
+    """Stations 25 m apart: a UE is in range of ~20 of them and, under random toggles, connected to ~10 at once -- the wide
+    kernel's dense fall-backs (more than four connections per UE: no sparse post-move rate pass) and long need-sets of its
+    sparse pre-move pass; every station shared by many UEs.  Against the oracle, 40 steps."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    scn = scenarios.grid_map(B, sharing, pitch=25, border=30).with_ues(num_static=U // 8, num_slow=U - U // 8 - U // 4, num_fast=U // 4)
+    m, bs, ues = build_from_scenario(scn)
+    core = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=31, reward=reward, rng='philox', env_id_base=2)
+    ob = _oracle_batch(scn, kind, reward, E, 31, env_id_base=2)
+    rng = np.random.default_rng(17)
+    core.reset(); ob.reset()
+    most = 0
+    for t in range(40):
+        a = rng.integers(0, B + 1, size=(E, U)).astype(np.uint8)
+        core.step(torch.from_numpy(a).cuda())
+        o_obs, o_rew, o_conn, o_pos = ob.step(a)
+        st = core.state_host()
+        assert np.array_equal(st['pos'], o_pos) and np.array_equal(st['conn'], o_conn), f'step {t}'
+        want = o_obs if kind == 'multi' else np.concatenate([o_obs[:, :, :B].reshape(E, -1), o_obs[:, :, B:2 * B].reshape(E, -1), o_obs[:, :, 2 * B]], axis=1)
+        np.testing.assert_allclose(core.obs.cpu().numpy(), want, rtol=RTOL_RATE, atol=ATOL_OBS, err_msg=f'step {t}')
+        tol = (ATOL_UTIL if kind == 'multi' else ATOL_OBS) * (U if reward == 'sum' else 1)
+        np.testing.assert_allclose(core.reward.cpu().numpy(), o_rew, atol=tol, rtol=0, err_msg=f'step {t}')
+        most = max(most, int(np.unpackbits(o_conn.view(np.uint8).reshape(E, U, 4), axis=2).sum(axis=2).max()))
+    assert most > 4, most
+    core.check()
+
+
 def test_long_horizon_soak(torch_cuda):
     """3 000 steps (30 episodes, resets in between) of 64 envs against the oracle: FP64 positions and masks must
     still be bit-identical at the end -- no drift, no error flag (UE outside the map, bad action)."""
