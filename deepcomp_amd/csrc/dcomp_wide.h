@@ -54,7 +54,7 @@ __device__ __forceinline__ void wide_xchg(float (&v)[N], SH &sh, int &buf, int w
 #pragma unroll
         for (int i = 0; i < N; i++) sh.xw[buf][wave][i] = v[i];
     }
-    __syncthreads();
+    if (!(DCOMP_ABLATE & 256)) __syncthreads();          // (ablation bit 256: timing without the cross-wave barriers; results are wrong)
     const int w0 = (wave / NW) * NW;
 #pragma unroll
     for (int i = 0; i < N; i++) {
