@@ -553,6 +553,10 @@ class _RefSurfaceEnv(_GymEnv):
     metadata = {'render.modes': ['human']}
 
     def __init__(self, env_config):
+        try:                                   # cooperative: gym.Env / RLlib's MultiAgentEnv may (in other versions) have an __init__
+            super().__init__()
+        except TypeError:                      # pragma: no cover - a base class that insists on arguments
+            pass
         self.episode_length = env_config['episode_length']
         self.map = env_config['map']
         self.bs_list = env_config['bs_list']
