@@ -378,6 +378,14 @@ def main():
         pending.clear()
         frag_pending[0] = frag_pending[1] = None
 
+    # The box's measured streaming rate is taken BEFORE the warm-up steps: it is part of the output anyway, and a
+    # GPU that has just streamed for ~20 ms starts the step launches closer to its steady clocks than one that sat idle
+    # through the set-up (the first launches after idle run 5-15 % slower, see roofline.steady_state).
+    stream_probe = None
+    if world == 1 and not args.no_stream:
+        bpe0 = bytes_per_env_step(U, B, args.kind)
+        stream_probe = stream_ceiling(torch, dev, E * (bpe0 - U * 33) // 4 * 4, E * U * 33 // 4 * 4)
+        stream_probe['when'] = 'before the warm-up steps'
     t_env = run(W, 0)
     drain()
     fence()
@@ -524,8 +532,7 @@ def main():
             out['roofline']['traffic_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r02f_c3_summary.txt'
         if world == 1 and not args.no_stream:
             # the launch writes (obs + reward + info + state) and reads (state + actions); ceiling for that mix
-            wr = E * (bpe - U * 33)
-            sc = stream_ceiling(torch, dev, wr // 4 * 4, E * U * 33 // 4 * 4)
+            sc = stream_probe
             sc['frac_of_fill'] = achieved / sc['fill_GBps']
             out['roofline']['measured_stream'] = sc
         if world == 1 and not args.no_also and default_workload:
