@@ -486,7 +486,7 @@ def main():
     if world == 1 and not T and frag_bufs is None:
         t = run(max(0, 300 - K), t_env)
         sp2 = []
-        ev_pool.extend(torch.cuda.Event(enable_timing=True) for _ in range(12))
+        ev_pool.extend(torch.cuda.Event(enable_timing=True) for _ in range(2 * (200 // L + 3)))
         run(200, t, sp2)
         torch.cuda.synchronize(dev)
         steady_ms = sum(a.elapsed_time(b) for a, b, _ in sp2) / sum(n for _, _, n in sp2)
