@@ -329,7 +329,7 @@ def main():
         def close():
             nonlocal open_span
             if open_span is not None:
-                b = ev_pool.pop()
+                b = ev_pool.pop() if ev_pool else torch.cuda.Event(enable_timing=True)
                 b.record()
                 spans.append((open_span[0], b, t - open_span[1]))
                 open_span = None
@@ -337,7 +337,7 @@ def main():
         def begin():
             nonlocal open_span
             if spans is not None and open_span is None:
-                a = ev_pool.pop()               # created before the timed region: hipEventCreate costs tens of microseconds,
+                a = ev_pool.pop() if ev_pool else torch.cuda.Event(enable_timing=True)   # normally created before the timed region: hipEventCreate costs tens of microseconds,
                 a.record()                      # and in front of the first launch that is idle GPU time inside a 1.7 ms region
                 open_span = (a, t)
         if T:
