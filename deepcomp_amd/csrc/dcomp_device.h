@@ -46,6 +46,9 @@
 #ifndef DCOMP_LOG2_MODE
 #define DCOMP_LOG2_MODE 2    // log2(d^2): 0 = plain v_log_f32, 1 = frexp range reduction, 2 = 2^-12 prescale (default)
 #endif
+#ifndef DCOMP_SPARSE_PRE
+#define DCOMP_SPARSE_PRE 1      // 1: sparse pre-move pass in step_kernel where the LDS row fits (B <= 11); 0: dense (A/B)
+#endif
 #ifndef DCOMP_CENTRAL_STAGED
 #define DCOMP_CENTRAL_STAGED 1  // 0: central observation rows are stored straight from registers (round 1; A/B only)
 #endif
@@ -588,6 +591,7 @@ struct alignas(16) BlockSharedT {
         };
     };
     float xw[4][B + 4];                                     // per-wave partials of the cross-wave exchange
+    double2 bs[B];                                          // BS positions for the per-lane station index of the sparse pre-move pass
 };
 
 // Sum `N` per-wave values across the NW waves of an env (values are wave-uniform when WG == 64).
@@ -628,10 +632,11 @@ __device__ __noinline__ unsigned long long maxcap_rate_key(double pl_c1, double 
 // Shared data rates of this UE at every BS.  station.py:152-220 with S_b = {u : conn[u,b]}.
 //   in : conn mask, l2snr[b], ewma, (px,py) for the max-cap arg-min
 //   out: dr[b] (0 where not connected), cnt[b] = |S_b|
-template <int B, int UPAD, int MP, class S = SegPadded>
+// PRE: the unshared rates of the connected pairs were computed by the sparse pre-move pass and wait in the lane's LDS row `prow`.
+template <int B, int UPAD, int MP, class S = SegPadded, bool PRE = false>
 __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, UPAD> &sh, uint32_t conn, const float (&l2)[B], float ewma,
                                              double px, double py, int u, int idx, int env_local, int wave, int lane, int gbase,
-                                             float (&dr)[B], float (&cnt)[B], int near_hint = -1, const S &sg = S{})
+                                             float (&dr)[B], float (&cnt)[B], int near_hint = -1, const S &sg = S{}, const float *prow = nullptr)
 {
     // near_hint (wave-uniform): eval_pairs' "a lane of this wave is within 1.26 m of a BS" for the position l2 belongs to
     // (1 / 0), or -1 = unknown, then the per-pair snr > 1/64 test is made here.
@@ -644,7 +649,8 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
         const bool c = (conn >> b) & 1u;
         unsigned long long m = __ballot(c);
         float dru = 0.f;
-        if (m != 0ull) {                                   // wave-uniform: skip BSs nobody in this wave is connected to
+        if (PRE) dru = c ? prow[b] : 0.f;                  // entries of unconnected stations are never read
+        else if (m != 0ull) {                              // wave-uniform: skip BSs nobody in this wave is connected to
             bool f;
             const float t = rate_unshared_small(l2[b], f);
             dru = c ? t : 0.f;
@@ -653,7 +659,7 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
         dr[b] = dru;
         cnt[b] = (float)seg_popcount<G::WG>(m, gbase, sg);
     }
-    if (near_hint < 0 ? (__ballot(fix) != 0ull) : (near_hint != 0)) {   // rare: a connected UE closer than 1.24 m to its BS (snr > 1/64)
+    if (!PRE && (near_hint < 0 ? (__ballot(fix) != 0ull) : (near_hint != 0))) {   // rare: a connected UE closer than 1.24 m to its BS (snr > 1/64)
 #pragma unroll
         for (int b = 0; b < B; b++)
             if (((conn >> b) & 1u) && l2[b] > RATE_SMALL_L2) dr[b] = rate_unshared_any(l2[b]);
@@ -1022,26 +1028,61 @@ __device__ __forceinline__ void step_once(const KParams &p, BlockSharedT<B, UPAD
                                           uint32_t episode, bool step_util, float dr_req, int vrange, double &px, double &py,
                                           unsigned long long &mv, uint32_t &conn, float &ewma, const S &sg)
 {
-    // 1. pairs at the pre-move position
-    float l2[B];
+    float l2[B], dr[B], cnt[B];
     uint32_t in_range = B >= 32 ? 0xFFFFFFFFu : ((1u << (B & 31)) - 1u);
     bool near_pre = false, near_post = false;
-    if (!(DCOMP_ABLATE & 32)) in_range = eval_pairs<B>(px, py, p, l2, &near_pre);
-    else { for (int b = 0; b < B; b++) l2[b] = -20.f; }
-    // 2. toggle (base.py:247-263 -> user.py:190-222)
     if (act > (uint32_t)B) { atomicOr(p.flags, DCOMP_FLAG_BAD_ACTION); act = 0; }
-    if (act > 0) {
-        const uint32_t bit = 1u << (act - 1);
-        if (conn & bit) conn &= ~bit;
-        else if (in_range & bit) {
-            conn |= bit;
-            if (MP == MP_GENERIC && (p.maxcap_mask & bit)) p.conn_since[(size_t)idx * B + (act - 1)] = (uint16_t)time;
+    // The pre-move position only matters where the UE is connected (rate before the move, base.py:446) and at the one station it
+    // acts on (in range -> may connect, user.py:203-222): each lane walks its OWN set bits -- per-lane station index, BS position
+    // from the LDS table -- and parks the unshared rate in its row of the (still idle) observation staging buffer; shared_rates
+    // picks it up where the UE is connected.  Trip count = the largest need-set in the wave (3-4) instead of B dense pair +
+    // rate evaluations per lane.  Where the row does not fit the staging buffer (B > 11) or a max-cap BS needs the aliased
+    // scratch: the dense form.
+    // Only in the plain step (STORE): the fused rollout is latency-bound, one wave per SIMD, and the LDS look-ups of this pass
+    // cost it 7 % (2.16 -> 2.32 us per step at 4 096 x 10 x 5); and only from 7 stations up (B = 5: 0.5 % slower).
+    constexpr bool SPARSE_OK = DCOMP_SPARSE_PRE && STORE && B >= 7 && !(DCOMP_ABLATE & 33) && 64 * (B + 1) <= StageGeo<B>::WORDS;
+    if (SPARSE_OK && !(MP == MP_GENERIC && p.any_maxcap)) {
+        float *const prow = sh.stage[wave] + lane * (B + 1);
+        const uint32_t act_bit = act ? 1u << (act - 1u) : 0u;
+        uint32_t need = active ? (conn | act_bit) : 0u, inr_old = 0u;
+        while (__ballot(need != 0u) != 0ull) {
+            if (need != 0u) {
+                const int b = __ffs((int)need) - 1;
+                need &= need - 1u;
+                const double2 bp = sh.bs[b];
+                bool ir, near;
+                float l;
+                pair_eval(px, py, bp.x, bp.y, p, ir, l, near);
+                if (near) {                                        // rare, per lane: within 1.26 m of the station
+                    const double dx = bp.x - px, dy = bp.y - py;
+                    if ((float)__builtin_fma(dy, dy, dx * dx) < 1e-20f) l = pair_eval_tiny(px, py, bp.x, bp.y, p);
+                }
+                inr_old |= (uint32_t)ir << b;
+                bool big;
+                float dru = rate_unshared_small(l, big);
+                if (big) dru = rate_unshared_any(l);               // rare: snr > 1/64
+                prow[b] = dru;
+            }
         }
+        conn ^= act_bit & (conn | inr_old);                        // toggle (base.py:247-263 -> user.py:190-222); generic pattern: no max-cap BS here
+        shared_rates<B, UPAD, MP, S, true>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, 0, sg, prow);
+    } else {
+        // 1. pairs at the pre-move position
+        if (!(DCOMP_ABLATE & 32)) in_range = eval_pairs<B>(px, py, p, l2, &near_pre);
+        else { for (int b = 0; b < B; b++) l2[b] = -20.f; }
+        // 2. toggle (base.py:247-263 -> user.py:190-222)
+        if (act > 0) {
+            const uint32_t bit = 1u << (act - 1);
+            if (conn & bit) conn &= ~bit;
+            else if (in_range & bit) {
+                conn |= bit;
+                if (MP == MP_GENERIC && (p.maxcap_mask & bit)) p.conn_since[(size_t)idx * B + (act - 1)] = (uint16_t)time;
+            }
+        }
+        // 3. rates before the move (base.py:446) -> reward_before (base.py:158-167)
+        if (!(DCOMP_ABLATE & 1)) shared_rates<B, UPAD, MP, S>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, (int)near_pre, sg);
+        else { for (int b = 0; b < B; b++) { dr[b] = 1.f; cnt[b] = 1.f; } }
     }
-    // 3. rates before the move (base.py:446) -> reward_before (base.py:158-167)
-    float dr[B], cnt[B];
-    if (!(DCOMP_ABLATE & 1)) shared_rates<B, UPAD, MP, S>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, (int)near_pre, sg);
-    else { for (int b = 0; b < B; b++) { dr[b] = 1.f; cnt[b] = 1.f; } }
     float curr = 0.f;
 #pragma unroll
     for (int b = 0; b < B; b++) curr += dr[b];
@@ -1099,6 +1140,10 @@ __device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<
         sg = S{g, u, (gbase + g - 1) * 4, (uint32_t)m, (uint32_t)(m >> 32)};
     }
     const int idx = env * p.U + u;
+    if (DCOMP_SPARSE_PRE && !ROLLOUT && B >= 7 && 64 * (B + 1) <= StageGeo<B>::WORDS) {   // BS table for the sparse pre-move pass
+        if (tid < B) sh.bs[tid] = make_double2(p.bs_x[tid], p.bs_y[tid]);
+        __syncthreads();
+    }
 
 #if DCOMP_BS_IN_LDS
 #pragma unroll
