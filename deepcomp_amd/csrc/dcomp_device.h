@@ -572,7 +572,11 @@ struct StageGeo {
     // 64 * (2B+1) contiguous floats: staged in ONE window when that fits ~6 KB (B <= 11), else in windows of the multi size.
     static constexpr int CENTRAL_ONE = 64 * (2 * B + 1) + 4;
     static constexpr int MULTI_WORDS = RPP * ROW + 4;       // + alignment phase
-    static constexpr int WORDS = (CENTRAL_ONE <= 1540 && CENTRAL_ONE > MULTI_WORDS) ? CENTRAL_ONE : MULTI_WORDS;
+    static constexpr int STAGE_WORDS = (CENTRAL_ONE <= 1540 && CENTRAL_ONE > MULTI_WORDS) ? CENTRAL_ONE : MULTI_WORDS;
+    // The sparse pre-move pass parks one row of B + 1 unshared rates per lane in the same bytes; B = 12..23 need 44 words more
+    // than the staging windows -- taken; B >= 24 would double the buffer (8 passes of 8 rows) -- not taken, dense pass there.
+    static constexpr int SPARSE_WORDS = 64 * (B + 1);
+    static constexpr int WORDS = (SPARSE_WORDS > STAGE_WORDS && SPARSE_WORDS <= STAGE_WORDS + 64) ? SPARSE_WORDS : STAGE_WORDS;
 };
 
 template <int B, int UPAD>
