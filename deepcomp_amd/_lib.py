@@ -54,10 +54,18 @@ class DcompEvents(ctypes.Structure):
                 ('add_xy', ctypes.c_void_p)]
 
 
+class DcompPolicy(ctypes.Structure):
+    _fields_ = [('policy', ctypes.c_int32), ('obs_kind', ctypes.c_int32), ('num_envs', ctypes.c_int32),
+                ('num_ue', ctypes.c_int32), ('num_bs', ctypes.c_int32), ('num_active', ctypes.c_int32),
+                ('epsilon', ctypes.c_float), ('cluster_mask', ctypes.c_void_p)]
+
+
+POLICY = {'3gpp': 0, 'fullcomp': 1, 'dynamic': 2, 'cluster': 3}
+
 EXPORTS = ['dcomp_create', 'dcomp_destroy', 'dcomp_state_sizes', 'dcomp_obs_dim', 'dcomp_reset', 'dcomp_step',
            'dcomp_step_dyn', 'dcomp_num_ue',
            'dcomp_rollout', 'dcomp_rollout_ex', 'dcomp_rollout_is_fused', 'dcomp_lanes_per_env', 'dcomp_check', 'dcomp_time', 'dcomp_episode', 'dcomp_set_episode', 'dcomp_set_seed', 'dcomp_set_tape', 'dcomp_get_counters', 'dcomp_set_counters', 'dcomp_mt_draw_tape',
-           'dcomp_connect_threshold', 'dcomp_last_error', 'dcomp_version', 'dcomp_selftest']
+           'dcomp_connect_threshold', 'dcomp_last_error', 'dcomp_version', 'dcomp_selftest', 'dcomp_heuristic_actions']
 
 _lib = None
 
@@ -111,6 +119,8 @@ def load():
     L.dcomp_last_error.restype = ctypes.c_char_p
     L.dcomp_version.restype = ctypes.c_char_p
     L.dcomp_selftest.argtypes = [i32, i32, vp, vp, vp, i64, vp]
+    if hasattr(L, 'dcomp_heuristic_actions'):
+        L.dcomp_heuristic_actions.argtypes = [ctypes.POINTER(DcompPolicy), vp, vp, vp]
     for name in EXPORTS:
         getattr(L, name)
     _lib = L

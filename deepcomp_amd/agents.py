@@ -4,7 +4,12 @@ The reference's heuristics (deepcomp/agent/heuristics.py) are pure functions of 
 SNR per BS) and ``obs['connected']``; here the same decisions are taken for every (env, UE) at once on the packed
 observation tensor the env kernel writes, so a whole heuristic-driven rollout stays on the GPU:
 
-    act = agents.FullCoMP()(env.obs_views())          # uint8 [E, U], feed straight into env.step(act)
+    act = agents.FullCoMP().act(env)                  # uint8 [E, U], feed straight into env.step(act)
+
+``agent.act(env)`` is the product path: ONE launch of the HIP policy kernel (dcomp_heuristic_actions, include/dcomp.h) on the
+packed observation tensor, multi-agent or central layout.  ``agent(obs_views)`` spells the same decision rules out as tensor
+expressions over ``[..., B]`` views -- the executable specification the kernel is tested against (and what checks the rules
+against the reference-recorded decisions of tests/golden/heuristics.npz without a GPU).
 
 Tie rules follow the reference: ``np.argmax`` / strict ``>`` scans pick the first (lowest-index) maximum,
 ``sorted(..., reverse=True)`` is stable.
@@ -40,6 +45,9 @@ def _views(obs):
 class Heuristic3GPP:
     """heuristics.py:13-38: at most one connection, to the BS with the highest SNR."""
 
+    def act(self, env, out=None):
+        return env.heuristic_actions('3gpp', out=out)
+
     def __call__(self, obs):
         dr, conn = _views(obs)
         best = _first_max(dr)
@@ -53,6 +61,9 @@ class Heuristic3GPP:
 class FullCoMP:
     """heuristics.py:41-65: greedily connect to every BS, strongest first."""
 
+    def act(self, env, out=None):
+        return env.heuristic_actions('fullcomp', out=out)
+
     def __call__(self, obs):
         dr, conn = _views(obs)
         B = dr.shape[-1]
@@ -65,6 +76,9 @@ class DynamicSelection:
 
     def __init__(self, epsilon):
         self.epsilon = epsilon
+
+    def act(self, env, out=None):
+        return env.heuristic_actions('dynamic', epsilon=self.epsilon, out=out)
 
     def __call__(self, obs):
         dr, conn = _views(obs)
@@ -91,6 +105,13 @@ class StaticClustering:
             for o in cl:
                 member[b, o] = True
         self.member = member.to(device)                       # member[b] = cluster mask of BS b
+        self._bits = None
+
+    def act(self, env, out=None):
+        if self._bits is None or self._bits.device != env.device:      # bit o of word b = cell o in b's cluster
+            w = (self.member.to(torch.int64) << torch.arange(self.member.shape[1], device=self.member.device)).sum(dim=1)
+            self._bits = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).to(env.device).contiguous()
+        return env.heuristic_actions('cluster', cluster_mask=self._bits, out=out)
 
     def _build(self):
         """heuristics.py:128-165 (random seed cell, then repeatedly the cell closest to the cluster centre)."""

@@ -617,6 +617,139 @@ extern "C" int dcomp_mt_draw_tape(const dcomp_cfg *cfg, const int64_t *seeds, in
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// heuristic baselines (deepcomp/agent/heuristics.py) on the packed observation tensor
+namespace {
+struct PolicyParams {
+    int policy, multi, U, B, active;
+    int aligned;                  // obs is 16-byte aligned (multi-agent layout: float4 loads)
+    int64_t rows;                 // E * U
+    float eps;
+    const uint32_t *cluster;
+};
+
+// One lane per (env, UE).  A wave first copies its 64 rows into LDS with consecutive lanes on consecutive addresses (per-lane
+// row reads would touch 64 cache lines per load instruction).  Multi-agent layout: the 64 rows of 4B+1 floats are ONE
+// contiguous, 256-byte aligned span -> 16-byte loads of the whole span (the ues_at_bs | util_at_bs half the rules do not read
+// shares its cache lines with connected | dr, so skipping it would not save HBM traffic); central layout (small tensors):
+// the connected and dr runs of each row, float by float.  Row stride in LDS 4B+1 / 2B+1 words: odd = conflict-free per-lane walks.
+__global__ void __launch_bounds__(256) heuristic_kernel(PolicyParams p, const float *__restrict__ obs, uint8_t *__restrict__ act)
+{
+    extern __shared__ float4 lds4[];
+    float *const lds = reinterpret_cast<float *>(lds4);
+    const int B = p.B, W = 2 * B, S = p.multi ? 4 * B + 1 : W + 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    float *buf = lds + wave * 64 * S;
+    const int64_t r0 = ((int64_t)blockIdx.x * wpb + wave) * 64;
+    const int64_t left = p.rows - r0;
+    const int nrows = left >= 64 ? 64 : left > 0 ? (int)left : 0;
+    if (p.multi) {                                                     // connected[B] | dr[B] lead the row (variants.py:255-269)
+        const float *src = obs + r0 * S;
+        const int nfl = nrows * S;
+        const int nq = p.aligned ? nfl >> 2 : 0;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 *src4 = reinterpret_cast<const f4 *>(src);
+        for (int q0 = lane; q0 < nq; q0 += 64 * 16) {                  // 16 loads in flight per lane, then the LDS stores
+            f4 v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = q0 + 64 * k < nq ? __builtin_nontemporal_load(src4 + q0 + 64 * k) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 16; k++) if (q0 + 64 * k < nq) reinterpret_cast<f4 *>(buf)[q0 + 64 * k] = v[k];
+        }
+        for (int i0 = 4 * nq + lane; i0 < nfl; i0 += 64 * 8) {         // tail / unaligned tensor: float by float
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = i0 + 64 * k < nfl ? src[i0 + 64 * k] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (i0 + 64 * k < nfl) buf[i0 + 64 * k] = v[k];
+        }
+    } else {                                                           // connected[U*B] | dr[U*B] | utility[U] (central.py:147-151)
+        const int64_t env_floats = (int64_t)p.U * (W + 1);
+        for (int i0 = lane; i0 < nrows * W; i0 += 64 * 8) {
+            float v[8];
+            int at[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = i0 + 64 * k;
+                const int row = i / W, col = i - row * W;
+                const int64_t r = r0 + row;
+                const int64_t e = r / p.U;
+                const int u = (int)(r - e * p.U);
+                at[k] = row * S + col;
+                v[k] = i < nrows * W ? obs[e * env_floats + (col < B ? u * B + col : p.U * B + u * B + col - B)] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (i0 + 64 * k < nrows * W) buf[at[k]] = v[k];
+        }
+    }
+    __syncthreads();
+    if (lane >= nrows) return;
+    const float *row = buf + lane * S;
+    const int64_t r = r0 + lane;
+    const int u = (int)(r % p.U);
+    uint32_t conn = 0;
+    float mx = -__builtin_huge_valf();
+    int best = 0;
+#pragma unroll 8
+    for (int b = 0; b < B; b++) {
+        conn |= (row[b] > 0.5f ? 1u : 0u) << b;
+        const float d = row[B + b];
+        if (d > mx) { mx = d; best = b; }                              // strict: the first maximum (np.argmax, heuristics.py:27)
+    }
+    int a = 0;
+    if (u >= p.active) a = 0;
+    else if (p.policy == DCOMP_POLICY_3GPP) {
+        if ((conn >> best) & 1u) a = 0;                                // heuristics.py:30-31: already at the best cell
+        else if (conn) a = __builtin_ffs((int)conn);                   // :33-36: drop the (first) other connection
+        else a = best + 1;                                             // :38
+    } else {
+        uint32_t sel = B == 32 ? ~0u : (1u << B) - 1u;                 // FullCoMP: every cell
+        if (p.policy == DCOMP_POLICY_DYNAMIC) {
+            const float thr = mx * p.eps;                              // heuristics.py:87-90
+            sel = 0;
+#pragma unroll 8
+            for (int b = 0; b < B; b++) sel |= (row[B + b] >= thr ? 1u : 0u) << b;
+        } else if (p.policy == DCOMP_POLICY_CLUSTER) sel = p.cluster[best];   // :172-176
+        const uint32_t drop = conn & ~sel;
+        if (drop) a = __builtin_ffs((int)drop);                        // :96-99 / :178-181: index order
+        else {
+            uint32_t cand = sel & ~conn;
+            float m2 = -__builtin_huge_valf();
+#pragma unroll 8
+            for (int b = 0; b < B; b++) {
+                const float d = row[B + b];
+                if (((cand >> b) & 1u) && d > m2) { m2 = d; a = b + 1; }   // strongest first, first of equals (:57-63, :101-106)
+            }
+        }
+    }
+    act[r] = (uint8_t)a;
+}
+}  // namespace
+
+extern "C" int dcomp_heuristic_actions(const dcomp_policy *p, const float *obs, uint8_t *action, void *stream)
+{
+    if (!p || !obs || !action) return fail(DCOMP_EINVAL, "null argument");
+    if (p->num_envs < 1 || p->num_ue < 1 || p->num_ue > DCOMP_MAX_UE || p->num_bs < 1 || p->num_bs > DCOMP_MAX_BS || p->num_bs > 32)
+        return fail(DCOMP_EINVAL, "need num_envs>=1, 1<=num_ue<=%d, 1<=num_bs<=32 (got %d, %d, %d)", DCOMP_MAX_UE, p->num_envs, p->num_ue, p->num_bs);
+    if (p->policy < DCOMP_POLICY_3GPP || p->policy > DCOMP_POLICY_CLUSTER) return fail(DCOMP_EINVAL, "unknown policy %d", p->policy);
+    if (p->obs_kind != DCOMP_CENTRAL && p->obs_kind != DCOMP_MULTI) return fail(DCOMP_EINVAL, "obs_kind must be DCOMP_CENTRAL or DCOMP_MULTI");
+    if (p->num_active < 0 || p->num_active > p->num_ue) return fail(DCOMP_EINVAL, "num_active (%d) outside [0, num_ue]", p->num_active);
+    if (p->policy == DCOMP_POLICY_CLUSTER && !p->cluster_mask) return fail(DCOMP_EINVAL, "DCOMP_POLICY_CLUSTER needs cluster_mask");
+    if (p->policy == DCOMP_POLICY_DYNAMIC && !(p->epsilon >= 0.f && p->epsilon <= 1.f)) return fail(DCOMP_EINVAL, "epsilon must be in [0, 1]");
+    PolicyParams k;
+    k.policy = p->policy; k.multi = p->obs_kind == DCOMP_MULTI; k.U = p->num_ue; k.B = p->num_bs; k.active = p->num_active;
+    k.rows = (int64_t)p->num_envs * p->num_ue; k.eps = p->epsilon; k.cluster = p->cluster_mask;
+    k.aligned = (reinterpret_cast<uintptr_t>(obs) & 15u) == 0;
+    const size_t per_wave = (size_t)64 * ((k.multi ? 4 : 2) * p->num_bs + 1) * sizeof(float);
+    int wpb = (int)(60 * 1024 / per_wave);
+    wpb = wpb > 4 ? 4 : wpb < 1 ? 1 : wpb;
+    const int64_t waves = (k.rows + 63) / 64;
+    dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
+    hipLaunchKernelGGL(heuristic_kernel, grid, block, per_wave * wpb, (hipStream_t)stream, k, obs, action);
+    HIP_TRY(hipGetLastError());
+    return DCOMP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // device self-tests
 namespace {
 __global__ void selftest_fp64(int op, const double *x, const double *y, double *out, int64_t n)

@@ -436,6 +436,29 @@ class BatchedMobileEnv:
                                                 ctypes.byref(opts), self._stream()))
         return (self.obs, self.reward) if out is None else (out['obs'], out['reward'])
 
+    def heuristic_actions(self, policy, epsilon=0.0, cluster_mask=None, obs=None, out=None):
+        """The reference's heuristic baselines (deepcomp/agent/heuristics.py) for every (env, UE) in one launch
+        (dcomp_heuristic_actions): reads the packed observation tensor (default: the one the last reset / step wrote) and
+        returns the uint8 [E, U] action tensor step() takes.  policy: '3gpp' | 'fullcomp' | 'dynamic' (epsilon) | 'cluster'
+        (cluster_mask: int32/uint32 [B] device tensor, bit o of word b = cell o in b's cluster); agents.py wraps this."""
+        obs = self.obs if obs is None else obs
+        self._require(obs, torch.float32, self.obs.numel(), 'obs')
+        if out is None:
+            out = torch.empty((self.E, self.U), dtype=torch.uint8, device=self.device)
+        self._require(out, torch.uint8, self.E * self.U, 'out')
+        if policy not in _lib.POLICY:
+            raise ValueError(f"policy must be one of {sorted(_lib.POLICY)}")
+        cm = None
+        if policy == 'cluster':
+            if cluster_mask is None:
+                raise ValueError("policy 'cluster' needs cluster_mask")
+            self._require(cluster_mask, torch.int32, self.B, 'cluster_mask')
+            cm = cluster_mask.data_ptr()
+        p = _lib.DcompPolicy(_lib.POLICY[policy], self.kind, self.E, self.U, self.B, self.num_ue, float(epsilon), cm)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.dcomp_heuristic_actions(ctypes.byref(p), obs.data_ptr(), out.data_ptr(), self._stream()))
+        return out
+
     @property
     def lanes_per_env(self):
         """Lanes an env occupies in step(): next power of two >= U, or U itself when the batch is packed tightly."""

@@ -222,6 +222,29 @@ const char *dcomp_version(void);
  * step: fills out[n] (device) from x[n], y[n] (device doubles).  op: 0 sqrt(x) 1 x/y 2 fma(y,y,x*x)
  * 3 segmented all-reduce sums of (float)x over groups of `width` lanes; 4 / 5 / 6: norm, x/norm, y/norm of the
  * vector (x, y) as the movement step computes them (one shared reciprocal; must equal sqrt and two divisions). */
+/* The reference's heuristic baselines (deepcomp/agent/heuristics.py) for every (env, UE) of a batch in one launch, reading
+ * the packed observation tensor dcomp_reset / dcomp_step wrote and writing the action tensor dcomp_step takes: a
+ * heuristic-driven rollout never leaves the device.  One decision per UE and step, as in the reference:
+ *   DCOMP_POLICY_3GPP     heuristics.py:13-38   at most one connection, to the strongest cell: stay | drop the other | connect
+ *   DCOMP_POLICY_FULLCOMP heuristics.py:41-65   connect to every cell in range, strongest unconnected cell first
+ *   DCOMP_POLICY_DYNAMIC  heuristics.py:68-106  the set {b: dr_b >= epsilon * max dr}: first drop connected cells outside the
+ *                                               set (index order), then connect inside it, strongest first
+ *   DCOMP_POLICY_CLUSTER  heuristics.py:109-187 the same with the set = static cluster of the strongest cell;
+ *                                               cluster_mask[b] (device, uint32 x num_bs): bit o set = cell o in b's cluster
+ * Ties as numpy / sorted() resolve them: the first (lowest-index) maximum.  obs_kind = layout of `obs` (DCOMP_MULTI:
+ * [E][num_ue][4B+1], DCOMP_CENTRAL: [E][num_ue(2B+1)]); UE slots >= num_active (zero-padded observations of a dynamic
+ * env, central.py:46-55) get action 0.  action: uint8 [E][num_ue]. */
+enum { DCOMP_POLICY_3GPP = 0, DCOMP_POLICY_FULLCOMP = 1, DCOMP_POLICY_DYNAMIC = 2, DCOMP_POLICY_CLUSTER = 3 };
+typedef struct dcomp_policy {
+    int32_t policy;              /* DCOMP_POLICY_* */
+    int32_t obs_kind;            /* DCOMP_CENTRAL | DCOMP_MULTI */
+    int32_t num_envs, num_ue, num_bs;
+    int32_t num_active;          /* UEs listed (<= num_ue) */
+    float epsilon;               /* DCOMP_POLICY_DYNAMIC (heuristics.py:75) */
+    const uint32_t *cluster_mask;/* DCOMP_POLICY_CLUSTER, device [num_bs] */
+} dcomp_policy;
+int dcomp_heuristic_actions(const dcomp_policy *p, const float *obs, uint8_t *action, void *stream);
+
 int dcomp_selftest(int op, int width, const double *x, const double *y, double *out, int64_t n, void *stream);
 
 #ifdef __cplusplus

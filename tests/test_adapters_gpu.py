@@ -130,3 +130,105 @@ def test_multi_agent_base_env_against_reference_runs(torch_cuda):
     for e in range(8):
         assert np.array_equal(oh[e, :, :B], gs[e]['step_obs_connected'][0])
         np.testing.assert_allclose(r[e].cpu().numpy(), gs[e]['step_reward'][0], atol=ATOL_UTIL, rtol=0)
+
+
+# ------------------------------------------------------------------------------------ heuristic policy kernel (f4)
+def _policy_env(kind, U, B, E, **kw):
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    scn = scenarios.grid_map(B, 'mixed').with_ues(num_static=U // 8, num_slow=U - U // 8 - U // 4, num_fast=U // 4)
+    m, bs, ues = build_from_scenario(scn)
+    return BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=5, rng='philox', **kw), bs
+
+
+def _spec_views(env, obs):
+    """[E, U, B] views of either layout for the tensor-expression form of the rules (agents.py __call__)."""
+    if env.kind == 1:
+        return {'connected': obs[..., :env.B], 'dr': obs[..., env.B:2 * env.B]}
+    E, U, B = env.E, env.U, env.B
+    return {'connected': obs[:, :U * B].reshape(E, U, B), 'dr': obs[:, U * B:2 * U * B].reshape(E, U, B)}
+
+
+@pytest.mark.parametrize('kind,U,B,E', [('multi', 32, 10, 300), ('central', 10, 5, 257), ('multi', 7, 3, 50), ('central', 33, 16, 21),
+                                        ('multi', 128, 32, 5), ('central', 5, 32, 9), ('multi', 1, 1, 70)])
+def test_policy_kernel_equals_the_rules(kind, U, B, E):
+    """dcomp_heuristic_actions against the tensor-expression form of the reference's rules (itself held against the
+    reference-recorded decisions in test_agents_cpu.py): identical actions on live observations AND on synthetic ones
+    full of exact ties / empty connection sets / everything connected."""
+    import torch
+    from deepcomp_amd import agents
+    env, bs = _policy_env(kind, U, B, E)
+    env.reset()
+    ags = [agents.Heuristic3GPP(), agents.FullCoMP(), agents.DynamicSelection(0.3), agents.DynamicSelection(1.0),
+           agents.DynamicSelection(0.0)]
+    if B >= 3:
+        ags.append(agents.StaticClustering(3, bs, seed=5, device='cuda'))
+    g = torch.Generator(device='cuda').manual_seed(1)
+    for t in range(12):
+        for ag in ags:
+            assert torch.equal(ag.act(env), ag(_spec_views(env, env.obs))), (type(ag).__name__, t)
+        env.step(ags[t % len(ags)].act(env))                     # sticky policies: many simultaneous connections
+    env.check()
+    syn = torch.zeros_like(env.obs)
+    v = _spec_views(env, syn)
+    v['dr'].copy_((torch.randint(0, 4, v['dr'].shape, generator=g, device='cuda') / 3.0))      # quantised: ties everywhere
+    v['connected'].copy_((torch.rand(v['connected'].shape, generator=g, device='cuda') < 0.4).float())
+    v['connected'][0] = 1.0
+    v['connected'][-1] = 0.0
+    v['dr'][E // 2] = 0.0
+    shifted = torch.zeros(syn.numel() + 1, device='cuda')[1:].view_as(syn)       # 4- but not 16-byte aligned: scalar copy path
+    shifted.copy_(syn)
+    assert shifted.data_ptr() % 16 != 0
+    for ag in ags:
+        want = ag(_spec_views(env, syn))
+        assert torch.equal(env.heuristic_actions(*_policy_args(ag), obs=syn), want), type(ag).__name__
+        assert torch.equal(env.heuristic_actions(*_policy_args(ag), obs=shifted), want), type(ag).__name__
+
+
+def _policy_args(ag):
+    from deepcomp_amd import agents
+    if isinstance(ag, agents.Heuristic3GPP):
+        return ('3gpp',)
+    if isinstance(ag, agents.FullCoMP):
+        return ('fullcomp',)
+    if isinstance(ag, agents.DynamicSelection):
+        return ('dynamic', ag.epsilon)
+    return ('cluster', 0.0, ag._bits)
+
+
+def test_policy_kernel_on_reference_recorded_decisions():
+    """The kernel on the observations of tests/golden/heuristics.npz (recorded from the reference's own agents,
+    gen_golden.py::gen_heuristics): same decisions as the reference took."""
+    import os
+    import torch
+    from deepcomp_amd import agents
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'heuristics.npz'))
+    dr, conn = G['obs_dr'], G['obs_connected']                                   # [T, U, B]
+    T, U, B = dr.shape
+    env, bs = _policy_env('multi', U, B, T)
+    obs = torch.zeros_like(env.obs)
+    obs[..., :B] = torch.from_numpy(conn).float().cuda()
+    obs[..., B:2 * B] = torch.from_numpy(dr).float().cuda()
+    for name, args in [('3gpp', ('3gpp',)), ('fullcomp', ('fullcomp',)), ('dynamic05', ('dynamic', 0.5)), ('dynamic09', ('dynamic', 0.9))]:
+        got = env.heuristic_actions(*args, obs=obs).cpu().numpy()
+        assert np.array_equal(got, G['act_' + name]), name
+    ag = agents.StaticClustering(3, bs, seed=1, device='cuda')
+    ag.act(env)
+    assert np.array_equal(env.heuristic_actions('cluster', 0.0, ag._bits, obs=obs).cpu().numpy(), G['act_static3'])
+
+
+def test_policy_kernel_argument_validation():
+    import torch
+    env, _ = _policy_env('multi', 4, 3, 8)
+    env.reset()
+    with pytest.raises(ValueError):
+        env.heuristic_actions('greedy')
+    with pytest.raises(ValueError):
+        env.heuristic_actions('cluster')
+    with pytest.raises(ValueError):
+        env.heuristic_actions('3gpp', obs=env.obs.double())
+    with pytest.raises(ValueError):
+        env.heuristic_actions('3gpp', out=torch.zeros((8, 3), dtype=torch.uint8, device='cuda'))
+    with pytest.raises(ValueError):
+        env.heuristic_actions('dynamic', epsilon=1.5)

@@ -400,7 +400,7 @@ def test_max_cap_near_ties_the_reference_confirmed(torch_cuda):
 
 @pytest.mark.parametrize('agent_name', ['fullcomp', '3gpp', 'dynamic', 'static'])
 def test_heuristic_driven_rollout_matches_oracle(torch_cuda, agent_name):
-    """Policy in the loop, everything on the device: a reference heuristic (deepcomp_amd/agents.py) reads the
+    """Policy in the loop, everything on the device: a reference heuristic (dcomp_heuristic_actions via agents.py) reads the
     kernel's observation tensor and its actions drive the next step; the oracle is stepped with the same
     actions.  Sticky policies build up many simultaneous connections per BS (unlike random actions)."""
     torch = torch_cuda
@@ -418,7 +418,7 @@ def test_heuristic_driven_rollout_matches_oracle(torch_cuda, agent_name):
     ob.reset()
     total_conn = 0
     for t in range(50):
-        act = agent(core.obs_views()).contiguous()
+        act = agent.act(core)                        # HIP policy kernel on the packed observation tensor
         core.step(act)
         o_obs, o_rew, o_conn, o_pos = ob.step(act.cpu().numpy())
         st = core.state_host()
