@@ -28,6 +28,23 @@ def test_abi_exports_every_declared_symbol(lib):
     assert b'gfx950' in lib.dcomp_version()
 
 
+def test_policy_entry_point_refuses_bad_arguments_on_the_host(lib):
+    """dcomp_heuristic_actions validates before it touches the device (raw pointers cross the ABI): no GPU needed."""
+    import ctypes
+    from deepcomp_amd import _lib
+    EINVAL = -1
+    good = dict(policy=1, obs_kind=_lib.MULTI, num_envs=4, num_ue=3, num_bs=5, num_active=3, epsilon=0.5, cluster_mask=None)
+    fake = ctypes.c_void_p(4096)                       # never dereferenced: every case below fails validation first
+    assert lib.dcomp_heuristic_actions(None, fake, fake, None) == EINVAL
+    for bad in (dict(policy=7), dict(obs_kind=5), dict(num_bs=33), dict(num_ue=0), dict(num_active=4), dict(policy=2, epsilon=1.5),
+                dict(policy=3)):
+        p = _lib.DcompPolicy(**{**good, **bad})
+        assert lib.dcomp_heuristic_actions(ctypes.byref(p), fake, fake, None) == EINVAL, bad
+        assert lib.dcomp_last_error()
+    p = _lib.DcompPolicy(**good)
+    assert lib.dcomp_heuristic_actions(ctypes.byref(p), None, fake, None) == EINVAL
+
+
 def test_connect_threshold_matches_reference_constant(lib):
     # SURVEY.md Appendix B: d_T(snr = 2e-8) = 68.92488308058013 m; "roughly 69 m" (station.py:9)
     assert lib.dcomp_connect_threshold() == pytest.approx(68.92488308058013, abs=1e-9)
