@@ -232,3 +232,28 @@ def test_policy_kernel_argument_validation():
         env.heuristic_actions('3gpp', out=torch.zeros((8, 3), dtype=torch.uint8, device='cuda'))
     with pytest.raises(ValueError):
         env.heuristic_actions('dynamic', epsilon=1.5)
+
+
+@pytest.mark.parametrize('kind', ['central', 'multi'])
+def test_policy_kernel_with_ue_arrival_and_departure(kind):
+    """Dynamic UE lists (base.py:433-443): the listed UEs are the first num_ue slots, the rest of the observation is zero
+    padding (central.py:46-55) -> action 0 there, the rules on the listed slots; the actions drive the env without an
+    assertion (bad action / UE outside the map) while UEs come and go."""
+    import torch
+    from deepcomp_amd import agents
+    E, U0, B, CAP = 37, 4, 5, 9
+    env, bs = _policy_env(kind, U0, B, E, ue_arrival={2: 2, 4: -1, 6: 3, 9: -2}, max_ues=CAP, episode_length=12)
+    env.reset()
+    ags = [agents.Heuristic3GPP(), agents.FullCoMP(), agents.DynamicSelection(0.4), agents.StaticClustering(2, bs, seed=3, device='cuda')]
+    seen = set()
+    for t in range(11):
+        n = env.num_ue
+        seen.add(n)
+        for ag in ags:
+            got = ag.act(env)
+            want = ag(_spec_views(env, env.obs)).clone()
+            want[:, n:] = 0
+            assert got.shape == (E, CAP) and torch.equal(got, want), (type(ag).__name__, t, n)
+        env.step(ags[t % len(ags)].act(env))
+    env.check()
+    assert len(seen) >= 4 and max(seen) > U0
