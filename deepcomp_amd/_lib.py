@@ -65,7 +65,7 @@ POLICY = {'3gpp': 0, 'fullcomp': 1, 'dynamic': 2, 'cluster': 3}
 EXPORTS = ['dcomp_create', 'dcomp_destroy', 'dcomp_state_sizes', 'dcomp_obs_dim', 'dcomp_reset', 'dcomp_step',
            'dcomp_step_dyn', 'dcomp_num_ue',
            'dcomp_rollout', 'dcomp_rollout_ex', 'dcomp_rollout_is_fused', 'dcomp_lanes_per_env', 'dcomp_check', 'dcomp_time', 'dcomp_episode', 'dcomp_set_episode', 'dcomp_set_seed', 'dcomp_set_tape', 'dcomp_get_counters', 'dcomp_set_counters', 'dcomp_mt_draw_tape',
-           'dcomp_connect_threshold', 'dcomp_last_error', 'dcomp_version', 'dcomp_selftest', 'dcomp_heuristic_actions']
+           'dcomp_connect_threshold', 'dcomp_last_error', 'dcomp_version', 'dcomp_selftest', 'dcomp_heuristic_actions', 'dcomp_set_policy']
 
 _lib = None
 
@@ -121,6 +121,8 @@ def load():
     L.dcomp_selftest.argtypes = [i32, i32, vp, vp, vp, i64, vp]
     if hasattr(L, 'dcomp_heuristic_actions'):
         L.dcomp_heuristic_actions.argtypes = [ctypes.POINTER(DcompPolicy), vp, vp, vp]
+    if hasattr(L, 'dcomp_set_policy'):
+        L.dcomp_set_policy.argtypes = [vp, ctypes.POINTER(DcompPolicy), vp]
     for name in EXPORTS:
         getattr(L, name)
     _lib = L

@@ -6,8 +6,10 @@ observation tensor the env kernel writes, so a whole heuristic-driven rollout st
 
     act = agents.FullCoMP().act(env)                  # uint8 [E, U], feed straight into env.step(act)
 
-``agent.act(env)`` is the product path: ONE launch of the HIP policy kernel (dcomp_heuristic_actions, include/dcomp.h) on the
-packed observation tensor, multi-agent or central layout.  ``agent(obs_views)`` spells the same decision rules out as tensor
+``agent.act(env)`` is the product path: the first call launches the HIP policy kernel (dcomp_heuristic_actions,
+include/dcomp.h) on the packed observation tensor, multi-agent or central layout, and registers the policy with the env
+(dcomp_set_policy); after that the step kernel itself writes the next actions next to the observation and ``act`` returns
+that tensor (envs stepped by the wide kernel keep the separate launch).  ``agent(obs_views)`` spells the same decision rules out as tensor
 expressions over ``[..., B]`` views -- the executable specification the kernel is tested against (and what checks the rules
 against the reference-recorded decisions of tests/golden/heuristics.npz without a GPU).
 
@@ -17,6 +19,19 @@ Tie rules follow the reference: ``np.argmax`` / strict ``>`` scans pick the firs
 import random
 
 import torch
+
+
+def _act(env, policy, epsilon=0.0, cluster_mask=None, out=None):
+    """The policy's actions on env.obs.  First call: the stand-alone policy kernel, and the policy is handed to the env
+    (env.set_policy) so that every later reset / step launch writes the next actions itself; from then on this returns
+    env.next_action without a launch.  Envs stepped by the wide kernel keep using the stand-alone kernel."""
+    key = (policy, float(epsilon), cluster_mask.data_ptr() if cluster_mask is not None else None)
+    if out is None and env._policy_key == key and env._next_action_fresh:
+        return env.next_action
+    if out is None and env._policy_key != key and not getattr(env, '_policy_refused', None) == key:
+        if not env.set_policy(policy, epsilon, cluster_mask):
+            env._policy_refused = key
+    return env.heuristic_actions(policy, epsilon=epsilon, cluster_mask=cluster_mask, out=out)
 
 
 def _first_max(values, mask=None):
@@ -46,7 +61,7 @@ class Heuristic3GPP:
     """heuristics.py:13-38: at most one connection, to the BS with the highest SNR."""
 
     def act(self, env, out=None):
-        return env.heuristic_actions('3gpp', out=out)
+        return _act(env, '3gpp', out=out)
 
     def __call__(self, obs):
         dr, conn = _views(obs)
@@ -62,7 +77,7 @@ class FullCoMP:
     """heuristics.py:41-65: greedily connect to every BS, strongest first."""
 
     def act(self, env, out=None):
-        return env.heuristic_actions('fullcomp', out=out)
+        return _act(env, 'fullcomp', out=out)
 
     def __call__(self, obs):
         dr, conn = _views(obs)
@@ -78,7 +93,7 @@ class DynamicSelection:
         self.epsilon = epsilon
 
     def act(self, env, out=None):
-        return env.heuristic_actions('dynamic', epsilon=self.epsilon, out=out)
+        return _act(env, 'dynamic', epsilon=self.epsilon, out=out)
 
     def __call__(self, obs):
         dr, conn = _views(obs)
@@ -111,7 +126,7 @@ class StaticClustering:
         if self._bits is None or self._bits.device != env.device:      # bit o of word b = cell o in b's cluster
             w = (self.member.to(torch.int64) << torch.arange(self.member.shape[1], device=self.member.device)).sum(dim=1)
             self._bits = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).to(env.device).contiguous()
-        return env.heuristic_actions('cluster', cluster_mask=self._bits, out=out)
+        return _act(env, 'cluster', cluster_mask=self._bits, out=out)
 
     def _build(self):
         """heuristics.py:128-165 (random seed cell, then repeatedly the cell closest to the cluster centre)."""

@@ -725,6 +725,23 @@ __global__ void __launch_bounds__(256) heuristic_kernel(PolicyParams p, const fl
 }
 }  // namespace
 
+extern "C" int dcomp_set_policy(dcomp_env *env, const dcomp_policy *p, uint8_t *next_action)
+{
+    if (!env) return fail(DCOMP_EINVAL, "null argument");
+    if (!p || !next_action) { env->kp.next_act = nullptr; return DCOMP_OK; }
+    if (env->kern.step == env->kern.step_wide && env->kern.step_wide)
+        return fail(DCOMP_EUNSUPPORTED, "the wide step kernel has no in-step policy output: use dcomp_heuristic_actions");
+    if (p->policy < DCOMP_POLICY_3GPP || p->policy > DCOMP_POLICY_CLUSTER) return fail(DCOMP_EINVAL, "unknown policy %d", p->policy);
+    if ((p->num_envs && p->num_envs != env->cfg.num_envs) || (p->num_ue && p->num_ue != env->kp.U) || (p->num_bs && p->num_bs != env->cfg.num_bs))
+        return fail(DCOMP_EINVAL, "policy shape (%d, %d, %d) is not the env's (%d, %d, %d)", p->num_envs, p->num_ue, p->num_bs,
+                    env->cfg.num_envs, env->kp.U, env->cfg.num_bs);
+    if (p->policy == DCOMP_POLICY_CLUSTER && !p->cluster_mask) return fail(DCOMP_EINVAL, "DCOMP_POLICY_CLUSTER needs cluster_mask");
+    if (p->policy == DCOMP_POLICY_DYNAMIC && !(p->epsilon >= 0.f && p->epsilon <= 1.f)) return fail(DCOMP_EINVAL, "epsilon must be in [0, 1]");
+    env->kp.policy = p->policy; env->kp.policy_eps = p->epsilon; env->kp.policy_cluster = p->cluster_mask;
+    env->kp.next_act = next_action;
+    return DCOMP_OK;
+}
+
 extern "C" int dcomp_heuristic_actions(const dcomp_policy *p, const float *obs, uint8_t *action, void *stream)
 {
     if (!p || !obs || !action) return fail(DCOMP_EINVAL, "null argument");

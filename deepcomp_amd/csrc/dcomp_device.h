@@ -101,6 +101,10 @@ struct KParams {
     // io (device)
     const uint8_t *action;
     float *obs, *reward, *sum_util, *ue_dr, *ue_util, *rb_out;
+    uint8_t *next_act;         // optional [E][U]: the heuristic policy's action on the observation this launch writes (dcomp_set_policy)
+    const uint32_t *policy_cluster;   // DCOMP_POLICY_CLUSTER: [B] cluster masks
+    int32_t policy;            // DCOMP_POLICY_*
+    float policy_eps;          // DCOMP_POLICY_DYNAMIC
     // tape (device)
     const int32_t *tape_pos0;
     const ushort4 *tape_triples;
@@ -762,7 +766,35 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
 // l2 / cnt are consumed (overwritten with the observation entries).
 // `active`: this lane owns a slot (row) of the env; `alive`: a UE currently sits in that slot (always the same unless
 // UEs arrive / depart, then dead slots produce zero rows: central.py:46-55); n_eff = UEs currently in the env.
-struct Outs { float *obs, *reward, *sum_util, *ue_dr, *ue_util, *rb_out; };   // where this step's outputs go
+struct Outs { float *obs, *reward, *sum_util, *ue_dr, *ue_util, *rb_out; uint8_t *next_act; };   // where this step's outputs go
+
+// The reference's heuristic baselines (agent/heuristics.py:13-187) on one UE's dr[] entries and connection mask -- the rules
+// and first-maximum ties of heuristic_kernel (dcomp_api.hip), evaluated on the registers write_outputs is about to store.
+template <int B>
+__device__ __forceinline__ int policy_action(const KParams &p, uint32_t conn, const float (&dr)[B])
+{
+    float mx = dr[0];
+    int best = 0;
+#pragma unroll
+    for (int b = 1; b < B; b++) if (dr[b] > mx) { mx = dr[b]; best = b; }          // np.argmax: the first maximum
+    if (p.policy == DCOMP_POLICY_3GPP)                                              // heuristics.py:30-38
+        return ((conn >> best) & 1u) ? 0 : conn ? __builtin_ffs((int)conn) : best + 1;
+    uint32_t sel = B == 32 ? ~0u : (1u << (B & 31)) - 1u;                           // FullCoMP: every cell
+    if (p.policy == DCOMP_POLICY_DYNAMIC) {                                         // heuristics.py:87-90
+        const float thr = mx * p.policy_eps;
+        sel = 0;
+#pragma unroll
+        for (int b = 0; b < B; b++) sel |= (dr[b] >= thr ? 1u : 0u) << b;
+    } else if (p.policy == DCOMP_POLICY_CLUSTER) sel = p.policy_cluster[best];      // heuristics.py:172-176
+    const uint32_t drop = conn & ~sel;
+    if (drop) return __builtin_ffs((int)drop);                                      // cells outside the set first, index order
+    const uint32_t cand = sel & ~conn;
+    float m2 = -__builtin_huge_valf();
+    int a = 0;
+#pragma unroll
+    for (int b = 0; b < B; b++) if (((cand >> b) & 1u) && dr[b] > m2) { m2 = dr[b]; a = b + 1; }   // strongest first
+    return a;
+}
 // STAGED: observation rows go through LDS and leave as linear 16-byte stores (1 KiB contiguous per store instruction) -- what
 // a bandwidth-bound launch needs.  false: straight from registers; the fused rollout kernel, used for small batches with
 // one or two waves per SIMD, is latency-bound and the LDS round trips cost it 0.7 us per step (2.88 -> 2.21 us at 4 096 x 10 x 5).
@@ -861,6 +893,10 @@ __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, B
         const float avg = tsum[b] * fast_rcp(fmaxf(cnt[b], 1.f)) * (1.0f / MAX_UTIL);
         tsum[b] = live ? avg : 0.f;
         cnt[b] = live ? cnt[b] * inv_u : 0.f;                                                   // variants.py:296
+    }
+    if (o.next_act) {                                               // uniform: heuristic policy on the entries just made
+        const int a = policy_action<B>(p, conn, l2);
+        if (active) o.next_act[idx] = (uint8_t)(live ? a : 0);
     }
     if ((DCOMP_ABLATE & 8) && kind == DCOMP_MULTI) {
         float acc = util_n + reward;
@@ -1183,7 +1219,7 @@ __device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<
             vrange = mv_cfg_pack(c.vel_lo, c.vel_hi, c.pause, c.border);
         }
     }
-    Outs o{p.obs, p.reward, p.sum_util, p.ue_dr, p.ue_util, p.rb_out};
+    Outs o{p.obs, p.reward, p.sum_util, p.ue_dr, p.ue_util, p.rb_out, p.next_act};
     if (!ROLLOUT) {
         step_once<B, UPAD, MP, true>(p, sh, o, true, active, env, env_local, u, idx, wave, lane, gbase, act, p.time, p.episode, step_util, dr_req,
                                vrange, px, py, mv, conn, ewma, sg);
@@ -1302,7 +1338,7 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void reset_kernel(const KParams p)
 #pragma unroll
     for (int b = 0; b < B; b++) cnt[b] = 0.f;
     const float util = ue_utility(0.f, step_util, dr_req);
-    const Outs o{p.obs, p.reward, p.sum_util, p.ue_dr, p.ue_util, p.rb_out};
+    const Outs o{p.obs, p.reward, p.sum_util, p.ue_dr, p.ue_util, p.rb_out, p.next_act};
     write_outputs<B, UPAD, true, true>(p, o, sh, active, env, env_local, u, idx, wave, lane, gbase, 0u, in_range, l2, cnt, util, 0.f, 0.f, alive,
                                  p.U0);
 }

@@ -135,6 +135,7 @@ class BatchedMobileEnv:
         self.episode_length = int(episode_length)
         self.rand_episodes = bool(rand_episodes)
         self.log_metrics = bool(log_metrics)
+        self._policy_key, self.next_action = None, None      # in-step heuristic policy (set_policy)
         self.want_reward_before = False      # per-UE pre-move reward (single-agent env), off by default: 4 B/UE of extra traffic
         if reward not in _lib.REWARD:
             raise NotImplementedError(f"Unexpected reward aggregation: {reward}")       # central.py:73
@@ -341,6 +342,8 @@ class BatchedMobileEnv:
             self._reseeded = False
             _lib.check(self._L.dcomp_reset(self._h, ctypes.byref(self._st), ctypes.byref(tape) if tape else None,
                                            ctypes.byref(self._out), self._stream()))
+        if self._policy_key is not None:
+            self._policy_launched()
         return self.obs
 
     def step(self, action):
@@ -363,6 +366,8 @@ class BatchedMobileEnv:
                                     self._out_ref if out is self._out else ctypes.byref(out), self._stream())
             if rc:
                 _lib.check(rc)
+            if self._policy_key is not None:
+                self._policy_launched()
             return
         t = self.time
         n_rem, n_add = self.schedule[t] if t < len(self.schedule) else (0, 0)      # base.py:433-443
@@ -374,6 +379,8 @@ class BatchedMobileEnv:
             ev = _lib.DcompEvents(n_rem, n_add, rem.data_ptr() if n_rem else None, add.data_ptr() if n_add else None)
         _lib.check(self._L.dcomp_step_dyn(self._h, ctypes.byref(self._st), ctypes.c_void_p(action.data_ptr()),
                                           ctypes.byref(out), ctypes.byref(ev), self._stream()))
+        if self._policy_key is not None:
+            self._policy_launched()
 
     @property
     def num_ue(self):
@@ -434,6 +441,8 @@ class BatchedMobileEnv:
         with torch.cuda.device(self.device):
             _lib.check(self._L.dcomp_rollout_ex(self._h, self._st_ref, ctypes.c_void_p(actions.data_ptr()), T, ctypes.byref(o),
                                                 ctypes.byref(opts), self._stream()))
+        if self._policy_key is not None:
+            self._policy_launched()
         return (self.obs, self.reward) if out is None else (out['obs'], out['reward'])
 
     def heuristic_actions(self, policy, epsilon=0.0, cluster_mask=None, obs=None, out=None):
@@ -458,6 +467,48 @@ class BatchedMobileEnv:
         with torch.cuda.device(self.device):
             _lib.check(self._L.dcomp_heuristic_actions(ctypes.byref(p), obs.data_ptr(), out.data_ptr(), self._stream()))
         return out
+
+    def set_policy(self, policy, epsilon=0.0, cluster_mask=None):
+        """Heuristic policy INSIDE the step (dcomp_set_policy): from now on every reset / step / rollout launch also writes
+        ``self.next_action`` (uint8 [E, U]) = the policy's action on the observation it writes -- what heuristic_actions()
+        returns on self.obs, without the second pass over the tensor.  Closed loop: ``env.step(env.next_action)``
+        (next_action alternates between two buffers, so the tensor a step was given is intact until the step after).
+        policy None switches it off.  Returns False (and leaves it off) for envs stepped by the wide kernel, where the
+        caller falls back to heuristic_actions(); agents.py::*.act(env) does all of this."""
+        if policy is None:
+            _lib.check(self._L.dcomp_set_policy(self._h, None, None))
+            self._policy_key, self.next_action = None, None
+            return True
+        if policy not in _lib.POLICY:
+            raise ValueError(f"policy must be one of {sorted(_lib.POLICY)}")
+        cm = None
+        if policy == 'cluster':
+            if cluster_mask is None:
+                raise ValueError("policy 'cluster' needs cluster_mask")
+            self._require(cluster_mask, torch.int32, self.B, 'cluster_mask')
+            cm = cluster_mask.data_ptr()
+        # two buffers, written alternately: the tensor handed to step() stays what the caller read until the step after
+        # (and with UE arrival / departure slots shift, so a step must not write the tensor it reads its actions from)
+        bufs = [torch.zeros((self.E, self.U), dtype=torch.uint8, device=self.device) for _ in range(2)]
+        p = _lib.DcompPolicy(_lib.POLICY[policy], self.kind, self.E, self.U, self.B, self.num_ue, float(epsilon), cm)
+        rc = self._L.dcomp_set_policy(self._h, ctypes.byref(p), bufs[0].data_ptr())
+        if rc == _lib.EUNSUPPORTED:
+            self._policy_key, self.next_action = None, None
+            return False
+        _lib.check(rc)
+        self._policy_bufs, self._policy_p, self._policy_cm, self._policy_flip = bufs, p, cluster_mask, 0
+        self.next_action = bufs[0]
+        self._policy_key = (policy, float(epsilon), cm)
+        self._next_action_fresh = False              # valid once a reset / step has run with the policy set
+        return True
+
+    def _policy_launched(self):
+        """Bookkeeping after a launch that wrote next_action; flips the two buffers of a dynamic env for the next launch."""
+        self.next_action = self._policy_bufs[self._policy_flip]
+        self._next_action_fresh = True
+        if len(self._policy_bufs) == 2:
+            self._policy_flip ^= 1
+            _lib.check(self._L.dcomp_set_policy(self._h, ctypes.byref(self._policy_p), self._policy_bufs[self._policy_flip].data_ptr()))
 
     @property
     def lanes_per_env(self):

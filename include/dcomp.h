@@ -245,6 +245,16 @@ typedef struct dcomp_policy {
 } dcomp_policy;
 int dcomp_heuristic_actions(const dcomp_policy *p, const float *obs, uint8_t *action, void *stream);
 
+/* The same rules INSIDE the step: after dcomp_set_policy every dcomp_reset / dcomp_step / dcomp_step_dyn / dcomp_rollout launch
+ * also writes next_action[E][num_ue] = the policy's action on the observation that launch writes (from the registers the
+ * observation is stored from: no second pass over the tensor), i.e. what dcomp_heuristic_actions would return on out->obs.
+ * A heuristic-driven loop is then `dcomp_step(env, st, next_action, out, s)` over and over (next_action may be the buffer
+ * the step reads its actions from: a lane reads its slot before it writes it -- except with UE arrival / departure, where
+ * slots shift: use two buffers there).  p: policy / epsilon / cluster_mask are read (cluster_mask must stay valid), the
+ * shape fields must be 0 or match the env; p == NULL or next_action == NULL switches it off.
+ * DCOMP_EUNSUPPORTED for envs stepped by the wide kernel (num_bs > 20 with >= 64 lanes per env): use dcomp_heuristic_actions. */
+int dcomp_set_policy(dcomp_env *env, const dcomp_policy *p, uint8_t *next_action);
+
 int dcomp_selftest(int op, int width, const double *x, const double *y, double *out, int64_t n, void *stream);
 
 #ifdef __cplusplus

@@ -58,6 +58,15 @@ def main():
             loop()
         env.reset()
         lp = timed(loop, 90)
+        def fused():
+            env.step(ag.act(env))                    # after the first call: the step kernel wrote next_action itself
+        env.reset()
+        for _ in range(20):
+            fused()
+        env.reset()
+        fl = timed(fused, 90) if env.next_action is not None else float('nan')
+        env.set_policy(None)
+        print(f'  {name:13s} in-step policy (dcomp_set_policy) + step {fl:.4f} ms = {E / fl * 1e3:.3e} env-steps/s')
         print(f'  {name:13s} kernel {k:.4f} ms ({read / k / 1e6:.0f} GB/s of connected|dr)   tensor-expression form {t:.3f} ms   '
               f'policy + step {lp:.4f} ms = {E / lp * 1e3:.3e} env-steps/s')
     env.check()
