@@ -46,7 +46,7 @@ class DcompTape(ctypes.Structure):
 
 class DcompRolloutOpts(ctypes.Structure):
     _fields_ = [('every_step', ctypes.c_int32), ('horizon', ctypes.c_int32), ('new_episode_draws', ctypes.c_int32),
-                ('reserved', ctypes.c_int32)]
+                ('policy_loop', ctypes.c_int32)]
 
 
 class DcompEvents(ctypes.Structure):

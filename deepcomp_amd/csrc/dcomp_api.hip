@@ -407,11 +407,17 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
         if (env->cfg.rng_mode == DCOMP_RNG_TAPE && inc) return fail(DCOMP_EINVAL, "tape mode replays the borrowed tape: only fixed episodes can reset inside a rollout");
     } else if ((rc = check_horizon(env, T))) return rc;
     if (env->dyn && every) return fail(DCOMP_EUNSUPPORTED, "every_step: not with UE arrival / departure");
+    const bool loop = opts && opts->policy_loop != 0;
+    if (loop) {
+        if (!env->kp.next_act) return fail(DCOMP_EINVAL, "policy_loop needs a policy (dcomp_set_policy)");
+        if (!env->fused) return fail(DCOMP_EUNSUPPORTED, "policy_loop needs the fused rollout kernel (dcomp_rollout_is_fused)");
+        if (L > 0 && env->time + T > L) return fail(DCOMP_EINVAL, "policy_loop must not cross the horizon (%d + %d > %d): dcomp_reset, then continue", env->time, T, L);
+    }
     const size_t EU = (size_t)env->cfg.num_envs * env->cap, E = (size_t)env->cfg.num_envs;
     const bool multi = env->cfg.env_kind == DCOMP_MULTI;
     const size_t obs_step = EU * (size_t)(multi ? 4 * env->cfg.num_bs + 1 : 2 * env->cfg.num_bs + 1);
     if (env->fused) {
-        kp.action = actions; kp.num_steps = T; kp.out_every_step = every; kp.horizon = L; kp.episode_inc = inc;
+        kp.action = actions; kp.num_steps = T; kp.out_every_step = every; kp.horizon = L; kp.episode_inc = inc; kp.policy_loop = loop;
         hipLaunchKernelGGL(env->kern.rollout, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
     }
     int time = env->time;

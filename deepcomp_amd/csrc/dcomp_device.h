@@ -104,6 +104,7 @@ struct KParams {
     uint8_t *next_act;         // optional [E][U]: the heuristic policy's action on the observation this launch writes (dcomp_set_policy)
     const uint32_t *policy_cluster;   // DCOMP_POLICY_CLUSTER: [B] cluster masks
     int32_t policy;            // DCOMP_POLICY_*
+    int32_t policy_loop;       // fused rollout: steps 1..T-1 act on the policy's decision, only actions[0] is read
     float policy_eps;          // DCOMP_POLICY_DYNAMIC
     // tape (device)
     const int32_t *tape_pos0;
@@ -802,7 +803,7 @@ template <int B, int UPAD, bool RESET, bool DYN = false, bool STAGED = true, cla
 __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, BlockSharedT<B, UPAD> &sh, bool active, int env, int env_local, int u, int idx,
                                               int wave, int lane, int gbase, uint32_t conn, uint32_t in_range,
                                               float (&l2)[B], float (&cnt)[B], float util, float curr_dr,
-                                              float reward_before, bool alive, int n_eff, const S &sg = S{})
+                                              float reward_before, bool alive, int n_eff, const S &sg = S{}, uint32_t *pol_next = nullptr)
 {
     using G = Geo<B, UPAD>;
     using SG = StageGeo<B>;
@@ -897,6 +898,7 @@ __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, B
     if (o.next_act) {                                               // uniform: heuristic policy on the entries just made
         const int a = policy_action<B>(p, conn, l2);
         if (active) o.next_act[idx] = (uint8_t)(live ? a : 0);
+        if (pol_next) *pol_next = live ? (uint32_t)a : 0u;
     }
     if ((DCOMP_ABLATE & 8) && kind == DCOMP_MULTI) {
         float acc = util_n + reward;
@@ -1066,7 +1068,7 @@ template <int B, int UPAD, int MP, bool STORE, class S>
 __device__ __forceinline__ void step_once(const KParams &p, BlockSharedT<B, UPAD> &sh, const Outs &o, bool emit, bool active, int env,
                                           int env_local, int u, int idx, int wave, int lane, int gbase, uint32_t act, uint32_t time,
                                           uint32_t episode, bool step_util, float dr_req, int vrange, double &px, double &py,
-                                          unsigned long long &mv, uint32_t &conn, float &ewma, const S &sg)
+                                          unsigned long long &mv, uint32_t &conn, float &ewma, const S &sg, uint32_t *pol_next = nullptr)
 {
     float l2[B], dr[B], cnt[B];
     uint32_t in_range = B >= 32 ? 0xFFFFFFFFu : ((1u << (B & 31)) - 1u);
@@ -1150,7 +1152,7 @@ __device__ __forceinline__ void step_once(const KParams &p, BlockSharedT<B, UPAD
     // 7. observation, reward, info
     if (emit)
         write_outputs<B, UPAD, false, false, STORE, S>(p, o, sh, active, env, env_local, u, idx, wave, lane, gbase, conn, in_range, l2, cnt,
-                                                    util, curr, reward_before, active, p.U, sg);
+                                                    util, curr, reward_before, active, p.U, sg, pol_next);
 }
 
 // MobileEnv.step for all envs: one launch = one step.  ROLLOUT = true is the fused rollout: p.num_steps consecutive steps
@@ -1231,10 +1233,12 @@ __device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<
         // wait for its own HBM round trip -- and, vmcnt being one in-order counter for loads and stores, for the previous
         // step's observation stores to drain.
         const uint8_t *actp = p.action + (active ? idx : 0);      // idle lanes read a valid byte, masked below: no exec-masked blocks
+        const int TT = p.policy_loop ? 1 : T;                      // closed loop: the tape is actions[0] only
+        uint32_t pol_next = 0u;                                    // the registered policy's action on the observation of step t-1
         uint32_t nb[8];                                            // the NEXT chunk's bytes, still in flight
         auto load_chunk = [&](int t0) {                            // 8 independent loads (steps past T re-read the last one)
 #pragma unroll
-            for (int j = 0; j < 8; j++) nb[j] = (uint32_t)actp[(size_t)min(t0 + j, T - 1) * EU];
+            for (int j = 0; j < 8; j++) nb[j] = (uint32_t)actp[(size_t)min(t0 + j, TT - 1) * EU];
         };
         load_chunk(0);
         unsigned long long act_cur = 0ull;
@@ -1252,8 +1256,9 @@ __device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<
                 load_chunk(t + 8);
             }
             act = active ? (uint32_t)(act_cur >> (8 * (t & 7))) & 0xFFu : 0u;
-            step_once<B, UPAD, MP, false, S>(p, sh, o, p.out_every_step || t == T - 1, active, env, env_local, u, idx, wave, lane, gbase, act, time,
-                                   episode, step_util, dr_req, vrange, px, py, mv, conn, ewma, sg);
+            if (p.policy_loop && t > 0) act = active ? pol_next : 0u;
+            step_once<B, UPAD, MP, false, S>(p, sh, o, p.out_every_step || t == T - 1 || p.policy_loop, active, env, env_local, u, idx, wave, lane,
+                                   gbase, act, time, episode, step_util, dr_req, vrange, px, py, mv, conn, ewma, sg, &pol_next);
             time += 1;
             if (p.out_every_step) {                                  // outputs of step t -> [T][...] buffers
                 const bool multi = p.kind == DCOMP_MULTI;

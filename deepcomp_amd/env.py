@@ -401,7 +401,7 @@ class BatchedMobileEnv:
         with torch.cuda.device(self.device):
             self._launch_step(action, out)
 
-    def rollout(self, actions, out=None, horizon=None, new_episode_draws=None):
+    def rollout(self, actions, out=None, horizon=None, new_episode_draws=None, _policy_steps=0):
         """T consecutive steps from an action tape [T, E, U] (uint8) in ONE host call -- and, for the narrow kernel
         (``fused_rollout``), ONE kernel launch with the UE state in registers in between (replaces the per-step loop of
         simulation.py:512-541).
@@ -417,6 +417,8 @@ class BatchedMobileEnv:
             raise ValueError("actions must be [T, E, U]")
         T = int(actions.shape[0])
         self._require(actions, torch.uint8, T * self.E * self.U, 'actions')
+        if _policy_steps:                        # closed loop (rollout_policy): the tape is one step, the rest is decided in the kernel
+            T = int(_policy_steps)
         L = int(horizon or 0)
         if new_episode_draws is None:
             new_episode_draws = self.rand_episodes
@@ -437,12 +439,39 @@ class BatchedMobileEnv:
                               ptr.get('ue_utility'), ptr.get('reward_before'))
         if self.rng_mode == _lib.RNG_TAPE:
             self._ensure_tape(min(T, L - self.time) if L else T)
-        opts = _lib.DcompRolloutOpts(1 if out is not None else 0, L, 1 if new_episode_draws else 0, 0)
+        opts = _lib.DcompRolloutOpts(1 if out is not None else 0, L, 1 if new_episode_draws else 0, 1 if _policy_steps else 0)
         with torch.cuda.device(self.device):
             _lib.check(self._L.dcomp_rollout_ex(self._h, self._st_ref, ctypes.c_void_p(actions.data_ptr()), T, ctypes.byref(o),
                                                 ctypes.byref(opts), self._stream()))
         if self._policy_key is not None:
             self._policy_launched()
+        return (self.obs, self.reward) if out is None else (out['obs'], out['reward'])
+
+    def rollout_policy(self, num_steps, out=None, horizon=None):
+        """num_steps steps of the closed loop `act = policy(obs); step(act)` with the policy registered through set_policy():
+        ONE launch per stretch of an episode on the fused kernel (dcomp_rollout_ex, policy_loop) -- the decisions never leave
+        the registers -- with reset() at the horizon in between (the reset launch decides the first action of the new
+        episode).  Falls back to one step launch per step where rollouts are not fused.  Needs a current next_action: call
+        it after reset() / step() with the policy set.  out: as in rollout(), [num_steps, ...] buffers of every step."""
+        if self._policy_key is None or not self._next_action_fresh:
+            raise RuntimeError("rollout_policy() needs set_policy() and a reset() / step() after it")
+        L = int(horizon or 0)
+        T, t0 = int(num_steps), 0
+        keys = ('obs', 'reward', 'sum_utility', 'ue_dr', 'ue_utility', 'reward_before')
+        while t0 < T:
+            if L and self.time >= L:
+                self.reset()
+            n = min(T - t0, L - self.time) if L else T - t0
+            frag = None if out is None else {k: out[k][t0:t0 + n] for k in keys if out.get(k) is not None}
+            if self.fused_rollout and not self.dynamic:
+                self.rollout(self.next_action.view(1, self.E, self.U), out=frag, _policy_steps=n)    # never crosses the horizon: no in-kernel reset
+            else:
+                for i in range(n):
+                    self.step(self.next_action)
+                    if frag is not None:
+                        for k in frag:
+                            frag[k][i].copy_(getattr(self, k))
+            t0 += n
         return (self.obs, self.reward) if out is None else (out['obs'], out['reward'])
 
     def heuristic_actions(self, policy, epsilon=0.0, cluster_mask=None, obs=None, out=None):

@@ -169,12 +169,18 @@ int dcomp_rollout(dcomp_env *env, const dcomp_state *st, const uint8_t *actions,
  *                       the new episode is not emitted.  0: never (then an episode has at most 65536 steps)
  *   new_episode_draws   Philox mode: 1 = every such reset starts the next episode's draws (rand_episodes = True),
  *                       0 = the same episode again (the reference re-seeds at reset, base.py:171-173).  Tape mode replays the
- *                       tape handed to the last dcomp_reset, so it must be 0 there. */
+ *                       tape handed to the last dcomp_reset, so it must be 0 there.
+ *   policy_loop         1: closed loop with the policy registered through dcomp_set_policy -- step 0 takes actions[0][E][U]
+ *                       (the next_action the previous launch wrote), every later step the policy's decision on the
+ *                       observation of the step before, taken from registers: a heuristic agent's whole evaluation run
+ *                       (simulation.py:512-541) in one launch; `actions` holds ONE step.  Needs the fused kernel
+ *                       (dcomp_rollout_is_fused; DCOMP_EUNSUPPORTED otherwise) and must not cross the horizon (the
+ *                       first observation of a new episode is not computed inside a rollout: dcomp_reset, then go on). */
 typedef struct dcomp_rollout_opts {
     int32_t every_step;
     int32_t horizon;
     int32_t new_episode_draws;
-    int32_t reserved;
+    int32_t policy_loop;
 } dcomp_rollout_opts;
 int dcomp_rollout_ex(dcomp_env *env, const dcomp_state *st, const uint8_t *actions, int32_t num_steps,
                      const dcomp_out *out, const dcomp_rollout_opts *opts, void *stream);

@@ -65,6 +65,19 @@ def main():
             fused()
         env.reset()
         fl = timed(fused, 90) if env.next_action is not None else float('nan')
+        if env.next_action is not None and env.fused_rollout:
+            env.reset()
+            env.rollout_policy(99)
+            env.reset()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                env.rollout_policy(99)
+                env.reset()
+            e1.record()
+            torch.cuda.synchronize()
+            per = e0.elapsed_time(e1) / 1000
+            print(f'  {name:13s} closed loop inside the fused rollout (policy_loop, 99 steps + reset per launch pair) {per * 1e3:.2f} us/step = {E / per * 1e3:.3e} env-steps/s')
         env.set_policy(None)
         print(f'  {name:13s} in-step policy (dcomp_set_policy) + step {fl:.4f} ms = {E / fl * 1e3:.3e} env-steps/s')
         print(f'  {name:13s} kernel {k:.4f} ms ({read / k / 1e6:.0f} GB/s of connected|dr)   tensor-expression form {t:.3f} ms   '
