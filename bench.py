@@ -526,10 +526,10 @@ def main():
                                                'how': f'200 launches timed after {max(300, K)} untimed ones (same HIP-event method)'}
         default_workload = (E, U, B, args.kind, args.sharing) == (65536, 32, 10, 'multi', 'mixed')
         if args.traffic_bytes is None and default_workload:
-            # PMC pass of this exact workload (profiles/r02g_c3_summary.txt): FETCH_SIZE 33 922 KB x2 (gfx950 wide-read
-            # correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE 426 452 KB, per launch
-            out['roofline']['traffic'] = (2 * 33922.37 + 426451.80) * 1024
-            out['roofline']['traffic_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r02g_c3_summary.txt'
+            # PMC pass of this exact workload (profiles/r02i_c3_summary.txt): FETCH_SIZE 33 931 KB x2 (gfx950 wide-read
+            # correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE 426 502 KB, per launch
+            out['roofline']['traffic'] = (2 * 33931.26 + 426502.09) * 1024
+            out['roofline']['traffic_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r02i_c3_summary.txt'
         if world == 1 and not args.no_stream:
             # the launch writes (obs + reward + info + state) and reads (state + actions); ceiling for that mix
             sc = stream_probe
