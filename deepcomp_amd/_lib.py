@@ -123,6 +123,8 @@ def load():
         L.dcomp_heuristic_actions.argtypes = [ctypes.POINTER(DcompPolicy), vp, vp, vp]
     if hasattr(L, 'dcomp_set_policy'):
         L.dcomp_set_policy.argtypes = [vp, ctypes.POINTER(DcompPolicy), vp]
+    if os.environ.get('DCOMP_LIB'):              # timing variants built from older sources lack the newest entry points
+        EXPORTS[:] = [n for n in EXPORTS if hasattr(L, n)]
     for name in EXPORTS:
         getattr(L, name)
     _lib = L

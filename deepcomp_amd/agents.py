@@ -9,7 +9,7 @@ observation tensor the env kernel writes, so a whole heuristic-driven rollout st
 ``agent.act(env)`` is the product path: the first call launches the HIP policy kernel (dcomp_heuristic_actions,
 include/dcomp.h) on the packed observation tensor, multi-agent or central layout, and registers the policy with the env
 (dcomp_set_policy); after that the step kernel itself writes the next actions next to the observation and ``act`` returns
-that tensor (envs stepped by the wide kernel keep the separate launch).  ``agent(obs_views)`` spells the same decision rules out as tensor
+that tensor.  ``agent(obs_views)`` spells the same decision rules out as tensor
 expressions over ``[..., B]`` views -- the executable specification the kernel is tested against (and what checks the rules
 against the reference-recorded decisions of tests/golden/heuristics.npz without a GPU).
 
@@ -24,7 +24,7 @@ import torch
 def _act(env, policy, epsilon=0.0, cluster_mask=None, out=None):
     """The policy's actions on env.obs.  First call: the stand-alone policy kernel, and the policy is handed to the env
     (env.set_policy) so that every later reset / step launch writes the next actions itself; from then on this returns
-    env.next_action without a launch.  Envs stepped by the wide kernel keep using the stand-alone kernel."""
+    env.next_action without a launch."""
     key = (policy, float(epsilon), cluster_mask.data_ptr() if cluster_mask is not None else None)
     if out is None and env._policy_key == key and env._next_action_fresh:
         return env.next_action

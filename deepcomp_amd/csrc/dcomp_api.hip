@@ -735,8 +735,6 @@ extern "C" int dcomp_set_policy(dcomp_env *env, const dcomp_policy *p, uint8_t *
 {
     if (!env) return fail(DCOMP_EINVAL, "null argument");
     if (!p || !next_action) { env->kp.next_act = nullptr; return DCOMP_OK; }
-    if (env->kern.step == env->kern.step_wide && env->kern.step_wide)
-        return fail(DCOMP_EUNSUPPORTED, "the wide step kernel has no in-step policy output: use dcomp_heuristic_actions");
     if (p->policy < DCOMP_POLICY_3GPP || p->policy > DCOMP_POLICY_CLUSTER) return fail(DCOMP_EINVAL, "unknown policy %d", p->policy);
     if ((p->num_envs && p->num_envs != env->cfg.num_envs) || (p->num_ue && p->num_ue != env->kp.U) || (p->num_bs && p->num_bs != env->cfg.num_bs))
         return fail(DCOMP_EINVAL, "policy shape (%d, %d, %d) is not the env's (%d, %d, %d)", p->num_envs, p->num_ue, p->num_bs,

@@ -769,6 +769,32 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
 // UEs arrive / depart, then dead slots produce zero rows: central.py:46-55); n_eff = UEs currently in the env.
 struct Outs { float *obs, *reward, *sum_util, *ue_dr, *ue_util, *rb_out; uint8_t *next_act; };   // where this step's outputs go
 
+// The same rules with the dr entries behind a functor (the wide kernel keeps a UE's row in LDS, not in registers).
+template <int B, class F>
+__device__ __forceinline__ int policy_action_fn(const KParams &p, uint32_t conn, F dr)
+{
+    float mx = dr(0);
+    int best = 0;
+#pragma unroll 4
+    for (int b = 1; b < B; b++) { const float d = dr(b); if (d > mx) { mx = d; best = b; } }
+    if (p.policy == DCOMP_POLICY_3GPP) return ((conn >> best) & 1u) ? 0 : conn ? __builtin_ffs((int)conn) : best + 1;
+    uint32_t sel = B == 32 ? ~0u : (1u << (B & 31)) - 1u;
+    if (p.policy == DCOMP_POLICY_DYNAMIC) {
+        const float thr = mx * p.policy_eps;
+        sel = 0;
+#pragma unroll 4
+        for (int b = 0; b < B; b++) sel |= (dr(b) >= thr ? 1u : 0u) << b;
+    } else if (p.policy == DCOMP_POLICY_CLUSTER) sel = p.policy_cluster[best];
+    const uint32_t drop = conn & ~sel;
+    if (drop) return __builtin_ffs((int)drop);
+    const uint32_t cand = sel & ~conn;
+    float m2 = -__builtin_huge_valf();
+    int a = 0;
+#pragma unroll 4
+    for (int b = 0; b < B; b++) { const float d = dr(b); if (((cand >> b) & 1u) && d > m2) { m2 = d; a = b + 1; } }
+    return a;
+}
+
 // The reference's heuristic baselines (agent/heuristics.py:13-187) on one UE's dr[] entries and connection mask -- the rules
 // and first-maximum ties of heuristic_kernel (dcomp_api.hip), evaluated on the registers write_outputs is about to store.
 template <int B>

@@ -444,6 +444,8 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
                 base[p.U * B + u * B + b] = fast_exp2(strow[b] - l2max);
             }
             base[2 * p.U * B + u] = util_n;
+            if (p.next_act)                                                       // dcomp_set_policy: the rules on the entries just stored
+                p.next_act[idx] = (uint8_t)policy_action_fn<B>(p, conn, [&](int b) { return fast_exp2(strow[b] - l2max); });
         }
         return;
     }
@@ -451,6 +453,10 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
     float *st = sh.drst[wave];
 #pragma unroll 4
     for (int b = 0; b < B; b++) strow[b] = fast_exp2(strow[b] - l2max);                       // variants.py:276-284
+    if (p.next_act) {                                                             // dcomp_set_policy (uniform): the rules on this UE's dr row
+        const int a = policy_action_fn<B>(p, conn, [&](int b) { return strow[b]; });
+        if (active) p.next_act[idx] = (uint8_t)a;
+    }
     wave_lds_fence();                                                             // the rows are this wave's own; the tables were fenced above
     // column slots of this lane: c = lane + 64 k.  Row layout: connected[B] | dr[B] | ues_at_bs[B] | util_at_bs[B] | utility
     constexpr int NSLOT = (4 * B + 63) / 64;                                      // the utility column (4B) goes separately, below

@@ -502,8 +502,8 @@ class BatchedMobileEnv:
         ``self.next_action`` (uint8 [E, U]) = the policy's action on the observation it writes -- what heuristic_actions()
         returns on self.obs, without the second pass over the tensor.  Closed loop: ``env.step(env.next_action)``
         (next_action alternates between two buffers, so the tensor a step was given is intact until the step after).
-        policy None switches it off.  Returns False (and leaves it off) for envs stepped by the wide kernel, where the
-        caller falls back to heuristic_actions(); agents.py::*.act(env) does all of this."""
+        policy None switches it off.  Returns False (and leaves it off) if the library refuses (DCOMP_EUNSUPPORTED; no kernel
+        does today), where the caller falls back to heuristic_actions(); agents.py::*.act(env) does all of this."""
         if policy is None:
             _lib.check(self._L.dcomp_set_policy(self._h, None, None))
             self._policy_key, self.next_action = None, None

@@ -258,7 +258,7 @@ int dcomp_heuristic_actions(const dcomp_policy *p, const float *obs, uint8_t *ac
  * the step reads its actions from: a lane reads its slot before it writes it -- except with UE arrival / departure, where
  * slots shift: use two buffers there).  p: policy / epsilon / cluster_mask are read (cluster_mask must stay valid), the
  * shape fields must be 0 or match the env; p == NULL or next_action == NULL switches it off.
- * DCOMP_EUNSUPPORTED for envs stepped by the wide kernel (num_bs > 20 with >= 64 lanes per env): use dcomp_heuristic_actions. */
+ * Every step kernel has it (narrow, tight, wide, dynamic); DCOMP_EUNSUPPORTED is reserved for kernels that might not. */
 int dcomp_set_policy(dcomp_env *env, const dcomp_policy *p, uint8_t *next_action);
 
 int dcomp_selftest(int op, int width, const double *x, const double *y, double *out, int64_t n, void *stream);

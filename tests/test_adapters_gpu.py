@@ -262,6 +262,7 @@ def test_policy_kernel_with_ue_arrival_and_departure(kind):
 @pytest.mark.parametrize('kind,U,B,E,kw', [('multi', 32, 10, 300, {}), ('central', 10, 5, 257, {}), ('multi', 7, 3, 50, {}),
                                            ('central', 33, 16, 21, {}), ('multi', 5, 6, 33000, {}),       # 33 000 x 5: tight packing
                                            ('central', 5, 32, 9, {}), ('multi', 100, 12, 9, {}),
+                                           ('multi', 128, 32, 5, {}), ('central', 70, 24, 7, {}), ('multi', 200, 21, 3, {}),   # wide kernel
                                            ('multi', 4, 5, 37, dict(ue_arrival={2: 2, 4: -1, 6: 3, 9: -2}, max_ues=9))])
 def test_in_step_policy_equals_the_policy_kernel(kind, U, B, E, kw):
     """dcomp_set_policy: the step / reset / rollout launches write next_action = dcomp_heuristic_actions(obs they wrote),
@@ -296,22 +297,6 @@ def test_in_step_policy_equals_the_policy_kernel(kind, U, B, E, kw):
     assert env.next_action is None
 
 
-def test_in_step_policy_refused_by_the_wide_kernel():
-    """num_bs > 20 with >= 64 lanes per env runs the wide kernel, which has no policy output: set_policy says so and
-    agent.act keeps launching the stand-alone kernel."""
-    import torch
-    from deepcomp_amd import agents
-    env, bs = _policy_env('multi', 128, 32, 5)
-    env.reset()
-    assert env.set_policy('fullcomp') is False and env.next_action is None
-    ag = agents.FullCoMP()
-    for t in range(3):
-        act = ag.act(env)
-        assert torch.equal(act, ag(_spec_views(env, env.obs)))
-        env.step(act)
-    env.check()
-
-
 @pytest.mark.parametrize('kind,U,B,E,rng', [('central', 10, 5, 4096, 'philox'), ('multi', 32, 10, 200, 'philox'), ('multi', 7, 3, 50, 'philox'),
                                             ('central', 12, 16, 40, 'philox'), ('multi', 5, 4, 9, 'reference'),
                                             ('multi', 128, 32, 3, 'philox')])
@@ -341,12 +326,10 @@ def test_closed_loop_rollout_equals_step_by_step(kind, U, B, E, rng):
             ref.step(ref.heuristic_actions(name, eps, cm))
             want_obs.append(ref.obs.clone()); want_rew.append(ref.reward.clone())
         ref.check()
-        fused_possible = env.set_policy(name, eps, cm)
+        assert env.set_policy(name, eps, cm)              # wide kernel (128 x 32): in-step policy, one launch per step
+        with pytest.raises(RuntimeError):
+            env.rollout_policy(T)                         # no next_action before the first reset / step
         env.reset()
-        if not fused_possible:                            # wide kernel: no in-step policy
-            with pytest.raises(RuntimeError):
-                env.rollout_policy(T)
-            continue
         out = {'obs': torch.empty((T,) + tuple(env.obs.shape), device='cuda'), 'reward': torch.empty((T,) + tuple(env.reward.shape), device='cuda')}
         env.rollout_policy(T, out=out, horizon=L)
         env.check()
