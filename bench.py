@@ -2,6 +2,7 @@
 """bench.py -- env-steps/s of the fused HIP env step on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 1000 --warmup 100
+    python bench.py --gpus N --steps K --warmup W            # no launcher: spawns its N ranks itself (one per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -167,6 +168,45 @@ def measure_steps(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev, 
             'lanes_per_env': env.lanes_per_env, 'how': f'{n} back-to-back launches after 300 untimed ones, HIP events'}
 
 
+def measure_sharded(torch, dist, BatchedMobileEnv, scenarios, build_from_scenario, dev, rank, world, backend, E, U, B, kind, steps=200, warm=100, L=100):
+    """N > 1, EVERY rank calls this: one GPU's share of a BASELINE multi-GPU configuration (config 4: 32 768 x 32 x 10 per GPU,
+    config 5: 4 096 x 128 x 32 per GPU) stepped by all ranks at once -- global env ids, no collective on the data path, barrier +
+    synchronize on both sides, MAX over ranks.  With world = 8 the job IS the BASELINE configuration."""
+    scn = scenarios.grid_map(B, 'mixed').with_ues(num_slow=U)
+    m, bs, ues = build_from_scenario(scn)
+    env = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=42, episode_length=L, rng='philox', rand_episodes=True, device=dev,
+                           env_id_base=rank * E)
+    g = torch.Generator(device=dev).manual_seed(11 + rank)
+    pool = torch.randint(0, B + 1, (4, E, U), generator=g, device=dev, dtype=torch.uint8)
+
+    def run(n, t=0):
+        for i in range(n):
+            if t % L == 0:
+                env.reset()
+            env.step(pool[t & 3])
+            t += 1
+        return t
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    t = run(warm)
+    fence()
+    t0 = time.perf_counter()
+    run(steps, t)
+    fence()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    env.check()
+    dt = float(tt.item())
+    bpe = survey_bytes_per_env_step(U, B, kind)
+    return {'value': world * E * steps / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'total_envs': world * E,
+            'envs_per_gpu': E, 'num_ue': U, 'num_bs': B, 'n_gpus': world,
+            'achieved_GBps_per_gpu': bpe * E * steps / dt / 1e9, 'frac_of_hbm_peak_per_gpu': bpe * E * steps / dt / 1e9 / HBM_PEAK_GBS,
+            'how': 'host clock over the step loop (resets included), barrier + synchronize on both sides, MAX over ranks'}
+
+
 def stream_ceiling(torch, dev, write_bytes, rw_bytes, iters=100):
     """"also report against a measured device-copy bandwidth on the box".  torch's own elementwise kernels
     (fill = write-only, out-of-place add = read + write) on buffers of the step kernel's traffic, HIP-event timed."""
@@ -186,6 +226,79 @@ def stream_ceiling(torch, dev, write_bytes, rw_bytes, iters=100):
     t_copy = timed(lambda: torch.add(src, 1.0, out=dst[:src.numel()]))
     return {'fill_GBps': write_bytes / t_fill / 1e9, 'copy_GBps': 2 * rw_bytes / t_copy / 1e9,
             'what': f'torch fill_ of {write_bytes / 1e6:.0f} MB (write-only) / out-of-place add of {rw_bytes / 1e6:.0f} MB (read+write)'}
+
+
+def self_spawn(n):
+    """`python bench.py --gpus N` with no launcher around it (the reference's scale-out needs none either: `num_workers`,
+    env_setup.py:266): start the N ranks here -- N copies of this command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    their environment, exactly what torch.distributed.run would have set -- relay their output and print rank 0's JSON line
+    LAST.  A rank that dies takes the others down (no hung rendezvous)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+                   DCOMP_BENCH_SPAWNED='1')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))   # only rank 0 owns stdout
+    import threading
+    got = {'json': None}
+
+    def relay():                                       # rank 0's stdout; the other ranks' goes to stderr (RCCL banners)
+        for line in procs[0].stdout:
+            if line.startswith('{"metric"'):
+                got['json'] = line.rstrip('\n')
+            else:
+                sys.stdout.write(line)
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    failed = None
+    while any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0) and failed is None:
+                failed = (r, p.returncode)
+        if failed is not None:                         # a dead rank would leave the others hanging in a collective / rendezvous
+            time.sleep(2.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    for p in procs:
+        p.wait()
+    th.join(timeout=10)
+    sys.stdout.flush()
+    bad = [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0]
+    if got['json'] is not None and not bad:
+        print(got['json'], flush=True)
+        sys.exit(0)
+    sys.stderr.write(f'bench.py: self-spawned ranks failed (rank, exit code): {bad or failed}\n')
+    sys.exit(1)
+
+
+def traffic_from_profile(workload_key):
+    """roofline.traffic comes from a TRACKED rocprofv3 --pmc summary (profiles/traffic.json, written by
+    tools/summarize_prof.py --traffic-json on the GPU box), never from a literal in this file: HBM bytes per launch =
+    FETCH_SIZE x 2 (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in KiB.  An entry taken
+    from other kernel sources than the ones this library was built from (content hash of deepcomp_amd/csrc + flags, no git
+    needed on the GPU box) is STALE: traffic is then null and the source says why."""
+    path = os.path.join(REPO, 'profiles', 'traffic.json')
+    try:
+        ent = json.load(open(path)).get(workload_key)
+    except (OSError, ValueError):
+        ent = None
+    if not ent:
+        return None, f'no entry for {workload_key!r} in profiles/traffic.json'
+    from deepcomp_amd import build as hip_build
+    src = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/{ent['tag']}_summary.txt, kernel {ent['kernel']}, commit {ent.get('commit', '?')}"
+    if ent.get('source_fingerprint') != hip_build.source_fingerprint():
+        return None, 'STALE (kernel sources changed since): ' + src
+    return (2.0 * ent['fetch_kib'] + ent['write_kib']) * 1024.0, src
 
 
 def main():
@@ -214,7 +327,11 @@ def main():
     ap.add_argument('--no-stream', action='store_true', help='skip the measured fill/copy bandwidth (roofline.measured_stream)')
     ap.add_argument('--no-check', action='store_true', help='skip the device error-flag check (ablation builds)')
     ap.add_argument('--traffic-bytes', type=float, default=None, help='HBM bytes per launch from a rocprofv3 --pmc pass')
+    ap.add_argument('--spawn', action='store_true', help='start the ranks from this process even for --gpus 1 (what --gpus N > 1 does by itself '
+                                                         'when no launcher set WORLD_SIZE)')
     args = ap.parse_args()
+    if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.spawn):
+        self_spawn(args.gpus)                  # does not return
 
     import torch
     import torch.distributed as dist
@@ -236,7 +353,13 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.same_device:
         local_rank = 0
-    use_dist = world > 1 or args.force_dist
+    spawned = os.environ.get('DCOMP_BENCH_SPAWNED') == '1'      # a rank self_spawn() started: always a process group, also with one rank
+    use_dist = world > 1 or args.force_dist or spawned
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; run `python bench.py --gpus {args.gpus}` without a "
+                 f"launcher (it spawns its ranks itself) or torch.distributed.run with --nproc-per-node {args.gpus}")
+    if not args.same_device and torch.cuda.device_count() < world:
+        sys.exit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible (--same-device --backend gloo: dry run on one)")
     if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -248,7 +371,6 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(args.backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 
@@ -474,6 +596,20 @@ def main():
             obs_probe = {'error': f'{type(ex).__name__}: {ex}'[:300]}
             torch.cuda.synchronize(dev)
 
+    # N > 1: the multi-GPU BASELINE configurations next to the weak-scaling headline -- config 4's split (32 768 x 32 x 10 per
+    # GPU: at N = 8 exactly the 262 144-env job) and config 5's (4 096 x 128 x 32 per GPU).  Every rank takes part.
+    sharded = None
+    if world > 1 and not args.no_also:
+        sharded = {}
+        mk = (torch, dist, BatchedMobileEnv, scenarios, build_from_scenario, dev, rank, world, args.backend)
+        for name, shape in (('config4_split_32768x32x10_per_gpu', (32768, 32, 10, 'multi')),
+                            ('config5_split_4096x128x32_per_gpu', (4096, 128, 32, 'multi'))):
+            try:
+                sharded[name] = measure_sharded(*mk, *shape)
+            except Exception as ex:            # noqa: BLE001 -- a side measurement must never cost the headline line
+                sharded[name] = {'error': f'{type(ex).__name__}: {ex}'[:300]}
+                torch.cuda.synchronize(dev)
+
     # Duration of one step-kernel launch, over the TIMED region itself: the event pairs run() recorded around each run of
     # back-to-back launches between two resets (an event pair per launch would also time the launch latency of an empty
     # queue: round 1's kernel_ms > ms_per_step).
@@ -520,16 +656,17 @@ def main():
             out['handoff'] = handoff
         if obs_probe is not None:
             out.setdefault('also', {})['obs_handoff_probe'] = obs_probe
+        if sharded:
+            out.setdefault('also', {}).update(sharded)
         if steady_ms is not None:
             out['roofline']['steady_state'] = {'kernel_ms': steady_ms, 'achieved': sbpe * E / (steady_ms * 1e-3) / 1e9,
                                                'frac': sbpe * E / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                'how': f'200 launches timed after {max(300, K)} untimed ones (same HIP-event method)'}
         default_workload = (E, U, B, args.kind, args.sharing) == (65536, 32, 10, 'multi', 'mixed')
-        if args.traffic_bytes is None and default_workload:
-            # PMC pass of this exact workload (profiles/r02i_c3_summary.txt): FETCH_SIZE 33 931 KB x2 (gfx950 wide-read
-            # correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE 426 502 KB, per launch
-            out['roofline']['traffic'] = (2 * 33931.26 + 426502.09) * 1024
-            out['roofline']['traffic_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r02i_c3_summary.txt'
+        if args.traffic_bytes is None:
+            out['roofline']['traffic'], out['roofline']['traffic_source'] = traffic_from_profile(f'{E}x{U}x{B}_{args.kind}_{args.sharing}')
+        else:
+            out['roofline']['traffic_source'] = '--traffic-bytes'
         if world == 1 and not args.no_stream:
             # the launch writes (obs + reward + info + state) and reads (state + actions); ceiling for that mix
             sc = stream_probe

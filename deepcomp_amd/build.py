@@ -58,6 +58,12 @@ def _fingerprint(extra_flags=()):
     return h.hexdigest()
 
 
+def source_fingerprint():
+    """Hash of the kernel sources + flags of the product build: profiles record it (tools/summarize_prof.py), bench.py compares
+    it with the library it runs -- a PMC figure taken from other sources is reported as stale.  Needs no git."""
+    return _fingerprint(_dev_flags())
+
+
 def up_to_date(extra_flags=()):
     extra_flags = [f for f in extra_flags if f not in _dev_flags()] + _dev_flags()
     if not (os.path.exists(LIB) and os.path.exists(STAMP)):

@@ -648,3 +648,28 @@ void orc_batch_step(orc_env **envs, int E, const uint8_t *action, float *obs, fl
         if (pos) for (int u = 0; u < U; u++) { pos[((size_t)i * U + u) * 2] = u < e->nU ? e->px[u] : 0.0; pos[((size_t)i * U + u) * 2 + 1] = u < e->nU ? e->py[u] : 0.0; }
     }
 }
+/* FP64 per-UE rates of every env of a batch, for the at-scale parity tests (north_star: 1e-5 RELATIVE on data-rate floats):
+ * curr_dr = sum of the cached per-connection rates (user.py:64-69), ewma (user.py:148-157), utility (user.py:76-92),
+ * dr_rel = snr_b / max_b snr_b in FP64 (variants.py:276-284) -- the observation entry before its float32 cast. */
+void orc_batch_rates(orc_env **envs, int E, double *curr_dr, double *ewma, double *utility, double *dr_rel, int num_threads)
+{
+    if (num_threads < 1) num_threads = 1;
+#pragma omp parallel for num_threads(num_threads) schedule(static)
+    for (int i = 0; i < E; i++) {
+        const orc_env *e = envs[i];
+        const int U = e->U, B = e->B;
+        for (int u = 0; u < U; u++) {
+            const int live = u < e->nU;
+            if (curr_dr) curr_dr[(size_t)i * U + u] = live ? ue_curr_dr(e, u) : 0.0;
+            if (ewma) ewma[(size_t)i * U + u] = live ? e->ewma[u] : 0.0;
+            if (utility) utility[(size_t)i * U + u] = live ? ue_utility(e, u) : 0.0;
+        }
+        if (dr_rel) {
+            double *c = malloc(sizeof(double) * U * B * 4 + sizeof(double) * U);
+            double *d = c + U * B, *n = d + U * B, *a = n + U * B, *ut = a + U * B;
+            orc_get_obs(e, c, d, ut, n, a);
+            memcpy(dr_rel + (size_t)i * U * B, d, sizeof(double) * U * B);
+            free(c);
+        }
+    }
+}

@@ -88,6 +88,7 @@ def lib():
         L.orc_batch_reset.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _c_fp, ctypes.c_int]
         L.orc_batch_step.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _c_u8p, _c_fp, _c_fp, _c_u32p,
                                      _c_dp, ctypes.c_int]
+        L.orc_batch_rates.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _c_dp, _c_dp, _c_dp, _c_dp, ctypes.c_int]
         L.orc_max_threads.restype = ctypes.c_int
         _lib = L
     return _lib
@@ -415,6 +416,20 @@ class OracleBatch:
         lib().orc_batch_step(self._handles, self.E, _p(a, _c_u8p), _p(obs, _c_fp), _p(rew, _c_fp), _p(conn, _c_u32p),
                              _p(pos, _c_dp), self.num_threads)
         return obs, rew, conn, pos
+
+
+    def rates(self, want_dr_rel=False):
+        """FP64 per-UE values of every env: curr_dr (sum of the connections' shared rates), ewma, utility [E, U] and, on
+        request, the relative SNR rows dr_rel [E, U, B] before their float32 cast -- what the at-scale parity tests hold the
+        device's ue_dr / ewma / obs.dr to at 1e-5 RELATIVE."""
+        E, U, B = self.E, self.U, self.B
+        out = {'curr_dr': np.zeros((E, U)), 'ewma': np.zeros((E, U)), 'utility': np.zeros((E, U))}
+        rel = np.zeros((E, U, B)) if want_dr_rel else None
+        lib().orc_batch_rates(self._handles, E, _p(out['curr_dr'], _c_dp), _p(out['ewma'], _c_dp), _p(out['utility'], _c_dp),
+                              _p(rel, _c_dp), self.num_threads)
+        if want_dr_rel:
+            out['dr_rel'] = rel
+        return out
 
 
 def snr(d):

@@ -57,3 +57,47 @@ def test_bench_two_ranks_sharing_the_device():
             f.write('two RCCL ranks on one device were refused:\n' + '\n'.join(why) + '\n---- tail\n' + out[-2000:])
         pytest.skip('RCCL refuses two ranks on one device: ' + ' | '.join(why)[:300])
     assert j['handoff']['rccl_ranks'] == 2 and j['n_gpus'] == 2 and j['handoff']['fragments'] == 4
+
+
+def test_bench_spawns_its_own_ranks_n2_gloo_same_device():
+    """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE in the environment (the form the driver uses for N = 1):
+    bench.py starts its two ranks itself.  Both share cuda:0 here, so the process group is gloo (RCCL refuses two ranks on one
+    device) -- everything else is the N > 1 control flow: global env ids per rank, RolloutGather fragments, the MAX-reduce of the
+    elapsed time, the multi-GPU BASELINE splits in `also`, ONE JSON line from rank 0."""
+    env_clean = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    cmd = [sys.executable, 'bench.py', '--gpus', '2', '--backend', 'gloo', '--same-device', '--gather', 'obs', '--fragment', '5',
+           '--envs', '2048', '--steps', '20', '--warmup', '10', '--no-cpu-baseline', '--no-stream', '--eps-length', '10']
+    r = subprocess.run(cmd, cwd=REPO, env=env_clean, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert r.returncode == 0 and lines, (r.stdout[-2000:], r.stderr[-3000:])
+    j = json.loads(lines[-1])                                   # the JSON line is the LAST line of stdout
+    assert j['n_gpus'] == 2 and j['handoff']['rccl_ranks'] == 2 and j['handoff']['backend'] == 'gloo'
+    assert j['handoff']['mode'] == 'obs' and j['handoff']['fragments'] == 4
+    assert j['handoff']['bytes_received_per_rank_per_fragment'] == 2 * 5 * 2048 * 32 * (41 + 1) * 4
+    assert j['value'] > 0 and j['config']['parallelism'] == 'env-shard x2'
+    c4 = j['also']['config4_split_32768x32x10_per_gpu']
+    c5 = j['also']['config5_split_4096x128x32_per_gpu']
+    assert c4['n_gpus'] == 2 and c4['total_envs'] == 65536 and c4['value'] > 0, c4
+    assert c5['n_gpus'] == 2 and c5['total_envs'] == 8192 and c5['value'] > 0, c5
+
+
+def test_bench_spawns_its_own_ranks_summary_mode_probe():
+    env_clean = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    cmd = [sys.executable, 'bench.py', '--gpus', '2', '--backend', 'gloo', '--same-device', '--fragment', '5', '--no-also'] + COMMON
+    r = subprocess.run(cmd, cwd=REPO, env=env_clean, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    j = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert j['handoff']['mode'] == 'summary' and j['handoff']['rccl_ranks'] == 2
+    p = j['also']['obs_handoff_probe']                          # the observation hand-off next to the summary mode
+    assert p['rccl_ranks'] == 2 and p['exposed_handoff_ms_per_fragment'] >= 0 and p['bytes_received_per_rank_per_fragment'] == 2 * p['bytes_sent_per_rank_per_fragment']
+
+
+def test_bench_self_spawn_single_rank_rccl():
+    """The self-spawning form with one rank: a real RCCL communicator of size 1 (`--spawn` forces the spawn path that
+    `--gpus N > 1` takes by itself)."""
+    env_clean = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '1', '--spawn', '--gather', 'summary'] + COMMON, cwd=REPO, env=env_clean,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    j = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert j['n_gpus'] == 1 and j['handoff']['rccl_ranks'] == 1 and j['handoff']['backend'] == 'rccl'

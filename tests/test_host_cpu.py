@@ -206,3 +206,23 @@ def test_fuzz_specs_are_plain_data():
     frozen = json.load(open(os.path.join(REPO, 'tests', 'golden', 'fuzz_maxcap_near_ties.json')))
     assert [s['U'] for s in frozen] == [130, 70] and all('max-cap' in s['sh'] for s in frozen)
     fuzz_parity.build_case(frozen[0])
+
+
+def test_bench_self_spawn_reports_a_dead_rank_instead_of_hanging():
+    """`python bench.py --gpus 2` without a launcher starts its ranks itself (bench.py::self_spawn).  Without a GPU the ranks
+    die at set-up: the parent must notice, take the survivors down and exit non-zero with a message -- not sit in a rendezvous."""
+    import subprocess
+    import sys
+    import time
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip('needs a box WITHOUT a GPU (the GPU suite runs the real thing)')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--backend', 'gloo', '--same-device', '--envs', '64', '--steps', '2',
+                        '--warmup', '1', '--no-cpu-baseline', '--no-also', '--no-stream'], cwd=REPO, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and 'self-spawned ranks failed' in r.stderr, (r.stdout[-500:], r.stderr[-1500:])
+    assert time.time() - t0 < 240
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]

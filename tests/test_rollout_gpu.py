@@ -7,6 +7,8 @@ Replaces the per-step evaluation loop of deepcomp/util/simulation.py:512-541 and
 import numpy as np
 import pytest
 
+from tests import parity
+
 pytestmark = pytest.mark.gpu
 
 
@@ -154,10 +156,12 @@ def test_fused_rollout_against_the_oracle(torch_cuda):
     rng = np.random.default_rng(0)
     a = rng.integers(0, B + 1, size=(T, E, U)).astype(np.uint8)
     env.reset(); ob.reset()
-    out = {'obs': torch.empty((T, E, U * (2 * B + 1)), device='cuda'), 'reward': torch.empty((T, E), device='cuda')}
+    out = {'obs': torch.empty((T, E, U * (2 * B + 1)), device='cuda'), 'reward': torch.empty((T, E), device='cuda'),
+           'ue_dr': torch.empty((T, E, U), device='cuda'), 'ue_utility': torch.empty((T, E, U), device='cuda')}
     env.rollout(torch.from_numpy(a).cuda(), out=out, horizon=L)
     env.check()
     got_obs, got_rew = out['obs'].cpu().numpy(), out['reward'].cpu().numpy()
+    got_dr, got_ut = out['ue_dr'].cpu().numpy(), out['ue_utility'].cpu().numpy()
     episode = 0
     for t in range(T):
         if t and t % L == 0:
@@ -166,11 +170,13 @@ def test_fused_rollout_against_the_oracle(torch_cuda):
                 o.set_episode(episode)
             ob.reset()
         o_obs, o_rew, o_conn, o_pos = ob.step(a[t])
-        want = np.concatenate([o_obs[:, :, :B].reshape(E, -1), o_obs[:, :, B:2 * B].reshape(E, -1), o_obs[:, :, 2 * B]], axis=1)
-        np.testing.assert_allclose(got_obs[t], want, rtol=1e-5, atol=1e-5, err_msg=f'step {t}')
+        # every step's per-UE data rate and relative-SNR block at 1e-5 RELATIVE against the oracle's FP64 values (tests/parity.py)
+        r = parity.assert_rates(env, ob, f'step {t}', ue_dr=got_dr[t], ue_utility=got_ut[t], ewma=False)
+        parity.assert_obs(got_obs[t], o_obs, 'central', U, B, dr_rel=r['dr_rel'], msg=f'step {t}')
         np.testing.assert_allclose(got_rew[t], o_rew, rtol=0, atol=1e-5, err_msg=f'step {t}')
     st = env.state_host()
     assert np.array_equal(st['pos'], o_pos) and np.array_equal(st['conn'], o_conn)
+    parity.assert_rates(env, ob, 'final state', ue_dr=got_dr[-1], ue_utility=got_ut[-1])          # incl. the EWMA the kernel stored
 
 
 def test_rollout_argument_validation(torch_cuda):
