@@ -143,7 +143,7 @@ class BatchedMobileEnv:
         self.rng_mode = _lib.RNG_PHILOX if rng == 'philox' else _lib.RNG_TAPE
         if rng not in ('philox', 'reference'):
             raise ValueError("rng must be 'philox' (counter-based, in-kernel) or 'reference' (stdlib-random draw tape)")
-        self.tape_depth = int(tape_depth or (self.episode_length // 3 + 4))
+        self._tape_depth_arg = tape_depth
         self.seed_value = seed if seed is not None else int(np.random.SeedSequence().generate_state(1)[0])
         self.env_id_base = int(env_id_base)
         # env e of a batch gets base seed `seed + 20000*e` (UE i adds 100*(i+1), base.py:138-143)
@@ -160,6 +160,11 @@ class BatchedMobileEnv:
         self.vel_specs, self._vlo, self._vhi = ent['vel_specs'], ent['vel_lo'], ent['vel_hi']
         self.init_xy, self._ix, self._iy = ent['init_xy'], ent['init_x'], ent['init_y']
         self._pause, self._border = ent['pause'], ent['border']
+        # A UE redraws (velocity, waypoint) at most once per pause_duration + 1 steps: it arrives, stands still for pause_duration
+        # steps and draws in the step it moves on (movement.py:158-181) -- every third step with the default pause of 2, EVERY
+        # step with pause_duration 0 and a velocity that covers the distance.  UEs that arrive during an episode pause 2 steps.
+        self._redraw_period = min([int(x) for x in self._pause] + ([2] if self.dynamic else [])) + 1
+        self.tape_depth = int(self._tape_depth_arg or (self.episode_length // self._redraw_period + 4))
 
         c = _lib.DcompCfg()
         c.num_envs, c.num_ue, c.num_bs = self.E, self.U0, B
@@ -250,13 +255,13 @@ class BatchedMobileEnv:
 
     def seed(self, seed=None):
         """MobileEnv.seed (base.py:132-143); None leaves the generators alone.  The new seed governs every draw from the
-        next reset() on (the gym convention `env.seed(s); env.reset()`); the reference also re-seeds the streams of the
-        episode in progress, whose remaining draws here still come from the tape / key the episode started with."""
+        next reset() on (the gym convention `env.seed(s); env.reset()`): it is STAGED here and applied by reset() -- the
+        remaining draws of an episode in progress keep coming from the tape / Philox key the episode started with, in both
+        RNG modes.  (The reference also re-seeds the streams of the running episode, base.py:138-143; none of its callers
+        seeds mid-episode -- INTEGRATION.md section 3.)"""
         if seed is None:
             return
         seed = int(seed)
-        if self.rng_mode == _lib.RNG_PHILOX:          # may fail: nothing below is changed before it succeeded
-            _lib.check(self._L.dcomp_set_seed(self._h, ctypes.c_uint64(seed & 0xFFFFFFFFFFFFFFFF)))
         self.seed_value = seed
         self.env_seeds = self.seed_value + self._seed_stride * (self.env_id_base + np.arange(self.E, dtype=np.int64))
         self._streams, self._fixed_tape, self._dyn_streams = None, None, None
@@ -306,13 +311,13 @@ class BatchedMobileEnv:
         return _lib.DcompTape(self._tape_dev[0].data_ptr(), self._tape_dev[1].data_ptr(), self.U0 + self.max_id if self.dynamic else 0)
 
     def _ensure_tape(self, steps=1):
-        """rng='reference': the episode's draw tape must cover the next `steps` steps.  A UE redraws at most every third step
-        (arrive, pause two steps: movement.py:158-181), so step t needs at most t // 3 + 2 triples.  Episodes that outlive
-        the tape -- the reference's done() is always None and --cont-train never resets (main.py:48-51) -- get a longer
-        one: the same draws, continued."""
+        """rng='reference': the episode's draw tape must cover the next `steps` steps.  A UE redraws at most once per
+        (smallest configured pause_duration + 1) steps (arrive, pause, draw when it moves on: movement.py:158-181), so step t
+        needs at most t // period + 2 triples.  Episodes that outlive the tape -- the reference's done() is always None and
+        --cont-train never resets (main.py:48-51) -- get a longer one: the same draws, continued."""
         if self.rng_mode != _lib.RNG_TAPE or self._tape_dev is None:
             return
-        need = (self.time + steps) // 3 + 3
+        need = (self.time + steps) // self._redraw_period + 3
         if need <= self._tape_depth_now:
             return
         depth = max(need, 2 * self._tape_depth_now)
@@ -337,8 +342,11 @@ class BatchedMobileEnv:
             if self.rng_mode == _lib.RNG_TAPE:
                 pos0, trip = self._draw_tape()
                 tape = self._upload_tape(pos0, trip)
-            elif not self.rand_episodes or self._reseeded:
-                self._L.dcomp_set_episode(self._h, 0)     # fixed episodes: same Philox counter word every reset
+            else:
+                if self._reseeded:                        # seed() since the last reset: the new Philox key starts here
+                    _lib.check(self._L.dcomp_set_seed(self._h, ctypes.c_uint64(int(self.seed_value) & 0xFFFFFFFFFFFFFFFF)))
+                if not self.rand_episodes or self._reseeded:
+                    self._L.dcomp_set_episode(self._h, 0)     # fixed episodes: same Philox counter word every reset
             self._reseeded = False
             _lib.check(self._L.dcomp_reset(self._h, ctypes.byref(self._st), ctypes.byref(tape) if tape else None,
                                            ctypes.byref(self._out), self._stream()))
@@ -583,6 +591,13 @@ class BatchedMobileEnv:
         self.flags.zero_()
         c = (ctypes.c_int64 * 5)(*sd['counters'])
         _lib.check(self._L.dcomp_set_counters(self._h, c))
+        if self._policy_key is not None:
+            # next_action still holds the decision for the observation of BEFORE the restore: redo it on the restored one (the
+            # stand-alone policy kernel gives what the in-step policy would have written -- tests/test_adapters_gpu.py holds the
+            # two equal), so that `step(env.next_action)` / rollout_policy() continue the checkpointed run bit-identically
+            policy, eps, _ = self._policy_key
+            self.heuristic_actions(policy, epsilon=eps, cluster_mask=self._policy_cm, obs=self.obs, out=self.next_action)
+            self._next_action_fresh = True
 
     def info(self):
         """base.py:383-411 as tensors."""

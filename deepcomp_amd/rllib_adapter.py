@@ -57,22 +57,35 @@ def _core_from_config(env_config, kind):
                             env_seeds=env_config.get('env_seeds'))
 
 
+def _warn_protocol_path(self):
+    """The protocol methods build E (x U) Python dicts per step: fine at RLlib's handful of envs per worker, not at E = 65 536."""
+    if self.core.E > 1024 and not getattr(self, '_warned_big', False):
+        import warnings
+        self._warned_big = True
+        warnings.warn(f"{type(self).__name__}: num_envs={self.core.E} through the per-env dict protocol costs Python time per env and step; "
+                      "use poll_tensors() / send_action_tensor() (device tensors, no per-env objects) for large batches", RuntimeWarning,
+                      stacklevel=3)
+
+
 class _LockStepResets:
     """RLlib resets env copies one by one (`reset_at(i)` / `try_reset(i)`, in whatever order its sampler walks them) when
-    they hit the horizon; the batch can only reset as a whole.  The FIRST reset request after a step (or a repeated request
-    for an index already served) resets the batch; the other indices are then served from that same reset."""
+    they hit the horizon; the batch can only reset as a whole.  The FIRST per-index reset request after a step (or a repeated
+    request for an index already served) resets the batch; the other indices are then served from that same reset.  A request
+    for the whole batch (`vector_reset()`, index None) ALWAYS resets: with rand_episodes every reset of the reference starts a
+    new episode (base.py:169-189), two of them in a row included."""
 
     def _init_resets(self):
         self._served = set()
         self._stepped = True             # nothing has been reset yet
 
     def _reset_for(self, index):
-        if self._stepped or index in self._served:
+        if index is None or self._stepped or index in self._served:
             self.core.reset()
             self._after_core_reset()
             self._served = set()
             self._stepped = False
-        self._served.add(index)
+        if index is not None:
+            self._served.add(index)
 
 
 class CentralVectorEnv(_VectorEnvBase, _LockStepResets):
@@ -84,12 +97,14 @@ class CentralVectorEnv(_VectorEnvBase, _LockStepResets):
         obs_space = spaces.Dict({'connected': spaces.MultiBinary(U * B), 'dr': spaces.Box(low=0, high=1, shape=(U * B,)),
                                  'utility': spaces.Box(low=-1, high=1, shape=(U,))})
         _VectorEnvBase.__init__(self, obs_space, spaces.MultiDiscrete([B + 1] * U), self.core.E)
+        self._ue_keys = [f'UE {ue}' for ue in env_config['ue_list']]          # the keys of info()'s vector_metrics (base.py:407-408)
         self._all = None
         self._obs = None
         self._init_resets()
 
     def _obs_list(self):
         U, B = self.core.U, self.core.B
+        _warn_protocol_path(self)
         self._all = self.core.outputs_host()                           # ONE D2H copy of obs + reward + info; below are views
         host = self._all['obs']
         self._obs = [{'connected': row[:U * B], 'dr': row[U * B:2 * U * B], 'utility': row[2 * U * B:]} for row in host]
@@ -99,8 +114,8 @@ class CentralVectorEnv(_VectorEnvBase, _LockStepResets):
         self._obs_list()
 
     def vector_reset(self):
-        self._reset_for(None)
-        self._served = set()
+        self._reset_for(None)                    # always a fresh reset; the per-index requests that follow get a new one too
+        self._stepped = True
         return self._obs
 
     def reset_at(self, index=None):
@@ -115,8 +130,10 @@ class CentralVectorEnv(_VectorEnvBase, _LockStepResets):
         self._stepped = True
         obs = self._obs_list()
         rew, su = self._all['reward'].tolist(), self._all['sum_utility'].tolist()
-        t = self.core.time
-        infos = [{'time': t, 'scalar_metrics': {'sum_utility': su[e]}} for e in range(self.core.E)]
+        dr, ut = self._all['ue_dr'].tolist(), self._all['ue_utility'].tolist()
+        t, keys = self.core.time, self._ue_keys
+        infos = [{'time': t, 'scalar_metrics': {'sum_utility': su[e]},                                  # base.py:383-411
+                  'vector_metrics': {'dr': dict(zip(keys, dr[e])), 'utility': dict(zip(keys, ut[e]))}} for e in range(self.core.E)]
         return obs, rew, [False] * self.core.E, infos
 
     # ---- zero-copy path
@@ -151,10 +168,10 @@ class MultiAgentBaseEnv(_BaseEnvBase, _LockStepResets):
         self._fresh = True
         self._init_resets()
         self._reset_for(None)
-        self._served = set()
 
     def _views(self):
         B = self.core.B
+        _warn_protocol_path(self)
         self._all = self.core.outputs_host()                            # ONE D2H copy of obs + reward + info
         host = self._all['obs']                                         # [E, U, 4B+1]
         return {e: {aid: {'connected': host[e, i, 0:B], 'dr': host[e, i, B:2 * B], 'ues_at_bs': host[e, i, 2 * B:3 * B],

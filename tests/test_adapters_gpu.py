@@ -59,6 +59,10 @@ def test_central_vector_env_against_reference_runs(torch_cuda):
             assert rew[e] == pytest.approx(float(gs[e]['step_reward'][t, 0]), abs=ATOL_OBS)
             assert infos[e]['time'] == int(gs[e]['step_time'][t])
             assert infos[e]['scalar_metrics']['sum_utility'] == pytest.approx(float(gs[e]['step_sum_utility'][t]), abs=ATOL_UTIL * U)
+            vm = infos[e]['vector_metrics']                                             # base.py:383-411: per-UE dr / utility by 'UE <id>'
+            assert list(vm['dr']) == [f'UE {u + 1}' for u in range(U)] == list(vm['utility'])
+            np.testing.assert_allclose(list(vm['dr'].values()), gs[e]['step_curr_dr'][t], rtol=RTOL_RATE, atol=1e-30)
+            np.testing.assert_allclose(list(vm['utility'].values()), gs[e]['step_utility'][t], rtol=0, atol=ATOL_UTIL)
             assert np.array_equal(flatten_obs(obs[e]), vec.poll_tensors()[0][e].cpu().numpy())
     # the horizon: RLlib resets the copies one by one, in its own order; every one must get ITS first observation
     order = [5, 2, 7, 0, 1, 3, 4, 6]
@@ -72,7 +76,16 @@ def test_central_vector_env_against_reference_runs(torch_cuda):
     obs, rew, _, _ = vec.vector_step([g['actions'][0].tolist() for g in gs])
     for e in range(8):
         _check_central(obs[e], gs[e], 'step', 0, U, B)                    # fixed episodes (base.py:171-173): the same episode again
+    # a request for the whole batch always resets (two in a row: two episodes), and so does a per-index request right after it
+    ep = vec.core.episode
+    vec.vector_reset(); vec.vector_reset()
+    assert vec.core.episode == ep + 2
+    _check_central(vec.reset_at(4), gs[4], 'reset', 0, U, B)
+    assert vec.core.episode == ep + 3
+    _check_central(vec.reset_at(1), gs[1], 'reset', 0, U, B)              # ... which then serves the other indices
+    assert vec.core.episode == ep + 3
     # zero-copy path == protocol path
+    vec.vector_step([g['actions'][0].tolist() for g in gs])
     vec.reset_at(0)
     a = torch.from_numpy(np.stack([g['actions'][0] for g in gs]).astype(np.uint8)).cuda()
     vec.send_action_tensor(a)

@@ -875,6 +875,66 @@ def test_tape_is_extended_for_episodes_that_outlive_it(torch_cuda, rand_episodes
     assert short.tape_depth > 2
 
 
+def test_default_tape_covers_short_pauses(torch_cuda):
+    """the default tape of rng='reference' was sized for pause_duration = 2 (a redraw at most every third step).
+    With pause_duration 0 / 1 and a velocity that covers the small map in one step a UE redraws every (other) step: the
+    default depth and the on-demand extension now follow the smallest configured pause -- no DCOMP_FLAG_TAPE_EMPTY, and the
+    same trajectory as with an amply sized tape, within one episode and across two that outlive it."""
+    torch = torch_cuda
+    from deepcomp_amd.entities import Basestation, Map, Point, RandomWaypoint, User
+    from deepcomp_amd.env import BatchedMobileEnv
+    m = Map(31, 27)
+    bs = [Basestation('A', Point(10, 10), 'resource-fair'), Basestation('B', Point(22, 15), 'rate-fair')]
+    ues = [User(str(i + 1), m, 'random', 'random', RandomWaypoint(m, vel, pause_duration=pd, border_buffer=bb))
+           for i, (vel, pd, bb) in enumerate([(60, 0, 10), ('fast', 0, 3), (40, 1, 10), ('slow', 2, 10), (9, 0, 13)])]
+    kw = dict(num_envs=5, seed=3, rng='reference', episode_length=60)
+    for rand in (False, True):
+        dflt = BatchedMobileEnv(m, bs, ues, 'multi', rand_episodes=rand, **kw)
+        ample = BatchedMobileEnv(m, bs, ues, 'multi', rand_episodes=rand, tape_depth=400, **kw)
+        assert dflt.tape_depth >= 60                     # one triple per step must fit (pause_duration 0)
+        g = torch.Generator(device='cuda').manual_seed(2)
+        for ep in range(2):
+            dflt.reset(); ample.reset()
+            for t in range(60 if ep == 0 else 150):      # the second episode outlives the default tape: extended on demand
+                a = torch.randint(0, 3, (5, 5), generator=g, device='cuda', dtype=torch.uint8)
+                dflt.step(a); ample.step(a)
+            dflt.check(); ample.check()                  # raises on DCOMP_FLAG_TAPE_EMPTY
+            assert torch.equal(dflt.pos, ample.pos) and torch.equal(dflt.mv, ample.mv) and torch.equal(dflt.obs, ample.obs)
+        cursors = dflt.state_host()['cursor']
+        assert int(cursors[:, 0].min()) >= 100           # the pause-0 UE on the one-step map drew (nearly) every step
+
+
+def test_checkpoint_resume_continues_a_heuristic_driven_run(torch_cuda):
+    """load_state_dict() left next_action holding the decision for the PRE-restore observation, so a heuristic-driven
+    run resumed with one stale action.  The restored env must continue `step(env.next_action)` bit-identically."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    scn = scenarios.grid_map(7, 'mixed').with_ues(num_slow=9, num_fast=3)
+    m, bs, ues = build_from_scenario(scn)
+
+    def make():
+        e = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=40, seed=8, rng='philox', rand_episodes=True, episode_length=50)
+        assert e.set_policy('dynamic', epsilon=0.4)
+        return e
+    a = make()
+    a.reset()
+    for _ in range(7):
+        a.step(a.next_action)
+    sd = a.state_dict()
+    b = make()
+    b.reset()
+    for _ in range(3):                                   # b is somewhere else, with another next_action
+        b.step(b.next_action)
+    b.load_state_dict(sd)
+    assert torch.equal(a.next_action, b.next_action)
+    for _ in range(9):
+        a.step(a.next_action); b.step(b.next_action)
+    assert torch.equal(a.pos, b.pos) and torch.equal(a.conn, b.conn) and torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward)
+    a.check(); b.check()
+
+
 def test_seed_on_a_live_env(torch_cuda):
     """MobileEnv.seed (base.py:132-143) on an existing env, counter-based and tape draws: after seed(s); reset() the env is
     indistinguishable from one constructed with seed s (round 1 raised NotImplementedError for Philox envs)."""
@@ -892,6 +952,14 @@ def test_seed_on_a_live_env(torch_cuda):
             a.step(acts[t])
         a.seed(None)                                     # no-op (base.py:133)
         assert a.seed_value == 11
+        if rng == 'philox':                              # the new key is staged until reset(): the episode in progress keeps its draws
+            c = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=16, seed=11, rng=rng, rand_episodes=rand, episode_length=6)
+            c.reset()
+            for t in range(4):
+                c.step(acts[t])
+            a.seed(977)
+            a.step(acts[4]); c.step(acts[4]); a.step(acts[5]); c.step(acts[5])
+            assert torch.equal(a.pos, c.pos) and torch.equal(a.mv, c.mv) and torch.equal(a.obs, c.obs), (rng, rand)
         a.seed(977)
         b = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=16, seed=977, rng=rng, rand_episodes=rand, episode_length=6)
         for ep in range(2):
