@@ -136,10 +136,10 @@ def measure_rollout(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev
     return out
 
 
-def measure_steps(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev, E, U, B, kind, steps=300, L=100):
+def measure_steps(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev, E, U, B, kind, steps=300, L=100, sharing='mixed'):
     """One launch per step on another shape (secondary figures): HIP events around back-to-back launches after 300 untimed
     ones (steady state), SURVEY 8(d) bytes / launch duration."""
-    scn = scenarios.grid_map(B, 'mixed').with_ues(num_slow=U)
+    scn = scenarios.grid_map(B, sharing).with_ues(num_slow=U)
     m, bs, ues = build_from_scenario(scn)
     env = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=42, episode_length=L, rng='philox', rand_episodes=True, device=dev)
     g = torch.Generator(device=dev).manual_seed(7)

@@ -24,7 +24,7 @@ static KernelPair lookup_kernels(int B, int upad, int mp)
 #define DCOMP_CASE(n) case n: return kernels_b##n(upad, mp);
         DCOMP_B_LIST(DCOMP_CASE)
 #undef DCOMP_CASE
-    default: return KernelPair{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    default: return KernelPair{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     }
 }
 }  // namespace dcomp
@@ -214,7 +214,8 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
         // it wins while the grid leaves the SIMDs under-occupied (4 096 x 10 x 5: one wave per SIMD, 2.2 vs 5.3 us per step).  A
         // grid of many waves per SIMD is throughput-bound: there the plain step kernel (fewer registers, coalesced staged
         // stores) launched once per step is faster and launch latency hides behind the running kernel.
-        long max_waves = 4 * 1024;                                   // 4 waves per SIMD of the 256 CUs
+        long max_waves = 3 * 1024;                                   // 3 waves per SIMD of the 256 CUs: what the rollout kernel's ~136 VGPRs leave room for
+                                                                     // (a fourth wave per SIMD would wait for a second round)
         if (const char *e = getenv("DCOMP_FUSE_MAX_WAVES")) max_waves = atol(e);
         const long waves = (long)env->grid * (DCOMP_BLOCK / 64);
         env->fused = !DYN && env->kern.step != env->kern.step_wide && env->kern.rollout != nullptr && waves <= max_waves;
@@ -228,7 +229,7 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
         if (!DYN && env->kern.step_tight && U1 >= 3 && (U1 & (U1 - 1)) != 0 && !kp.any_maxcap && env->kern.step != env->kern.step_wide) {
             const int gpw = 64 / U1;
             const double padded_use = (double)U1 / env->upad, tight_use = (double)(gpw * U1) / 64.0;
-            int want = waves >= 4 * 1024 && tight_use >= 1.4 * padded_use;
+            int want = waves >= 4 * 1024 && tight_use >= 1.4 * padded_use;     // (never together with the fused rollout: <= 3 * 1024 waves)
             if (const char *e = getenv("DCOMP_TIGHT")) want = atoi(e) != 0;       // tests / A-B: force on or off
             if (want) {
                 const int magic = 65536 / U1 + 1;
@@ -417,8 +418,11 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
     const bool multi = env->cfg.env_kind == DCOMP_MULTI;
     const size_t obs_step = EU * (size_t)(multi ? 4 * env->cfg.num_bs + 1 : 2 * env->cfg.num_bs + 1);
     if (env->fused) {
+        // the kernel addresses step t's outputs as (idx + t * E * U) on the caller's base pointers with 32-bit row indices
+        if (every && (uint64_t)T * EU >= ((uint64_t)1 << 31)) return fail(DCOMP_EINVAL, "rollout fragment too long: num_steps * num_envs * num_ue must stay below 2^31 (split the rollout)");
         kp.action = actions; kp.num_steps = T; kp.out_every_step = every; kp.horizon = L; kp.episode_inc = inc; kp.policy_loop = loop;
-        hipLaunchKernelGGL(env->kern.rollout, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
+        // with a registered policy: the variant that carries the rules (next_action of every emitted step, the closed loop)
+        hipLaunchKernelGGL(kp.next_act ? env->kern.rollout_pol : env->kern.rollout, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
     }
     int time = env->time;
     int64_t episode = env->episode;

@@ -58,6 +58,18 @@
 #ifndef DCOMP_FORCE_KIND
 #define DCOMP_FORCE_KIND -1     // experiment: compile write_outputs for one env kind only (register-pressure bisection)
 #endif
+#ifndef DCOMP_SCALAR_DRAW
+#define DCOMP_SCALAR_DRAW 2    // Philox draws of the few redrawing lanes on the scalar unit (draw_triple_wave): 0 never, 1 every kernel, 2 fused rollout only
+#endif
+#ifndef DCOMP_MOVE_SELECTS
+#define DCOMP_MOVE_SELECTS 2   // move_ue as straight-line code with selects instead of branches: 0 never, 1 every kernel, 2 fused rollout only
+#endif
+#ifndef DCOMP_EXP_NO_RESET
+#define DCOMP_EXP_NO_RESET 0
+#endif
+#ifndef DCOMP_EXP_NO_TAPE
+#define DCOMP_EXP_NO_TAPE 0
+#endif
 #ifndef DCOMP_NT_STATE
 #define DCOMP_NT_STATE 0     // experiment: bit 0 non-temporal state loads, bit 1 non-temporal state stores
 #endif
@@ -277,6 +289,20 @@ __device__ __forceinline__ void stream_store(T *ptr, T v)
     *ptr = v;
 #endif
 }
+// N consecutive floats of one lane as 16-byte pieces + a remainder: global stores need dword alignment only, so a lane's run of
+// B or 4B+1 floats leaves as ceil(N / 4) store instructions instead of N -- what counts in the latency-bound fused rollout,
+// where every store instruction of 64 scattered 4-byte pieces occupies the memory pipeline as long as one of 64 x 16 bytes.
+template <int N>
+__device__ __forceinline__ void store_run(float *dst, const float (&v)[N])
+{
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+#pragma unroll
+    for (int i = 0; i + 4 <= N; i += 4) { f4u q; q.x = v[i]; q.y = v[i + 1]; q.z = v[i + 2]; q.w = v[i + 3]; *reinterpret_cast<f4u *>(dst + i) = q; }
+    constexpr int R = N & ~3;
+    if constexpr (N - R >= 2) { f2u q; q.x = v[R]; q.y = v[R + 1]; *reinterpret_cast<f2u *>(dst + R) = q; }
+    if constexpr ((N - R) & 1) dst[N - 1] = v[N - 1];
+}
 // LDS ops of one wave execute in order; this only stops the compiler from moving LDS accesses across it.
 __device__ __forceinline__ void wave_lds_fence()
 {
@@ -349,15 +375,18 @@ __shared__ double g_bs_lds[2 * DCOMP_MAX_BS];
 // `near_wave` (optional, wave-uniform): some lane of this wave is within NEAR_D2^(1/2) = 1.26 m of a BS.  That one test
 // triggers both rare fix-ups: the exact d + 1e-16 of a UE sitting ON a BS (here) and, in shared_rates, the rate of a pair
 // with snr > 1/64 (d < 1.24 m), which the short log1p series does not cover.
+// bsx / bsy (optional): the BS table in registers of the caller's choosing -- the fused rollout keeps it in VGPRs, see
+// step_kernel_body; nullptr: the kernel-argument segment (SGPRs).
 template <int B>
-__device__ __forceinline__ uint32_t eval_pairs(double px, double py, const KParams &p, float (&l2)[B], bool *near_wave = nullptr)
+__device__ __forceinline__ uint32_t eval_pairs(double px, double py, const KParams &p, float (&l2)[B], bool *near_wave = nullptr,
+                                               const double *bsx = nullptr, const double *bsy = nullptr)
 {
     uint32_t in_range = 0;
     bool anynear = false;
 #pragma unroll
     for (int b = 0; b < B; b++) {
         bool ir, near;
-        pair_eval(px, py, DCOMP_BSX(b), DCOMP_BSY(b), p, ir, l2[b], near);
+        pair_eval(px, py, bsx ? bsx[b] : DCOMP_BSX(b), bsy ? bsy[b] : DCOMP_BSY(b), p, ir, l2[b], near);
         in_range |= (uint32_t)ir << b;
         anynear |= near;
     }
@@ -366,8 +395,9 @@ __device__ __forceinline__ uint32_t eval_pairs(double px, double py, const KPara
     if (nw) {                                    // rare (~3 % of the wavefronts): a lane within 1.26 m of a BS
 #pragma unroll
         for (int b = 0; b < B; b++) {
-            float t = pair_eval_tiny(px, py, p.bs_x[b], p.bs_y[b], p);
-            double dx = p.bs_x[b] - px, dy = p.bs_y[b] - py;
+            const double bx = bsx ? bsx[b] : p.bs_x[b], by = bsy ? bsy[b] : p.bs_y[b];
+            float t = pair_eval_tiny(px, py, bx, by, p);
+            double dx = bx - px, dy = by - py;
             if ((float)__builtin_fma(dy, dy, dx * dx) < 1e-20f) l2[b] = t;
         }
     }
@@ -455,6 +485,42 @@ __device__ __forceinline__ void draw_triple(const KParams &p, int env, uint32_t 
         wy = bb + __umulhi(r[2], (uint32_t)(p.map_h - 2 * (int)bb + 1));
     }
 }
+// The same draw for the FEW lanes of a wavefront that redraw in a given step (a UE redraws once per leg of its walk: 1-2 of 64
+// lanes per step), on the SCALAR unit: the wave walks its redrawing lanes, reads the lane's counter words with v_readlane and
+// runs Philox on uniform values -- s_mul_hi_u32 / s_mul_i32 / s_xor_b32, which do not occupy the vector ALU -- then hands
+// the three results to that lane with v_cndmask.  The vector form (draw_triple under `if (redraw)`) issues the ~95 VALU
+// instructions of the ten rounds for the whole wave whenever ANY lane redraws, i.e. in most steps: 6-12 % of the step's VALU
+// work.  Same integers either way.  `redraw` may be false in every lane; lanes outside the caller's branch do not take part.
+template <bool SCALAR>
+__device__ __forceinline__ void draw_triple_wave(const KParams &p, int env, uint32_t uidw, uint32_t k, uint32_t episode, bool redraw,
+                                                 uint32_t &vel, uint32_t &wx, uint32_t &wy, int mcfg)
+{
+    if (!SCALAR || (!DCOMP_EXP_NO_TAPE && p.rng_mode == DCOMP_RNG_TAPE)) {           // host-drawn tape: a per-lane load
+        if (redraw) draw_triple(p, env, uidw, k, episode, vel, wx, wy, mcfg);
+        return;
+    }
+    const int lane = (int)(threadIdx.x & 63u);
+    unsigned long long need = __ballot(redraw);
+    while (need != 0ull) {                                   // uniform: one trip per redrawing lane
+        const int l = __ffsll((long long)need) - 1;
+        need &= need - 1ull;
+        // The key is uniform and loop-invariant, and so are the ten round keys derived from it: left alone, the compiler hoists the
+        // whole key schedule out of the step loop and parks it in 20 scalar registers the loop does not have.  Opaque copies keep
+        // the schedule where it is used (a few s_add per draw).
+        uint32_t k0 = p.seed_lo, k1 = p.seed_hi, eb = p.env_base;
+        asm volatile("" : "+s"(k0), "+s"(k1), "+s"(eb));
+        const uint32_t e_s = (uint32_t)__builtin_amdgcn_readlane(env, l), u_s = (uint32_t)__builtin_amdgcn_readlane((int)uidw, l);
+        const uint32_t k_s = (uint32_t)__builtin_amdgcn_readlane((int)k, l), m_s = (uint32_t)__builtin_amdgcn_readlane(mcfg, l);
+        uint32_t r[4] = {0x12345678u + k_s * 977u, 0x9abcdef0u ^ u_s * 2654435761u, 0x0fedcba9u + e_s * 40503u, 0u};
+        if (!(DCOMP_ABLATE & 128)) philox4x32_10(eb + e_s, ((u_s & 0x7FFFu) - 1u) | (u_s & UID_BORN), episode, k_s + 1u, k0, k1, r);
+        const uint32_t vlo = m_s & 0xFFu, vhi = (m_s >> 8) & 0xFFu, bb = (m_s >> 23) & 0xFFu;
+        const uint32_t v_s = vlo + __umulhi(r[0], vhi - vlo + 1u);                              // movement.py:112-117
+        const uint32_t x_s = bb + __umulhi(r[1], (uint32_t)(p.map_w - 2 * (int)bb + 1));        // movement.py:126-127
+        const uint32_t y_s = bb + __umulhi(r[2], (uint32_t)(p.map_h - 2 * (int)bb + 1));
+        const bool mine = lane == l;
+        vel = mine ? v_s : vel; wx = mine ? x_s : wx; wy = mine ? y_s : wy;
+    }
+}
 // Movement parameters of the UE with id word uidw when the caller does not hold them (UE lists that change: dcomp_dyn.h).
 __device__ __forceinline__ int load_mv_cfg(const KParams &p, uint32_t uidw)
 {
@@ -494,30 +560,53 @@ __device__ __forceinline__ void norm_and_unit(double vx, double vy, double &nrm,
 
 // One RandomWaypoint step in FP64, in the reference's operation order.  movement.py:132-181.
 // Contraction is off: the only fused op is the explicit fma of the 2-element dot product (numpy).
+// LAT (the fused rollout: latency-bound, one wave per SIMD, short of scalar registers): the redrawing lanes' Philox on the scalar
+// unit and straight-line code with selects -- in a wave of 64 UEs some lane takes every side of every branch in nearly every
+// step, so the branches only add exec-mask bookkeeping; lanes that stay put run the normalisation on a zero vector and
+// discard the NaNs.  The throughput-bound step kernels keep the branchy form with the vector Philox: measured on one box,
+// the LAT form costs them 1.5 % (config 3) to 5.7 % (65 536 x 10 x 5 central) -- their SIMDs have other waves to run while one
+// sits in a branch, and the scalar unit is shared by the four SIMDs of a CU.  Same FP64 operations, same results.
+template <bool LAT = false>
 __device__ __forceinline__ void move_ue(const KParams &p, int env, uint32_t uidw, uint32_t episode, double &px, double &py,
                                         unsigned long long &mv, int mcfg)
 {
 #pragma clang fp contract(off)
+    constexpr bool SCALAR = DCOMP_SCALAR_DRAW == 1 || (DCOMP_SCALAR_DRAW == 2 && LAT);
+    constexpr bool SELECTS = DCOMP_MOVE_SELECTS == 1 || (DCOMP_MOVE_SELECTS == 2 && LAT);
     uint32_t wxi = (uint32_t)(mv & 0xFFFF), wyi = (uint32_t)((mv >> 16) & 0xFFFF), vel = (uint32_t)((mv >> 32) & 0xFF);
     uint32_t pz = (uint32_t)((mv >> 40) & 0xFF), cursor = (uint32_t)(mv >> 48);
     uint32_t pausing = (pz >> 7) & 1, cp = pz & 0x7Fu;
     const uint32_t pause_dur = ((uint32_t)mcfg >> 16) & 0x7Fu;
     double wx = (double)wxi, wy = (double)wyi;
     if (px == wx && py == wy) pausing = 1;                          // movement.py:169-170
-    bool stay = false;
-    if (pausing) {
-        if (cp < pause_dur) { cp += 1; stay = true; }               // movement.py:172-175
-        else {                                                      // movement.py:176 -> reset()
-            draw_triple(p, env, uidw, cursor, episode, vel, wxi, wyi, mcfg);
-            cursor += 1; pausing = 0; cp = 0;
-            wx = (double)wxi; wy = (double)wyi;
-        }
-    }
-    if (!stay) {
-        // movement.py:142: `curr_pos.distance(waypoint) <= velocity` with distance = sqrt(dx*dx + dy*dy).
-        // sqrt is monotone and correctly rounded, so the test is `q <= qmax(vel)`, qmax = largest double whose
-        // rounded sqrt is <= vel: vel^2, plus one ulp when the mantissa m of vel has m < sqrt(2)
-        // (dcomp_create verifies this closed form against a brute-force sqrt table for vel = 0..255).
+    const bool stay = pausing && cp < pause_dur;                    // movement.py:172-175
+    const bool redraw = pausing && !stay;                           // movement.py:176 -> reset(): new velocity + waypoint, then move
+    cp = stay ? cp + 1u : cp;
+    draw_triple_wave<SCALAR>(p, env, uidw, cursor, episode, redraw, vel, wxi, wyi, mcfg);
+    cursor = redraw ? cursor + 1u : cursor;
+    pausing = redraw ? 0u : pausing;
+    cp = redraw ? 0u : cp;
+    wx = (double)wxi; wy = (double)wyi;                             // (unchanged unless redrawn)
+    // movement.py:142: `curr_pos.distance(waypoint) <= velocity` with distance = sqrt(dx*dx + dy*dy).
+    // sqrt is monotone and correctly rounded, so the test is `q <= qmax(vel)`, qmax = largest double whose
+    // rounded sqrt is <= vel: vel^2, plus one ulp when the mantissa m of vel has m < sqrt(2)
+    // (dcomp_create verifies this closed form against a brute-force sqrt table for vel = 0..255).
+    if (SELECTS) {
+        double dx = px - wx, dy = py - wy;
+        double q = dx * dx + dy * dy;
+        const uint32_t v2 = vel * vel;
+        double qmax = (double)v2;
+        const int e2 = 2 * (31 - __clz((int)(vel | 1u)));
+        const double ulp = __builtin_ldexp(1.0, e2 - 52);
+        qmax = (vel > 0u && v2 < (2u << e2)) ? qmax + ulp : qmax;
+        const bool snap = q <= qmax;                                // snap onto the waypoint
+        double vx = wx - px, vy = wy - py;
+        double nrm, nx, ny;
+        norm_and_unit(vx, vy, nrm, nx, ny);                         // np.linalg.norm, then two divisions (movement.py:151)
+        const double mx = px + (double)vel * nx, my = py + (double)vel * ny;
+        px = stay ? px : snap ? wx : mx;
+        py = stay ? py : snap ? wy : my;
+    } else if (!stay) {
         double dx = px - wx, dy = py - wy;
         double q = dx * dx + dy * dy;
         const uint32_t v2 = vel * vel;
@@ -534,7 +623,7 @@ __device__ __forceinline__ void move_ue(const KParams &p, int env, uint32_t uidw
             nrm = __builtin_sqrt(__builtin_fma(vy, vy, vx * vx));
             nx = vx / nrm; ny = vy / nrm;
 #else
-            norm_and_unit(vx, vy, nrm, nx, ny);                            // np.linalg.norm, then two divisions (movement.py:151)
+            norm_and_unit(vx, vy, nrm, nx, ny);                     // np.linalg.norm, then two divisions (movement.py:151)
 #endif
             px = px + (double)vel * nx;
             py = py + (double)vel * ny;
@@ -642,10 +731,14 @@ __device__ __noinline__ unsigned long long maxcap_rate_key(double pl_c1, double 
 //   in : conn mask, l2snr[b], ewma, (px,py) for the max-cap arg-min
 //   out: dr[b] (0 where not connected), cnt[b] = |S_b|
 // PRE: the unshared rates of the connected pairs were computed by the sparse pre-move pass and wait in the lane's LDS row `prow`.
-template <int B, int UPAD, int MP, class S = SegPadded, bool PRE = false>
+// CARRY (fused rollout): the UNSHARED rate of every station at the UE's current position is computed once per position -- by the
+// post-move call of step t (exported through `dru_io`, for all B stations, connected or not) and reused by the pre-move call of
+// step t + 1 (`dru_io` read: no exp2 / series at all): 1 = export, 2 = import.
+template <int B, int UPAD, int MP, class S = SegPadded, bool PRE = false, int CARRY = 0>
 __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, UPAD> &sh, uint32_t conn, const float (&l2)[B], float ewma,
                                              double px, double py, int u, int idx, int env_local, int wave, int lane, int gbase,
-                                             float (&dr)[B], float (&cnt)[B], int near_hint = -1, const S &sg = S{}, const float *prow = nullptr)
+                                             float (&dr)[B], float (&cnt)[B], int near_hint = -1, const S &sg = S{}, const float *prow = nullptr,
+                                             float *dru_io = nullptr)
 {
     // near_hint (wave-uniform): eval_pairs' "a lane of this wave is within 1.26 m of a BS" for the position l2 belongs to
     // (1 / 0), or -1 = unknown, then the per-pair snr > 1/64 test is made here.
@@ -659,7 +752,13 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
         unsigned long long m = __ballot(c);
         float dru = 0.f;
         if (PRE) dru = c ? prow[b] : 0.f;                  // entries of unconnected stations are never read
-        else if (m != 0ull) {                              // wave-uniform: skip BSs nobody in this wave is connected to
+        else if (CARRY == 2) dru = c ? dru_io[b] : 0.f;    // computed by the previous step's post-move call
+        else if (CARRY == 1) {                             // every station: the next step may connect to any of them
+            bool f;
+            const float t = rate_unshared_small(l2[b], f);
+            dru_io[b] = t;
+            dru = c ? t : 0.f;
+        } else if (m != 0ull) {                            // wave-uniform: skip BSs nobody in this wave is connected to
             bool f;
             const float t = rate_unshared_small(l2[b], f);
             dru = c ? t : 0.f;
@@ -668,10 +767,12 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
         dr[b] = dru;
         cnt[b] = (float)seg_popcount<G::WG>(m, gbase, sg);
     }
-    if (!PRE && (near_hint < 0 ? (__ballot(fix) != 0ull) : (near_hint != 0))) {   // rare: a connected UE closer than 1.24 m to its BS (snr > 1/64)
+    if (!PRE && CARRY != 2 && (near_hint < 0 ? (__ballot(fix) != 0ull) : (near_hint != 0))) {   // rare: a connected UE closer than 1.24 m to its BS (snr > 1/64)
 #pragma unroll
-        for (int b = 0; b < B; b++)
-            if (((conn >> b) & 1u) && l2[b] > RATE_SMALL_L2) dr[b] = rate_unshared_any(l2[b]);
+        for (int b = 0; b < B; b++) {
+            if (CARRY == 1) { if (l2[b] > RATE_SMALL_L2) { dru_io[b] = rate_unshared_any(l2[b]); if ((conn >> b) & 1u) dr[b] = dru_io[b]; } }
+            else if (((conn >> b) & 1u) && l2[b] > RATE_SMALL_L2) dr[b] = rate_unshared_any(l2[b]);
+        }
     }
 #pragma unroll
     for (int b = 0; b < B; b++) {
@@ -825,7 +926,10 @@ __device__ __forceinline__ int policy_action(const KParams &p, uint32_t conn, co
 // STAGED: observation rows go through LDS and leave as linear 16-byte stores (1 KiB contiguous per store instruction) -- what
 // a bandwidth-bound launch needs.  false: straight from registers; the fused rollout kernel, used for small batches with
 // one or two waves per SIMD, is latency-bound and the LDS round trips cost it 0.7 us per step (2.88 -> 2.21 us at 4 096 x 10 x 5).
-template <int B, int UPAD, bool RESET, bool DYN = false, bool STAGED = true, class S = SegPadded>
+// POL: the in-step heuristic policy (o.next_act / pol_next): -1 = decided at run time (one uniform branch), 0 = compiled out,
+// 1 = compiled in.  The fused rollout is instantiated both ways: it is latency-bound with one wave per SIMD, and the extra live
+// values of the run-time form cost the plain tape-driven rollout 8 % (round 2: 2.15 -> 2.33 us per step at 4 096 x 10 x 5).
+template <int B, int UPAD, bool RESET, bool DYN = false, bool STAGED = true, class S = SegPadded, int POL = -1>
 __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, BlockSharedT<B, UPAD> &sh, bool active, int env, int env_local, int u, int idx,
                                               int wave, int lane, int gbase, uint32_t conn, uint32_t in_range,
                                               float (&l2)[B], float (&cnt)[B], float util, float curr_dr,
@@ -921,9 +1025,9 @@ __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, B
         tsum[b] = live ? avg : 0.f;
         cnt[b] = live ? cnt[b] * inv_u : 0.f;                                                   // variants.py:296
     }
-    if (o.next_act) {                                               // uniform: heuristic policy on the entries just made
+    if (POL != 0 && (POL == 1 || o.next_act)) {                     // uniform: heuristic policy on the entries just made
         const int a = policy_action<B>(p, conn, l2);
-        if (active) o.next_act[idx] = (uint8_t)(live ? a : 0);
+        if (active && o.next_act) o.next_act[idx] = (uint8_t)(live ? a : 0);
         if (pol_next) *pol_next = live ? (uint32_t)a : 0u;
     }
     if ((DCOMP_ABLATE & 8) && kind == DCOMP_MULTI) {
@@ -933,15 +1037,16 @@ __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, B
     } else if (kind == DCOMP_MULTI && !STAGED) {
         if (active) {
             if (o.reward) o.reward[idx] = alive ? reward : 0.f;
-            float *row = o.obs + (size_t)idx * SG::ROW;
+            float rowv[SG::ROW];
 #pragma unroll
             for (int b = 0; b < B; b++) {
-                row[b] = (float)((conn >> b) & 1u);
-                row[B + b] = l2[b];
-                row[2 * B + b] = cnt[b];
-                row[3 * B + b] = tsum[b];
+                rowv[b] = (float)((conn >> b) & 1u);
+                rowv[B + b] = l2[b];
+                rowv[2 * B + b] = cnt[b];
+                rowv[3 * B + b] = tsum[b];
             }
-            row[4 * B] = util_n;
+            rowv[4 * B] = util_n;
+            store_run<SG::ROW>(o.obs + (size_t)idx * SG::ROW, rowv);       // the lane's 4B+1 consecutive floats
         }
     } else if (kind == DCOMP_MULTI) {
         if (active && o.reward) stream_store(&o.reward[idx], alive ? reward : 0.f);
@@ -1039,11 +1144,11 @@ __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, B
     } else if (active) {                                                       // envs wider than a wavefront: direct stores
         if (o.reward && u == 0) o.reward[env] = reward;
         float *base = o.obs + (size_t)env * U * (2 * B + 1);
+        float cv[B];
 #pragma unroll
-        for (int b = 0; b < B; b++) {
-            base[u * B + b] = (float)((conn >> b) & 1u);
-            base[U * B + u * B + b] = l2[b];
-        }
+        for (int b = 0; b < B; b++) cv[b] = (float)((conn >> b) & 1u);
+        store_run<B>(base + u * B, cv);                                        // the lane's B consecutive floats of each block
+        store_run<B>(base + U * B + u * B, l2);
         base[2 * U * B + u] = util_n;
     }
 }
@@ -1090,12 +1195,23 @@ __device__ __forceinline__ void store_state(const KParams &p, int idx, double px
 // The UE state is passed by reference and stays in registers; `emit` (uniform): write observation / reward / info to `o`.
 // STORE: write the state back BEFORE the outputs (plain step) -- position, movement word and EWMA are then dead while the
 // observation rows are staged, which is worth a wave per SIMD (73 vs 92 VGPRs at B = 10).
-template <int B, int UPAD, int MP, bool STORE, class S>
+// Pairs of a UE at its current position, carried from one step of the fused rollout to the next: a UE stands where the
+// previous step's move left it, so the post-move evaluation of step t (log2 snr of every station, in-range mask, "a lane of this
+// wave is near a station") IS the pre-move evaluation of step t + 1 -- the rollout kernel keeps it in registers instead of
+// redoing B pair evaluations (FP64 distance, log2) per UE and step.  A plain step cannot: the values would have to go through HBM.
+template <int B>
+struct PairCarry { float l2[B]; float dru[B]; uint32_t in_range; bool near; };   // dru: unshared rate per station (shared_rates CARRY)
+
+template <int B, int UPAD, int MP, bool STORE, class S, int POL = -1, bool CARRY = false>
 __device__ __forceinline__ void step_once(const KParams &p, BlockSharedT<B, UPAD> &sh, const Outs &o, bool emit, bool active, int env,
                                           int env_local, int u, int idx, int wave, int lane, int gbase, uint32_t act, uint32_t time,
                                           uint32_t episode, bool step_util, float dr_req, int vrange, double &px, double &py,
-                                          unsigned long long &mv, uint32_t &conn, float &ewma, const S &sg, uint32_t *pol_next = nullptr)
+                                          unsigned long long &mv, uint32_t &conn, float &ewma, const S &sg, uint32_t *pol_next = nullptr,
+                                          const double *bsx = nullptr, const double *bsy = nullptr, PairCarry<B> *carry = nullptr,
+                                          int env_shift = 0, int idx_shift = 0)
 {
+    // env_shift / idx_shift (uniform): where this step's outputs go in [T][...] fragment buffers -- the fused rollout writes step t
+    // at env + t * E / idx + t * E * U of the SAME base pointers (no per-step pointer arithmetic on seven 64-bit scalars)
     float l2[B], dr[B], cnt[B];
     uint32_t in_range = B >= 32 ? 0xFFFFFFFFu : ((1u << (B & 31)) - 1u);
     bool near_pre = false, near_post = false;
@@ -1136,7 +1252,11 @@ __device__ __forceinline__ void step_once(const KParams &p, BlockSharedT<B, UPAD
         shared_rates<B, UPAD, MP, S, true>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, 0, sg, prow);
     } else {
         // 1. pairs at the pre-move position
-        if (!(DCOMP_ABLATE & 32)) in_range = eval_pairs<B>(px, py, p, l2, &near_pre);
+        if (CARRY) {                                  // = the previous step's post-move pairs (fused rollout)
+#pragma unroll
+            for (int b = 0; b < B; b++) l2[b] = carry->l2[b];
+            in_range = carry->in_range; near_pre = carry->near;
+        } else if (!(DCOMP_ABLATE & 32)) in_range = eval_pairs<B>(px, py, p, l2, &near_pre, bsx, bsy);
         else { for (int b = 0; b < B; b++) l2[b] = -20.f; }
         // 2. toggle (base.py:247-263 -> user.py:190-222)
         if (act > 0) {
@@ -1148,7 +1268,8 @@ __device__ __forceinline__ void step_once(const KParams &p, BlockSharedT<B, UPAD
             }
         }
         // 3. rates before the move (base.py:446) -> reward_before (base.py:158-167)
-        if (!(DCOMP_ABLATE & 1)) shared_rates<B, UPAD, MP, S>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, (int)near_pre, sg);
+        if (CARRY) shared_rates<B, UPAD, MP, S, false, 2>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, (int)near_pre, sg, nullptr, carry->dru);
+        else if (!(DCOMP_ABLATE & 1)) shared_rates<B, UPAD, MP, S>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, (int)near_pre, sg);
         else { for (int b = 0; b < B; b++) { dr[b] = 1.f; cnt[b] = 1.f; } }
     }
     float curr = 0.f;
@@ -1158,27 +1279,36 @@ __device__ __forceinline__ void step_once(const KParams &p, BlockSharedT<B, UPAD
     const float reward_before = clamp_med3(util_pre, MIN_UTIL, MAX_UTIL) * (1.0f / MAX_UTIL);
     // 4. move (base.py:447 -> user.py:159-173)
     if (active && !(DCOMP_ABLATE & 2)) {
-        move_ue(p, env, (uint32_t)u + 1u, episode, px, py, mv, vrange);
+        move_ue<!STORE>(p, env, (uint32_t)u + 1u, episode, px, py, mv, vrange);       // !STORE = the fused rollout
         if (px < 0.0 || py < 0.0 || px > (double)p.map_w || py > (double)p.map_h) atomicOr(p.flags, DCOMP_FLAG_OUTSIDE_MAP);
     }
     // 5. pairs at the new position; drop lost connections (user.py:175-188); EWMA from the stale rates (user.py:148-157)
-    if (!(DCOMP_ABLATE & 64)) in_range = eval_pairs<B>(px, py, p, l2, &near_post);
+    if (!(DCOMP_ABLATE & 64)) in_range = eval_pairs<B>(px, py, p, l2, &near_post, bsx, bsy);
+    if (CARRY) {
+#pragma unroll
+        for (int b = 0; b < B; b++) carry->l2[b] = l2[b];
+        carry->in_range = in_range; carry->near = near_post;
+    }
     conn &= in_range;
     float stale = 0.f;
 #pragma unroll
     for (int b = 0; b < B; b++) stale += ((conn >> b) & 1u) ? dr[b] : 0.f;
     ewma = __builtin_fmaf(0.9f, stale, 0.1f * ewma);   // one explicit contraction: every kernel variant rounds alike
     // 6. rates after the move (base.py:451)
-    if (!(DCOMP_ABLATE & 4)) shared_rates<B, UPAD, MP, S>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, (int)near_post, sg);
+    if (CARRY) shared_rates<B, UPAD, MP, S, false, 1>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, (int)near_post, sg, nullptr, carry->dru);
+    else if (!(DCOMP_ABLATE & 4)) shared_rates<B, UPAD, MP, S>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, (int)near_post, sg);
     curr = 0.f;
 #pragma unroll
     for (int b = 0; b < B; b++) curr += dr[b];
     const float util = ue_utility(curr, step_util, dr_req);
     if (STORE && active) store_state(p, idx, px, py, mv, conn, ewma);
     // 7. observation, reward, info
-    if (emit)
-        write_outputs<B, UPAD, false, false, STORE, S>(p, o, sh, active, env, env_local, u, idx, wave, lane, gbase, conn, in_range, l2, cnt,
-                                                    util, curr, reward_before, active, p.U, sg, pol_next);
+    if (emit) {
+        Outs o2 = o;                                  // next_action is ONE [E][U] buffer, not a [T][...] fragment: undo the shift for it
+        if (POL != 0 && o2.next_act) o2.next_act -= idx_shift;
+        write_outputs<B, UPAD, false, false, STORE, S, POL>(p, o2, sh, active, env + env_shift, env_local, u, idx + idx_shift, wave, lane, gbase, conn,
+                                                         in_range, l2, cnt, util, curr, reward_before, active, p.U, sg, pol_next);
+    }
 }
 
 // MobileEnv.step for all envs: one launch = one step.  ROLLOUT = true is the fused rollout: p.num_steps consecutive steps
@@ -1186,7 +1316,17 @@ __device__ __forceinline__ void step_once(const KParams &p, BlockSharedT<B, UPAD
 // boundary, no state round trip through HBM, no host launch per step (the loop this replaces: simulation.py:512-541).
 // Two instantiations on purpose: with the step loop around it the compiler hoists the kernel-argument loads (BS table) out
 // of the loop and spills them (73 -> 163 VGPRs, 0.081 -> 0.099 ms at config 3), so the plain step keeps its loop-free code.
-template <int B, int UPAD, int MP, bool ROLLOUT, bool TIGHT = false>
+// A uniform value the compiler must keep in a VECTOR register: the asm hides that every lane holds the same bits.  The fused
+// rollout's step loop wants ~110 scalar registers (kernel-argument pointers and constants, the BS table, loop counters, saved
+// exec masks of the divergent branches) and has 102: the compiler spilled 93 of them into VGPR lanes and paid a v_readlane /
+// v_writelane for every use inside the loop.  The kernel runs at <= 4 waves per SIMD, where VGPRs are free up to 128.
+__device__ __forceinline__ double in_vgpr(double v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+template <int B, int UPAD, int MP, bool ROLLOUT, bool TIGHT = false, int POL = -1>
 __device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<B, UPAD> &sh)
 {
     using G = Geo<B, UPAD>;
@@ -1247,7 +1387,7 @@ __device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<
             vrange = mv_cfg_pack(c.vel_lo, c.vel_hi, c.pause, c.border);
         }
     }
-    Outs o{p.obs, p.reward, p.sum_util, p.ue_dr, p.ue_util, p.rb_out, p.next_act};
+    Outs o{p.obs, p.reward, p.sum_util, p.ue_dr, p.ue_util, p.rb_out, POL == 0 ? nullptr : p.next_act};
     if (!ROLLOUT) {
         step_once<B, UPAD, MP, true>(p, sh, o, true, active, env, env_local, u, idx, wave, lane, gbase, act, p.time, p.episode, step_util, dr_req,
                                vrange, px, py, mv, conn, ewma, sg);
@@ -1255,11 +1395,26 @@ __device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<
         const int T = p.num_steps;
         const size_t EU = (size_t)p.E * p.U;
         uint32_t time = p.time, episode = p.episode;
+        double bsx[B], bsy[B];                                     // the BS table in VGPRs (see in_vgpr)
+#pragma unroll
+        for (int b = 0; b < B; b++) { bsx[b] = in_vgpr(p.bs_x[b]); bsy[b] = in_vgpr(p.bs_y[b]); }
+        PairCarry<B> carry;
+        auto refresh_carry = [&]() {                               // pairs + unshared rates at the position the state holds
+            carry.in_range = eval_pairs<B>(px, py, p, carry.l2, &carry.near, bsx, bsy);
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                bool f;
+                carry.dru[b] = rate_unshared_small(carry.l2[b], f);
+                if (f) carry.dru[b] = rate_unshared_any(carry.l2[b]);       // (per lane; once per launch / episode)
+            }
+        };
+        refresh_carry();
         // Actions: 8 steps' bytes per lane are fetched at a time, one chunk ahead.  A load per step would make every step
         // wait for its own HBM round trip -- and, vmcnt being one in-order counter for loads and stores, for the previous
         // step's observation stores to drain.
         const uint8_t *actp = p.action + (active ? idx : 0);      // idle lanes read a valid byte, masked below: no exec-masked blocks
-        const int TT = p.policy_loop ? 1 : T;                      // closed loop: the tape is actions[0] only
+        const bool ploop = POL != 0 && p.policy_loop;               // closed loop: steps 1..T-1 act on the policy's own decision
+        const int TT = ploop ? 1 : T;                              // ... the tape is actions[0] only
         uint32_t pol_next = 0u;                                    // the registered policy's action on the observation of step t-1
         uint32_t nb[8];                                            // the NEXT chunk's bytes, still in flight
         auto load_chunk = [&](int t0) {                            // 8 independent loads (steps past T re-read the last one)
@@ -1268,13 +1423,15 @@ __device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<
         };
         load_chunk(0);
         unsigned long long act_cur = 0ull;
+        int env_shift = 0, idx_shift = 0;                          // (dcomp_rollout_ex keeps T * E * U below 2^31)
 #pragma unroll 1
         for (int t = 0; t < T; t++) {
-            if (p.horizon > 0 && time == (uint32_t)p.horizon) {    // RLlib's horizon (env_setup.py:281): reset(), then step
+            if (!DCOMP_EXP_NO_RESET && p.horizon > 0 && time == (uint32_t)p.horizon) {    // RLlib's horizon (env_setup.py:281): reset(), then step
                 episode += p.episode_inc;
                 time = 0;
                 conn = 0u; ewma = 0.f;
                 if (active) reset_ue(p, env, u, episode, px, py, mv);
+                refresh_carry();
             }
             if ((t & 7) == 0) {                                    // first use of the bytes requested 8 steps ago; request the next 8
                 const uint32_t lo = nb[0] | (nb[1] << 8) | (nb[2] << 16) | (nb[3] << 24), hi = nb[4] | (nb[5] << 8) | (nb[6] << 16) | (nb[7] << 24);
@@ -1282,19 +1439,12 @@ __device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<
                 load_chunk(t + 8);
             }
             act = active ? (uint32_t)(act_cur >> (8 * (t & 7))) & 0xFFu : 0u;
-            if (p.policy_loop && t > 0) act = active ? pol_next : 0u;
-            step_once<B, UPAD, MP, false, S>(p, sh, o, p.out_every_step || t == T - 1 || p.policy_loop, active, env, env_local, u, idx, wave, lane,
-                                   gbase, act, time, episode, step_util, dr_req, vrange, px, py, mv, conn, ewma, sg, &pol_next);
+            if (ploop && t > 0) act = active ? pol_next : 0u;
+            step_once<B, UPAD, MP, false, S, POL, true>(p, sh, o, p.out_every_step || t == T - 1 || ploop, active, env, env_local, u, idx, wave, lane,
+                                                        gbase, act, time, episode, step_util, dr_req, vrange, px, py, mv, conn, ewma, sg,
+                                                        POL != 0 ? &pol_next : nullptr, bsx, bsy, &carry, env_shift, idx_shift);
             time += 1;
-            if (p.out_every_step) {                                  // outputs of step t -> [T][...] buffers
-                const bool multi = p.kind == DCOMP_MULTI;
-                o.obs += EU * (size_t)(multi ? 4 * B + 1 : 2 * B + 1);
-                if (o.reward) o.reward += multi ? EU : (size_t)p.E;
-                if (o.sum_util) o.sum_util += p.E;
-                if (o.ue_dr) o.ue_dr += EU;
-                if (o.ue_util) o.ue_util += EU;
-                if (o.rb_out) o.rb_out += EU;
-            }
+            if (p.out_every_step) { env_shift += p.E; idx_shift += (int)EU; }   // outputs of step t + 1 -> the next slice of the [T][...] buffers
             // the max-cap and 'sum'-reward scratch of the next step aliases the observation staging other waves may still be copying out
             if ((MP == MP_GENERIC && p.any_maxcap) || (p.kind == DCOMP_MULTI && p.reward_agg == DCOMP_REWARD_SUM)) __syncthreads();
         }
@@ -1322,11 +1472,13 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel_tight(const KParams p
     step_kernel_body<B, UPAD, MP, false, true>(p, sh);
 }
 
-template <int B, int UPAD, int MP>
+// POL = 0: the action-tape rollout (no policy code in it); POL = 1: with a registered heuristic policy -- next_action of every
+// emitted step and, with policy_loop, the closed loop act = policy(obs); step(act) inside the launch.
+template <int B, int UPAD, int MP, int POL>
 __global__ __launch_bounds__(DCOMP_BLOCK) void rollout_kernel(const KParams p)
 {
     __shared__ BlockSharedT<B, UPAD> sh;
-    step_kernel_body<B, UPAD, MP, true>(p, sh);
+    step_kernel_body<B, UPAD, MP, true, false, POL>(p, sh);
 }
 
 // MobileEnv.reset (base.py:169-189): user.py:98-116 + movement.py:110-122 + first observation.
@@ -1382,7 +1534,7 @@ namespace dcomp {
 using KernelFn = void (*)(const KParams);
 // step_wide: organisation for envs of >= 64 lanes (dcomp_wide.h); nullptr for narrower envs.  It has no max-cap
 // path, the host falls back to `step` when a BS is max-cap.
-struct KernelPair { KernelFn step, reset, step_wide, step_dyn, rollout, step_tight; };   // step_dyn: UEs arrive / depart (dcomp_dyn.h), UPAD <= 64
+struct KernelPair { KernelFn step, reset, step_wide, step_dyn, rollout, step_tight, rollout_pol; };   // step_dyn: UEs arrive / depart (dcomp_dyn.h), UPAD <= 64
 
 template <int B, int UPAD, int MP>
 inline KernelFn wide_or_null()
@@ -1393,14 +1545,14 @@ inline KernelFn wide_or_null()
     else return nullptr;
 }
 
-template <int B, int UPAD, int MP>
+template <int B, int UPAD, int MP, int POL = 0>
 inline KernelFn rollout_or_null()
 {
     // The fused rollout serves small batches (dcomp_create: <= 4 waves per SIMD).  Not instantiated where it is never or hardly
     // ever picked -- shapes the wide kernel takes over, envs of more than one wavefront -- those are also the costly ones to
     // build; dcomp_rollout then launches the step kernel once per step (same results).
     if constexpr (UPAD > 64 || (UPAD >= 64 && B > DCOMP_WIDE_MIN_B)) return nullptr;
-    else return rollout_kernel<B, UPAD, MP>;
+    else return rollout_kernel<B, UPAD, MP, POL>;
 }
 
 template <int B, int UPAD, int MP>
@@ -1424,11 +1576,11 @@ inline KernelPair make_pair_(int mp)
     // narrow variants would never be launched there and are the most expensive instantiations of the build: left out.
     if constexpr (UPAD >= 64 && B > DCOMP_WIDE_MIN_B) {
         const KernelFn w = mp == MP_RES_FAIR ? wide_or_null<B, UPAD, MP_RES_FAIR>() : mp == MP_MIXED ? wide_or_null<B, UPAD, MP_MIXED>() : wide_or_null<B, UPAD, MP_GENERIC>();
-        return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, w, dyn_or_null<B, UPAD>(), nullptr, nullptr};
+        return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, w, dyn_or_null<B, UPAD>(), nullptr, nullptr, nullptr};
     } else {
-    if (mp == MP_RES_FAIR) return KernelPair{step_kernel<B, UPAD, MP_RES_FAIR>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_RES_FAIR>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_GENERIC>(), tight_or_null<B, UPAD, MP_GENERIC>()};   // (all-resource-fair: the generic variants, run-time modes, serve the fused rollout and the tight packing -- build time)
-    if (mp == MP_MIXED) return KernelPair{step_kernel<B, UPAD, MP_MIXED>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_MIXED>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_MIXED>(), tight_or_null<B, UPAD, MP_MIXED>()};
-    return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_GENERIC>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_GENERIC>(), tight_or_null<B, UPAD, MP_GENERIC>()};
+    if (mp == MP_RES_FAIR) return KernelPair{step_kernel<B, UPAD, MP_RES_FAIR>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_RES_FAIR>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_GENERIC>(), tight_or_null<B, UPAD, MP_GENERIC>(), rollout_or_null<B, UPAD, MP_GENERIC, 1>()};   // (all-resource-fair: the generic variants, run-time modes, serve the fused rollout and the tight packing -- build time)
+    if (mp == MP_MIXED) return KernelPair{step_kernel<B, UPAD, MP_MIXED>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_MIXED>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_MIXED>(), tight_or_null<B, UPAD, MP_MIXED>(), rollout_or_null<B, UPAD, MP_MIXED, 1>()};
+    return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_GENERIC>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_GENERIC>(), tight_or_null<B, UPAD, MP_GENERIC>(), rollout_or_null<B, UPAD, MP_GENERIC, 1>()};
     }
 }
 
@@ -1447,7 +1599,7 @@ inline KernelPair kernels_for_upad(int upad, int mp)
     case 64: return make_pair_<B, 64>(mp);
     case 128: return make_pair_<B, 128>(mp);
     case 256: return make_pair_<B, 256>(mp);
-    default: return KernelPair{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    default: return KernelPair{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     }
 #endif
 }
