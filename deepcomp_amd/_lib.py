@@ -46,7 +46,8 @@ class DcompTape(ctypes.Structure):
 
 class DcompRolloutOpts(ctypes.Structure):
     _fields_ = [('every_step', ctypes.c_int32), ('horizon', ctypes.c_int32), ('new_episode_draws', ctypes.c_int32),
-                ('policy_loop', ctypes.c_int32)]
+                ('policy_loop', ctypes.c_int32), ('ev_n_remove', ctypes.c_void_p), ('ev_n_add', ctypes.c_void_p),
+                ('ev_remove_idx', ctypes.c_void_p), ('ev_add_xy', ctypes.c_void_p)]
 
 
 class DcompEvents(ctypes.Structure):

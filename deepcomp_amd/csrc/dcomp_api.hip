@@ -389,8 +389,8 @@ extern "C" int dcomp_step_dyn(dcomp_env *env, const dcomp_state *st, const uint8
 extern "C" int dcomp_num_ue(const dcomp_env *env) { return env ? env->cur_ue : -1; }
 
 // T consecutive steps.  step_kernel runs them in ONE launch (state in registers in between); the wide and the dynamic-UE
-// kernels are launched once per step.  Same results either way, and the same as T dcomp_step calls (+ dcomp_reset calls
-// at the horizon).
+// kernels are launched once per step.  Same results either way, and the same as T dcomp_step / dcomp_step_dyn calls (+
+// dcomp_reset calls at the horizon).
 static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *actions, int32_t T, const dcomp_out *out,
                         const dcomp_rollout_opts *opts, void *stream)
 {
@@ -401,54 +401,110 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
     if (env->episode < 0) return fail(DCOMP_EINVAL, "rollout() before reset()");
     const int L = opts ? opts->horizon : 0, every = opts ? (opts->every_step != 0) : 0;
     const uint32_t inc = (opts && opts->new_episode_draws) ? 1u : 0u;
+    const int32_t *ev_rem = opts ? opts->ev_n_remove : nullptr, *ev_add = opts ? opts->ev_n_add : nullptr;
+    const bool tape = env->cfg.rng_mode == DCOMP_RNG_TAPE;
     if (L < 0 || L > 65536) return fail(DCOMP_EINVAL, "horizon must be 0 (none) .. 65536");
     if (L > 0) {
-        if (env->dyn) return fail(DCOMP_EUNSUPPORTED, "in-rollout reset: not with UE arrival / departure (the event schedule is fed per step)");
         if (env->time > L) return fail(DCOMP_EINVAL, "env.time %d is already beyond the horizon %d", env->time, L);
-        if (env->cfg.rng_mode == DCOMP_RNG_TAPE && inc) return fail(DCOMP_EINVAL, "tape mode replays the borrowed tape: only fixed episodes can reset inside a rollout");
+        if (tape && inc) return fail(DCOMP_EINVAL, "tape mode replays the borrowed tape: only fixed episodes can reset inside a rollout");
+        if (tape && env->dyn) return fail(DCOMP_EUNSUPPORTED, "tape mode with UE arrival / departure: every episode needs its own host-drawn tape "
+                                                              "(the reference re-seeds UEs by list position at reset, base.py:171-173); dcomp_reset between rollouts");
     } else if ((rc = check_horizon(env, T))) return rc;
-    if (env->dyn && every) return fail(DCOMP_EUNSUPPORTED, "every_step: not with UE arrival / departure");
+    if (!env->dyn && (ev_rem || ev_add)) return fail(DCOMP_EINVAL, "handle was created without max_ues (fixed UE list): no arrival / departure events");
     const bool loop = opts && opts->policy_loop != 0;
     if (loop) {
         if (!env->kp.next_act) return fail(DCOMP_EINVAL, "policy_loop needs a policy (dcomp_set_policy)");
         if (!env->fused) return fail(DCOMP_EUNSUPPORTED, "policy_loop needs the fused rollout kernel (dcomp_rollout_is_fused)");
-        if (L > 0 && env->time + T > L) return fail(DCOMP_EINVAL, "policy_loop must not cross the horizon (%d + %d > %d): dcomp_reset, then continue", env->time, T, L);
     }
     const size_t EU = (size_t)env->cfg.num_envs * env->cap, E = (size_t)env->cfg.num_envs;
     const bool multi = env->cfg.env_kind == DCOMP_MULTI;
     const size_t obs_step = EU * (size_t)(multi ? 4 * env->cfg.num_bs + 1 : 2 * env->cfg.num_bs + 1);
+    auto out_slice = [&](KParams &k, int t) {                  // where step t's outputs go
+        if (!every) return;
+        k.obs = out->obs + obs_step * t;
+        if (out->reward) k.reward = out->reward + (multi ? EU : E) * t;
+        if (out->sum_utility) k.sum_util = out->sum_utility + E * t;
+        if (out->ue_dr) k.ue_dr = out->ue_dr + EU * t;
+        if (out->ue_utility) k.ue_util = out->ue_utility + EU * t;
+        if (out->reward_before) k.rb_out = out->reward_before + EU * t;
+    };
+    auto launch_reset = [&](KParams &k) {                      // MobileEnv.reset at the horizon (base.py:169-189); its observation lands
+        env->time = 0;                                         // where the next step's will (and is overwritten by it)
+        env->episode += inc;
+        env->cur_ue = env->cfg.num_ue; env->n_removed = env->n_arrived = 0;
+        k.cur_ue = env->cur_ue;
+        k.episode = (uint32_t)env->episode;
+        k.time = 0u;
+        hipLaunchKernelGGL(env->kern.reset, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, k);
+    };
     if (env->fused) {
         // the kernel addresses step t's outputs as (idx + t * E * U) on the caller's base pointers with 32-bit row indices
         if (every && (uint64_t)T * EU >= ((uint64_t)1 << 31)) return fail(DCOMP_EINVAL, "rollout fragment too long: num_steps * num_envs * num_ue must stay below 2^31 (split the rollout)");
-        kp.action = actions; kp.num_steps = T; kp.out_every_step = every; kp.horizon = L; kp.episode_inc = inc; kp.policy_loop = loop;
-        // with a registered policy: the variant that carries the rules (next_action of every emitted step, the closed loop)
-        hipLaunchKernelGGL(kp.next_act ? env->kern.rollout_pol : env->kern.rollout, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
-    }
-    int time = env->time;
-    int64_t episode = env->episode;
-    for (int t = 0; t < T; t++) {
-        const bool do_reset = L > 0 && time == L;
-        if (do_reset) { time = 0; episode += inc; }
-        if (!env->fused) {
-            if (every) {
-                kp.obs = out->obs + obs_step * t;
-                if (out->reward) kp.reward = out->reward + (multi ? EU : E) * t;
-                if (out->sum_utility) kp.sum_util = out->sum_utility + E * t;
-                if (out->ue_dr) kp.ue_dr = out->ue_dr + EU * t;
-                if (out->ue_utility) kp.ue_util = out->ue_utility + EU * t;
-                if (out->reward_before) kp.rb_out = out->reward_before + EU * t;
+        const dcomp::KernelFn kern = kp.next_act ? env->kern.rollout_pol : env->kern.rollout;   // with a registered policy: the variant that carries the rules
+        if (!loop || L == 0 || env->time + T <= L) {
+            // ONE launch; resets at the horizon of a tape-driven rollout happen inside the kernel
+            kp.action = actions; kp.num_steps = T; kp.out_every_step = every; kp.horizon = L; kp.episode_inc = inc; kp.policy_loop = loop;
+            hipLaunchKernelGGL(kern, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
+            int time = env->time;
+            int64_t episode = env->episode;
+            for (int t = 0; t < T; t++) {
+                if (L > 0 && time == L) { time = 0; episode += inc; }
+                time += 1;
             }
-            kp.episode = (uint32_t)episode;
-            if (do_reset) hipLaunchKernelGGL(env->kern.reset, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
-            kp.action = actions + EU * t;
-            kp.time = (uint32_t)time;
-            launch_step(env, kp, stream);
+            env->time = time;
+            env->episode = episode;
+        } else {
+            // Closed loop across episode boundaries: one launch per stretch of an episode; at the horizon the reset kernel computes
+            // the first observation of the new episode and the policy's action on it (next_action), which the next stretch starts from.
+            const uint8_t *act_src = actions;
+            for (int t = 0; t < T;) {
+                if (env->time == L) {
+                    out_slice(kp, t);
+                    launch_reset(kp);
+                    act_src = kp.next_act;
+                }
+                const int n = T - t < L - env->time ? T - t : L - env->time;
+                out_slice(kp, t);
+                kp.action = act_src; kp.num_steps = n; kp.out_every_step = every; kp.horizon = 0; kp.episode_inc = 0; kp.policy_loop = 1;
+                kp.time = (uint32_t)env->time; kp.episode = (uint32_t)env->episode;
+                hipLaunchKernelGGL(kern, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
+                env->time += n;
+                t += n;
+                act_src = kp.next_act;                             // (a lane reads its slot before it writes it)
+            }
         }
-        time += 1;
+        HIP_TRY(hipGetLastError());
+        return DCOMP_OK;
+    }
+    // one launch per step: wide envs, envs whose UE list changes (event feed), batches too large for the latency-optimised kernel
+    size_t rem_off = 0, add_off = 0;
+    for (int t = 0; t < T; t++) {
+        out_slice(kp, t);
+        if (L > 0 && env->time == L) launch_reset(kp);
+        kp.episode = (uint32_t)env->episode;
+        kp.action = actions + EU * t;
+        kp.time = (uint32_t)env->time;
+        kp.n_remove = kp.n_add = 0;
+        if (env->dyn) {                                            // base.py:433-443: this step's departures / arrivals
+            const int nrem = ev_rem ? ev_rem[t] : 0, nadd = ev_add ? ev_add[t] : 0;
+            if (nrem < 0 || nadd < 0 || (nrem > 0 && nadd > 0)) return fail(DCOMP_EINVAL, "step %d: one step either adds or removes UEs (base.py:436-443)", t);
+            if (env->cur_ue - nrem < 1) return fail(DCOMP_EINVAL, "step %d: cannot remove %d of %d UEs", t, nrem, env->cur_ue);
+            if (env->cur_ue + nadd > env->cap) return fail(DCOMP_EINVAL, "step %d: %d + %d UEs exceed max_ues = %d", t, env->cur_ue, nadd, env->cap);
+            if (tape && ((nrem && !opts->ev_remove_idx) || (nadd && !opts->ev_add_xy)))
+                return fail(DCOMP_EINVAL, "tape mode: events need the host-drawn indices / border points");
+            kp.cur_ue = env->cur_ue;
+            kp.n_remove = nrem; kp.n_add = nadd;
+            kp.ev_remove = (tape && nrem) ? opts->ev_remove_idx + rem_off : nullptr;
+            kp.ev_add_xy = (tape && nadd) ? opts->ev_add_xy + add_off : nullptr;
+            kp.ev_rem_base = env->n_removed; kp.ev_add_base = env->n_arrived;
+            rem_off += E * (size_t)nrem; add_off += E * (size_t)nadd * 2;
+            env->cur_ue += nadd - nrem;
+            env->n_removed += (uint32_t)nrem; env->n_arrived += (uint32_t)nadd;
+        }
+        launch_step(env, kp, stream);
+        env->time += 1;
     }
     HIP_TRY(hipGetLastError());
-    env->time = time;
-    env->episode = episode;
     return DCOMP_OK;
 }
 

@@ -4,149 +4,112 @@
 // Same semantics as step_kernel; different organisation, because with B = 32 fully unrolled register arrays
 // (log2 snr, rates, counts, sums: 5 x 32 VGPRs) cap occupancy at 2 waves/SIMD:
 //   * one wavefront holds UEs of ONE env, so everything per (env, BS) -- connected-UE count, sum 1/rate, sum
-//     priority, sum utility -- is wave-uniform: it lives in scalar registers / LDS tables, not in per-lane arrays;
-//   * the BS loop is a real loop over chunks of BC = 3 or 4 stations (not unrolled over B: bounded registers and code size); the
-//     post-move log2 snr of all B stations is parked in the lane's own LDS row, which later becomes the `dr` transpose;
-//   * the move is done FIRST (it does not depend on rates), so one sweep over the BS chunks can evaluate the pre-move
-//     pair, the post-move pair, the toggle, the pre-move rate, the drop and the stale-rate EWMA term of a station
-//     together (user.py:148-188), without keeping B pre-move rates alive;
+//     priority, sum utility -- is wave-uniform per station: it lives in small LDS tables, not in per-lane arrays;
+//   * every lane owns a ROW of B floats in LDS (`strow`): first the unshared rates at the stations it is connected to
+//     before the move, then the post-move log2 snr of all B stations, in between the unshared rates after the move, at the
+//     end the normalised `dr` observation entries, which the row-by-row observation stores read column-wise (the transpose);
+//   * rates are SPARSE: a UE is connected to 1-4 of the 32 stations, and only there does a rate exist.  Each lane walks its own
+//     set bits (per-lane station index; BS position, per-station totals from LDS tables) for the pair / rate evaluation at the
+//     pre-move position, for the rate series after the move and for the final shared rates;
+//   * per-station sums over an env's UEs are TRANSPOSED: lane l owns station l & 31 and adds up the rows of its own half-wave
+//     (conflict-free column reads of the rows, broadcast reads of the row's connection mask); halves are combined with one
+//     cross-lane move, the waves of an env through a per-wave table and ONE workgroup barrier per sum (three per step: rates
+//     before the move, rates after the move, utilities).  Round 2 swept the stations in chunks of 6 with a 64-lane butterfly per
+//     station and sum (12 barriers, ~1 400 of the kernel's 2 800 VALU instructions per wave);
+//   * the only dense per-station work left is what the observation format makes irreducible: the post-move pair evaluation of
+//     all B stations (every station's relative SNR is an observation entry) and the row stores;
 //   * observation rows (4B+1 floats, 516 B at B = 32) are written row by row: lane c owns column c, c+64, c+128; the
-//     per-env columns (ues_at_bs, util_at_bs) are preloaded once per lane from an LDS table, the per-UE `dr` columns
-//     come from an LDS transpose, `connected` / `utility` of row r are wave-uniform (v_readlane).  Every store
-//     instruction writes 256 contiguous bytes.
+//     per-env columns (ues_at_bs, util_at_bs) are preloaded once per lane, the per-UE `dr` columns come from the rows in LDS,
+//     `connected` / `utility` of row r are wave-uniform (v_readlane).  Every store instruction writes 256 contiguous bytes.
 #pragma once
 #include <type_traits>
 
 namespace dcomp {
 
-#ifndef DCOMP_WIDE_BC
-#define DCOMP_WIDE_BC 4
+#ifndef DCOMP_WIDE_PC
+#define DCOMP_WIDE_PC 8          // stations per trip of the dense post-move pair evaluation (BS positions: one s_load burst per trip)
 #endif
-#ifndef DCOMP_WIDE_BC_MIXED
-#define DCOMP_WIDE_BC_MIXED 6
+#ifndef DCOMP_WIDE_K
+#define DCOMP_WIDE_K 4           // connections per UE the register fast paths hold; a wave with a busier UE takes the LDS detours
 #endif
-constexpr int WIDE_BC = DCOMP_WIDE_BC;
-constexpr int WIDE_BC_MAX = DCOMP_WIDE_BC_MIXED > DCOMP_WIDE_BC ? DCOMP_WIDE_BC_MIXED : DCOMP_WIDE_BC;   // BSs per chunk: 4 -> ~100 VGPRs (4-5 waves/SIMD), 8 -> ~145 (3 waves/SIMD)
-// The CLI-default 'mixed' pattern cycles resource- / rate- / proportional-fair with the station index: chunks of THREE make the
-// model of every chunk slot a compile-time constant (no scalar mode tests and branches per station): 0.1021 -> 0.0926 ms at config
-// 5's per-GPU share.  The other patterns are faster with 4 (resource-fair 0.077 vs 0.086 ms, generic 0.105 vs 0.115 ms).
-constexpr int wide_bc(int mp) { return mp == MP_MIXED ? DCOMP_WIDE_BC_MIXED : WIDE_BC; }
 
 template <int B, int UPAD>
 struct alignas(16) WideShared {
-    float drst[4][64 * (B + 1)];          // per-wave transpose of the per-UE `dr` observation (row stride B+1: conflict-free)
-    float xw[2][4][2 * WIDE_BC_MAX];          // double-buffered per-wave partials of the cross-wave exchange
-    // (sized to the shape: 4 workgroups of this kernel must keep fitting into the CU's 160 KB of LDS)
-    float4 tab[256 / UPAD][32];           // per env in this block and station: {|S_b|, sum utility, min utility, sum of all utilities}
-    float4 part[UPAD > 64 ? 4 : 1][32];   // the same per wave (cross-wave combine when an env spans several waves)
-    double2 bs[32];                       // BS positions, indexed PER LANE in the sparse pre-move pass
-    uint32_t nb_conn[256];                // conn' of the block's UEs (column sums below; 'sum' reward)
-    float nb_util[256];                   // utility of the block's UEs
-    float nb_rb[256];                     // 'sum' reward: reward_before of the block's UEs
+    // per-wave rows, one per lane: B floats at stride B + 1 (odd for B = 32: a lane walking its own row and 32 lanes reading one
+    // column are both conflict-free, and every cell address is `base + constant`: no per-access arithmetic)
+    float drst[4][64 * (B + 1)];
+    uint2 row_ci[256];                    // per UE row: {connection mask, 2nd word}: nothing the rate sums need; the UE's utility (bits) for the utility sums
+    float4 part_a[4][32];                 // per wave and station: rate sums before the move {count, sum}, later the utility sums
+                                          // {count, sum utility, min utility, sum of all utilities}
+    union {
+        float2 part_b[4][32];             // per wave and station: rate sums after the move {count, sum}
+        float nb_rb[256];                 // 'sum' reward: reward_before of the block's UEs (after part_b's last reader)
+    };
+    double2 bs[32];                       // BS positions, indexed PER LANE in the sparse passes
+    float xw[2][4];                       // central reward: per-wave partials
 };
+// (39.6 KB at B = 32: four workgroups per CU, as before)
 
-// Combine N wave-uniform partials over the NW waves of an env; one barrier per call (buffers alternate).
-template <int N, int NW, class Op, class SH>
-__device__ __forceinline__ void wide_xchg(float (&v)[N], SH &sh, int &buf, int wave, int lane)
+template <int B>
+__device__ __forceinline__ int wide_col(int row, int c) { return row * (B + 1) + c; }
+
+// Sharing model of station b for a PER-LANE b (station.py:152-202): compile-time patterns need no table.
+template <int MP>
+__device__ __forceinline__ int wide_mode_of(const KParams &p, const int32_t *lds_modes, int b)
 {
-    if (NW == 1) return;
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < N; i++) sh.xw[buf][wave][i] = v[i];
-    }
-    if (!(DCOMP_ABLATE & 256)) __syncthreads();          // (ablation bit 256: timing without the cross-wave barriers; results are wrong)
-    const int w0 = (wave / NW) * NW;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        float a = sh.xw[buf][w0][i];
-#pragma unroll
-        for (int k = 1; k < NW; k++) a = Op::f(a, sh.xw[buf][w0 + k][i]);
-        v[i] = a;
-    }
-    buf ^= 1;
+    if (MP == MP_RES_FAIR) return DCOMP_RES_FAIR;
+    if (MP == MP_MIXED) { const int m3 = b - 3 * ((b * 11) >> 5); return m3 == 0 ? DCOMP_RES_FAIR : m3 == 1 ? DCOMP_RATE_FAIR : DCOMP_PROP_FAIR; }   // b % 3 for b < 32
+    return lds_modes[b];
 }
 
-// Shared rates of one chunk of base stations (station.py:152-220).  c[j]: connected to BS c0+j; l2[j]: log2 snr.
-// Returns the shared rate per station in dr[j] (0 where not connected) and |S_b| in cnt[j].
-// PRE: l2[j] already holds the UNSHARED rate of the connected pairs (the sparse pre-move pass of step_kernel_wide).
-template <int B, int NW, int MP, int BCC, bool FULL, bool PRE = false, class SH>
-__device__ __forceinline__ void wide_chunk_rates(const KParams &p, SH &sh, int &buf, int c0, const bool (&c)[BCC],
-                                                 const float (&l2)[BCC], float inv_ewma, int wave, int lane,
-                                                 float (&dr)[BCC], float (&cnt)[BCC], bool near_hint)
+// What a UE parks in its row for a station it is connected to: the TERM of that station's sum over its UEs -- rate-fair: 1 / rate
+// (station.py:177-180), proportional-fair: rate / (ewma + eps) (station.py:150,192-195), resource-fair: nothing is summed, the
+// rate itself waits there.  The summing lanes then only mask and add.
+__device__ __forceinline__ float wide_park(int mode, float dru, float inv_e)
 {
-    // near_hint (wave-uniform): some lane of this wave may be within 1.26 m of a BS (pair_eval's flag); only then can a pair
-    // have snr > 1/64, which the short series does not cover (see shared_rates)
-    float ex[2 * BCC];               // [0,BC): counts, [BC,2BC): sums
-#pragma unroll
-    for (int j = 0; j < BCC; j++) {
-        dr[j] = 0.f; ex[j] = 0.f; ex[BCC + j] = 0.f;
-        if (FULL || c0 + j < B) {
-            const unsigned long long m = __ballot(c[j]);
-            bool f = false;                                    // straight-line: with 64 UEs of one env per wave a station is
-            const float t = PRE ? l2[j] : rate_unshared_small(l2[j], f);   // rarely empty, and a skip branch per station costs more
-            dr[j] = c[j] ? t : 0.f;
-            ex[j] = (float)group_popcount<64>(m, 0);
-        }
+    return mode == DCOMP_RATE_FAIR ? fast_rcp(dru) : mode == DCOMP_PROP_FAIR ? dru * inv_e : dru;
+}
+
+// Transposed per-station sums over the UEs of this wave: lane l owns station l & 31 and the 32 rows of its half-wave.
+// Per row: the station's bit of the row's connection mask as 0 / -1 (v_bfe_i32), AND, add -- 4 VALU.  Returns {number of
+// connected UEs, sum of their terms} of the lane's station over the WAVE (both halves combined).
+template <int B, int MP, class SH>
+__device__ __forceinline__ float2 wide_rate_sums(SH &sh, int wave, int lane)
+{
+    const int sb = lane & 31, sbc = sb < B ? sb : 0;              // (lanes of stations that do not exist add up station 0, unused)
+    const int half0 = (lane & 32);                                // first row of my half-wave within the wave
+    const float *col = sh.drst[wave] + wide_col<B>(half0, sbc);   // my station's column, first row of my half
+    const uint2 *ci = sh.row_ci + wave * 64 + half0;
+    int n = 0;
+    float a = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 32; r++) {
+        const int m = __builtin_amdgcn_sbfe((int)ci[r].x, sbc, 1);            // 0 / -1; the mask read is a broadcast within the half-wave
+        n -= m;
+        if (MP != MP_RES_FAIR)                                                 // (resource-fair everywhere: counts only, station.py:171-173)
+            a += __int_as_float(__float_as_int(col[r * (B + 1)]) & m);        // consecutive banks within the half-wave
     }
-    if (!PRE && near_hint) {
-#pragma unroll
-        for (int j = 0; j < BCC; j++) if ((FULL || c0 + j < B) && c[j] && l2[j] > RATE_SMALL_L2) dr[j] = rate_unshared_any(l2[j]);
-    }
-    bool any_sum = false;
-#pragma unroll
-    for (int j = 0; j < BCC; j++) {
-        if (FULL || c0 + j < B) {
-            const int mode = bs_mode_of<MP>(p, c0 + j);
-            if (mode == DCOMP_RATE_FAIR) { ex[BCC + j] = c[j] ? fast_rcp(dr[j]) : 0.f; any_sum = true; }
-            else if (mode == DCOMP_PROP_FAIR) { ex[BCC + j] = dr[j] * inv_ewma; any_sum = true; }
-        }
-    }
-    if (MP == MP_MIXED && BCC % 3 == 0) {
-        // chunks start at a multiple of 3: slots 0, 3, ... are resource-fair (bs_mode_of) and need no sum over the UEs
-        constexpr int NS = BCC - BCC / 3;
-        float sv[NS];
-#pragma unroll
-        for (int j = 0, k = 0; j < BCC; j++) if (j % 3 != 0) sv[k++] = ex[BCC + j];
-        group_reduce_vec<64, OpSum, NS>(sv);
-#pragma unroll
-        for (int j = 0, k = 0; j < BCC; j++) if (j % 3 != 0) ex[BCC + j] = sv[k++];
-    } else if (any_sum) {                // uniform (modes are uniform)
-        float sv[BCC];
-#pragma unroll
-        for (int j = 0; j < BCC; j++) sv[j] = ex[BCC + j];
-        group_reduce_vec<64, OpSum, BCC>(sv);
-#pragma unroll
-        for (int j = 0; j < BCC; j++) ex[BCC + j] = sv[j];
-    }
-    wide_xchg<2 * BCC, NW, OpSum>(ex, sh, buf, wave, lane);
-#pragma unroll
-    for (int j = 0; j < BCC; j++) {
-        cnt[j] = ex[j];
-        if (FULL || c0 + j < B) {
-            const int mode = bs_mode_of<MP>(p, c0 + j);
-            const float dru = dr[j], agg = ex[BCC + j];
-            float out;
-            if (mode == DCOMP_RES_FAIR) out = dru * fast_rcp(fmaxf(cnt[j], 1.f));
-            else if (mode == DCOMP_RATE_FAIR) out = fast_rcp(agg);
-            else out = (dru * inv_ewma) * fast_rcp(agg + EPS) * dru;       // proportional-fair (max-cap never gets here)
-            dr[j] = c[j] ? out : 0.f;
-        }
-    }
+    float nf = (float)n;
+    nf += __shfl_xor(nf, 32, 64);
+    a += __shfl_xor(a, 32, 64);
+    return make_float2(nf, a);
 }
 
 template <int B, int UPAD, int MP>
 __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
 {
     static_assert(UPAD >= 64, "wide kernel: one wavefront holds UEs of a single env");
-    constexpr int NW = UPAD / 64, GPB = 256 / UPAD, BC = wide_bc(MP), ROW = 4 * B + 1;
-    __shared__ WideShared<B, UPAD> sh;
+    constexpr int NW = UPAD / 64, GPB = 256 / UPAD, ROW = 4 * B + 1, K = DCOMP_WIDE_K, PC = DCOMP_WIDE_PC;
+    using SH = WideShared<B, UPAD>;
+    __shared__ SH sh;
+    __shared__ int32_t lds_modes[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int env_local = wave / NW, u = (wave % NW) * 64 + lane;
     const int env = blockIdx.x * GPB + env_local;
     const bool active = (env < p.E) && (u < p.U);
     const int idx = env * p.U + u;
-    int buf = 0;
-    if (tid < B) sh.bs[tid] = make_double2(p.bs_x[tid], p.bs_y[tid]);          // for the per-lane station index of the sparse pass
+    const int w0 = (wave / NW) * NW;                               // first wave of my env
+    if (tid < B) { sh.bs[tid] = make_double2(p.bs_x[tid], p.bs_y[tid]); lds_modes[tid] = p.bs_mode[tid]; }
 
     double px = 0.0, py = 0.0;
     unsigned long long mv = 0;
@@ -172,73 +135,137 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
 
     __syncthreads();                                                              // BS table
 
-    // ---- pre-move pass, SPARSE: the pre-move position only matters where this UE is connected (its rate before the move:
+    float *const st = sh.drst[wave];
+    float *const myrow = st + wide_col<B>(lane, 0);
+    auto cell = [&](int b) -> float & { return myrow[b]; };                       // my row, station b
+    // log2 snr (+ offset) and unshared rate of this UE at station b, at the position it stands on (per-lane b)
+    auto pair_at = [&](int b, bool &ir) -> float {
+        const double2 bp = sh.bs[b];
+        bool near;
+        float l2;
+        pair_eval(px, py, bp.x, bp.y, p, ir, l2, near);
+        if (near) {                                            // rare, per lane: within 1.26 m of the station
+            const double dx = bp.x - px, dy = bp.y - py;
+            if ((float)__builtin_fma(dy, dy, dx * dx) < 1e-20f) l2 = pair_eval_tiny(px, py, bp.x, bp.y, p);
+        }
+        return l2;
+    };
+    auto rate_of = [&](float l2) -> float {
+        bool big;
+        float dru = rate_unshared_small(l2, big);
+        if (big) dru = rate_unshared_any(l2);                  // rare: snr > 1/64
+        return dru;
+    };
+
+    // ---- 1. pre-move pass, SPARSE: the pre-move position only matters where this UE is connected (its rate before the move:
     // base.py:446, and the stale-rate EWMA term) and at the station it acts on (in range -> may connect, user.py:203-222):
-    // typically 1-4 of the B stations.  Each lane walks ITS OWN set bits -- per-lane station index, BS position from the LDS
-    // table -- and parks the unshared rate of station b in strow[b]; the station sweep below picks it up where the UE is
-    // connected (other entries are never read) before it overwrites strow[b] with the post-move log2 snr.  The trip count is
-    // the largest need-set in the wave (~5) instead of B = 32 dense evaluations of pair, log2 and rate series per lane.
-    float *const strow = sh.drst[wave] + lane * (B + 1);      // this lane's row: pre-move rates -> log2 snr' -> normalised dr
+    // typically 1-4 of the B stations.  The station's sum term (wide_park) is parked in the lane's row, the unshared rate itself
+    // waits in one of K registers (a wave with a UE of more than K stations to look at evaluates it again in step 3).
     const uint32_t act_bit = act ? 1u << (act - 1u) : 0u;
+    const float inv_ewma_old = fast_rcp(ewma + EPS);
     uint32_t inr_old = 0;                                      // in range at the OLD position (only bits of `need` are set)
+    const uint32_t need0 = active ? (conn | act_bit) : 0u;
+    const bool many_pre = __ballot(__builtin_popcount(need0) > K) != 0ull;        // wave-uniform, rare
+    float druk[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) druk[k] = 0.f;
     {
-        uint32_t need = active ? (conn | act_bit) : 0u;
+        uint32_t need = need0;
+        int k = 0;
         while (__ballot(need != 0u) != 0ull) {
             if (need != 0u) {
                 const int b = __ffs((int)need) - 1;
                 need &= need - 1u;
-                const double2 bp = sh.bs[b];
-                bool ir, near;
-                float l2;
-                pair_eval(px, py, bp.x, bp.y, p, ir, l2, near);
-                if (near) {                                        // rare, per lane: within 1.26 m of the station
-                    const double dx = bp.x - px, dy = bp.y - py;
-                    if ((float)__builtin_fma(dy, dy, dx * dx) < 1e-20f) l2 = pair_eval_tiny(px, py, bp.x, bp.y, p);
-                }
+                bool ir;
+                const float dru = rate_of(pair_at(b, ir));
                 inr_old |= (uint32_t)ir << b;
-                bool big;
-                float dru = rate_unshared_small(l2, big);
-                if (big) dru = rate_unshared_any(l2);              // rare: snr > 1/64
-                strow[b] = dru;
+#pragma unroll
+                for (int j = 0; j < K; j++) if (j == k) druk[j] = dru;
+                cell(b) = wide_park(wide_mode_of<MP>(p, lds_modes, b), dru, inv_ewma_old);
             }
+            k++;
         }
     }
     // toggle (base.py:259-263 -> user.py:190-222): connected -> disconnect; not connected and in range at the pre-move position -> connect
     conn ^= act_bit & (conn | inr_old);
-    // move (base.py:447 -> user.py:159-173)
+    const uint32_t conn_pre = active ? conn : 0u;
+    sh.row_ci[tid] = make_uint2(conn_pre, 0u);
+    wave_lds_fence();
+    // ---- 2. per-station {|S_b|, sum} before the move (station.py:152-202), transposed
+    {
+        const float2 s = wide_rate_sums<B, MP>(sh, wave, lane);
+        if (lane < 32) sh.part_a[wave][lane] = make_float4(s.x, s.y, 0.f, 0.f);
+    }
+    if (NW > 1) __syncthreads(); else wave_lds_fence();
+    // ---- 3. shared rates before the move, where connected (sparse) -> reward_before (base.py:158-167); the rates stay in K
+    // registers for the stale-rate EWMA term (user.py:148-157) -- a wave with a UE of more than K connections parks them in the
+    // rows instead and the pair loop below picks them up
+    float curr = 0.f, outk[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) outk[k] = 0.f;
+    auto shared_rate = [&](int b, float parked, float dru, auto part) -> float {
+        float n = 0.f, a = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w++) { n += part[w0 + w][b].x; a += part[w0 + w][b].y; }
+        const int mode = wide_mode_of<MP>(p, lds_modes, b);
+        if (mode == DCOMP_RES_FAIR) return dru * fast_rcp(fmaxf(n, 1.f));                          // station.py:171-173
+        if (mode == DCOMP_RATE_FAIR) return fast_rcp(a);                                           // station.py:180
+        return parked * fast_rcp(a + EPS) * dru;                                                   // station.py:194-195 (parked = rate / ewma)
+    };
+    {
+        uint32_t todo = need0;                                 // the stations of step 1, in the same order: slot k of druk
+        int k = 0;
+        while (__ballot(todo != 0u) != 0ull) {
+            if (todo != 0u) {
+                const int b = __ffs((int)todo) - 1;
+                todo &= todo - 1u;
+                if ((conn_pre >> b) & 1u) {
+                    float dru = 0.f;
+                    if (many_pre) { bool ir; dru = rate_of(pair_at(b, ir)); }
+                    else {
+#pragma unroll
+                        for (int j = 0; j < K; j++) if (j == k) dru = druk[j];
+                    }
+                    const float out = shared_rate(b, cell(b), dru, sh.part_a);
+                    curr += out;
+                    if (many_pre) cell(b) = out;
+                    else {
+#pragma unroll
+                        for (int j = 0; j < K; j++) if (j == k) outk[j] = out;
+                    }
+                }
+            }
+            k++;
+        }
+    }
+    const float util_pre = ue_utility(curr, step_util, dr_req);
+    const float reward_before = clamp_med3(util_pre, MIN_UTIL, MAX_UTIL) * (1.0f / MAX_UTIL);
+    // ---- 4. move (base.py:447 -> user.py:159-173)
     if (active) {
         move_ue(p, env, (uint32_t)u + 1u, p.episode, px, py, mv, vrange);
         if (px < 0.0 || py < 0.0 || px > (double)p.map_w || py > (double)p.map_h) atomicOr(p.flags, DCOMP_FLAG_OUTSIDE_MAP);
     }
-
-    // ---- sweep 1: pre-move shared rates, post-move pairs, drop, stale-rate EWMA term; post-move log2 snr parked in strow[]
+    // ---- 5. pairs at the new position, ALL stations (every station's relative SNR is an observation entry): log2 snr into the row
     uint32_t inr_new = 0;
-    bool near_any = false;                                     // wave-uniform: a lane is within 1.26 m of some BS at the NEW position
-    float curr = 0.f, stale = 0.f, l2max = -1e30f;
-    const float inv_ewma_old = fast_rcp(ewma + EPS);
-    auto sweep1 = [&](const int c0, auto full_tag) {
+    float stale = 0.f, l2max = -1e30f;
+    auto pairs = [&](const int c0, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;       // every slot of the chunk is a station: no bounds tests
-        bool c[BC];
-        float dru[BC], l2n[BC], dr[BC], cnt[BC];
+        float l2n[PC];
         bool anytiny = false;
 #pragma unroll
-        for (int j = 0; j < BC; j++) {
+        for (int j = 0; j < PC; j++) {
             const int b = c0 + j;
-            c[j] = (FULL || b < B) && ((conn >> b) & 1u);
-            dru[j] = 0.f; l2n[j] = -30.f;
+            l2n[j] = -30.f;
             if (FULL || b < B) {
                 bool inr_n, t1;
                 pair_eval(px, py, p.bs_x[b], p.bs_y[b], p, inr_n, l2n[j], t1);
                 anytiny |= t1;
                 inr_new |= (uint32_t)inr_n << b;
-                dru[j] = strow[b];                             // the sparse pass's rate where connected; unused otherwise
             }
         }
-        const bool near_chunk = __ballot(anytiny) != 0ull;       // a lane within 1.26 m of one of these stations (new position)
-        near_any |= near_chunk;
-        if (near_chunk) {
+        if (__ballot(anytiny) != 0ull) {                       // a lane within 1.26 m of one of these stations (new position)
 #pragma unroll
-            for (int j = 0; j < BC; j++) {
+            for (int j = 0; j < PC; j++) {
                 const int b = c0 + j;
                 if (FULL || b < B) {
                     const double dx = p.bs_x[b] - px, dy = p.bs_y[b] - py;
@@ -246,84 +273,88 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
                 }
             }
         }
-        wide_chunk_rates<B, NW, MP, BC, FULL, true>(p, sh, buf, c0, c, dru, inv_ewma_old, wave, lane, dr, cnt, false);
 #pragma unroll
-        for (int j = 0; j < BC; j++) {
+        for (int j = 0; j < PC; j++) {
             const int b = c0 + j;
             if (FULL || b < B) {
-                curr += dr[j];
-                stale += ((inr_new >> b) & 1u) ? dr[j] : 0.f;                     // dr[j] is 0 unless connected
+                if (many_pre) {                                // the pre-move shared rate waits in the row: stale-rate EWMA term
+                    const float old = myrow[c0 + j];
+                    stale += (((conn_pre & inr_new) >> b) & 1u) ? old : 0.f;
+                }
                 l2max = fmaxf(l2max, l2n[j]);
-                strow[b] = l2n[j];
+                myrow[c0 + j] = l2n[j];
             }
         }
     };
-    constexpr int NFULL = B / BC * BC;
+    constexpr int NFULL = B / PC * PC;
 #pragma unroll 1
-    for (int c0 = 0; c0 < NFULL; c0 += BC) sweep1(c0, std::true_type{});
-    if constexpr (NFULL < B) sweep1(NFULL, std::false_type{});
-    const float util_pre = ue_utility(curr, step_util, dr_req);
-    const float reward_before = clamp_med3(util_pre, MIN_UTIL, MAX_UTIL) * (1.0f / MAX_UTIL);
-    conn &= inr_new;                                                              // user.py:175-188
-    ewma = __builtin_fmaf(0.9f, stale, 0.1f * ewma);   // one explicit contraction: every kernel variant rounds alike                                            // user.py:148-157
-
-    // ---- sweep 2: rates after the move (base.py:451).  The unshared rate is only needed where the UE is (still) connected:
-    // a sparse pass like the pre-move one computes it for the lane's own set bits and puts it into strow[b]; the log2 snr it
-    // displaces there (needed again for the `dr` observation) waits in four registers and is put back after the sweep.  A
-    // wavefront in which some UE holds more than four connections takes the dense path (rate series for every station).
-    curr = 0.f;
-    const float inv_ewma = fast_rcp(ewma + EPS);
-    const uint32_t conn_post = active ? conn : 0u;
-    const bool dense2 = __ballot(__builtin_popcount(conn_post) > 4) != 0ull;      // wave-uniform, rare
-    float sv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (!dense2) {
-        uint32_t todo = conn_post;
+    for (int c0 = 0; c0 < NFULL; c0 += PC) pairs(c0, std::true_type{});
+    if constexpr (NFULL < B) pairs(NFULL, std::false_type{});
+    if (!many_pre) {                                           // the usual case: the rates are in registers, in the order of `need0`
+        uint32_t todo = need0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (__ballot(todo != 0u) == 0ull) break;
-            if (todo != 0u) {
-                const int b = __ffs((int)todo) - 1;
-                todo &= todo - 1u;
-                const float l2 = strow[b];
-                sv[k] = l2;
-                bool big;
-                float dru = rate_unshared_small(l2, big);
-                if (big) dru = rate_unshared_any(l2);              // rare: snr > 1/64
-                strow[b] = dru;
-            }
+        for (int k = 0; k < K; k++) {
+            const int b = todo ? __ffs((int)todo) - 1 : 0;
+            stale += (todo && (((conn_pre & inr_new) >> b) & 1u)) ? outk[k] : 0.f;
+            todo &= todo - 1u;
         }
     }
-    auto sweep2 = [&](const int c0, auto full_tag, auto pre_tag) {
-        constexpr bool FULL = decltype(full_tag)::value, PRE = decltype(pre_tag)::value;
-        bool c[BC];
-        float l2c[BC], dr[BC], cnt[BC];
+    conn &= inr_new;                                                              // user.py:175-188
+    ewma = __builtin_fmaf(0.9f, stale, 0.1f * ewma);   // one explicit contraction: every kernel variant rounds alike   // user.py:148-157
+
+    // ---- 6. rates after the move (base.py:451), sparse: the sum term of the stations the UE is (still) connected to goes into
+    // the row in place of the log2 snr, which waits in K registers together with the unshared rate (a wave with a UE of more
+    // than K connections evaluates the pair again instead)
+    const float inv_ewma = fast_rcp(ewma + EPS);
+    const uint32_t conn_post = active ? conn : 0u;
+    const bool many_post = __ballot(__builtin_popcount(conn_post) > K) != 0ull;   // wave-uniform, rare
+    float sv[K];
 #pragma unroll
-        for (int j = 0; j < BC; j++) {
-            const int b = c0 + j;
-            c[j] = (FULL || b < B) ? (bool)((conn >> b) & 1u) : false;
-            l2c[j] = (FULL || b < B) ? strow[b] : -30.f;           // PRE: the unshared rate where connected (unused elsewhere)
-        }
-        wide_chunk_rates<B, NW, MP, BC, FULL, PRE>(p, sh, buf, c0, c, l2c, inv_ewma, wave, lane, dr, cnt, near_any);
-#pragma unroll
-        for (int j = 0; j < BC; j++) if (FULL || c0 + j < B) curr += dr[j];
-    };
-    if (!dense2) {
-#pragma unroll 1
-        for (int c0 = 0; c0 < NFULL; c0 += BC) sweep2(c0, std::true_type{}, std::true_type{});
-        if constexpr (NFULL < B) sweep2(NFULL, std::false_type{}, std::true_type{});
-        uint32_t todo = conn_post;                                 // put the log2 snr back
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < K; k++) { sv[k] = 0.f; druk[k] = 0.f; }
+    {
+        uint32_t todo = conn_post;
+        int k = 0;
+        while (__ballot(todo != 0u) != 0ull) {
             if (todo != 0u) {
                 const int b = __ffs((int)todo) - 1;
                 todo &= todo - 1u;
-                strow[b] = sv[k];
+                const float l2 = cell(b);
+                const float dru = rate_of(l2);
+#pragma unroll
+                for (int j = 0; j < K; j++) if (j == k) { sv[j] = l2; druk[j] = dru; }
+                cell(b) = wide_park(wide_mode_of<MP>(p, lds_modes, b), dru, inv_ewma);
             }
+            k++;
         }
-    } else {
-#pragma unroll 1
-        for (int c0 = 0; c0 < NFULL; c0 += BC) sweep2(c0, std::true_type{}, std::false_type{});
-        if constexpr (NFULL < B) sweep2(NFULL, std::false_type{}, std::false_type{});
+    }
+    sh.row_ci[tid] = make_uint2(conn_post, 0u);
+    wave_lds_fence();
+    float my_cnt;                                              // |S_b| after the move of the lane's station, over my wave (the utility sums reuse it)
+    {
+        const float2 s = wide_rate_sums<B, MP>(sh, wave, lane);
+        my_cnt = s.x;
+        if (lane < 32) sh.part_b[wave][lane] = s;
+    }
+    if (NW > 1) __syncthreads(); else wave_lds_fence();
+    curr = 0.f;
+    {
+        uint32_t todo = conn_post;
+        int k = 0;
+        while (__ballot(todo != 0u) != 0ull) {
+            if (todo != 0u) {
+                const int b = __ffs((int)todo) - 1;
+                todo &= todo - 1u;
+                float l2 = 0.f, dru = 0.f;
+                if (many_post) { bool ir; l2 = pair_at(b, ir); dru = rate_of(l2); }       // the pair again (same code, same bits)
+                else {
+#pragma unroll
+                    for (int j = 0; j < K; j++) if (j == k) { l2 = sv[j]; dru = druk[j]; }
+                }
+                curr += shared_rate(b, cell(b), dru, sh.part_b);
+                cell(b) = l2;                                      // put the log2 snr back
+            }
+            k++;
+        }
     }
     const float util = ue_utility(curr, step_util, dr_req);
     if (active) {
@@ -333,55 +364,44 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
         p.ewma[idx] = ewma;
     }
 
-    // ---- sweep 3: per-BS utility aggregates (station.py:63-83), reward, per-env observation tables
-    // Transposed: what a station needs -- |S_b|, sum and min of the utilities of its UEs -- is a function of just TWO words
-    // per UE (connection mask, utility).  Every lane parks those two words in LDS; lane l then owns station l & 31 and adds up
-    // the 32 UEs of its own half-wave (rows it reads are broadcast within the half), the two halves and the env's waves are
-    // combined, and the totals go to a per-env table.  ~5 VALU per (station, UE-row) pair of a half-wave instead of a 64-lane
-    // butterfly per station and sum kind, and 2 workgroup barriers per step instead of one or two per chunk of stations.
+    // ---- 7. per-BS utility aggregates (station.py:63-83), transposed like the rate sums: what a station needs -- |S_b|, sum and
+    // min of the utilities of its UEs -- is a function of just TWO words per UE (connection mask, utility).
     const bool multi = p.kind == DCOMP_MULTI;
-    sh.nb_conn[tid] = active ? conn : 0u;
-    sh.nb_util[tid] = active ? util : 0.f;
+    sh.row_ci[tid].y = __float_as_uint(active ? util : 0.f);      // (.x already holds the post-move masks)
     wave_lds_fence();
     {
-        const int sb = lane & 31;                                 // my station (B <= 32)
-        const int r0 = tid & ~31;                                 // first UE row of my half-wave
-        float n = 0.f, t = 0.f, mn = MAX_UTIL, ta = 0.f;          // ta: sum of ALL utilities (info sum_utility, base.py:383-411)
+        const int sb = lane & 31, sbc = sb < B ? sb : 0;          // my station (B <= 32)
+        const uint2 *ci = sh.row_ci + (tid & ~31);                // the rows of my half-wave
+        float t = 0.f, mn = MAX_UTIL, ta = 0.f;                   // ta: sum of ALL utilities (info sum_utility, base.py:383-411)
         if (multi && p.reward_agg == DCOMP_REWARD_MIN) {          // the minimum is only needed by the 'min' reward (multi_agent.py:81-85)
 #pragma unroll 8
             for (int r = 0; r < 32; r++) {
-                const uint32_t cj = sh.nb_conn[r0 + r];
-                const float uj = sh.nb_util[r0 + r];
-                const bool bit = (cj >> sb) & 1u;
-                n += bit ? 1.f : 0.f;
-                t += bit ? uj : 0.f;
-                mn = bit ? min_med3(mn, uj) : mn;
+                const uint2 c = ci[r];
+                const int m = __builtin_amdgcn_sbfe((int)c.x, sbc, 1);
+                const float uj = __uint_as_float(c.y);
+                t += __int_as_float((int)c.y & m);
+                mn = m ? min_med3(mn, uj) : mn;
                 ta += uj;
             }
         } else {
 #pragma unroll 8
             for (int r = 0; r < 32; r++) {
-                const uint32_t cj = sh.nb_conn[r0 + r];
-                const float uj = sh.nb_util[r0 + r];
-                const bool bit = (cj >> sb) & 1u;
-                n += bit ? 1.f : 0.f;
-                t += bit ? uj : 0.f;
-                ta += uj;
+                const uint2 c = ci[r];
+                const int m = __builtin_amdgcn_sbfe((int)c.x, sbc, 1);
+                t += __int_as_float((int)c.y & m);
+                ta += __uint_as_float(c.y);
             }
         }
-        n += __shfl_xor(n, 32, 64); t += __shfl_xor(t, 32, 64); mn = min_med3(mn, __shfl_xor(mn, 32, 64)); ta += __shfl_xor(ta, 32, 64);
-        if (NW > 1) {
-            if (lane < 32) sh.part[wave][sb] = make_float4(n, t, mn, ta);
-            __syncthreads();
-            const int w0 = (wave / NW) * NW;
-            float4 a = sh.part[w0][sb];
-#pragma unroll
-            for (int k = 1; k < NW; k++) { const float4 q = sh.part[w0 + k][sb]; a.x += q.x; a.y += q.y; a.z = min_med3(a.z, q.z); a.w += q.w; }
-            n = a.x; t = a.y; mn = a.z; ta = a.w;
-        }
-        if ((wave % NW) == 0 && lane < 32) sh.tab[env_local][sb] = make_float4(n, t, mn, ta);
+        t += __shfl_xor(t, 32, 64); mn = min_med3(mn, __shfl_xor(mn, 32, 64)); ta += __shfl_xor(ta, 32, 64);
+        if (lane < 32) sh.part_a[wave][sb] = make_float4(my_cnt, t, mn, ta);     // (the pre-move sums in part_a were consumed before the barrier of step 6)
     }
-    __syncthreads();                                                              // tables (and nb_*) visible to the block
+    __syncthreads();                                                              // per-wave tables (and nb_*) visible to the block
+    auto station = [&](int b) -> float4 {                                         // totals of station b over the env's waves
+        float4 a = sh.part_a[w0][b];
+#pragma unroll
+        for (int k = 1; k < NW; k++) { const float4 q = sh.part_a[w0 + k][b]; a.x += q.x; a.y += q.y; a.z = min_med3(a.z, q.z); a.w += q.w; }
+        return a;
+    };
     float rn = 0.f, rt = 0.f, rmin = util;
     const float inv_u = 1.0f / (float)p.U;
     if (multi && p.reward_agg != DCOMP_REWARD_SUM) {                              // multi_agent.py:60-71, 81-85
@@ -391,32 +411,35 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
             if (todo != 0u) {
                 const int b = __ffs((int)todo) - 1;
                 todo &= todo - 1u;
-                const float4 q = sh.tab[env_local][b];
+                const float4 q = station(b);
                 rn += q.x; rt += q.y; rmin = fminf(rmin, q.x > 0.f ? q.z : MAX_UTIL);
             }
         }
     }
     float reward = 0.f;
     if (!multi) {                                                                 // central.py:65-73
-        float r[1];
-        if (p.reward_agg == DCOMP_REWARD_MIN) {
-            r[0] = group_reduce<64, OpMin>(active ? reward_before : 1.f);
-            wide_xchg<1, NW, OpMin>(r, sh, buf, wave, lane);
-        } else {
-            r[0] = group_reduce<64, OpSum>(active ? reward_before : 0.f);
-            wide_xchg<1, NW, OpSum>(r, sh, buf, wave, lane);
-            if (p.reward_agg == DCOMP_REWARD_AVG) r[0] = r[0] / (float)p.U;
+        float r;
+        const bool is_min = p.reward_agg == DCOMP_REWARD_MIN;
+        if (is_min) r = group_reduce<64, OpMin>(active ? reward_before : 1.f);
+        else r = group_reduce<64, OpSum>(active ? reward_before : 0.f);
+        if (NW > 1) {
+            if (lane == 0) sh.xw[0][wave] = r;
+            __syncthreads();
+            r = sh.xw[0][w0];
+#pragma unroll
+            for (int k = 1; k < NW; k++) r = is_min ? OpMin::f(r, sh.xw[0][w0 + k]) : r + sh.xw[0][w0 + k];
         }
-        reward = r[0];
+        if (p.reward_agg == DCOMP_REWARD_AVG) r = r / (float)p.U;
+        reward = r;
     } else {                                                                      // multi_agent.py:39-95
         reward = util;
         if (p.reward_agg == DCOMP_REWARD_SUM) {
-            sh.nb_rb[tid] = reward_before;                                        // (nb_conn was written in sweep 3)
+            sh.nb_rb[tid] = reward_before;                                        // (row_ci[].x: the post-move masks)
             __syncthreads();
             if (inr_new != 0) {
                 float s = 0.f;
                 const int base = env_local * UPAD;
-                for (int v = 0; v < p.U; v++) if (sh.nb_conn[base + v] & conn) s += sh.nb_rb[base + v];
+                for (int v = 0; v < p.U; v++) if (sh.row_ci[base + v].x & conn) s += sh.nb_rb[base + v];
                 reward = s;
             }
         } else if (p.reward_agg == DCOMP_REWARD_AVG) {
@@ -425,7 +448,7 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
             reward = rmin;
         }
     }
-    if (p.sum_util && active && u == 0) p.sum_util[env] = sh.tab[env_local][0].w;  // base.py:383-411
+    if (p.sum_util && active && u == 0) p.sum_util[env] = station(0).w;           // base.py:383-411
     if (active) {
         if (p.ue_dr) p.ue_dr[idx] = curr;
         if (p.ue_util) p.ue_util[idx] = util;
@@ -441,20 +464,19 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
 #pragma unroll 4
             for (int b = 0; b < B; b++) {
                 base[u * B + b] = (float)((conn >> b) & 1u);
-                base[p.U * B + u * B + b] = fast_exp2(strow[b] - l2max);
+                base[p.U * B + u * B + b] = fast_exp2(cell(b) - l2max);
             }
             base[2 * p.U * B + u] = util_n;
             if (p.next_act)                                                       // dcomp_set_policy: the rules on the entries just stored
-                p.next_act[idx] = (uint8_t)policy_action_fn<B>(p, conn, [&](int b) { return fast_exp2(strow[b] - l2max); });
+                p.next_act[idx] = (uint8_t)policy_action_fn<B>(p, conn, [&](int b) { return fast_exp2(cell(b) - l2max); });
         }
         return;
     }
-    // transpose the per-UE dr columns through LDS (lane r -> row r)
-    float *st = sh.drst[wave];
+    // the per-UE dr columns: normalise in place, the row loop reads them column-wise (lane r's row -> output row r)
 #pragma unroll 4
-    for (int b = 0; b < B; b++) strow[b] = fast_exp2(strow[b] - l2max);                       // variants.py:276-284
+    for (int b = 0; b < B; b++) cell(b) = fast_exp2(cell(b) - l2max);                         // variants.py:276-284
     if (p.next_act) {                                                             // dcomp_set_policy (uniform): the rules on this UE's dr row
-        const int a = policy_action_fn<B>(p, conn, [&](int b) { return strow[b]; });
+        const int a = policy_action_fn<B>(p, conn, [&](int b) { return cell(b); });
         if (active) p.next_act[idx] = (uint8_t)a;
     }
     wave_lds_fence();                                                             // the rows are this wave's own; the tables were fenced above
@@ -465,9 +487,9 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
     for (int k = 0; k < NSLOT; k++) {
         const int c = lane + 64 * k;
         pre[k] = 0.f;
-        if (c >= 2 * B && c < 3 * B) pre[k] = sh.tab[env_local][c - 2 * B].x * inv_u;                    // variants.py:296
+        if (c >= 2 * B && c < 3 * B) pre[k] = station(c - 2 * B).x * inv_u;                               // variants.py:296
         else if (c >= 3 * B && c < 4 * B) {                                                                 // variants.py:299
-            const float4 q = sh.tab[env_local][c - 3 * B];
+            const float4 q = station(c - 3 * B);
             pre[k] = q.x > 0.f ? q.y * fast_rcp(q.x) * (1.0f / MAX_UTIL) : 0.f;
         }
     }
@@ -491,14 +513,14 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
                     if (c < 4 * B) {
                         float v = pre[k];
                         if (c < B) v = (float)((conn_r >> c) & 1u);
-                        else if (c < 2 * B) v = st[r * (B + 1) + (c - B)];
+                        else if (c < 2 * B) v = st[wide_col<B>(r, c - B)];   // (r uniform: base + constant)
                         orow[c] = v;         // plain store: non-temporal 4-byte stores bypass L2 write-combining (measured slower)
                     }
                 }
             }
         }
         if (lane < 4 && r0 + lane < nrows)
-            p.obs[(row0 + r0 + lane) * ROW + 4 * B] = sh.nb_util[wave * 64 + r0 + lane] * (1.0f / MAX_UTIL);
+            p.obs[(row0 + r0 + lane) * ROW + 4 * B] = __uint_as_float(sh.row_ci[wave * 64 + r0 + lane].y) * (1.0f / MAX_UTIL);
     }
 }
 

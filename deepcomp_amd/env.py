@@ -419,8 +419,6 @@ class BatchedMobileEnv:
         the outputs of EVERY step (a rollout fragment).  horizon: reset the envs inside the rollout whenever env.time has
         reached it (RLlib's horizon = episode_length, env_setup.py:281); same sequence as `if time == L: reset()` before
         every step."""
-        if self.dynamic:
-            raise NotImplementedError("rollout() has no event feed; step an env with UE arrival one step at a time")
         if actions.dim() != 3:
             raise ValueError("actions must be [T, E, U]")
         T = int(actions.shape[0])
@@ -430,9 +428,9 @@ class BatchedMobileEnv:
         L = int(horizon or 0)
         if new_episode_draws is None:
             new_episode_draws = self.rand_episodes
-        if L and self.rng_mode == _lib.RNG_TAPE and (self.rand_episodes or new_episode_draws):
-            raise NotImplementedError("rng='reference' with rand_episodes: every episode needs a fresh host-drawn tape; "
-                                      "reset() between rollouts instead of passing horizon")
+        if L and self.rng_mode == _lib.RNG_TAPE and (self.rand_episodes or new_episode_draws or self.dynamic):
+            raise NotImplementedError("rng='reference' with rand_episodes or UE arrival / departure: every episode needs a fresh host-drawn "
+                                      "tape; reset() between rollouts instead of passing horizon")
         o = self._out
         if out is not None:
             self._require(out['obs'], torch.float32, T * self.obs.numel(), "out['obs']")
@@ -448,6 +446,8 @@ class BatchedMobileEnv:
         if self.rng_mode == _lib.RNG_TAPE:
             self._ensure_tape(min(T, L - self.time) if L else T)
         opts = _lib.DcompRolloutOpts(1 if out is not None else 0, L, 1 if new_episode_draws else 0, 1 if _policy_steps else 0)
+        if self.dynamic:
+            keep = self._rollout_events(T, L, opts)          # host / device arrays the call reads: alive until it has been enqueued
         with torch.cuda.device(self.device):
             _lib.check(self._L.dcomp_rollout_ex(self._h, self._st_ref, ctypes.c_void_p(actions.data_ptr()), T, ctypes.byref(o),
                                                 ctypes.byref(opts), self._stream()))
@@ -455,24 +455,58 @@ class BatchedMobileEnv:
             self._policy_launched()
         return (self.obs, self.reward) if out is None else (out['obs'], out['reward'])
 
+    def _rollout_events(self, T, L, opts):
+        """UE departures / arrivals of the next T steps (base.py:433-443) for dcomp_rollout_ex's event feed: the schedule is
+        configuration (identical in every env, indexed by env.time, starting over after a reset at the horizon); in
+        rng='reference' mode the list positions / border points are drawn here, in step order, from the same host streams
+        step() uses.  Returns the arrays to keep alive."""
+        n_rem, n_add = np.zeros(T, dtype=np.int32), np.zeros(T, dtype=np.int32)
+        rem_blocks, add_blocks = [], []
+        t_env, cur = self.time, self.num_ue
+        for t in range(T):
+            if L and t_env == L:
+                t_env, cur = 0, self.U0
+            r, a = self.schedule[t_env] if t_env < len(self.schedule) else (0, 0)
+            n_rem[t], n_add[t] = r, a
+            if self.rng_mode == _lib.RNG_TAPE:
+                if r:
+                    rem_blocks.append(self._dyn_streams.departures(r, cur).astype(np.int32).reshape(-1))
+                if a:
+                    add_blocks.append(self._dyn_streams.arrivals(a).astype(np.int32).reshape(-1))
+            cur += a - r
+            t_env += 1
+        keep = [n_rem, n_add]
+        opts.ev_n_remove, opts.ev_n_add = n_rem.ctypes.data, n_add.ctypes.data
+        for name, blocks in (('ev_remove_idx', rem_blocks), ('ev_add_xy', add_blocks)):
+            if blocks:
+                d = torch.from_numpy(np.concatenate(blocks)).to(self.device)
+                keep.append(d)
+                setattr(opts, name, d.data_ptr())
+        self._ev_keep = keep
+        return keep
+
     def rollout_policy(self, num_steps, out=None, horizon=None):
-        """num_steps steps of the closed loop `act = policy(obs); step(act)` with the policy registered through set_policy():
-        ONE launch per stretch of an episode on the fused kernel (dcomp_rollout_ex, policy_loop) -- the decisions never leave
-        the registers -- with reset() at the horizon in between (the reset launch decides the first action of the new
-        episode).  Falls back to one step launch per step where rollouts are not fused.  Needs a current next_action: call
-        it after reset() / step() with the policy set.  out: as in rollout(), [num_steps, ...] buffers of every step."""
+        """num_steps steps of the closed loop `act = policy(obs); step(act)` with the policy registered through set_policy().
+        On the fused kernel (dcomp_rollout_ex, policy_loop) this is ONE call: one launch per stretch of an episode -- the
+        decisions never leave the registers -- and at the horizon a reset launch that also decides the first action of the new
+        episode; no host work in between.  Falls back to one step launch per step where rollouts are not fused.  Needs a
+        current next_action: call it after reset() / step() with the policy set.  out: as in rollout(), [num_steps, ...]
+        buffers of every step."""
         if self._policy_key is None or not self._next_action_fresh:
             raise RuntimeError("rollout_policy() needs set_policy() and a reset() / step() after it")
         L = int(horizon or 0)
         T, t0 = int(num_steps), 0
         keys = ('obs', 'reward', 'sum_utility', 'ue_dr', 'ue_utility', 'reward_before')
+        host_resets = L and self.rng_mode == _lib.RNG_TAPE and self.rand_episodes      # a fresh host-drawn tape per episode
+        if self.fused_rollout and not self.dynamic and not host_resets:
+            return self.rollout(self.next_action.view(1, self.E, self.U), out=out, horizon=L, _policy_steps=T)
         while t0 < T:
             if L and self.time >= L:
                 self.reset()
             n = min(T - t0, L - self.time) if L else T - t0
             frag = None if out is None else {k: out[k][t0:t0 + n] for k in keys if out.get(k) is not None}
             if self.fused_rollout and not self.dynamic:
-                self.rollout(self.next_action.view(1, self.E, self.U), out=frag, _policy_steps=n)    # never crosses the horizon: no in-kernel reset
+                self.rollout(self.next_action.view(1, self.E, self.U), out=frag, _policy_steps=n)
             else:
                 for i in range(n):
                     self.step(self.next_action)

@@ -166,21 +166,36 @@ int dcomp_rollout(dcomp_env *env, const dcomp_state *st, const uint8_t *actions,
  *                       every step (a rollout fragment for the learner); 0: outputs of the last step only
  *   horizon             > 0: whenever env.time has reached it the envs are reset before the next step, inside the rollout --
  *                       what RLlib does at its `horizon` = episode_length (env_setup.py:281); the first observation of
- *                       the new episode is not emitted.  0: never (then an episode has at most 65536 steps)
+ *                       the new episode is not emitted (policy_loop: it is written to out->obs of a last-step-only rollout and
+ *                       overwritten by the next step).  0: never (then an episode has at most 65536 steps)
  *   new_episode_draws   Philox mode: 1 = every such reset starts the next episode's draws (rand_episodes = True),
  *                       0 = the same episode again (the reference re-seeds at reset, base.py:171-173).  Tape mode replays the
  *                       tape handed to the last dcomp_reset, so it must be 0 there.
  *   policy_loop         1: closed loop with the policy registered through dcomp_set_policy -- step 0 takes actions[0][E][U]
  *                       (the next_action the previous launch wrote), every later step the policy's decision on the
  *                       observation of the step before, taken from registers: a heuristic agent's whole evaluation run
- *                       (simulation.py:512-541) in one launch; `actions` holds ONE step.  Needs the fused kernel
- *                       (dcomp_rollout_is_fused; DCOMP_EUNSUPPORTED otherwise) and must not cross the horizon (the
- *                       first observation of a new episode is not computed inside a rollout: dcomp_reset, then go on). */
+ *                       (simulation.py:512-541) in one call; `actions` holds ONE step.  Needs the fused kernel
+ *                       (dcomp_rollout_is_fused; DCOMP_EUNSUPPORTED otherwise).  With a horizon the run may cross episode
+ *                       boundaries: at each one the library launches the reset kernel -- which writes the first observation of
+ *                       the new episode AND the policy's action on it -- and continues the loop from that action: one launch
+ *                       per stretch of an episode plus one reset launch per episode, no host work in between.
+ *   ev_n_remove/ev_n_add  UE departures / arrivals of an env with a changing UE list (cfg.max_ues > 0), per step of THIS
+ *                       rollout: host arrays [num_steps]; entry t = the UEs that leave / arrive in step t (base.py:433-443; the
+ *                       schedule is configuration, identical in every env).  NULL: no events.  Such envs are launched once
+ *                       per step (dcomp_step_dyn's kernel); with a horizon the schedule entries are indexed by rollout step,
+ *                       so the caller lays the episode's schedule out again after every reset.
+ *   ev_remove_idx/ev_add_xy  tape mode only (NULL with Philox draws): the host-drawn list positions / border points of those
+ *                       events (see dcomp_events), device arrays, the blocks [E][n_remove] resp. [E][n_add][2] of the steps
+ *                       that have events concatenated in step order. */
 typedef struct dcomp_rollout_opts {
     int32_t every_step;
     int32_t horizon;
     int32_t new_episode_draws;
     int32_t policy_loop;
+    const int32_t *ev_n_remove;
+    const int32_t *ev_n_add;
+    const int32_t *ev_remove_idx;
+    const int32_t *ev_add_xy;
 } dcomp_rollout_opts;
 int dcomp_rollout_ex(dcomp_env *env, const dcomp_state *st, const uint8_t *actions, int32_t num_steps,
                      const dcomp_out *out, const dcomp_rollout_opts *opts, void *stream);

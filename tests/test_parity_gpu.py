@@ -429,8 +429,9 @@ def _dyn_kwargs(g):
     return dict(ue_arrival=arr, new_ue_interval=interval if interval > 0 else None, max_ues=int(g['cfg_max_ues']))
 
 
+@pytest.mark.parametrize('via_rollout', [False, True])
 @pytest.mark.parametrize('name', DYN)
-def test_golden_dynamic_ue_trajectory(torch_cuda, name):
+def test_golden_dynamic_ue_trajectory(torch_cuda, name, via_rollout):
     """UE arrival / departure (base.py:433-443, 592-618) against reference-run fixtures: slot order, ids, masks,
     FP64 positions exact (incl. the reference's reseed-by-list-position behaviour across episodes)."""
     torch = torch_cuda
@@ -479,6 +480,18 @@ def test_golden_dynamic_ue_trajectory(torch_cuda, name):
     for ep in range(int(g['cfg_episodes'])):
         core.reset()
         cmp('reset', ep, False)
+        if via_rollout:                                  # the same episode through rollout()'s event feed, in fragments of 1-7 steps
+            L, frag = int(g['cfg_eps_len']), 1
+            left = L
+            while left:
+                n = min(frag, left)
+                acts = torch.from_numpy(g['actions'][t:t + n].astype(np.uint8).reshape(n, 1, -1)).cuda()
+                core.rollout(acts)
+                t += n; left -= n
+                cmp('step', t - 1, True)
+                frag = frag % 7 + 2
+            core.check()
+            continue
         for _ in range(int(g['cfg_eps_len'])):
             core.step(torch.from_numpy(g['actions'][t].astype(np.uint8).reshape(1, -1)).cuda())
             cmp('step', t, True)

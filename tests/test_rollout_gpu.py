@@ -179,6 +179,57 @@ def test_fused_rollout_against_the_oracle(torch_cuda):
     parity.assert_rates(env, ob, 'final state', ue_dr=got_dr[-1], ue_utility=got_ut[-1])          # incl. the EWMA the kernel stored
 
 
+@pytest.mark.parametrize('kind,rng,L', [('multi', 'philox', 30), ('central', 'philox', 30), ('multi', 'reference', 0), ('central', 'philox', 0)])
+def test_rollout_with_ue_arrival_and_departure(torch_cuda, kind, rng, L):
+    """rollout() of an env whose UE list changes (base.py:433-443, 592-618): the schedule is fed to dcomp_rollout_ex per step
+    (counts; in rng='reference' mode also the host-drawn list positions / border points), resets at the horizon included.
+    Bit-identical to `if time == L: reset(); step()` issued one call at a time -- every step's outputs, ids, state."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    E, T = 40, 70 if L else 28
+    arrival = {2: 3, 5: -2, 9: 4, 14: -3, 20: 2, 21: 2, 26: -4}
+    scn = scenarios.large_map('mixed').with_ues(num_static=1, num_slow=3, num_fast=2)
+    m, bs, ues = build_from_scenario(scn)
+    B = len(bs)
+    mk = lambda: BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=21, rng=rng, rand_episodes=(rng == 'philox'), episode_length=L or 30,
+                                  ue_arrival=arrival)
+    ref, env = mk(), mk()
+    U = ref.U
+    g = torch.Generator(device='cuda').manual_seed(5)
+    acts = torch.randint(0, B + 1, (T, E, U), generator=g, device='cuda', dtype=torch.uint8)
+    keys = ('obs', 'reward', 'sum_utility', 'ue_dr', 'ue_utility')
+    want = {k: [] for k in keys}
+    ref.reset()
+    for t in range(T):
+        if L and ref.time == L:
+            ref.reset()
+        ref.step(acts[t])
+        for k in keys:
+            want[k].append(getattr(ref, k).clone())
+    ref.check()
+    want = {k: torch.stack(v) for k, v in want.items()}
+    env.reset()
+    out = {k: torch.full_like(v, float('nan')) for k, v in want.items()}
+    cut = 11
+    env.rollout(acts[:cut], out={k: v[:cut] for k, v in out.items()}, horizon=L or None)      # two fragments: events and state carry over
+    env.rollout(acts[cut:], out={k: v[cut:] for k, v in out.items()}, horizon=L or None)
+    env.check()
+    for k in keys:
+        assert torch.equal(out[k], want[k]), k
+    assert env.time == ref.time and env.episode == ref.episode and env.num_ue == ref.num_ue
+    for k in ('pos', 'mv', 'conn', 'ewma', 'uid'):
+        assert torch.equal(getattr(env, k), getattr(ref, k)), k
+    last = mk()                                              # last-step outputs only
+    last.reset()
+    last.rollout(acts[:cut])
+    assert torch.equal(last.obs, want['obs'][cut - 1]) and torch.equal(last.reward, want['reward'][cut - 1])
+    if rng == 'reference':
+        with pytest.raises(NotImplementedError):
+            last.rollout(acts[:2], horizon=30)               # a fresh host-drawn tape per episode: reset() between rollouts
+
+
 def test_rollout_argument_validation(torch_cuda):
     """Raw pointers cross the ABI: wrong dtype / device / size must be refused on the host."""
     torch = torch_cuda
