@@ -92,8 +92,28 @@ def build(force=False, jobs=None, extra_flags=()):
                                                                    '-o', o]))
     o_api = os.path.join(OBJ, 'dcomp_api.o')
     tasks.append((o_api, [hipcc] + CXXFLAGS + list(extra_flags) + ['-c', os.path.join(CSRC, 'dcomp_api.hip'), '-o', o_api]))
+
+    def obj_stamp(t):
+        """An object is rebuilt when its command line or one of ITS inputs changed: the per-station-count objects do not
+        include dcomp_api.hip (an ABI-side edit recompiles one file and relinks, seconds instead of minutes)."""
+        h = hashlib.sha256(' '.join(t[1]).encode())
+        for f in _sources():
+            if f.endswith('dcomp_api.hip') and not t[0].endswith('dcomp_api.o'):
+                continue
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, 'rb').read())
+        return h.hexdigest()
+
+    def compile_one(t):
+        stamp, want = t[0] + '.stamp', obj_stamp(t)
+        if not force and os.path.exists(t[0]) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+            return ''
+        out = _run(t[1])
+        with open(stamp, 'w') as f:
+            f.write(want + '\n')
+        return out
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
-        for out in ex.map(lambda t: _run(t[1]), tasks):
+        for out in ex.map(compile_one, tasks):
             if out.strip():
                 sys.stderr.write(out)
     _run([hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + [t[0] for t in tasks] + ['-lpthread'])

@@ -430,7 +430,7 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
     };
     auto launch_reset = [&](KParams &k) {                      // MobileEnv.reset at the horizon (base.py:169-189); its observation lands
         env->time = 0;                                         // where the next step's will (and is overwritten by it)
-        env->episode += inc;
+        env->episode += tape ? 1 : inc;                        // (tape mode: `episode` counts resets, as dcomp_reset does; the draws do not use it)
         env->cur_ue = env->cfg.num_ue; env->n_removed = env->n_arrived = 0;
         k.cur_ue = env->cur_ue;
         k.episode = (uint32_t)env->episode;
@@ -448,7 +448,7 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
             int time = env->time;
             int64_t episode = env->episode;
             for (int t = 0; t < T; t++) {
-                if (L > 0 && time == L) { time = 0; episode += inc; }
+                if (L > 0 && time == L) { time = 0; episode += tape ? 1 : inc; }
                 time += 1;
             }
             env->time = time;
