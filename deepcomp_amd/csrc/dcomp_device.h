@@ -49,6 +49,9 @@
 #ifndef DCOMP_SPARSE_PRE
 #define DCOMP_SPARSE_PRE 1      // 1: sparse pre-move pass in step_kernel where the LDS row fits (B <= 11); 0: dense (A/B)
 #endif
+#ifndef DCOMP_SPARSE_MIN_B
+#define DCOMP_SPARSE_MIN_B 7      // the sparse pre-move pass from this many stations up (B = 5: 0.5 % slower than the dense pass)
+#endif
 #ifndef DCOMP_CENTRAL_STAGED
 #define DCOMP_CENTRAL_STAGED 1  // 0: central observation rows are stored straight from registers (round 1; A/B only)
 #endif
@@ -1224,7 +1227,7 @@ __device__ __forceinline__ void step_once(const KParams &p, BlockSharedT<B, UPAD
     // scratch: the dense form.
     // Only in the plain step (STORE): the fused rollout is latency-bound, one wave per SIMD, and the LDS look-ups of this pass
     // cost it 7 % (2.16 -> 2.32 us per step at 4 096 x 10 x 5); and only from 7 stations up (B = 5: 0.5 % slower).
-    constexpr bool SPARSE_OK = DCOMP_SPARSE_PRE && STORE && B >= 7 && !(DCOMP_ABLATE & 33) && 64 * (B + 1) <= StageGeo<B>::WORDS;
+    constexpr bool SPARSE_OK = DCOMP_SPARSE_PRE && STORE && B >= DCOMP_SPARSE_MIN_B && !(DCOMP_ABLATE & 33) && 64 * (B + 1) <= StageGeo<B>::WORDS;
     if (SPARSE_OK && !(MP == MP_GENERIC && p.any_maxcap)) {
         float *const prow = sh.stage[wave] + lane * (B + 1);
         const uint32_t act_bit = act ? 1u << (act - 1u) : 0u;
@@ -1348,7 +1351,7 @@ __device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<
         sg = S{g, u, (gbase + g - 1) * 4, (uint32_t)m, (uint32_t)(m >> 32)};
     }
     const int idx = env * p.U + u;
-    if (DCOMP_SPARSE_PRE && !ROLLOUT && B >= 7 && 64 * (B + 1) <= StageGeo<B>::WORDS) {   // BS table for the sparse pre-move pass
+    if (DCOMP_SPARSE_PRE && !ROLLOUT && B >= DCOMP_SPARSE_MIN_B && 64 * (B + 1) <= StageGeo<B>::WORDS) {   // BS table for the sparse pre-move pass
         if (tid < B) sh.bs[tid] = make_double2(p.bs_x[tid], p.bs_y[tid]);
         __syncthreads();
     }

@@ -500,22 +500,40 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
     // behind its rows: one store instruction per four rows instead of a single-lane store per row -- and close in time to
     // the rest of the row.  (All 64 utility entries in ONE scattered store after the loop is faster while the observation
     // buffer fits the 256 MB Infinity Cache -- 4 096 envs -- and 45 % slower beyond: lines leave L2 partially written.)
+    // Straight-line per row: every lane reads "its" dr cell of the row (lanes that own another kind of column read cell 0 and
+    // drop it), the selects are per-lane constants -- no exec-mask branches, and the four LDS reads of a group of rows are in
+    // flight together (the branchy form waited for each row's read: 64 exposed LDS round trips per wave).
+    bool is_conn[NSLOT], is_dr[NSLOT];
+    int dcol[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; k++) {
+        const int c = lane + 64 * k;
+        is_conn[k] = c < B;
+        is_dr[k] = c >= B && c < 2 * B;
+        dcol[k] = is_dr[k] ? c - B : 0;
+    }
     for (int r0 = 0; r0 < ((DCOMP_ABLATE & 8) ? 0 : nrows); r0 += 4) {
+        float d[4][NSLOT];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++) {
+            const int r = min(r0 + k4, 63);
+#pragma unroll
+            for (int k = 0; k < NSLOT; k++)
+                if (64 * k < 2 * B && 64 * k + 64 > B) d[k4][k] = st[wide_col<B>(r, dcol[k])];     // (slot holds dr columns: compile-time)
+        }
 #pragma unroll
         for (int k4 = 0; k4 < 4; k4++) {
             const int r = r0 + k4;
-            if (r < nrows) {
+            if (r < nrows) {                                                      // uniform
                 const uint32_t conn_r = (uint32_t)__builtin_amdgcn_readlane((int)conn, r);
                 float *orow = p.obs + (row0 + r) * ROW;
 #pragma unroll
                 for (int k = 0; k < NSLOT; k++) {
                     const int c = lane + 64 * k;
-                    if (c < 4 * B) {
-                        float v = pre[k];
-                        if (c < B) v = (float)((conn_r >> c) & 1u);
-                        else if (c < 2 * B) v = st[wide_col<B>(r, c - B)];   // (r uniform: base + constant)
-                        orow[c] = v;         // plain store: non-temporal 4-byte stores bypass L2 write-combining (measured slower)
-                    }
+                    float v = pre[k];
+                    if (64 * k < 2 * B && 64 * k + 64 > B) v = is_dr[k] ? d[k4][k] : v;
+                    if (64 * k < B) v = is_conn[k] ? (float)((conn_r >> (c & 31)) & 1u) : v;
+                    if (4 * B - 64 * k >= 64 || c < 4 * B) orow[c] = v;  // plain store: non-temporal 4-byte stores bypass L2 write-combining (measured slower)
                 }
             }
         }
