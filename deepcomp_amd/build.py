@@ -20,7 +20,8 @@ OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(CSRC, 'libdcomp_hip.so')
 ARCH = 'gfx950'
 # fast-honor-pragmas: `#pragma clang fp contract(off)` in the FP64 movement code must win (bit-exact positions)
-CXXFLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast-honor-pragmas',
+# offload-compress: the gfx950 code objects (32 station counts x 7 lane widths x the kernel variants) are stored compressed: 98 -> ~20 MB
+CXXFLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast-honor-pragmas', '--offload-compress',
             '-Wall', '-Wno-unused-function']
 
 

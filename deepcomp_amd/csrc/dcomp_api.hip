@@ -24,7 +24,7 @@ static KernelPair lookup_kernels(int B, int upad, int mp)
 #define DCOMP_CASE(n) case n: return kernels_b##n(upad, mp);
         DCOMP_B_LIST(DCOMP_CASE)
 #undef DCOMP_CASE
-    default: return KernelPair{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    default: return KernelPair{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     }
 }
 }  // namespace dcomp
@@ -283,7 +283,8 @@ static void launch_step(dcomp_env *env, KParams &kp, void *stream)
 {
     if (env->tight_g) {
         kp.tight_g = env->tight_g; kp.tight_gpw = env->tight_gpw; kp.tight_magic = env->tight_magic;
-        hipLaunchKernelGGL(env->kern.step_tight, dim3(env->tight_grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
+        const dcomp::KernelFn k = (env->cfg.env_kind == DCOMP_CENTRAL && env->kern.tight_central) ? env->kern.tight_central : env->kern.step_tight;
+        hipLaunchKernelGGL(k, dim3(env->tight_grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
         return;
     }
     hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
@@ -440,7 +441,8 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
     if (env->fused) {
         // the kernel addresses step t's outputs as (idx + t * E * U) on the caller's base pointers with 32-bit row indices
         if (every && (uint64_t)T * EU >= ((uint64_t)1 << 31)) return fail(DCOMP_EINVAL, "rollout fragment too long: num_steps * num_envs * num_ue must stay below 2^31 (split the rollout)");
-        const dcomp::KernelFn kern = kp.next_act ? env->kern.rollout_pol : env->kern.rollout;   // with a registered policy: the variant that carries the rules
+        // with a registered policy: the variant that carries the rules; tape-driven central envs: the central-only instantiation
+        const dcomp::KernelFn kern = kp.next_act ? env->kern.rollout_pol : (!multi && env->kern.rollout_central) ? env->kern.rollout_central : env->kern.rollout;
         if (!loop || L == 0 || env->time + T <= L) {
             // ONE launch; resets at the horizon of a tape-driven rollout happen inside the kernel
             kp.action = actions; kp.num_steps = T; kp.out_every_step = every; kp.horizon = L; kp.episode_inc = inc; kp.policy_loop = loop;

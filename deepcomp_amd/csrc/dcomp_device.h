@@ -932,7 +932,10 @@ __device__ __forceinline__ int policy_action(const KParams &p, uint32_t conn, co
 // POL: the in-step heuristic policy (o.next_act / pol_next): -1 = decided at run time (one uniform branch), 0 = compiled out,
 // 1 = compiled in.  The fused rollout is instantiated both ways: it is latency-bound with one wave per SIMD, and the extra live
 // values of the run-time form cost the plain tape-driven rollout 8 % (round 2: 2.15 -> 2.33 us per step at 4 096 x 10 x 5).
-template <int B, int UPAD, bool RESET, bool DYN = false, bool STAGED = true, class S = SegPadded, int POL = -1>
+// KIND: the env kind (central.py / multi_agent.py layouts and rewards): -1 = read from the argument block, DCOMP_CENTRAL =
+// compiled for the central env only.  The latency-bound fused rollout and the tight-packing kernel -- the two that serve the
+// small central shapes (BASELINE config 2; 65 536 x 10 x 5) -- have a central-only instantiation: 4 % each, same box A/B.
+template <int B, int UPAD, bool RESET, bool DYN = false, bool STAGED = true, class S = SegPadded, int POL = -1, int KIND = -1>
 __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, BlockSharedT<B, UPAD> &sh, bool active, int env, int env_local, int u, int idx,
                                               int wave, int lane, int gbase, uint32_t conn, uint32_t in_range,
                                               float (&l2)[B], float (&cnt)[B], float util, float curr_dr,
@@ -941,7 +944,7 @@ __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, B
     using G = Geo<B, UPAD>;
     using SG = StageGeo<B>;
     const int U = p.U;
-    const int kind = DCOMP_FORCE_KIND >= 0 ? DCOMP_FORCE_KIND : p.kind;
+    const int kind = KIND >= 0 ? KIND : DCOMP_FORCE_KIND >= 0 ? DCOMP_FORCE_KIND : p.kind;
     // per-BS utility aggregates over connected UEs (station.py:63-83)
     float tsum[B];
 #pragma unroll
@@ -1205,7 +1208,7 @@ __device__ __forceinline__ void store_state(const KParams &p, int idx, double px
 template <int B>
 struct PairCarry { float l2[B]; float dru[B]; uint32_t in_range; bool near; };   // dru: unshared rate per station (shared_rates CARRY)
 
-template <int B, int UPAD, int MP, bool STORE, class S, int POL = -1, bool CARRY = false>
+template <int B, int UPAD, int MP, bool STORE, class S, int POL = -1, bool CARRY = false, int KIND = -1>
 __device__ __forceinline__ void step_once(const KParams &p, BlockSharedT<B, UPAD> &sh, const Outs &o, bool emit, bool active, int env,
                                           int env_local, int u, int idx, int wave, int lane, int gbase, uint32_t act, uint32_t time,
                                           uint32_t episode, bool step_util, float dr_req, int vrange, double &px, double &py,
@@ -1309,7 +1312,7 @@ __device__ __forceinline__ void step_once(const KParams &p, BlockSharedT<B, UPAD
     if (emit) {
         Outs o2 = o;                                  // next_action is ONE [E][U] buffer, not a [T][...] fragment: undo the shift for it
         if (POL != 0 && o2.next_act) o2.next_act -= idx_shift;
-        write_outputs<B, UPAD, false, false, STORE, S, POL>(p, o2, sh, active, env + env_shift, env_local, u, idx + idx_shift, wave, lane, gbase, conn,
+        write_outputs<B, UPAD, false, false, STORE, S, POL, KIND>(p, o2, sh, active, env + env_shift, env_local, u, idx + idx_shift, wave, lane, gbase, conn,
                                                          in_range, l2, cnt, util, curr, reward_before, active, p.U, sg, pol_next);
     }
 }
@@ -1329,7 +1332,7 @@ __device__ __forceinline__ double in_vgpr(double v)
     return v;
 }
 
-template <int B, int UPAD, int MP, bool ROLLOUT, bool TIGHT = false, int POL = -1>
+template <int B, int UPAD, int MP, bool ROLLOUT, bool TIGHT = false, int POL = -1, int KIND = -1>
 __device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<B, UPAD> &sh)
 {
     using G = Geo<B, UPAD>;
@@ -1392,8 +1395,8 @@ __device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<
     }
     Outs o{p.obs, p.reward, p.sum_util, p.ue_dr, p.ue_util, p.rb_out, POL == 0 ? nullptr : p.next_act};
     if (!ROLLOUT) {
-        step_once<B, UPAD, MP, true>(p, sh, o, true, active, env, env_local, u, idx, wave, lane, gbase, act, p.time, p.episode, step_util, dr_req,
-                               vrange, px, py, mv, conn, ewma, sg);
+        step_once<B, UPAD, MP, true, S, -1, false, KIND>(p, sh, o, true, active, env, env_local, u, idx, wave, lane, gbase, act, p.time, p.episode,
+                                                         step_util, dr_req, vrange, px, py, mv, conn, ewma, sg);
     } else {
         const int T = p.num_steps;
         const size_t EU = (size_t)p.E * p.U;
@@ -1443,13 +1446,13 @@ __device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<
             }
             act = active ? (uint32_t)(act_cur >> (8 * (t & 7))) & 0xFFu : 0u;
             if (ploop && t > 0) act = active ? pol_next : 0u;
-            step_once<B, UPAD, MP, false, S, POL, true>(p, sh, o, p.out_every_step || t == T - 1 || ploop, active, env, env_local, u, idx, wave, lane,
+            step_once<B, UPAD, MP, false, S, POL, true, KIND>(p, sh, o, p.out_every_step || t == T - 1 || ploop, active, env, env_local, u, idx, wave, lane,
                                                         gbase, act, time, episode, step_util, dr_req, vrange, px, py, mv, conn, ewma, sg,
                                                         POL != 0 ? &pol_next : nullptr, bsx, bsy, &carry, env_shift, idx_shift);
             time += 1;
             if (p.out_every_step) { env_shift += p.E; idx_shift += (int)EU; }   // outputs of step t + 1 -> the next slice of the [T][...] buffers
             // the max-cap and 'sum'-reward scratch of the next step aliases the observation staging other waves may still be copying out
-            if ((MP == MP_GENERIC && p.any_maxcap) || (p.kind == DCOMP_MULTI && p.reward_agg == DCOMP_REWARD_SUM)) __syncthreads();
+            if ((MP == MP_GENERIC && p.any_maxcap) || ((KIND >= 0 ? KIND : p.kind) == DCOMP_MULTI && p.reward_agg == DCOMP_REWARD_SUM)) __syncthreads();
         }
     }
     if (ROLLOUT && active) store_state(p, idx, px, py, mv, conn, ewma);
@@ -1468,20 +1471,20 @@ __global__ DCOMP_STEP_BOUNDS void step_kernel(const KParams p)
 }
 
 // step_kernel with envs packed tightly (see SegT): only where dcomp_create ever picks it -- UE lists of 5, 9, 10, 17-21.
-template <int B, int UPAD, int MP>
+template <int B, int UPAD, int MP, int KIND = -1>
 __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel_tight(const KParams p)
 {
     __shared__ BlockSharedT<B, UPAD> sh;
-    step_kernel_body<B, UPAD, MP, false, true>(p, sh);
+    step_kernel_body<B, UPAD, MP, false, true, -1, KIND>(p, sh);
 }
 
 // POL = 0: the action-tape rollout (no policy code in it); POL = 1: with a registered heuristic policy -- next_action of every
 // emitted step and, with policy_loop, the closed loop act = policy(obs); step(act) inside the launch.
-template <int B, int UPAD, int MP, int POL>
+template <int B, int UPAD, int MP, int POL, int KIND = -1>
 __global__ __launch_bounds__(DCOMP_BLOCK) void rollout_kernel(const KParams p)
 {
     __shared__ BlockSharedT<B, UPAD> sh;
-    step_kernel_body<B, UPAD, MP, true, false, POL>(p, sh);
+    step_kernel_body<B, UPAD, MP, true, false, POL, KIND>(p, sh);
 }
 
 // MobileEnv.reset (base.py:169-189): user.py:98-116 + movement.py:110-122 + first observation.
@@ -1537,7 +1540,7 @@ namespace dcomp {
 using KernelFn = void (*)(const KParams);
 // step_wide: organisation for envs of >= 64 lanes (dcomp_wide.h); nullptr for narrower envs.  It has no max-cap
 // path, the host falls back to `step` when a BS is max-cap.
-struct KernelPair { KernelFn step, reset, step_wide, step_dyn, rollout, step_tight, rollout_pol; };   // step_dyn: UEs arrive / depart (dcomp_dyn.h), UPAD <= 64
+struct KernelPair { KernelFn step, reset, step_wide, step_dyn, rollout, step_tight, rollout_pol, rollout_central, tight_central; };   // step_dyn: UEs arrive / depart (dcomp_dyn.h), UPAD <= 64
 
 template <int B, int UPAD, int MP>
 inline KernelFn wide_or_null()
@@ -1548,20 +1551,20 @@ inline KernelFn wide_or_null()
     else return nullptr;
 }
 
-template <int B, int UPAD, int MP, int POL = 0>
+template <int B, int UPAD, int MP, int POL = 0, int KIND = -1>
 inline KernelFn rollout_or_null()
 {
     // The fused rollout serves small batches (dcomp_create: <= 4 waves per SIMD).  Not instantiated where it is never or hardly
     // ever picked -- shapes the wide kernel takes over, envs of more than one wavefront -- those are also the costly ones to
     // build; dcomp_rollout then launches the step kernel once per step (same results).
     if constexpr (UPAD > 64 || (UPAD >= 64 && B > DCOMP_WIDE_MIN_B)) return nullptr;
-    else return rollout_kernel<B, UPAD, MP, POL>;
+    else return rollout_kernel<B, UPAD, MP, POL, KIND>;
 }
 
-template <int B, int UPAD, int MP>
+template <int B, int UPAD, int MP, int KIND = -1>
 inline KernelFn tight_or_null()
 {
-    if constexpr (UPAD == 8 || UPAD == 16 || UPAD == 32) return step_kernel_tight<B, UPAD, MP>;
+    if constexpr (UPAD == 8 || UPAD == 16 || UPAD == 32) return step_kernel_tight<B, UPAD, MP, KIND>;
     else return nullptr;
 }
 
@@ -1579,11 +1582,11 @@ inline KernelPair make_pair_(int mp)
     // narrow variants would never be launched there and are the most expensive instantiations of the build: left out.
     if constexpr (UPAD >= 64 && B > DCOMP_WIDE_MIN_B) {
         const KernelFn w = mp == MP_RES_FAIR ? wide_or_null<B, UPAD, MP_RES_FAIR>() : mp == MP_MIXED ? wide_or_null<B, UPAD, MP_MIXED>() : wide_or_null<B, UPAD, MP_GENERIC>();
-        return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, w, dyn_or_null<B, UPAD>(), nullptr, nullptr, nullptr};
+        return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, w, dyn_or_null<B, UPAD>(), nullptr, nullptr, nullptr, nullptr, nullptr};
     } else {
-    if (mp == MP_RES_FAIR) return KernelPair{step_kernel<B, UPAD, MP_RES_FAIR>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_RES_FAIR>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_GENERIC>(), tight_or_null<B, UPAD, MP_GENERIC>(), rollout_or_null<B, UPAD, MP_GENERIC, 1>()};   // (all-resource-fair: the generic variants, run-time modes, serve the fused rollout and the tight packing -- build time)
-    if (mp == MP_MIXED) return KernelPair{step_kernel<B, UPAD, MP_MIXED>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_MIXED>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_MIXED>(), tight_or_null<B, UPAD, MP_MIXED>(), rollout_or_null<B, UPAD, MP_MIXED, 1>()};
-    return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_GENERIC>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_GENERIC>(), tight_or_null<B, UPAD, MP_GENERIC>(), rollout_or_null<B, UPAD, MP_GENERIC, 1>()};
+    if (mp == MP_RES_FAIR) return KernelPair{step_kernel<B, UPAD, MP_RES_FAIR>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_RES_FAIR>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_GENERIC>(), tight_or_null<B, UPAD, MP_GENERIC>(), rollout_or_null<B, UPAD, MP_GENERIC, 1>(), rollout_or_null<B, UPAD, MP_GENERIC, 0, DCOMP_CENTRAL>(), tight_or_null<B, UPAD, MP_GENERIC, DCOMP_CENTRAL>()};   // (all-resource-fair: the generic variants, run-time modes, serve the fused rollout and the tight packing -- build time)
+    if (mp == MP_MIXED) return KernelPair{step_kernel<B, UPAD, MP_MIXED>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_MIXED>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_MIXED>(), tight_or_null<B, UPAD, MP_MIXED>(), rollout_or_null<B, UPAD, MP_MIXED, 1>(), rollout_or_null<B, UPAD, MP_MIXED, 0, DCOMP_CENTRAL>(), tight_or_null<B, UPAD, MP_MIXED, DCOMP_CENTRAL>()};
+    return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_GENERIC>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_GENERIC>(), tight_or_null<B, UPAD, MP_GENERIC>(), rollout_or_null<B, UPAD, MP_GENERIC, 1>(), rollout_or_null<B, UPAD, MP_GENERIC, 0, DCOMP_CENTRAL>(), tight_or_null<B, UPAD, MP_GENERIC, DCOMP_CENTRAL>()};
     }
 }
 
@@ -1602,7 +1605,7 @@ inline KernelPair kernels_for_upad(int upad, int mp)
     case 64: return make_pair_<B, 64>(mp);
     case 128: return make_pair_<B, 128>(mp);
     case 256: return make_pair_<B, 256>(mp);
-    default: return KernelPair{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    default: return KernelPair{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     }
 #endif
 }
