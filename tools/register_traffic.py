@@ -24,7 +24,7 @@ def main():
     vals = {}
     for line in txt.splitlines():
         line = line.strip()
-        if kern in line and ('FETCH_SIZE' in line or 'WRITE_SIZE' in line):
+        if line.startswith('void ') and kern in line and ("{'FETCH_SIZE'" in line or "{'WRITE_SIZE'" in line):
             d = ast.literal_eval(line[line.index('{'):line.index('}') + 1])
             vals.update(d)
     if 'FETCH_SIZE' not in vals or 'WRITE_SIZE' not in vals:
