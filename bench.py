@@ -210,9 +210,16 @@ def measure_sharded(torch, dist, BatchedMobileEnv, scenarios, build_from_scenari
 def measure_also(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev):
     """The other BASELINE configurations that fit one GPU, next to the headline (secondary figures)."""
     mk = (torch, BatchedMobileEnv, scenarios, build_from_scenario, dev)
+    central = measure_steps(*mk, 65536, 10, 5, 'central')
+    # the same batch through rollout(): short central rows take the fused kernel at every batch size once a rollout is >= 4 steps
+    # long (no kernel boundary: the 5.4 us per-launch constant is a quarter of this shape's step; DESIGN.md section 4)
+    r = measure_rollout(*mk, 65536, 10, 5, 'central', T=50, steps=1500)
+    central['through_rollout_T50'] = {'ms_per_step': r['ms_per_step'], 'fused_one_launch': r['fused_one_launch'],
+                                      'achieved_GBps': r['achieved_GBps_algorithmic'], 'frac_of_hbm_peak': r['achieved_GBps_algorithmic'] / HBM_PEAK_GBS,
+                                      'how': '50 steps per launch, every step\'s outputs into [T, ...] buffers, resets at the horizon inside the kernel'}
     return {'config2_4096x10x5_central_fused_rollout': measure_rollout(*mk, 4096, 10, 5, 'central', T=100, steps=4000, launches_too=True),
             'config5_share_4096x128x32_multi': measure_steps(*mk, 4096, 128, 32, 'multi'),
-            'central_65536x10x5': measure_steps(*mk, 65536, 10, 5, 'central'),
+            'central_65536x10x5': central,
             'config4_share_32768x32x10_multi': measure_steps(*mk, 32768, 32, 10, 'multi')}      # last: the headline's own kernel
 
 

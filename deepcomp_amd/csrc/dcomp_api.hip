@@ -54,6 +54,7 @@ struct dcomp_env {
     UeCfg *d_ue_cfg;
     bool dyn;                  // UE list changes during an episode (cfg.max_ues > 0)
     bool fused;                // kern.step is step_kernel: T steps in one launch (the wide / dynamic kernels step once per launch)
+    bool fused_long;           // ... for rollouts of >= 4 steps at ANY batch size (small central rows: see dcomp_create)
     int upad, grid;
     int tight_g, tight_gpw, tight_magic, tight_grid;   // step_kernel's tight packing of non-power-of-two UE lists (0 = off)
     int cap, cur_ue;            // slots per env; UEs currently listed
@@ -219,6 +220,13 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
         if (const char *e = getenv("DCOMP_FUSE_MAX_WAVES")) max_waves = atol(e);
         const long waves = (long)env->grid * (DCOMP_BLOCK / 64);
         env->fused = !DYN && env->kern.step != env->kern.step_wide && env->kern.rollout != nullptr && waves <= max_waves;
+        // Central envs with short rows (2B + 1 <= 17 floats per UE) are faster through the fused kernel at EVERY batch size once a
+        // rollout is a few steps long: no kernel boundary (5.4 us per launch, a quarter of a 65 536 x 10 x 5 step), no state round
+        // trip, pairs carried from step to step -- 65 536 x 10 x 5: 16.3 vs 19-20 us per step, 16 384: 4.2 vs 11.2, 262 144: 58 vs
+        // 63 (T = 50).  Rows of the multi-agent layout (4B + 1 floats per lane, stored straight from registers) stream too
+        // badly for that: 65 536 x 32 x 10: 129 vs 77 us.
+        env->fused_long = !DYN && env->kern.step != env->kern.step_wide && env->kern.rollout != nullptr &&
+                          cfg->env_kind == DCOMP_CENTRAL && B <= 8 && !getenv("DCOMP_NO_FUSED_LONG");
         // Tight packing of UE lists whose length is not a power of two (dcomp_device.h, struct Seg): G = U lanes per env,
         // 64 / G envs per wavefront, segmented ds_bpermute reductions (~13 instead of 4 instructions each).  It pays where the
         // launch is throughput-bound and the padding wastes many lanes: >= 4 padded waves per SIMD and >= 1.4x the lanes in use
@@ -415,7 +423,7 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
     const bool loop = opts && opts->policy_loop != 0;
     if (loop) {
         if (!env->kp.next_act) return fail(DCOMP_EINVAL, "policy_loop needs a policy (dcomp_set_policy)");
-        if (!env->fused) return fail(DCOMP_EUNSUPPORTED, "policy_loop needs the fused rollout kernel (dcomp_rollout_is_fused)");
+        if (!env->fused && !env->fused_long) return fail(DCOMP_EUNSUPPORTED, "policy_loop needs the fused rollout kernel (dcomp_rollout_is_fused)");
     }
     const size_t EU = (size_t)env->cfg.num_envs * env->cap, E = (size_t)env->cfg.num_envs;
     const bool multi = env->cfg.env_kind == DCOMP_MULTI;
@@ -438,7 +446,7 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
         k.time = 0u;
         hipLaunchKernelGGL(env->kern.reset, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, k);
     };
-    if (env->fused) {
+    if (env->fused || (env->fused_long && (T >= 4 || loop))) {
         // the kernel addresses step t's outputs as (idx + t * E * U) on the caller's base pointers with 32-bit row indices
         if (every && (uint64_t)T * EU >= ((uint64_t)1 << 31)) return fail(DCOMP_EINVAL, "rollout fragment too long: num_steps * num_envs * num_ue must stay below 2^31 (split the rollout)");
         // with a registered policy: the variant that carries the rules; tape-driven central envs: the central-only instantiation
@@ -522,7 +530,7 @@ extern "C" int dcomp_rollout_ex(dcomp_env *env, const dcomp_state *st, const uin
     return rollout_impl(env, st, actions, num_steps, out, opts, stream);
 }
 
-extern "C" int dcomp_rollout_is_fused(const dcomp_env *env) { return env ? (env->fused ? 1 : 0) : -1; }
+extern "C" int dcomp_rollout_is_fused(const dcomp_env *env) { return env ? ((env->fused || env->fused_long) ? 1 : 0) : -1; }
 extern "C" int dcomp_lanes_per_env(const dcomp_env *env) { return env ? (env->tight_g ? env->tight_g : env->upad) : -1; }
 
 extern "C" int dcomp_check(dcomp_env *env, const dcomp_state *st, void *stream)

@@ -157,7 +157,10 @@ int dcomp_num_ue(const dcomp_env *env);               /* UEs currently in every 
 /* T consecutive steps from an action tape actions[T][E][U] with no host work in between; outputs of the LAST step only.
  * Replaces the per-step Python loop of simulation.py:512-541.  The narrow kernel (dcomp_rollout_is_fused() == 1) runs all T
  * steps in ONE launch with the UE state in registers in between; envs of >= 64 lanes with more than 20 BSs and envs with UE
- * arrival / departure are launched once per step.  Results are identical to T dcomp_step calls either way. */
+ * arrival / departure are launched once per step.  Fused: batches of up to 3 waves per SIMD, and central envs of <= 8 stations
+ * at any batch size when num_steps >= 4.  Connection masks, positions and movement state are identical to T dcomp_step calls
+ * either way; the floats are bit-identical too unless dcomp_step packs the envs tightly (dcomp_lanes_per_env: UE lists of 5, 9,
+ * 10, 17-21 in batches of >= 4 096 waves), whose per-env sums run in scan order instead of butterfly order (<= 2e-6 relative). */
 int dcomp_rollout(dcomp_env *env, const dcomp_state *st, const uint8_t *actions, int32_t num_steps,
                   const dcomp_out *out, void *stream);
 

@@ -246,3 +246,33 @@ def test_rollout_argument_validation(torch_cuda):
         env.step_into(good[0], torch.zeros((8, 4, 12), device='cuda'), torch.zeros((8, 4), device='cuda'))
     with pytest.raises(ValueError):
         env.step_into(good[0].to(torch.int64), env.obs, env.reward)
+
+
+def test_long_rollouts_of_small_central_envs_are_fused_at_any_batch_size(torch_cuda):
+    """Central envs of <= 8 stations go through the fused kernel for rollouts of >= 4 steps however large the batch (short rows
+    stream well from registers and the kernel boundary is a quarter of such a step); shorter rollouts and multi-agent envs of
+    that size keep one launch per step.  Same masks / positions as step() -- the floats too, except for the summation order of
+    the tightly packed step kernel this batch size selects (<= 2e-6)."""
+    torch = torch_cuda
+    E, U, B, T = 20000, 10, 5, 12
+    big = _make('central', U, B, E)
+    assert big.fused_rollout and big.lanes_per_env == U              # step(): tight packing; rollout(): fused
+    multi = _make('multi', U, B, E)
+    assert not multi.fused_rollout
+    ref = _make('central', U, B, E)
+    g = torch.Generator(device='cuda').manual_seed(4)
+    acts = torch.randint(0, B + 1, (T, E, U), generator=g, device='cuda', dtype=torch.uint8)
+    big.reset(); ref.reset()
+    out = {'obs': torch.empty((T,) + tuple(big.obs.shape), device='cuda'), 'reward': torch.empty((T, E), device='cuda')}
+    big.rollout(acts, out=out)
+    for t in range(T):
+        ref.step(acts[t])
+        torch.testing.assert_close(out['obs'][t], ref.obs, rtol=2e-6, atol=2e-6)
+        torch.testing.assert_close(out['reward'][t], ref.reward, rtol=0, atol=2e-6)
+    big.check(); ref.check()
+    assert torch.equal(big.pos, ref.pos) and torch.equal(big.conn, ref.conn) and torch.equal(big.mv, ref.mv)
+    torch.testing.assert_close(big.ewma, ref.ewma, rtol=1e-5, atol=1e-30)
+    big.rollout(acts[:2])                                            # a 2-step rollout: one (tightly packed) launch per step, like step()
+    ref.step(acts[0]); ref.step(acts[1])
+    torch.testing.assert_close(big.obs, ref.obs, rtol=2e-6, atol=2e-6)   # (the EWMA history differs in its last bits; masks must not)
+    assert torch.equal(big.conn, ref.conn) and torch.equal(big.pos, ref.pos)

@@ -1,5 +1,9 @@
-export DCOMP_LIB=$GRAFT_REPO_ROOT/deepcomp_amd/csrc/variants/libdcomp_hip_wb128.so
-python -m pytest tests/test_parity_gpu.py tests/test_adapters_gpu.py -q -m gpu -k "128 or 256 or 200 or 100 or 64 or per_gpu_shares or dense_cells" 2>&1 | grep -v "no kernel built" | tail -8 > gpurun_out/r3_t15_pytest.log
-unset DCOMP_LIB
-python tools/ab_lib.py run wb256 wb128 --rounds 3 --only c5,c5big > gpurun_out/r3_t15_ab.log 2>&1
-grep "passed\|failed" gpurun_out/r3_t15_pytest.log; tail -4 gpurun_out/r3_t15_ab.log
+python -m pytest tests -m gpu -q 2>&1 | tail -6 > gpurun_out/r3_t16_pytest.log
+tail -4 gpurun_out/r3_t16_pytest.log
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r3_t16_bench.json
+python -c "
+import json; j=json.load(open('gpurun_out/r3_t16_bench.json')); r=j['roofline']
+print(j['value'], j['ms_per_step'], r['kernel_ms'], r['frac'], r['traffic'], r['traffic_source'][:60])
+for k,v in j['also'].items():
+    if isinstance(v, dict): print(k, {a:(round(b,5) if isinstance(b,float) else b) for a,b in v.items() if a in ('ms_per_step','kernel_ms','frac_of_hbm_peak','through_rollout_T50')})
+"
