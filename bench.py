@@ -297,12 +297,14 @@ def self_spawn(n):
     sys.exit(1)
 
 
-def traffic_from_profile(workload_key):
-    """roofline.traffic comes from a TRACKED rocprofv3 --pmc summary (profiles/traffic.json, written by
-    tools/summarize_prof.py --traffic-json on the GPU box), never from a literal in this file: HBM bytes per launch =
-    FETCH_SIZE x 2 (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in KiB.  An entry taken
-    from other kernel sources than the ones this library was built from (content hash of deepcomp_amd/csrc + flags, no git
-    needed on the GPU box) is STALE: traffic is then null and the source says why."""
+def traffic_from_profile(workload_key, kernel_name=None):
+    """roofline.traffic comes from a TRACKED rocprofv3 --pmc summary (profiles/traffic.json, registered by
+    tools/register_traffic.py from a summary tools/summarize_prof.py wrote on the GPU box), never from a literal in this file:
+    HBM bytes per launch = FETCH_SIZE x 2 (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in
+    KiB.  An entry is valid while (a) the KERNEL sources the profiled library was built from are the ones this library was built
+    from -- content hash of csrc/dcomp_inst.hip + the device headers + flags (build.kernel_fingerprint; no git needed on the GPU
+    box; host-side ABI edits cannot change a kernel's traffic) -- and (b) the library dispatches this workload to the very
+    instantiation that was profiled (dcomp_step_kernel_name).  Otherwise it is STALE: traffic is null and the source says why."""
     path = os.path.join(REPO, 'profiles', 'traffic.json')
     try:
         ent = json.load(open(path)).get(workload_key)
@@ -312,8 +314,10 @@ def traffic_from_profile(workload_key):
         return None, f'no entry for {workload_key!r} in profiles/traffic.json'
     from deepcomp_amd import build as hip_build
     src = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/{ent['tag']}_summary.txt, kernel {ent['kernel']}, commit {ent.get('commit', '?')}"
-    if ent.get('source_fingerprint') != hip_build.source_fingerprint():
+    if ent.get('kernel_fingerprint') != hip_build.kernel_fingerprint() and ent.get('source_fingerprint') != hip_build.source_fingerprint():
         return None, 'STALE (kernel sources changed since): ' + src
+    if kernel_name is not None and kernel_name != ent['kernel']:
+        return None, f'STALE (this library dispatches to {kernel_name}): ' + src
     return (2.0 * ent['fetch_kib'] + ent['write_kib']) * 1024.0, src
 
 
@@ -672,7 +676,7 @@ def main():
                                       f'all-gather of end-of-episode rewards + sum_utility ({4 * E * (env.reward.numel() // E + 1) * world / 1e6:.1f} MB) every {L} steps, async')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': args.traffic_bytes, 'kernel': 'dcomp::step_kernel', 'kernel_ms': kern_ms,
+                         'traffic': args.traffic_bytes, 'kernel': 'dcomp::' + (env.step_kernel_name or 'step_kernel'), 'kernel_ms': kern_ms,
                          'kernel_ms_how': f'HIP events over the timed region: {sum(n for _, _, n in spans)} launches in {len(spans)} back-to-back run(s) between resets',
                          'launch_bound': kern_ms < 0.02,
                          'algorithmic_bytes_per_env_step': sbpe, 'layout_bytes_per_env_step': bpe},
@@ -688,7 +692,7 @@ def main():
                                                'frac': sbpe * E / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                'how': f'200 launches timed after {max(300, K)} untimed ones (same HIP-event method)'}
         if args.traffic_bytes is None:
-            out['roofline']['traffic'], out['roofline']['traffic_source'] = traffic_from_profile(f'{E}x{U}x{B}_{args.kind}_{args.sharing}')
+            out['roofline']['traffic'], out['roofline']['traffic_source'] = traffic_from_profile(f'{E}x{U}x{B}_{args.kind}_{args.sharing}', env.step_kernel_name)
         else:
             out['roofline']['traffic_source'] = '--traffic-bytes'
         if world == 1 and not args.no_stream:

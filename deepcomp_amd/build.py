@@ -59,6 +59,22 @@ def _fingerprint(extra_flags=()):
     return h.hexdigest()
 
 
+KERNEL_SOURCES = ('dcomp_device.h', 'dcomp_wide.h', 'dcomp_dyn.h', 'dcomp_blist.h', 'dcomp_inst.hip')
+
+
+def kernel_fingerprint(read=None):
+    """Hash of what the step / reset / rollout KERNELS are compiled from (the per-station-count objects: csrc/dcomp_inst.hip and
+    the headers it includes, + flags) -- not the host side of the ABI (dcomp_api.hip, include/dcomp.h), whose edits cannot change
+    a kernel's HBM traffic.  bench.py accepts a tracked --pmc profile while this hash AND the name of the dispatched kernel
+    (dcomp_step_kernel_name) match.  read(name) -> bytes: fingerprint of another tree (tools/register_traffic.py --backfill)."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), 'rb').read() if read is None else read(f))
+    h.update(' '.join(CXXFLAGS + _dev_flags()).encode())
+    return h.hexdigest()
+
+
 def source_fingerprint():
     """Hash of the kernel sources + flags of the product build: profiles record it (tools/summarize_prof.py), bench.py compares
     it with the library it runs -- a PMC figure taken from other sources is reported as stale.  Needs no git."""

@@ -53,6 +53,7 @@ struct dcomp_env {
     dcomp::KernelPair kern;
     UeCfg *d_ue_cfg;
     bool dyn;                  // UE list changes during an episode (cfg.max_ues > 0)
+    int mp_pattern;            // sharing-pattern specialisation the kernels were looked up with (dcomp::MP_*)
     bool fused;                // kern.step is step_kernel: T steps in one launch (the wide / dynamic kernels step once per launch)
     bool fused_long;           // ... for rollouts of >= 4 steps at ANY batch size (small central rows: see dcomp_create)
     int upad, grid;
@@ -131,6 +132,7 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
         for (int b = 0; b < B; b++) if (cfg->bs_sharing[b] != cyc[b % 3]) mp = dcomp::MP_GENERIC;
     }
     env->kern = dcomp::lookup_kernels(B, env->upad, mp);
+    env->mp_pattern = mp;
     if (!env->kern.step) { delete env; return fail(DCOMP_EUNSUPPORTED, "no kernel built for num_bs=%d (built: " DCOMP_B_LIST_STR ")", B); }
     {
         // the wide kernel (UPAD >= 64) always uses 256-thread workgroups; the others DCOMP_BLOCK
@@ -532,6 +534,21 @@ extern "C" int dcomp_rollout_ex(dcomp_env *env, const dcomp_state *st, const uin
 
 extern "C" int dcomp_rollout_is_fused(const dcomp_env *env) { return env ? ((env->fused || env->fused_long) ? 1 : 0) : -1; }
 extern "C" int dcomp_lanes_per_env(const dcomp_env *env) { return env ? (env->tight_g ? env->tight_g : env->upad) : -1; }
+
+// The instantiation dcomp_step launches for this env, spelled as rocprofv3 prints it ("step_kernel<10, 32, 2>"): bench.py ties a
+// tracked --pmc profile to the kernel the library really dispatches to.
+extern "C" int dcomp_step_kernel_name(const dcomp_env *env, char *buf, int32_t len)
+{
+    if (!env || !buf || len < 1) return fail(DCOMP_EINVAL, "null argument");
+    const int B = env->cfg.num_bs, W = env->upad, MP = env->mp_pattern;
+    if (env->tight_g) {
+        const bool cen = env->cfg.env_kind == DCOMP_CENTRAL && env->kern.tight_central;
+        std::snprintf(buf, (size_t)len, "step_kernel_tight<%d, %d, %d, %d>", B, W, MP, cen ? 0 : -1);
+    } else if (env->dyn) std::snprintf(buf, (size_t)len, "step_kernel_dyn<%d, %d, %d>", B, W, MP);
+    else if (env->kern.step == env->kern.step_wide && env->kern.step_wide) std::snprintf(buf, (size_t)len, "step_kernel_wide<%d, %d, %d>", B, W, MP);
+    else std::snprintf(buf, (size_t)len, "step_kernel<%d, %d, %d>", B, W, MP);
+    return DCOMP_OK;
+}
 
 extern "C" int dcomp_check(dcomp_env *env, const dcomp_state *st, void *stream)
 {

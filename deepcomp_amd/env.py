@@ -225,6 +225,7 @@ class BatchedMobileEnv:
         self._tape_dev = None
         self._streams = None
         self._fixed_tape = None
+        self._live = None                    # seed(immediate=True) in a running fixed episode: (new env seeds, cursors at that time)
 
     # ------------------------------------------------------------------ helpers
     def _make_out(self, obs, reward):
@@ -253,19 +254,65 @@ class BatchedMobileEnv:
     def episode(self):
         return self._L.dcomp_episode(self._h)
 
-    def seed(self, seed=None):
-        """MobileEnv.seed (base.py:132-143); None leaves the generators alone.  The new seed governs every draw from the
-        next reset() on (the gym convention `env.seed(s); env.reset()`): it is STAGED here and applied by reset() -- the
-        remaining draws of an episode in progress keep coming from the tape / Philox key the episode started with, in both
-        RNG modes.  (The reference also re-seeds the streams of the running episode, base.py:138-143; none of its callers
-        seeds mid-episode -- INTEGRATION.md section 3.)"""
+    def seed(self, seed=None, immediate=False):
+        """MobileEnv.seed (base.py:132-143); None leaves the generators alone.
+
+        immediate=False (the batched API): the gym convention `env.seed(s); env.reset()` -- the new seed is STAGED here and
+        governs every draw from the next reset() on; the remaining draws of an episode in progress keep coming from the tape /
+        Philox key the episode started with, in both RNG modes.
+
+        immediate=True (what the reference-named classes pass in rng='reference' mode): the reference to the letter.  Both
+        streams of every UE are re-seeded AT ONCE, so the waypoints / velocities a UE still draws in the running episode come
+        from the start of its new movement stream (base.py:138-143 -> user.py:94-96); the next reset() of a
+        rand_episodes=False env re-seeds with the CONFIGURED seed again (base.py:171-173: seed() then only shapes the rest of
+        the running episode), a rand_episodes=True env carries the new streams on.  Held against reference-run trajectories
+        (tests/golden/reseed_*.npz).  Fixed UE lists only; with UE arrival / departure the seed is staged."""
         if seed is None:
             return
         seed = int(seed)
+        if immediate and self.rng_mode == _lib.RNG_TAPE and not self.dynamic:
+            return self._seed_live(seed)
         self.seed_value = seed
         self.env_seeds = self.seed_value + self._seed_stride * (self.env_id_base + np.arange(self.E, dtype=np.int64))
         self._streams, self._fixed_tape, self._dyn_streams = None, None, None
+        self._live = None
         self._reseeded = True                         # reset() starts the new key's episode 0
+
+    def _seed_live(self, seed):
+        """seed(immediate=True), rng='reference': splice the new streams into the tape of the running episode."""
+        seeds = seed + self._seed_stride * (self.env_id_base + np.arange(self.E, dtype=np.int64))
+        live = self._tape_dev is not None
+        cursor = ((self.mv >> 48) & 0xFFFF).cpu().numpy().astype(np.int64) if live else None   # triples consumed so far, per (env, UE)
+        if self.rand_episodes:
+            self.seed_value, self.env_seeds = seed, seeds
+            if self._streams is None:                 # no reset() yet: the first one starts the new streams
+                return
+            spliced = self._streams.reseed_live(seeds, cursor)
+            if spliced is None:
+                return
+        else:                                         # reset() goes back to self.env_seeds (base.py:171-173): only the running episode changes
+            if not live:
+                return
+            self._live = (seeds, cursor)
+            spliced = self._live_fixed_tape(self._tape_depth_now)
+        pos0, trip = spliced
+        torch.cuda.current_stream(self.device).synchronize()       # steps in flight still read the old tape
+        old = self._tape_dev
+        tape = self._upload_tape(pos0, trip)
+        _lib.check(self._L.dcomp_set_tape(self._h, ctypes.byref(tape), int(trip.shape[1])))
+        del old
+
+    def _live_fixed_tape(self, depth):
+        """rand_episodes=False after a live re-seed: row (e, i) = the configured seed's triples up to the cursor at the time of
+        seed(), the new seed's stream from there on (both stateless: the C++ MT19937 draws any depth again)."""
+        pos0, trip = _rng.mt_tape(self._cfg, self.env_seeds, depth)
+        seeds, cursor = self._live
+        _, fresh = _rng.mt_tape(self._cfg, seeds, depth)
+        for i, c in enumerate(cursor):
+            c = int(c)
+            if c < depth:
+                trip[i, c:] = fresh[i, :depth - c]
+        return pos0, trip
 
     def _draw_tape_dynamic(self):
         """Reference-exact draws with UE arrival: see rng.DynamicStdlibStreams (initial UEs keep their generators)."""
@@ -301,6 +348,7 @@ class BatchedMobileEnv:
             else:
                 consumed = ((self.mv >> 48) & 0xFFFF).cpu().numpy()
             return self._streams.draw_episode(reseed=False, consumed=consumed)
+        self._live = None
         if self._fixed_tape is None:          # re-seeded at every reset (base.py:171-173): same tape every episode
             self._fixed_tape = _rng.mt_tape(self._cfg, self.env_seeds, self.tape_depth)
         return self._fixed_tape
@@ -325,6 +373,8 @@ class BatchedMobileEnv:
             pos0, trip = self._dyn_streams.extend(depth)
         elif self.rand_episodes:
             pos0, trip = self._streams.extend(depth)
+        elif self._live is not None:
+            pos0, trip = self._live_fixed_tape(depth)
         else:
             pos0, trip = self._fixed_tape = _rng.mt_tape(self._cfg, self.env_seeds, depth)     # stateless: same prefix, longer
         torch.cuda.current_stream(self.device).synchronize()       # steps in flight still read the old tape
@@ -587,6 +637,15 @@ class BatchedMobileEnv:
         return self._L.dcomp_lanes_per_env(self._h)
 
     @property
+    def step_kernel_name(self):
+        """The kernel instantiation step() launches, as rocprofv3 prints it ('step_kernel<10, 32, 2>'); None with an older library."""
+        if not hasattr(self._L, 'dcomp_step_kernel_name'):
+            return None
+        buf = ctypes.create_string_buffer(96)
+        _lib.check(self._L.dcomp_step_kernel_name(self._h, buf, 96))
+        return buf.value.decode()
+
+    @property
     def fused_rollout(self):
         """True when rollout() runs its T steps in one kernel launch."""
         return self._L.dcomp_rollout_is_fused(self._h) == 1
@@ -768,7 +827,9 @@ class _RefSurfaceEnv(_GymEnv):
         return float(self._host['sum_utility'][0])
 
     def seed(self, seed=None):
-        self.core.seed(seed)
+        """base.py:132-143, to the letter in rng='reference' mode: the running episode continues on the new streams at once
+        (BatchedMobileEnv.seed, immediate=True); counter-based draws and changing UE lists stage the seed until reset()."""
+        self.core.seed(seed, immediate=True)
 
     def _host_view(self):
         if self._view_cache is None:

@@ -52,10 +52,41 @@ class StdlibStreams:
         self.U = len(self.vel)
         self._seed_all()
         self._states = None
+        self._shift = None
+        self._trip = None
 
     def _seed_all(self):
         self.pos_rng = [[random.Random(s + 100 * (i + 1)) for i in range(self.U)] for s in self.seeds]
         self.mov_rng = [[random.Random(s + 100 * (i + 1)) for i in range(self.U)] for s in self.seeds]
+
+    def reseed_live(self, seeds, consumed=None):
+        """MobileEnv.seed() on a live env (base.py:132-143): BOTH streams of every UE start over at once, from the new seeds.
+        What a UE still draws in the running episode comes from the start of its new movement stream: returns the episode's
+        triples with row (e, i) continued from position consumed[e*U+i] (the cursor field of the state) by the new stream --
+        None when no episode has been drawn yet (the next reset() then simply starts the new streams)."""
+        self.seeds = [int(s) for s in seeds]
+        self._seed_all()
+        if self._trip is None:
+            self._states = None
+            return None
+        E, U, D = len(self.seeds), self.U, self.depth
+        trip = self._trip.copy()
+        self._states, self._shift = [], [int(c) for c in consumed]
+        for e in range(E):
+            st_e = []
+            for i in range(U):
+                mr = self.mov_rng[e][i]
+                lo, hi = self.vel[i]
+                st = [mr.getstate()]
+                for k in range(self._shift[e * U + i], D):
+                    trip[e * U + i, k, 0] = mr.randint(lo, hi) if lo != hi else lo
+                    trip[e * U + i, k, 1] = mr.randint(self.border[i], self.w - self.border[i])
+                    trip[e * U + i, k, 2] = mr.randint(self.border[i], self.h - self.border[i])
+                    st.append(mr.getstate())
+                st_e.append(st)
+            self._states.append(st_e)
+        self._trip = trip
+        return self._pos0, trip
 
     def draw_episode(self, reseed, consumed=None):
         """consumed[E*U]: movement triples the previous episode used (the cursor field of the state)."""
@@ -66,7 +97,9 @@ class StdlibStreams:
             assert consumed is not None
             for e in range(E):
                 for i in range(U):
-                    self.mov_rng[e][i].setstate(self._states[e][i][int(consumed[e * U + i])])
+                    shift = self._shift[e * U + i] if self._shift else 0      # triples drawn before a live re-seed
+                    self.mov_rng[e][i].setstate(self._states[e][i][int(consumed[e * U + i]) - shift])
+        self._shift = None
         pos0 = np.zeros((E * U, 2), dtype=np.int32)
         trip = np.zeros((E * U, D, 4), dtype=np.uint16)
         self._states = []

@@ -207,6 +207,10 @@ int dcomp_lanes_per_env(const dcomp_env *env);         /* lanes an env occupies 
                                                          * num_ue itself when envs are packed tightly (throughput-bound batches of
                                                          * UE lists that are not a power of two long; DCOMP_TIGHT=0/1 overrides) */
 
+/* Name of the kernel instantiation dcomp_step launches for this env, as rocprofv3 prints it (e.g. "step_kernel<10, 32, 2>" =
+ * <num_bs, lanes per env, sharing pattern>): measurement tooling ties a tracked profile to what really runs. */
+int dcomp_step_kernel_name(const dcomp_env *env, char *buf, int32_t len);
+
 /* Synchronises `stream`, reads the sticky flags and maps them to DCOMP_EACTION / DCOMP_ETAPE /
  * DCOMP_EPOS (the reference raises AssertionError in these cases).  Clears the flags. */
 int dcomp_check(dcomp_env *env, const dcomp_state *st, void *stream);

@@ -123,10 +123,34 @@ class RefRngTape:
         self.init_xy = init_xy if init_xy is not None else [(-1, -1)] * self.U
         self._seed_streams()
         self._states = None
+        self._shift = None
+        self._trip = None
 
-    def _seed_streams(self):
-        self.pos_rng = [random.Random(self.seed + 100 * (i + 1)) for i in range(self.U)]
-        self.mov_rng = [random.Random(self.seed + 100 * (i + 1)) for i in range(self.U)]
+    def _seed_streams(self, seed=None):
+        seed = self.seed if seed is None else seed
+        self.pos_rng = [random.Random(seed + 100 * (i + 1)) for i in range(self.U)]
+        self.mov_rng = [random.Random(seed + 100 * (i + 1)) for i in range(self.U)]
+
+    def reseed_live(self, seed, cursors=None):
+        """MobileEnv.seed(seed) on a live env (base.py:132-143): BOTH streams of every UE start over from seed + 100*(i+1) at
+        once.  What UE i still draws in the running episode comes from the start of its new movement stream: returns the
+        episode's triples with row i continued from position cursors[i] (= triples consumed so far, OracleEnv.cursors()) by
+        the new stream, or None when no episode has been drawn yet.  The configured seed stays what reset() of a
+        rand_episodes=False env re-seeds with (base.py:171-173)."""
+        self._seed_streams(seed)
+        if self._trip is None:
+            self._states = None
+            return None
+        trip = self._trip.copy()
+        self._states, self._shift = [], [int(c) for c in cursors]
+        for i in range(self.U):
+            st = [self.mov_rng[i].getstate()]
+            for k in range(self._shift[i], self.depth):
+                trip[i, k] = self._triple(i)
+                st.append(self.mov_rng[i].getstate())
+            self._states.append(st)
+        self._trip = trip
+        return trip
 
     def _triple(self, i):
         r, v = self.mov_rng[i], self.vel_specs[i]
@@ -144,7 +168,8 @@ class RefRngTape:
         elif self._states is not None:
             assert consumed is not None, "rand_episodes=True needs the consumed-triple counts of the last episode"
             for i in range(self.U):
-                self.mov_rng[i].setstate(self._states[i][int(consumed[i])])
+                self.mov_rng[i].setstate(self._states[i][int(consumed[i]) - (self._shift[i] if self._shift else 0)])
+        self._shift = None
         pos0 = np.zeros((self.U, 2), dtype=np.int32)
         trip = np.zeros((self.U, self.depth, 3), dtype=np.int32)
         self._states = []
@@ -157,6 +182,7 @@ class RefRngTape:
                 trip[i, k] = self._triple(i)
                 st.append(self.mov_rng[i].getstate())
             self._states.append(st)
+        self._trip = trip
         return pos0, trip
 
 

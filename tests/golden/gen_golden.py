@@ -12,6 +12,7 @@ fixed action tape and records inputs + outputs as ``.npz`` data files:
   G4 movement.npz       RandomWaypoint traces (slow / fast / static)         (movement.py:110-181)
   G5 traj_*.npz         full reset()+step() trajectories, central + multi    (base.py:169-189,413-466, ...)
   G6 estack_*.npz       the E-axis stack: env e seeded 42 + 20000*e
+  G9 reseed_*.npz       MobileEnv.seed() on a live env, mid-episode and before a reset      (base.py:132-143,171-173)
 
 Fixtures are data only: numbers in, numbers out.  Usage:  python tests/golden/gen_golden.py
 """
@@ -118,8 +119,10 @@ def snapshot(env, kind, obs, reward=None, info=None):
 
 
 def run_trajectory(name, scn, kind, seed, num_steps, reward='avg', tape_mode='uniform', rand_episodes=False,
-                   episodes=1, eps_len=100, scripted=None, save=True):
-    """reset() then num_steps x step(); optionally several episodes (reset in between)."""
+                   episodes=1, eps_len=100, scripted=None, save=True, seed_at=None, seed_before_reset=None):
+    """reset() then num_steps x step(); optionally several episodes (reset in between).
+    seed_at {global step index: s}: env.seed(s) (base.py:132-143) right before that step -- the streams of the RUNNING episode are
+    re-seeded; seed_before_reset {episode: s}: env.seed(s) right before that episode's reset()."""
     m, bs_list, ue_list = build_ref(scn, scn.ue_specs)
     cfg = env_config(m, bs_list, ue_list, seed, eps_len=eps_len, reward=reward, rand_episodes=rand_episodes)
     env = (CentralRelNormEnv if kind == 'central' else MultiAgentMobileEnv)(cfg)
@@ -129,10 +132,14 @@ def run_trajectory(name, scn, kind, seed, num_steps, reward='avg', tape_mode='un
         tape[:len(scripted)] = np.asarray(scripted, dtype=np.int32)
     resets, steps = [], []
     t = 0
-    for _ in range(episodes):
+    for ep in range(episodes):
+        if seed_before_reset and ep in seed_before_reset:
+            env.seed(int(seed_before_reset[ep]))
         obs = env.reset()
         resets.append(snapshot(env, kind, obs))
         for _ in range(num_steps):
+            if seed_at and t in seed_at:
+                env.seed(int(seed_at[t]))
             a = tape[t]
             action = [int(x) for x in a] if kind == 'central' else {ue.id: int(a[i]) for i, ue in enumerate(ue_list)}
             obs, reward_v, done, info = env.step(action)
@@ -157,6 +164,10 @@ def run_trajectory(name, scn, kind, seed, num_steps, reward='avg', tape_mode='un
         'cfg_eps_len': np.array(eps_len, dtype=np.int32),
         'actions': tape,
     }
+    if seed_at:
+        out['cfg_seed_at'] = np.array(sorted((int(k), int(v)) for k, v in seed_at.items()), dtype=np.int64)
+    if seed_before_reset:
+        out['cfg_seed_before_reset'] = np.array(sorted((int(k), int(v)) for k, v in seed_before_reset.items()), dtype=np.int64)
     if any('pause_duration' in s or 'border_buffer' in s for s in scn.ue_specs):      # non-default RandomWaypoint parameters
         out['cfg_ue_pause'] = np.array([s.get('pause_duration', 2) for s in scn.ue_specs], dtype=np.int32)
         out['cfg_ue_border'] = np.array([s.get('border_buffer', 10) for s in scn.ue_specs], dtype=np.int32)
@@ -336,6 +347,18 @@ def gen_movement_params():
                    rand_episodes=True)
 
 
+def gen_reseed():
+    """MobileEnv.seed() on a LIVE env (base.py:132-143): every UE stream is re-seeded at once, mid-episode; reset() of a
+    rand_episodes=False env goes back to the configured seed (base.py:171-173), a rand_episodes=True env keeps the new streams."""
+    scn = scenarios.medium_map('mixed').with_ues(num_slow=2, num_fast=2)
+    for spec, pd in zip(scn.ue_specs, (2, 0, 1, 2)):
+        spec['pause_duration'] = pd
+    run_trajectory('reseed_medium4x3_multi_fixed_s42', scn, 'multi', 42, 30, episodes=3, eps_len=30, tape_mode='sticky',
+                   seed_at={7: 977, 19: 5, 41: 123456}, seed_before_reset={2: 31337})
+    run_trajectory('reseed_medium4x3_central_rand_s43', scn, 'central', 43, 30, episodes=3, eps_len=30, tape_mode='sticky',
+                   rand_episodes=True, seed_at={0: 8, 11: 977, 50: 4242}, seed_before_reset={2: 31337})
+
+
 def gen_estack():
     """E-axis parity: env e uses base seed 42 + 20000*e."""
     for e in range(8):
@@ -409,6 +432,10 @@ def run_dynamic_trajectory(name, scn, kind, seed, num_steps, ue_arrival=None, ne
         'cfg_arrival_n': np.array([arr[k] for k in sorted(arr.keys())], dtype=np.int32),
         'actions': tape,
     }
+    if seed_at:
+        out['cfg_seed_at'] = np.array(sorted((int(k), int(v)) for k, v in seed_at.items()), dtype=np.int64)
+    if seed_before_reset:
+        out['cfg_seed_before_reset'] = np.array(sorted((int(k), int(v)) for k, v in seed_before_reset.items()), dtype=np.int64)
     if any('pause_duration' in s or 'border_buffer' in s for s in scn.ue_specs):      # non-default RandomWaypoint parameters
         out['cfg_ue_pause'] = np.array([s.get('pause_duration', 2) for s in scn.ue_specs], dtype=np.int32)
         out['cfg_ue_border'] = np.array([s.get('border_buffer', 10) for s in scn.ue_specs], dtype=np.int32)
@@ -505,6 +532,7 @@ if __name__ == '__main__':
     gen_movement()
     gen_trajectories()
     gen_movement_params()
+    gen_reseed()
     gen_estack()
     gen_heuristics()
     gen_dynamic()

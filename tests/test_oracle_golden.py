@@ -161,6 +161,40 @@ def test_trajectory(name):
         assert consumed.max() <= trip.shape[1]
 
 
+RESEED = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'reseed_*.npz')))
+
+
+@pytest.mark.parametrize('name', RESEED)
+def test_seed_on_a_live_env(name):
+    """MobileEnv.seed() while an episode runs and right before a reset (base.py:132-143, 171-173), reference-run fixtures:
+    the running episode continues on the start of the new streams; reset() of a rand_episodes=False env re-seeds with the
+    CONFIGURED seed, a rand_episodes=True env keeps the new streams."""
+    g = load(name)
+    assert RESEED and 'cfg_seed_at' in g.files
+    env, tape, U = make_env_from_fixture(g)
+    kind = int(g['cfg_kind'])
+    episodes = int(g['cfg_episodes'])
+    steps_per_ep = g['actions'].shape[0] // episodes
+    seed_at = {int(t): int(s) for t, s in g['cfg_seed_at']}
+    before_reset = {int(e): int(s) for e, s in g['cfg_seed_before_reset']} if 'cfg_seed_before_reset' in g.files else {}
+    t, consumed, pos0 = 0, None, None
+    for ep in range(episodes):
+        if ep in before_reset:
+            tape.reseed_live(before_reset[ep], consumed)
+        pos0, trip = tape.draw_episode(consumed)
+        env.set_tape(pos0, trip)
+        env.reset()
+        check_snapshot(env, g, 'reset', ep, kind)
+        for _ in range(steps_per_ep):
+            if t in seed_at:
+                env.set_tape(pos0, tape.reseed_live(seed_at[t], env.cursors()))
+            env.step(g['actions'][t])
+            check_snapshot(env, g, 'step', t, kind)
+            np.testing.assert_allclose(env.reward(), g['step_reward'][t], rtol=1e-9, atol=1e-12, err_msg=f'reward[{t}]')
+            t += 1
+        consumed = env.cursors()
+
+
 def test_bad_action_rejected():
     env = orc.OracleEnv(150, 100, [(50, 50), (100, 50)], ['resource-fair'] * 2, ['slow'] * 2)
     env.set_philox(1, 0)

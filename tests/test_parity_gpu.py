@@ -984,6 +984,54 @@ def test_seed_on_a_live_env(torch_cuda):
         assert a._fingerprint() == b._fingerprint()
 
 
+RESEED = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'reseed_*.npz')))
+
+
+@pytest.mark.parametrize('surface', [False, True])
+@pytest.mark.parametrize('name', RESEED)
+def test_seed_on_a_live_env_like_the_reference(torch_cuda, name, surface):
+    """MobileEnv.seed() (base.py:132-143) to the letter, against trajectories the reference itself ran with seed() calls in the
+    middle of episodes and right before a reset: the running episode continues on the START of the new streams at once; reset()
+    of a rand_episodes=False env re-seeds with the configured seed again (base.py:171-173), a rand_episodes=True env keeps the
+    new streams.  surface: through the drop-in class (`env.seed(s)` as a caller of the reference would write it)."""
+    torch = torch_cuda
+    assert RESEED
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    seed_at = {int(t): int(s) for t, s in g['cfg_seed_at']}
+    before_reset = {int(e): int(s) for e, s in g['cfg_seed_before_reset']}
+    if surface:
+        from deepcomp_amd.env import CentralRelNormEnv, MultiAgentMobileEnv
+        m, bs, ues = _entities_from_fixture(g)
+        cfg = {'episode_length': int(g['cfg_eps_len']), 'seed': int(g['cfg_seed']), 'map': m, 'bs_list': bs, 'ue_list': ues,
+               'rand_episodes': bool(g['cfg_rand_episodes']), 'new_ue_interval': None, 'reward': 'avg', 'max_ues': None,
+               'ue_arrival': None, 'log_metrics': True}
+        env = (CentralRelNormEnv if int(g['cfg_kind']) == 0 else MultiAgentMobileEnv)(cfg)
+        core, seed = env.core, env.seed
+    else:
+        core = _core_from_fixture(g)
+        seed = lambda s_: core.seed(s_, immediate=True)                                   # noqa: E731
+    episodes = int(g['cfg_episodes'])
+    steps = g['actions'].shape[0] // episodes
+    t = 0
+    for ep in range(episodes):
+        if ep in before_reset:
+            seed(before_reset[ep])
+        core.reset()
+        _compare(core, g, 'reset', ep)
+        for _ in range(steps):
+            if t in seed_at:
+                seed(seed_at[t])
+            a = g['actions'][t].astype(np.uint8).reshape(1, -1)
+            if surface:                      # the host-I/O mode of the E = 1 classes reads actions from its pinned buffer
+                core.action_host.copy_(torch.from_numpy(a))
+                core.step(core.action_host)
+            else:
+                core.step(torch.from_numpy(a).cuda())
+            _compare(core, g, 'step', t, with_reward=True)
+            t += 1
+        core.check()
+
+
 def test_rollout_buffer_and_unaligned_outputs(torch_cuda):
     """step_into() writes rows into arbitrary (4-byte aligned) slices of a rollout buffer: odd sizes exercise the
     alignment phase of the LDS copy-out; rollout() == the same steps issued one by one."""
@@ -1133,3 +1181,21 @@ def test_policy_map_helpers(torch_cuda):
     assert env3.get_max_num_ue() == env3.get_num_diff_ues() == 3
     with pytest.raises(NotImplementedError):
         env3.render()
+
+
+def test_step_kernel_name_is_what_the_profiles_say(torch_cuda):
+    """dcomp_step_kernel_name: the instantiation dcomp_step launches, spelled as rocprofv3 prints it -- bench.py only reports a
+    tracked --pmc traffic figure for the kernel the library really dispatches to (profiles/traffic.json entries name theirs)."""
+    import json
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    db = json.load(open(os.path.join(os.path.dirname(GOLDEN), '..', 'profiles', 'traffic.json')))
+    for key, (E, U, B, kind) in {'65536x32x10_multi_mixed': (65536, 32, 10, 'multi'), '32768x32x10_multi_mixed': (32768, 32, 10, 'multi'),
+                                 '4096x128x32_multi_mixed': (4096, 128, 32, 'multi'), '65536x10x5_central_mixed': (65536, 10, 5, 'central')}.items():
+        m, bs, ues = build_from_scenario(scenarios.grid_map(B, 'mixed').with_ues(num_slow=U))
+        env = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=1, rng='philox')
+        assert env.step_kernel_name == db[key]['kernel'], key
+        del env
+    m, bs, ues = build_from_scenario(scenarios.grid_map(5, 'resource-fair').with_ues(num_slow=10))
+    assert BatchedMobileEnv(m, bs, ues, 'multi', num_envs=64, seed=1, rng='philox').step_kernel_name == 'step_kernel<5, 16, 1>'

@@ -2,6 +2,7 @@
 """Register the HBM traffic of a tracked rocprofv3 --pmc summary in profiles/traffic.json (what bench.py's roofline.traffic reads).
 
     python tools/register_traffic.py <tag> <workload-key> <kernel-substring>
+    python tools/register_traffic.py --backfill <commit>      (kernel_fingerprint for entries profiled at <commit>)
     e.g.  python tools/register_traffic.py r03a_c3 65536x32x10_multi_mixed 'step_kernel<10, 32, 2>'
 
 Reads profiles/<tag>_summary.txt (written by tools/summarize_prof.py on the GPU box): the per-dispatch FETCH_SIZE / WRITE_SIZE
@@ -17,10 +18,41 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def backfill(commit):
+    """Entries registered before kernel_fingerprint existed: `git show <commit>:<file>` rebuilds the tree the profile names, its
+    FULL fingerprint must equal the entry's source_fingerprint (proof that this is the profiled tree), then the kernel-only
+    fingerprint of that same tree is recorded."""
+    sys.path.insert(0, REPO)
+    from deepcomp_amd import build as b
+
+    def show(path):
+        return subprocess.check_output(['git', '-C', REPO, 'show', f'{commit}:{path}'])
+    h = b.hashlib.sha256()
+    for f in b._sources():
+        h.update(os.path.basename(f).encode())
+        h.update(show(os.path.relpath(f, REPO)))
+    h.update(' '.join(b.CXXFLAGS).encode())
+    full, kern = h.hexdigest(), b.kernel_fingerprint(read=lambda name: show('deepcomp_amd/csrc/' + name))
+    path = os.path.join(REPO, 'profiles', 'traffic.json')
+    db = json.load(open(path))
+    n = 0
+    for key, ent in db.items():
+        if ent.get('source_fingerprint') == full and not ent.get('kernel_fingerprint'):
+            ent['kernel_fingerprint'] = kern
+            n += 1
+    with open(path, 'w') as f:
+        json.dump(db, f, indent=1, sort_keys=True)
+        f.write('\n')
+    print(f'{commit}: full fingerprint {full[:16]}..., kernel fingerprint {kern[:16]}...; {n} entries completed')
+
+
 def main():
+    if sys.argv[1] == '--backfill':
+        return backfill(sys.argv[2])
     tag, key, kern = sys.argv[1:4]
     txt = open(os.path.join(REPO, 'profiles', f'{tag}_summary.txt')).read()
     fp = re.search(r'^source_fingerprint: (\S+)', txt, re.M)
+    kfp = re.search(r'^kernel_fingerprint: (\S+)', txt, re.M)
     vals = {}
     for line in txt.splitlines():
         line = line.strip()
@@ -36,7 +68,7 @@ def main():
     path = os.path.join(REPO, 'profiles', 'traffic.json')
     db = json.load(open(path)) if os.path.exists(path) else {}
     db[key] = {'tag': tag, 'kernel': kern, 'fetch_kib': vals['FETCH_SIZE'], 'write_kib': vals['WRITE_SIZE'],
-               'source_fingerprint': fp.group(1) if fp else None, 'commit': commit,
+               'source_fingerprint': fp.group(1) if fp else None, 'kernel_fingerprint': kfp.group(1) if kfp else None, 'commit': commit,
                'bytes_per_launch': (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0,
                'note': 'bytes = (2 x FETCH_SIZE [gfx950 wide-read correction] + WRITE_SIZE) KiB per launch'}
     with open(path, 'w') as f:

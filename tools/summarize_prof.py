@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 try:                                    # which kernel sources these numbers belong to (bench.py: roofline.traffic_source)
     from deepcomp_amd import build as _b
     print('source_fingerprint:', _b.source_fingerprint())
+    print('kernel_fingerprint:', _b.kernel_fingerprint())
 except Exception as ex:                 # noqa: BLE001
     print('source_fingerprint: unknown', ex)
 
