@@ -26,7 +26,8 @@ class DcompCfg(ctypes.Structure):
                 ('device', ctypes.c_int32), ('max_ues', ctypes.c_int32), ('seed', ctypes.c_uint64),
                 ('env_id_base', ctypes.c_int64), ('bs_x', _dp), ('bs_y', _dp), ('bs_sharing', _ip),
                 ('ue_util', _ip), ('ue_dr_req', _fp), ('ue_vel_lo', _ip), ('ue_vel_hi', _ip),
-                ('ue_init_x', _ip), ('ue_init_y', _ip), ('ue_pause_duration', _ip), ('ue_border_buffer', _ip)]
+                ('ue_init_x', _ip), ('ue_init_y', _ip), ('ue_pause_duration', _ip), ('ue_border_buffer', _ip),
+                ('ue_velocity', _dp)]
 
 
 class DcompState(ctypes.Structure):

@@ -52,6 +52,7 @@ struct dcomp_env {
     KParams kp;                 // constant part pre-filled
     dcomp::KernelPair kern;
     UeCfg *d_ue_cfg;
+    double2 *d_ue_velq = nullptr;   // {velocity, qmax} of UEs whose fixed velocity is no integer in 0..255 (cfg.ue_velocity)
     bool dyn;                  // UE list changes during an episode (cfg.max_ues > 0)
     int mp_pattern;            // sharing-pattern specialisation the kernels were looked up with (dcomp::MP_*)
     bool fused;                // kern.step is step_kernel: T steps in one launch (the wide / dynamic kernels step once per launch)
@@ -123,6 +124,7 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
     env->cfg = *cfg;
     env->cfg.bs_x = env->cfg.bs_y = nullptr;   // host arrays are not retained
     env->cfg.ue_pause_duration = env->cfg.ue_border_buffer = nullptr;
+    env->cfg.ue_velocity = nullptr;
     env->cap = CAP; env->dyn = DYN; env->cur_ue = U; env->n_removed = env->n_arrived = 0;
     env->upad = next_pow2(CAP) < 4 ? 4 : next_pow2(CAP);
     int mp = dcomp::MP_RES_FAIR;            // sharing pattern -> specialised kernel (dcomp_device.h bs_mode_of)
@@ -207,6 +209,29 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
     if (e == hipSuccess) e = hipMemcpy(env->d_ue_cfg, uc.data(), sizeof(UeCfg) * U, hipMemcpyHostToDevice);
     if (e != hipSuccess) { delete env; return fail(DCOMP_EHIP, "device setup failed: %s", hipGetErrorString(e)); }
     kp.ue_cfg = env->d_ue_cfg;
+    if (cfg->ue_velocity) {
+        // movement.py:116-117 / 142-156 with a velocity that is no integer in 0..255: the device takes {v, qmax(v)} from a table,
+        // qmax(v) = largest double q with sqrt_rn(q) <= v -- `distance <= velocity` without a square root, as for the integers
+        std::vector<double> vq(2 * (size_t)U, -1.0);
+        bool any = false;
+        for (int u = 0; u < U; u++) {
+            const double v = cfg->ue_velocity[u];
+            if (!(v >= 0.0)) continue;
+            if (!std::isfinite(v) || v > 1e6) { dcomp_destroy(env); return fail(DCOMP_EINVAL, "ue %d: velocity %g out of range", u, v); }
+            if (cfg->ue_vel_lo[u] != cfg->ue_vel_hi[u]) { dcomp_destroy(env); return fail(DCOMP_EINVAL, "ue %d: ue_velocity needs a fixed range (lo == hi)", u); }
+            double q = v * v;
+            while (q > 0.0 && std::sqrt(q) > v) q = std::nextafter(q, 0.0);
+            while (std::sqrt(std::nextafter(q, INFINITY)) <= v) q = std::nextafter(q, INFINITY);
+            vq[2 * u] = v; vq[2 * u + 1] = q;
+            any = true;
+        }
+        if (any) {
+            e = hipMalloc((void **)&env->d_ue_velq, sizeof(double) * 2 * U);
+            if (e == hipSuccess) e = hipMemcpy(env->d_ue_velq, vq.data(), sizeof(double) * 2 * U, hipMemcpyHostToDevice);
+            if (e != hipSuccess) { dcomp_destroy(env); return fail(DCOMP_EHIP, "device setup failed: %s", hipGetErrorString(e)); }
+            kp.ue_velq = env->d_ue_velq;
+        }
+    }
     if (env->kern.step_wide && !kp.any_maxcap && !getenv("DCOMP_NO_WIDE")) env->kern.step = env->kern.step_wide;
     if (DYN) {
         if (!env->kern.step_dyn) { dcomp_destroy(env); return fail(DCOMP_EUNSUPPORTED, "no dynamic-UE kernel for this shape"); }
@@ -261,6 +286,7 @@ extern "C" int dcomp_destroy(dcomp_env *env)
 {
     if (!env) return DCOMP_OK;
     if (env->d_ue_cfg) (void)hipFree(env->d_ue_cfg);
+    if (env->d_ue_velq) (void)hipFree(env->d_ue_velq);
     delete env;
     return DCOMP_OK;
 }

@@ -125,6 +125,8 @@ struct KParams {
     const int32_t *tape_pos0;
     const ushort4 *tape_triples;
     const UeCfg *ue_cfg;
+    const double2 *ue_velq;    // optional [U0]: fixed velocities that are not an integer in 0..255 (movement.py:116-117 takes any number):
+                               //   {velocity, largest q with sqrt(q) <= velocity}; x < 0: this UE uses the integer in its movement word
     int32_t tape_depth;
     int32_t tape_ids;          // tapes per env: initial UEs by position, then one per id of an arriving UE
     int32_t E, U;              // U = slots per env (max_ues, base.py:79-84)
@@ -561,6 +563,55 @@ __device__ __forceinline__ void norm_and_unit(double vx, double vy, double &nrm,
     ny = __builtin_fma(__builtin_fma(-g, qy, vy), rc, qy);
 }
 
+// The position update of one movement step (movement.py:132-156) once pause / redraw are settled: snap onto the waypoint when it
+// is within one step, else walk `velocity` along the unit vector.  SELECTS: straight-line form of the fused rollout (move_ue).
+// TABLE: the UE's velocity may come from p.ue_velq (any non-negative number) instead of the integer in its movement word.
+template <bool SELECTS, bool TABLE>
+__device__ __forceinline__ void advance_ue(const KParams &p, uint32_t uidw, uint32_t vel, bool stay, double wx, double wy, double &px, double &py)
+{
+#pragma clang fp contract(off)
+    double velf, qmax;
+    {
+        const uint32_t v2 = vel * vel;
+        qmax = (double)v2;
+        const int e2 = 2 * (31 - __clz((int)(vel | 1u)));
+        qmax = (vel > 0u && v2 < (2u << e2)) ? qmax + __builtin_ldexp(1.0, e2 - 52) : qmax;
+        velf = (double)vel;
+    }
+    if (TABLE) {
+        const double2 vq = (uidw & UID_BORN) ? make_double2(-1.0, 0.0) : p.ue_velq[(uidw & 0x7FFFu) - 1u];
+        velf = vq.x < 0.0 ? velf : vq.x;
+        qmax = vq.x < 0.0 ? qmax : vq.y;
+    }
+    if (SELECTS) {
+        double dx = px - wx, dy = py - wy;
+        double q = dx * dx + dy * dy;
+        const bool snap = q <= qmax;                                // snap onto the waypoint
+        double vx = wx - px, vy = wy - py;
+        double nrm, nx, ny;
+        norm_and_unit(vx, vy, nrm, nx, ny);                         // np.linalg.norm, then two divisions (movement.py:151)
+        const double mx = px + velf * nx, my = py + velf * ny;
+        px = stay ? px : snap ? wx : mx;
+        py = stay ? py : snap ? wy : my;
+    } else if (!stay) {
+        double dx = px - wx, dy = py - wy;
+        double q = dx * dx + dy * dy;
+        if (q <= qmax) { px = wx; py = wy; }                        // snap onto the waypoint
+        else {
+            double vx = wx - px, vy = wy - py;
+            double nrm, nx, ny;
+#if DCOMP_COMPILER_DIV
+            nrm = __builtin_sqrt(__builtin_fma(vy, vy, vx * vx));
+            nx = vx / nrm; ny = vy / nrm;
+#else
+            norm_and_unit(vx, vy, nrm, nx, ny);                     // np.linalg.norm, then two divisions (movement.py:151)
+#endif
+            px = px + velf * nx;
+            py = py + velf * ny;
+        }
+    }
+}
+
 // One RandomWaypoint step in FP64, in the reference's operation order.  movement.py:132-181.
 // Contraction is off: the only fused op is the explicit fma of the 2-element dot product (numpy).
 // LAT (the fused rollout: latency-bound, one wave per SIMD, short of scalar registers): the redrawing lanes' Philox on the scalar
@@ -594,44 +645,11 @@ __device__ __forceinline__ void move_ue(const KParams &p, int env, uint32_t uidw
     // sqrt is monotone and correctly rounded, so the test is `q <= qmax(vel)`, qmax = largest double whose
     // rounded sqrt is <= vel: vel^2, plus one ulp when the mantissa m of vel has m < sqrt(2)
     // (dcomp_create verifies this closed form against a brute-force sqrt table for vel = 0..255).
-    if (SELECTS) {
-        double dx = px - wx, dy = py - wy;
-        double q = dx * dx + dy * dy;
-        const uint32_t v2 = vel * vel;
-        double qmax = (double)v2;
-        const int e2 = 2 * (31 - __clz((int)(vel | 1u)));
-        const double ulp = __builtin_ldexp(1.0, e2 - 52);
-        qmax = (vel > 0u && v2 < (2u << e2)) ? qmax + ulp : qmax;
-        const bool snap = q <= qmax;                                // snap onto the waypoint
-        double vx = wx - px, vy = wy - py;
-        double nrm, nx, ny;
-        norm_and_unit(vx, vy, nrm, nx, ny);                         // np.linalg.norm, then two divisions (movement.py:151)
-        const double mx = px + (double)vel * nx, my = py + (double)vel * ny;
-        px = stay ? px : snap ? wx : mx;
-        py = stay ? py : snap ? wy : my;
-    } else if (!stay) {
-        double dx = px - wx, dy = py - wy;
-        double q = dx * dx + dy * dy;
-        const uint32_t v2 = vel * vel;
-        double qmax = (double)v2;
-        if (vel > 0u) {
-            const int e2 = 2 * (31 - __clz((int)vel));
-            if (v2 < (2u << e2)) qmax += __builtin_ldexp(1.0, e2 - 52);
-        }
-        if (q <= qmax) { px = wx; py = wy; }                        // snap onto the waypoint
-        else {
-            double vx = wx - px, vy = wy - py;
-            double nrm, nx, ny;
-#if DCOMP_COMPILER_DIV
-            nrm = __builtin_sqrt(__builtin_fma(vy, vy, vx * vx));
-            nx = vx / nrm; ny = vy / nrm;
-#else
-            norm_and_unit(vx, vy, nrm, nx, ny);                     // np.linalg.norm, then two divisions (movement.py:151)
-#endif
-            px = px + (double)vel * nx;
-            py = py + (double)vel * ny;
-        }
-    }
+    // Velocities that are not an integer in 0..255 (a caller's RandomWaypoint(map, velocity=2.5)): {velocity, qmax} from a per-UE
+    // table the host built with the same definition -- a wave-uniform branch on a kernel argument, taken by no env of the
+    // reference's own scenarios.
+    if (p.ue_velq != nullptr) advance_ue<SELECTS, true>(p, uidw, vel, stay, wx, wy, px, py);
+    else advance_ue<SELECTS, false>(p, uidw, vel, stay, wx, wy, px, py);
     mv = mv_pack(wxi, wyi, vel, pausing, cp, cursor);
 }
 

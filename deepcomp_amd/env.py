@@ -76,13 +76,16 @@ def parse_entities(map, bs_list, ue_list):
         mvt = ue.movement
         pd, bb = getattr(mvt, 'pause_duration', 2), getattr(mvt, 'border_buffer', 10)
         v = mvt.init_velocity
-        if not isinstance(v, str) and float(v) != int(v):
-            raise NotImplementedError(f"UE {ue.id}: velocity {v} is not an integer (the movement word stores velocities as integers)")
+        if not isinstance(v, str) and not 0 <= float(v) <= 1e6:
+            raise NotImplementedError(f"UE {ue.id}: velocity {v} outside 0..1e6")
         if int(pd) != pd or int(bb) != bb or not 0 <= pd <= 127 or not 1 <= bb <= 255:
             raise NotImplementedError(f"UE {ue.id}: pause_duration={pd} / border_buffer={bb}: integers in 0..127 / 1..255 are implemented")
         pause.append(int(pd)); border.append(int(bb))
     vel_specs = [ue.movement.init_velocity for ue in ue_list]
-    vr = [_rng.vel_range(v) for v in vel_specs]
+    # movement.py:116-117: a fixed velocity is whatever number the caller passed.  Integers in 0..255 live in the movement word;
+    # anything else (2.5, 300) goes to the device as a per-UE number (dcomp_cfg.ue_velocity) and the word's field stays 0.
+    vel_num = np.array([-1.0 if isinstance(v, str) or (float(v) == int(v) and int(v) <= 255) else float(v) for v in vel_specs], dtype=np.float64)
+    vr = [_rng.vel_range(v) if n < 0 else (0, 0) for v, n in zip(vel_specs, vel_num)]
     init_xy = [(_coord(ue.init_pos_x), _coord(ue.init_pos_y)) for ue in ue_list]
     return {
         'map_w': int(map.width), 'map_h': int(map.height),
@@ -92,7 +95,8 @@ def parse_entities(map, bs_list, ue_list):
         'ue_ids': [ue.id for ue in ue_list],
         'ue_util': np.array([_lib.UTILITY[ue.util_func] for ue in ue_list], dtype=np.int32),
         'ue_dr_req': np.array([float(ue.dr_req) for ue in ue_list], dtype=np.float32),
-        'vel_specs': vel_specs,
+        'vel_specs': [v if n < 0 else 0 for v, n in zip(vel_specs, vel_num)],      # what the draw tapes see: a fixed 0, never drawn
+        'vel_num': vel_num,
         'vel_lo': np.array([r[0] for r in vr], dtype=np.int32), 'vel_hi': np.array([r[1] for r in vr], dtype=np.int32),
         'init_xy': init_xy,
         'init_x': np.array([p[0] for p in init_xy], dtype=np.int32), 'init_y': np.array([p[1] for p in init_xy], dtype=np.int32),
@@ -160,6 +164,7 @@ class BatchedMobileEnv:
         self.vel_specs, self._vlo, self._vhi = ent['vel_specs'], ent['vel_lo'], ent['vel_hi']
         self.init_xy, self._ix, self._iy = ent['init_xy'], ent['init_x'], ent['init_y']
         self._pause, self._border = ent['pause'], ent['border']
+        self._vel_num = ent['vel_num'] if (ent['vel_num'] >= 0).any() else None
         # A UE redraws (velocity, waypoint) at most once per pause_duration + 1 steps: it arrives, stands still for pause_duration
         # steps and draws in the step it moves on (movement.py:158-181) -- every third step with the default pause of 2, EVERY
         # step with pause_duration 0 and a velocity that covers the distance.  UEs that arrive during an episode pause 2 steps.
@@ -182,6 +187,8 @@ class BatchedMobileEnv:
         c.ue_vel_lo, c.ue_vel_hi = self._vlo.ctypes.data_as(ip), self._vhi.ctypes.data_as(ip)
         c.ue_init_x, c.ue_init_y = self._ix.ctypes.data_as(ip), self._iy.ctypes.data_as(ip)
         c.ue_pause_duration, c.ue_border_buffer = self._pause.ctypes.data_as(ip), self._border.ctypes.data_as(ip)
+        if self._vel_num is not None:
+            c.ue_velocity = self._vel_num.ctypes.data_as(dp)
         self._cfg = c
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
@@ -738,6 +745,13 @@ class BatchedMobileEnv:
                     'util_at_bs': o[..., 3 * B:4 * B], 'utility': o[..., 4 * B:4 * B + 1]}
         return {'connected': o[..., 0:U * B], 'dr': o[..., U * B:2 * U * B], 'utility': o[..., 2 * U * B:]}
 
+    def _vel_host(self, vel):
+        """Velocities as numbers: the movement word's integer, or the configured number of a UE whose velocity is not one."""
+        if self._vel_num is not None and not self.dynamic:
+            fixed = self._vel_num >= 0
+            vel[:, fixed] = self._vel_num[fixed]
+        return vel
+
     def state_host(self):
         """Host copy of the raw state (parity dumps)."""
         mv = self.mv.cpu().numpy().astype(np.uint64)
@@ -745,7 +759,7 @@ class BatchedMobileEnv:
         return {
             'pos': self.pos.cpu().numpy().reshape(E, U, 2),
             'wp': np.stack([(mv & 0xFFFF).astype(np.float64), ((mv >> 16) & 0xFFFF).astype(np.float64)], -1).reshape(E, U, 2),
-            'vel': ((mv >> 32) & 0xFF).astype(np.float64).reshape(E, U),
+            'vel': self._vel_host(((mv >> 32) & 0xFF).astype(np.float64).reshape(E, U)),
             'pausing': ((mv >> 47) & 1).astype(np.int32).reshape(E, U),
             'curr_pause': ((mv >> 40) & 0x7F).astype(np.int32).reshape(E, U),
             'cursor': ((mv >> 48) & 0xFFFF).astype(np.int32).reshape(E, U),

@@ -83,6 +83,9 @@ typedef struct dcomp_cfg {
     const int32_t *ue_pause_duration;      /* host [U] RandomWaypoint.pause_duration, 0..127 (movement.py:87,172-176); NULL = 2 */
     const int32_t *ue_border_buffer;       /* host [U] RandomWaypoint.border_buffer, 1..255 (movement.py:87,126-127); NULL = 10.
                                             * UEs that arrive during an episode always get the defaults (base.py:597-599). */
+    const double *ue_velocity;             /* host [U] or NULL: fixed velocity of UE u as a number when it is not an integer in
+                                            * 0..255 (movement.py:116-117 takes whatever the caller passed, e.g. 2.5), >= 0;
+                                            * negative / NaN = use the integer range above.  Such a UE never draws a velocity. */
 } dcomp_cfg;
 
 typedef struct dcomp_state {     /* device, caller-allocated; sizes via dcomp_state_sizes() */

@@ -44,6 +44,7 @@ struct orc_env {
     double *bs_x, *bs_y;
     int32_t *bs_sharing, *ue_util, *vel_lo, *vel_hi, *init_x, *init_y;
     int32_t *pause_dur, *border;   /* per configured UE: RandomWaypoint(pause_duration, border_buffer), movement.py:87-104 */
+    double *vel_fixed;        /* per configured UE: a fixed velocity given as a number (movement.py:116-117), < 0: drawn / integer */
     double *ue_dr_req;
     /* UE state: user.py:27-46, movement.py:96-104 */
     double *px, *py, *wx, *wy, *vel, *ewma;
@@ -253,6 +254,8 @@ static void movement_reset(orc_env *e, int u)
         e->wx[u] = bb + (int)mulhi32(r[1], (uint32_t)(e->map_w - 2 * bb + 1));
         e->wy[u] = bb + (int)mulhi32(r[2], (uint32_t)(e->map_h - 2 * bb + 1));
     }
+    /* movement.py:116-117: `self.velocity = self.init_velocity` -- any number the caller configured, never drawn */
+    if (!ue_born(e, u) && e->vel_fixed[ue_idnum(e, u) - 1] >= 0.0) e->vel[u] = e->vel_fixed[ue_idnum(e, u) - 1];
     e->pausing[u] = 0;
     e->curr_pause[u] = 0;
 }
@@ -423,6 +426,11 @@ void orc_set_movement(orc_env *e, int n, const int32_t *pause_duration, const in
 {
     for (int u = 0; u < n && u < e->U; u++) { e->pause_dur[u] = pause_duration[u]; e->border[u] = border_buffer[u]; }
 }
+/* fixed velocities of the first n configured UEs as numbers (RandomWaypoint(map, velocity=2.5)); negative: leave as configured */
+void orc_set_velocity(orc_env *e, int n, const double *velocity)
+{
+    for (int u = 0; u < n && u < e->U; u++) e->vel_fixed[u] = velocity[u];
+}
 int orc_num_ue(const orc_env *e) { return e->nU; }
 /* per initial UE: movement triples consumed this episode (at removal, or so far if still listed) */
 void orc_get_orig_consumed(const orc_env *e, int32_t *out)
@@ -551,6 +559,8 @@ orc_env *orc_create(int U, int B, int map_w, int map_h, int kind, int reward_agg
     e->vel_lo = dup_mem(vel_lo, sizeof(int32_t) * U); e->vel_hi = dup_mem(vel_hi, sizeof(int32_t) * U);
     e->pause_dur = dup_mem(NULL, sizeof(int32_t) * U); e->border = dup_mem(NULL, sizeof(int32_t) * U);
     for (int u = 0; u < U; u++) { e->pause_dur[u] = PAUSE_DURATION; e->border[u] = BORDER_BUFFER; }
+    e->vel_fixed = dup_mem(NULL, sizeof(double) * U);
+    for (int u = 0; u < U; u++) e->vel_fixed[u] = -1.0;
     e->init_x = dup_mem(init_x, sizeof(int32_t) * U); e->init_y = dup_mem(init_y, sizeof(int32_t) * U);
     if (!ue_dr_req) for (int u = 0; u < U; u++) e->ue_dr_req[u] = 1.0;
     if (!init_x) for (int u = 0; u < U; u++) e->init_x[u] = -1;
@@ -573,7 +583,7 @@ void orc_destroy(orc_env *e)
 {
     if (!e) return;
     free(e->bs_x); free(e->bs_y); free(e->bs_sharing); free(e->ue_util); free(e->ue_dr_req); free(e->vel_lo); free(e->vel_hi);
-    free(e->pause_dur); free(e->border);
+    free(e->pause_dur); free(e->border); free(e->vel_fixed);
     free(e->init_x); free(e->init_y); free(e->px); free(e->py); free(e->wx); free(e->wy); free(e->vel); free(e->ewma);
     free(e->reward_before); free(e->reward); free(e->pausing); free(e->curr_pause); free(e->cursor); free(e->ue_nbs);
     free(e->ue_bs); free(e->ue_dr); free(e->bs_ues); free(e->bs_nues); free(e->tape_pos0); free(e->tape_triples); free(e->uid); free(e->orig_consumed);

@@ -77,6 +77,7 @@ def lib():
         L.orc_philox4x32_10.argtypes = [_c_u32p, _c_u32p, _c_u32p]
         L.orc_set_initial_ues.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.orc_set_movement.argtypes = [ctypes.c_void_p, ctypes.c_int, _c_ip, _c_ip]
+        L.orc_set_velocity.argtypes = [ctypes.c_void_p, ctypes.c_int, _c_dp]
         L.orc_probe_data_rate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _c_dp]
         L.orc_probe_data_rate.restype = ctypes.c_double
         L.orc_set_events.argtypes = [ctypes.c_void_p, ctypes.c_int, _c_ip, ctypes.c_int, _c_ip]
@@ -104,7 +105,14 @@ def vel_range(v):
         return 1, 3
     if v == 'fast' or v == -2:
         return 5, 10
+    if float(v) != int(v):                 # a fixed velocity that is no integer (movement.py:116-117): never drawn, see vel_number
+        return 0, 0
     return int(v), int(v)
+
+
+def vel_number(v):
+    """Fixed velocity given as a non-integer number (RandomWaypoint(map, velocity=2.5)) -> that number, else -1."""
+    return float(v) if not isinstance(v, str) and float(v) >= 0 and float(v) != int(v) else -1.0
 
 
 class RefRngTape:
@@ -220,6 +228,9 @@ class OracleEnv:
         self.h = ctypes.c_void_p(self.h)
         if pad:
             L.orc_set_initial_ues(self.h, self.U0)
+        self._velnum = np.asarray([vel_number(v) for v in vel_specs[:self.U0]], dtype=np.float64)
+        if (self._velnum >= 0).any():
+            L.orc_set_velocity(self.h, self.U0, _p(self._velnum, _c_dp))
         if pause is not None or border is not None:                 # RandomWaypoint(pause_duration, border_buffer), movement.py:87-104
             self._pause = np.asarray([2] * self.U0 if pause is None else pause, dtype=np.int32)
             self._border = np.asarray([10] * self.U0 if border is None else border, dtype=np.int32)

@@ -164,6 +164,10 @@ def run_trajectory(name, scn, kind, seed, num_steps, reward='avg', tape_mode='un
         'cfg_eps_len': np.array(eps_len, dtype=np.int32),
         'actions': tape,
     }
+    if any(not isinstance(s['velocity'], str) and float(s['velocity']) != int(s['velocity']) for s in scn.ue_specs):
+        # fixed velocities that are no integers (movement.py:116-117 takes any number): the number itself, -1 elsewhere
+        out['cfg_ue_vel_num'] = np.array([-1.0 if isinstance(s['velocity'], str) or float(s['velocity']) == int(s['velocity'])
+                                          else float(s['velocity']) for s in scn.ue_specs], dtype=np.float64)
     if seed_at:
         out['cfg_seed_at'] = np.array(sorted((int(k), int(v)) for k, v in seed_at.items()), dtype=np.int64)
     if seed_before_reset:
@@ -347,6 +351,20 @@ def gen_movement_params():
                    rand_episodes=True)
 
 
+def gen_velocity_numbers():
+    """RandomWaypoint(map, velocity=<any number>) (movement.py:96,116-117): fixed velocities that are not integers, next to drawn ones."""
+    scn = scenarios.custom_map('mixed').with_ues(num_slow=2, num_fast=1, num_static=3)
+    for spec, v in zip(scn.ue_specs[:3], (2.5, 0.3, 7.125)):            # the three 'static' UEs; the slow / fast ones keep drawing theirs
+        spec['velocity'] = v
+    scn.ue_specs[2]['pause_duration'] = 0
+    run_trajectory('traj_custom6x4_multi_velocity_numbers_s42', scn, 'multi', 42, 150, tape_mode='sticky', eps_len=150)
+    scn = scenarios.medium_map('mixed').with_ues(num_static=3)
+    for spec, v in zip(scn.ue_specs, (11.7, 1e-3, 3.0000000001)):
+        spec['velocity'] = v
+    run_trajectory('traj_medium3x3_central_velocity_numbers_2eps_rand_s43', scn, 'central', 43, 60, episodes=2, eps_len=60,
+                   rand_episodes=True)
+
+
 def gen_reseed():
     """MobileEnv.seed() on a LIVE env (base.py:132-143): every UE stream is re-seeded at once, mid-episode; reset() of a
     rand_episodes=False env goes back to the configured seed (base.py:171-173), a rand_episodes=True env keeps the new streams."""
@@ -432,10 +450,9 @@ def run_dynamic_trajectory(name, scn, kind, seed, num_steps, ue_arrival=None, ne
         'cfg_arrival_n': np.array([arr[k] for k in sorted(arr.keys())], dtype=np.int32),
         'actions': tape,
     }
-    if seed_at:
-        out['cfg_seed_at'] = np.array(sorted((int(k), int(v)) for k, v in seed_at.items()), dtype=np.int64)
-    if seed_before_reset:
-        out['cfg_seed_before_reset'] = np.array(sorted((int(k), int(v)) for k, v in seed_before_reset.items()), dtype=np.int64)
+    if any(not isinstance(s['velocity'], str) and float(s['velocity']) != int(s['velocity']) for s in scn.ue_specs):
+        out['cfg_ue_vel_num'] = np.array([-1.0 if isinstance(s['velocity'], str) or float(s['velocity']) == int(s['velocity'])
+                                          else float(s['velocity']) for s in scn.ue_specs], dtype=np.float64)
     if any('pause_duration' in s or 'border_buffer' in s for s in scn.ue_specs):      # non-default RandomWaypoint parameters
         out['cfg_ue_pause'] = np.array([s.get('pause_duration', 2) for s in scn.ue_specs], dtype=np.int32)
         out['cfg_ue_border'] = np.array([s.get('border_buffer', 10) for s in scn.ue_specs], dtype=np.int32)
@@ -532,6 +549,7 @@ if __name__ == '__main__':
     gen_movement()
     gen_trajectories()
     gen_movement_params()
+    gen_velocity_numbers()
     gen_reseed()
     gen_estack()
     gen_heuristics()

@@ -106,6 +106,8 @@ def make_env_from_fixture(g, depth=64):
     U = g['cfg_ue_vel'].shape[0]
     w, h = (int(x) for x in g['cfg_map_wh'])
     vel = [int(v) for v in g['cfg_ue_vel']]
+    if 'cfg_ue_vel_num' in (g.files if hasattr(g, 'files') else g):                  # fixed velocities that are no integers (movement.py:116-117)
+        vel = [float(n) if n >= 0 else v for v, n in zip(vel, g['cfg_ue_vel_num'])]
     init = [tuple(int(v) for v in xy) for xy in g['cfg_ue_init_xy']]
     pause = [int(v) for v in g['cfg_ue_pause']] if 'cfg_ue_pause' in (g.files if hasattr(g, 'files') else g) else None      # RandomWaypoint parameters away
     border = [int(v) for v in g['cfg_ue_border']] if 'cfg_ue_border' in (g.files if hasattr(g, 'files') else g) else None   # from the defaults (movement.py:87)
@@ -220,6 +222,8 @@ def dyn_setup(g, depth=48):
     'slow' tape per possible id of an arriving UE (seed + 100*id, base.py:602-604)."""
     w, h = (int(x) for x in g['cfg_map_wh'])
     vel = [int(v) for v in g['cfg_ue_vel']]
+    if 'cfg_ue_vel_num' in (g.files if hasattr(g, 'files') else g):                  # fixed velocities that are no integers (movement.py:116-117)
+        vel = [float(n) if n >= 0 else v for v, n in zip(vel, g['cfg_ue_vel_num'])]
     U0, M, seed = len(vel), int(g['cfg_max_ues']), int(g['cfg_seed'])
     L = int(g['cfg_eps_len'])
     arr = {int(t): int(n) for t, n in zip(g['cfg_arrival_t'], g['cfg_arrival_n'])} or None

@@ -41,8 +41,9 @@ def _entities_from_fixture(g):
     U = len(g['cfg_ue_vel'])
     pause = [int(v) for v in g['cfg_ue_pause']] if 'cfg_ue_pause' in g.files else [2] * U           # movement.py:87 defaults
     border = [int(v) for v in g['cfg_ue_border']] if 'cfg_ue_border' in g.files else [10] * U
+    vnum = g['cfg_ue_vel_num'] if 'cfg_ue_vel_num' in g.files else [-1.0] * U           # velocities that are no integers (movement.py:116-117)
     ues = [User(str(i + 1), m, xy[i][0], xy[i][1],
-                RandomWaypoint(m, vel.get(int(v), int(v)), pause_duration=pause[i], border_buffer=border[i]),
+                RandomWaypoint(m, float(vnum[i]) if vnum[i] >= 0 else vel.get(int(v), int(v)), pause_duration=pause[i], border_buffer=border[i]),
                 util_func='log' if int(u) == 0 else 'step', dr_req=float(r))
            for i, (v, u, r) in enumerate(zip(g['cfg_ue_vel'], g['cfg_ue_util'], g['cfg_ue_dr_req']))]
     return m, bs, ues
@@ -305,8 +306,9 @@ def test_tight_packing_oracle_parity(torch_cuda, shape, monkeypatch):
 @pytest.mark.parametrize('kind,U,B,E', [('multi', 32, 10, 256), ('central', 10, 5, 300), ('multi', 128, 32, 6), ('multi', 70, 9, 20)])
 def test_movement_parameters_philox(torch_cuda, kind, U, B, E):
     """RandomWaypoint(pause_duration, border_buffer) per UE away from the defaults 2 / 10 (movement.py:87-104; round 1 refused
-    them): counter-based draws against the oracle, 90 steps incl. a reset, through step() and through the fused rollout.
-    (The reference-run fixtures traj_*pause_border* pin the same parameters in tape mode.)"""
+    them) and fixed velocities that are no integers in 0..255 (round 2 refused them): counter-based draws against the oracle, 90
+    steps incl. a reset, through step() and through the fused rollout.
+    (The reference-run fixtures traj_*pause_border* / traj_*velocity_numbers* pin the same parameters in tape mode.)"""
     torch = torch_cuda
     from deepcomp_amd import scenarios
     from deepcomp_amd.entities import build_from_scenario
@@ -314,6 +316,8 @@ def test_movement_parameters_philox(torch_cuda, kind, U, B, E):
     scn = scenarios.grid_map(B, 'mixed').with_ues(num_slow=U - U // 2, num_fast=U // 2)
     for i, spec in enumerate(scn.ue_specs):
         spec['pause_duration'], spec['border_buffer'] = (0, 1, 2, 5, 9, 30, 127)[i % 7], (1, 10, 25, 49, 3)[i % 5]
+        if i % 4 == 3:          # movement.py:116-117: a fixed velocity is any number -- not an integer, or beyond the movement word's 8 bits
+            spec['velocity'] = (2.5, 0.3, 7.125, 300.0, 11.7, 1e-3)[(i // 4) % 6]
     m, bs, ues = build_from_scenario(scn)
     core = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=99, rng='philox', rand_episodes=True, episode_length=45)
     roll = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=99, rng='philox', rand_episodes=True, episode_length=45)

@@ -42,6 +42,8 @@ def random_spec(rng):
     vel, util, req, init = [], [], [], []
     for i in range(U):
         v = [0, 'slow', 'fast', int(rng.integers(1, 30))][int(rng.integers(0, 4))]
+        if not isinstance(v, str) and rng.random() < 0.3:      # movement.py:116-117: any number is a velocity (2.5, 0.001, 300)
+            v = [round(float(rng.uniform(0, 40)), 3), float(rng.uniform(0, 3)), float(rng.integers(256, 400))][int(rng.integers(0, 3))]
         uf = 'step' if rng.random() < 0.25 else 'log'
         rq = float(rng.choice([1.0, 0.5, 3.0, 20.0]))
         r = rng.random()
