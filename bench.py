@@ -297,7 +297,7 @@ def self_spawn(n):
     sys.exit(1)
 
 
-def traffic_from_profile(workload_key, kernel_name=None):
+def traffic_from_profile(workload_key, kernel_name=None, want_entry=False):
     """roofline.traffic comes from a TRACKED rocprofv3 --pmc summary (profiles/traffic.json, registered by
     tools/register_traffic.py from a summary tools/summarize_prof.py wrote on the GPU box), never from a literal in this file:
     HBM bytes per launch = FETCH_SIZE x 2 (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in
@@ -318,7 +318,26 @@ def traffic_from_profile(workload_key, kernel_name=None):
         return None, 'STALE (kernel sources changed since): ' + src
     if kernel_name is not None and kernel_name != ent['kernel']:
         return None, f'STALE (this library dispatches to {kernel_name}): ' + src
+    if want_entry:
+        return ent, src
     return (2.0 * ent['fetch_kib'] + ent['write_kib']) * 1024.0, src
+
+
+SIMDS, CLOCK_GHZ, CYCLES_PER_VALU = 1024, 2.4, 4      # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies a 16-lane SIMD for 4 cycles
+
+
+def valu_bound(ent, kernel_ms):
+    """the path is transcendental / VALU heavy for a streaming kernel, so the vector-issue bound is reported
+    next to the HBM one.  SQ_INSTS_VALU per launch (tracked --pmc profile) x 4 cycles, spread over 1 024 SIMDs at the 2.4 GHz peak
+    clock = the shortest time the launch's vector instructions can issue in (FP64 and transcendental instructions take longer
+    than 4 cycles, so the true floor is higher and `frac` a lower bound of the ALU occupancy)."""
+    n = ent.get('valu_insts_per_launch')
+    if not n:
+        return None
+    floor_ms = n * CYCLES_PER_VALU / (SIMDS * CLOCK_GHZ * 1e9) * 1e3
+    return {'insts_per_launch': n, 'insts_per_wave': n / ent['waves_per_launch'] if ent.get('waves_per_launch') else None,
+            'issue_floor_ms': floor_ms, 'frac': floor_ms / kernel_ms,
+            'peak': f'{SIMDS} SIMDs x {CLOCK_GHZ} GHz / {CYCLES_PER_VALU} cycles per wave64 VALU instruction'}
 
 
 def main():
@@ -692,7 +711,11 @@ def main():
                                                'frac': sbpe * E / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                'how': f'200 launches timed after {max(300, K)} untimed ones (same HIP-event method)'}
         if args.traffic_bytes is None:
-            out['roofline']['traffic'], out['roofline']['traffic_source'] = traffic_from_profile(f'{E}x{U}x{B}_{args.kind}_{args.sharing}', env.step_kernel_name)
+            ent, src = traffic_from_profile(f'{E}x{U}x{B}_{args.kind}_{args.sharing}', env.step_kernel_name, want_entry=True)
+            out['roofline']['traffic'] = (2.0 * ent['fetch_kib'] + ent['write_kib']) * 1024.0 if ent else None
+            out['roofline']['traffic_source'] = src
+            if ent and valu_bound(ent, kern_ms):
+                out['roofline']['valu'] = valu_bound(ent, kern_ms)
         else:
             out['roofline']['traffic_source'] = '--traffic-bytes'
         if world == 1 and not args.no_stream:

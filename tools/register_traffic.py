@@ -56,7 +56,7 @@ def main():
     vals = {}
     for line in txt.splitlines():
         line = line.strip()
-        if line.startswith('void ') and kern in line and ("{'FETCH_SIZE'" in line or "{'WRITE_SIZE'" in line):
+        if line.startswith('void ') and kern in line and '{' in line:
             d = ast.literal_eval(line[line.index('{'):line.index('}') + 1])
             vals.update(d)
     if 'FETCH_SIZE' not in vals or 'WRITE_SIZE' not in vals:
@@ -67,10 +67,16 @@ def main():
         commit = '?'
     path = os.path.join(REPO, 'profiles', 'traffic.json')
     db = json.load(open(path)) if os.path.exists(path) else {}
+    old = db.get(key, {})
+    if old.get('tag') == tag:                      # the same profile registered again (new fields): it still belongs to the tree it was taken from
+        commit = old.get('commit', commit)
     db[key] = {'tag': tag, 'kernel': kern, 'fetch_kib': vals['FETCH_SIZE'], 'write_kib': vals['WRITE_SIZE'],
                'source_fingerprint': fp.group(1) if fp else None, 'kernel_fingerprint': kfp.group(1) if kfp else None, 'commit': commit,
                'bytes_per_launch': (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0,
+               'valu_insts_per_launch': vals.get('SQ_INSTS_VALU'), 'waves_per_launch': vals.get('SQ_WAVES'),
                'note': 'bytes = (2 x FETCH_SIZE [gfx950 wide-read correction] + WRITE_SIZE) KiB per launch'}
+    if old.get('tag') == tag and not db[key]['kernel_fingerprint']:
+        db[key]['kernel_fingerprint'] = old.get('kernel_fingerprint')
     with open(path, 'w') as f:
         json.dump(db, f, indent=1, sort_keys=True)
         f.write('\n')
