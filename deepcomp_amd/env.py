@@ -273,11 +273,13 @@ class BatchedMobileEnv:
         from the start of its new movement stream (base.py:138-143 -> user.py:94-96); the next reset() of a
         rand_episodes=False env re-seeds with the CONFIGURED seed again (base.py:171-173: seed() then only shapes the rest of
         the running episode), a rand_episodes=True env carries the new streams on.  Held against reference-run trajectories
-        (tests/golden/reseed_*.npz).  Fixed UE lists only; with UE arrival / departure the seed is staged."""
+        (tests/golden/reseed_*.npz, reseeddyn_*.npz).  With UE arrival / departure the UEs of the CURRENT list -- arrived ones
+        too -- are re-seeded by list position, the departure / arrival-point generators restart, later arrivals keep the
+        configured seed (base.py:601-604)."""
         if seed is None:
             return
         seed = int(seed)
-        if immediate and self.rng_mode == _lib.RNG_TAPE and not self.dynamic:
+        if immediate and self.rng_mode == _lib.RNG_TAPE:
             return self._seed_live(seed)
         self.seed_value = seed
         self.env_seeds = self.seed_value + self._seed_stride * (self.env_id_base + np.arange(self.E, dtype=np.int64))
@@ -289,6 +291,22 @@ class BatchedMobileEnv:
         """seed(immediate=True), rng='reference': splice the new streams into the tape of the running episode."""
         seeds = seed + self._seed_stride * (self.env_id_base + np.arange(self.E, dtype=np.int64))
         live = self._tape_dev is not None
+        if self.dynamic:
+            if self._dyn_streams is None or not live:        # no episode yet
+                if self.rand_episodes:                       # ... the first reset() starts the new streams; a fixed-episode env re-seeds
+                    self.seed_value, self.env_seeds = seed, seeds        #     with the configured seed anyway (base.py:171-173)
+                return
+            E, U, n = self.E, self.U, self.num_ue
+            uid = self.uid.cpu().numpy().astype(np.uint16).reshape(E, U)
+            cur = ((self.mv >> 48) & 0xFFFF).cpu().numpy().reshape(E, U)
+            lists = [[(int(w & 0x7FFF), bool(w & 0x8000)) for w in uid[e, :n]] for e in range(E)]
+            pos0, trip = self._dyn_streams.reseed_live(seeds, lists, cur)
+            torch.cuda.current_stream(self.device).synchronize()       # steps in flight still read the old tape
+            old = self._tape_dev
+            tape = self._upload_tape(pos0, trip)
+            _lib.check(self._L.dcomp_set_tape(self._h, ctypes.byref(tape), int(trip.shape[1])))
+            del old
+            return
         cursor = ((self.mv >> 48) & 0xFFFF).cpu().numpy().astype(np.int64) if live else None   # triples consumed so far, per (env, UE)
         if self.rand_episodes:
             self.seed_value, self.env_seeds = seed, seeds

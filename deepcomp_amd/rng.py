@@ -195,6 +195,51 @@ class DynamicStdlibStreams:
         self.map_rng = [random.Random(s) for s in self.seeds]
         self.glob = [random.Random(s) for s in self.seeds]
         self._states = None
+        self._shift = None          # [e][i]: triples initial UE i had drawn before a live re-seed (reseed_live)
+        self._live_born = {}        # (e, id) -> (seed, cursor): arrived UEs re-seeded live, for extend()
+
+    def _born_row(self, trip, row, seed, cursor, upto):
+        """Row of an arrived UE re-seeded live: 'slow', default border (base.py:597-599), new stream from `cursor` on."""
+        r = random.Random(seed)
+        for k in range(cursor, upto):
+            trip[row, k, :3] = (r.randint(1, 3), r.randint(10, self.w - 10), r.randint(10, self.h - 10))
+
+    def reseed_live(self, seeds, lists, cursors):
+        """MobileEnv.seed() while an episode with a changing UE list runs (base.py:132-143).  Per env: the global generator
+        (departures, base.py:611) and the map's (arrival points, map.py:52-65) restart from the new seed; every UE of the CURRENT
+        list -- initial or arrived -- gets `seed + 100*(position + 1)` for both streams.  lists[e] = [(id, born)] in list order,
+        cursors[e][slot] = movement triples consumed so far.  Returns (pos0, triples) with the rows of the listed UEs continued
+        from their cursor by the new streams.  UEs that arrive later are still seeded with the CONFIGURED seed (base.py:601-604:
+        env_seed), initial UEs that have left keep their old stream, and reset() of a rand_episodes=False env re-seeds with the
+        configured seed as always (self.seeds is not touched)."""
+        E, U0, D = len(self.seeds), self.U0, self.depth
+        ids = U0 + self.max_id
+        trip = self._trip.copy()
+        if self._shift is None:
+            self._shift = [[0] * U0 for _ in range(E)]
+        for e in range(E):
+            s = int(seeds[e])
+            self.map_rng[e].seed(s)
+            self.glob[e].seed(s)
+            for pos, (uid, born) in enumerate(lists[e]):
+                sd, cur = s + 100 * (pos + 1), int(cursors[e][pos])
+                if born:
+                    self._live_born[(e, uid)] = (sd, cur)
+                    self._born_row(trip, e * ids + U0 + uid - 1, sd, cur, D)
+                    continue
+                i = uid - 1
+                self.pos_rng[e][i].seed(sd)
+                mr = self.mov_rng[e][i]
+                mr.seed(sd)
+                lo, hi = self.vel[i]
+                st = [mr.getstate()]
+                for k in range(cur, D):
+                    trip[e * ids + i, k, :3] = (mr.randint(lo, hi) if lo != hi else lo, mr.randint(self.border[i], self.w - self.border[i]),
+                                                mr.randint(self.border[i], self.h - self.border[i]))
+                    st.append(mr.getstate())
+                self._states[e][i], self._shift[e][i] = st, cur
+        self._trip = trip
+        return self._pos0, trip
 
     def draw_episode(self, end_lists=None, consumed=None):
         """end_lists[e] = [(id, born)] of env e's list at the end of the previous episode; consumed[e][i] = movement
@@ -203,7 +248,9 @@ class DynamicStdlibStreams:
         if self._states is not None:
             for e in range(E):
                 for i in range(U0):
-                    self.mov_rng[e][i].setstate(self._states[e][i][int(consumed[e][i])])
+                    shift = self._shift[e][i] if self._shift else 0
+                    self.mov_rng[e][i].setstate(self._states[e][i][int(consumed[e][i]) - shift])
+        self._shift, self._live_born = None, {}
         if not self.rand_episodes:
             for e, s in enumerate(self.seeds):
                 self.map_rng[e].seed(s)
@@ -256,6 +303,9 @@ class DynamicStdlibStreams:
                 mr = random.Random(s + 100 * (j + 1))
                 for k in range(new_depth):
                     trip[e * ids + U0 + j, k, :3] = (mr.randint(1, 3), mr.randint(10, self.w - 10), mr.randint(10, self.h - 10))
+                if (e, j + 1) in self._live_born:               # an arrived UE that seed() re-seeded while the episode ran
+                    sd, cur = self._live_born[(e, j + 1)]
+                    self._born_row(trip, e * ids + U0 + j, sd, cur, new_depth)
         self.depth, self._trip = new_depth, trip
         return self._pos0, trip
 

@@ -369,11 +369,38 @@ class DynRefStreams:
         self.pos_rng = [random.Random(seed + 100 * (i + 1)) for i in range(self.U0)]
         self.mov_rng = [random.Random(seed + 100 * (i + 1)) for i in range(self.U0)]
         self._states = None
+        self._shift = [0] * self.U0
+
+    def reseed_live(self, seed, trip_all, slots):
+        """MobileEnv.seed(seed) while an episode with a changing UE list runs (base.py:132-143): every UE of the CURRENT list --
+        initial or arrived -- gets seed + 100*(position + 1) for both streams.  slots = [(uid, born, cursor)] in list order;
+        trip_all = the episode's triples, rows by id (initial UEs, then one row per id of an arriving UE).  Returns trip_all with
+        the rows of the listed UEs continued from their cursor by the new movement streams.  UEs that arrive later are still
+        seeded with the CONFIGURED seed (base.py:601-604), initial UEs that have left keep their old stream."""
+        trip = trip_all.copy()
+        depth = trip.shape[1]
+        for pos, (uid, born, cur) in enumerate(slots):
+            s, cur = seed + 100 * (pos + 1), int(cur)
+            if born:                                             # a User created by add_new_ue: 'slow', default border (base.py:597-599)
+                r, (lo, hi), row = random.Random(s), (1, 3), self.U0 + uid - 1
+            else:
+                self.pos_rng[uid - 1].seed(s)
+                self.mov_rng[uid - 1].seed(s)
+                r, (lo, hi), row = self.mov_rng[uid - 1], self.vel[uid - 1], uid - 1
+                self._states[uid - 1] = [r.getstate()]
+                self._shift[uid - 1] = cur
+            for k in range(cur, depth):
+                v = r.randint(lo, hi) if lo != hi else lo
+                trip[row, k] = (v, r.randint(10, self.w - 10), r.randint(10, self.h - 10))
+                if not born:
+                    self._states[uid - 1].append(r.getstate())
+        return trip
 
     def draw_episode(self, end_list=None, consumed=None):
         if self._states is not None:
             for i in range(self.U0):
-                self.mov_rng[i].setstate(self._states[i][int(consumed[i])])
+                self.mov_rng[i].setstate(self._states[i][int(consumed[i]) - self._shift[i]])
+        self._shift = [0] * self.U0
         if not self.rand_episodes:
             order = [(i + 1, False) for i in range(self.U0)] if end_list is None else end_list
             for pos, (uid, born) in enumerate(order):
@@ -411,6 +438,11 @@ class RefEventDraws:
     def new_episode(self):
         if not self.rand_episodes:
             self._seed()
+
+    def reseed_live(self, seed):
+        """MobileEnv.seed(seed) on a live env: the global generator and the map's restart from `seed` (base.py:134-136); the
+        configured seed stays what reset() of a rand_episodes=False env goes back to."""
+        self.map_rng, self.glob = random.Random(seed), random.Random(seed)
 
     def departures(self, n_remove, num_ue):
         out = []

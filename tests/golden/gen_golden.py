@@ -377,6 +377,15 @@ def gen_reseed():
                    rand_episodes=True, seed_at={0: 8, 11: 977, 50: 4242}, seed_before_reset={2: 31337})
 
 
+def gen_reseed_dynamic():
+    """MobileEnv.seed() on a live env whose UE list changes: UEs that arrived are re-seeded by list position too, the global
+    generator (departures) and the map's (arrival points) restart; later arrivals still get the configured seed (base.py:601-604)."""
+    run_dynamic_trajectory('reseeddyn_large_multi_2eps_rand_s42', scenarios.large_map('mixed').with_ues(num_static=1, num_slow=2), 'multi',
+                           42, 30, ue_arrival={2: 2, 9: -1, 12: 2, 20: -3}, episodes=2, rand_episodes=True, seed_at={5: 977, 16: 31, 44: 8})
+    run_dynamic_trajectory('reseeddyn_custom_central_2eps_fixed_s43', scenarios.custom_map('mixed').with_ues(num_slow=2, num_fast=1), 'central',
+                           43, 30, ue_arrival={3: 2, 6: -1, 8: 1, 10: -2, 15: 3, 22: -2}, episodes=2, rand_episodes=False, seed_at={7: 977, 41: 5})
+
+
 def gen_estack():
     """E-axis parity: env e uses base seed 42 + 20000*e."""
     for e in range(8):
@@ -388,7 +397,7 @@ def gen_estack():
 
 
 def run_dynamic_trajectory(name, scn, kind, seed, num_steps, ue_arrival=None, new_ue_interval=None, episodes=1,
-                           rand_episodes=False, reward='avg', save=True):
+                           rand_episodes=False, reward='avg', save=True, seed_at=None):
     """G8: UE arrival / departure (base.py:433-443, 592-618).  Per-UE arrays are padded to max_ues; `num_ue` and
     `ue_ids` say which slots are alive (slot = position in env.ue_list, the order central observations use)."""
     m, bs_list, ue_list = build_ref(scn, scn.ue_specs)
@@ -429,6 +438,8 @@ def run_dynamic_trajectory(name, scn, kind, seed, num_steps, ue_arrival=None, ne
         obs = env.reset()
         resets.append(snap(obs))
         for _ in range(num_steps):
+            if seed_at and t in seed_at:                 # MobileEnv.seed() on the live env, right before global step t
+                env.seed(int(seed_at[t]))
             a = tape[t]
             action = [int(x) for x in a] if kind == 'central' else {ue.id: int(a[i]) for i, ue in enumerate(env.ue_list)}
             obs, reward_v, done, info = env.step(action)
@@ -450,6 +461,8 @@ def run_dynamic_trajectory(name, scn, kind, seed, num_steps, ue_arrival=None, ne
         'cfg_arrival_n': np.array([arr[k] for k in sorted(arr.keys())], dtype=np.int32),
         'actions': tape,
     }
+    if seed_at:
+        out['cfg_seed_at'] = np.array(sorted((int(k), int(v)) for k, v in seed_at.items()), dtype=np.int64)
     if any(not isinstance(s['velocity'], str) and float(s['velocity']) != int(s['velocity']) for s in scn.ue_specs):
         out['cfg_ue_vel_num'] = np.array([-1.0 if isinstance(s['velocity'], str) or float(s['velocity']) == int(s['velocity'])
                                           else float(s['velocity']) for s in scn.ue_specs], dtype=np.float64)
@@ -551,6 +564,7 @@ if __name__ == '__main__':
     gen_movement_params()
     gen_velocity_numbers()
     gen_reseed()
+    gen_reseed_dynamic()
     gen_estack()
     gen_heuristics()
     gen_dynamic()

@@ -280,6 +280,44 @@ def test_dynamic_ue_trajectory(name):
         consumed, end_list = env.orig_consumed(), env.end_of_episode_list()
 
 
+RESEED_DYN = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'reseeddyn_*.npz')))
+
+
+@pytest.mark.parametrize('name', RESEED_DYN)
+def test_seed_on_a_live_env_with_ue_arrival(name):
+    """MobileEnv.seed() mid-episode while UEs arrive / depart (base.py:132-143): listed UEs -- initial and arrived -- are re-seeded
+    by list position, departures / arrival points restart from the new seed, later arrivals keep the configured seed."""
+    g = load(name)
+    assert RESEED_DYN
+    env, init_tape, new_tape, events, sched, U0, M = dyn_setup(g)
+    kind, episodes, L = int(g['cfg_kind']), int(g['cfg_episodes']), int(g['cfg_eps_len'])
+    seed_at = {int(t): int(s) for t, s in g['cfg_seed_at']}
+    t, consumed, end_list = 0, None, None
+    for ep in range(episodes):
+        p0, t0 = init_tape.draw_episode(end_list, consumed)
+        p1, t1 = new_tape.draw_episode()
+        pos_all, trip_all = np.concatenate([p0, p1]), np.concatenate([t0, t1])
+        env.set_tape_ids(pos_all, trip_all)
+        events.new_episode()
+        env.reset()
+        dyn_check(env, g, 'reset', ep, kind, M)
+        for k in range(L):
+            if t in seed_at:
+                cur = env.cursors()
+                slots = [(uid, born, int(cur[s_])) for s_, (uid, born) in enumerate(env.end_of_episode_list())]
+                trip_all = init_tape.reseed_live(seed_at[t], trip_all, slots)
+                events.reseed_live(seed_at[t])
+                env.set_tape_ids(pos_all, trip_all)
+            n_rem, n_add = sched[k]
+            if n_rem or n_add:
+                env.set_events(events.departures(n_rem, env.num_ue()), events.arrivals(n_add))
+            env.step(g['actions'][t])
+            dyn_check(env, g, 'step', t, kind, M)
+            np.testing.assert_allclose(env.reward(), g['step_reward'][t], rtol=1e-9, atol=1e-12, err_msg=f'reward[{t}]')
+            t += 1
+        consumed, end_list = env.orig_consumed(), env.end_of_episode_list()
+
+
 # ------------------------------------------------------------------ G9 single-agent env (base.py:227-245, 350-369)
 @pytest.mark.parametrize('name,scn_args', [('single_custom3x4_s42', ('custom', 2, 1)), ('single_small2x2_s43', ('small', 2, 0))])
 def test_single_agent_env(name, scn_args):

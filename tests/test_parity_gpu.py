@@ -424,7 +424,7 @@ def test_heuristic_driven_rollout_matches_oracle(torch_cuda, agent_name):
 
 
 # ------------------------------------------------------------------------------------ UE arrival / departure
-DYN = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'dyn_*.npz')))
+DYN = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'dyn_*.npz')) + glob.glob(os.path.join(GOLDEN, 'reseeddyn_*.npz')))
 
 
 def _dyn_kwargs(g):
@@ -437,7 +437,9 @@ def _dyn_kwargs(g):
 @pytest.mark.parametrize('name', DYN)
 def test_golden_dynamic_ue_trajectory(torch_cuda, name, via_rollout):
     """UE arrival / departure (base.py:433-443, 592-618) against reference-run fixtures: slot order, ids, masks,
-    FP64 positions exact (incl. the reference's reseed-by-list-position behaviour across episodes)."""
+    FP64 positions exact (incl. the reference's reseed-by-list-position behaviour across episodes).  reseeddyn_*: with
+    MobileEnv.seed() calls in the middle of episodes (base.py:132-143; listed UEs incl. arrived ones re-seeded by position, the
+    departure / arrival-point generators restart)."""
     torch = torch_cuda
     from deepcomp_amd.entities import Basestation, Map, Point, RandomWaypoint, User
     from deepcomp_amd.env import BatchedMobileEnv
@@ -480,6 +482,7 @@ def test_golden_dynamic_ue_trajectory(torch_cuda, name, via_rollout):
             np.testing.assert_allclose(r, g['step_reward'][i], atol=ATOL_UTIL if kind == 'multi' else ATOL_OBS, rtol=0)
             assert float(core.sum_utility.cpu().numpy()[0]) == pytest.approx(float(g['step_sum_utility'][i]), abs=ATOL_UTIL * M)
 
+    seed_at = {int(t_): int(s_) for t_, s_ in g['cfg_seed_at']} if 'cfg_seed_at' in g.files else {}
     t = 0
     for ep in range(int(g['cfg_episodes'])):
         core.reset()
@@ -488,7 +491,9 @@ def test_golden_dynamic_ue_trajectory(torch_cuda, name, via_rollout):
             L, frag = int(g['cfg_eps_len']), 1
             left = L
             while left:
-                n = min(frag, left)
+                if t in seed_at:
+                    core.seed(seed_at[t], immediate=True)
+                n = min([frag, left] + [ts - t for ts in seed_at if ts > t])          # a fragment ends where the caller seeds
                 acts = torch.from_numpy(g['actions'][t:t + n].astype(np.uint8).reshape(n, 1, -1)).cuda()
                 core.rollout(acts)
                 t += n; left -= n
@@ -497,6 +502,8 @@ def test_golden_dynamic_ue_trajectory(torch_cuda, name, via_rollout):
             core.check()
             continue
         for _ in range(int(g['cfg_eps_len'])):
+            if t in seed_at:
+                core.seed(seed_at[t], immediate=True)
             core.step(torch.from_numpy(g['actions'][t].astype(np.uint8).reshape(1, -1)).cuda())
             cmp('step', t, True)
             t += 1
