@@ -503,9 +503,20 @@ class BatchedMobileEnv:
         L = int(horizon or 0)
         if new_episode_draws is None:
             new_episode_draws = self.rand_episodes
-        if L and self.rng_mode == _lib.RNG_TAPE and (self.rand_episodes or new_episode_draws or self.dynamic):
-            raise NotImplementedError("rng='reference' with rand_episodes or UE arrival / departure: every episode needs a fresh host-drawn "
-                                      "tape; reset() between rollouts instead of passing horizon")
+        if L and self.rng_mode == _lib.RNG_TAPE and (self.rand_episodes or new_episode_draws or self.dynamic) and not _policy_steps:
+            # rng='reference' with streams that continue across episodes (or UEs re-seeded by list position at reset): every episode
+            # needs a tape the HOST draws from where the previous one stopped, so the rollout is cut at the episode boundaries --
+            # one launch per stretch, reset() (cursors read back, new tape) in between.  Same sequence as `if time == L: reset()`
+            # before every step, like the in-kernel reset of the other modes.
+            keys = ('obs', 'reward', 'sum_utility', 'ue_dr', 'ue_utility', 'reward_before')
+            t0 = 0
+            while t0 < T:
+                if self.time >= L:
+                    self.reset()
+                n = min(T - t0, L - self.time)
+                self.rollout(actions[t0:t0 + n], out=None if out is None else {k: out[k][t0:t0 + n] for k in keys if out.get(k) is not None})
+                t0 += n
+            return (self.obs, self.reward) if out is None else (out['obs'], out['reward'])
         o = self._out
         if out is not None:
             self._require(out['obs'], torch.float32, T * self.obs.numel(), "out['obs']")

@@ -128,10 +128,22 @@ def test_rollout_reference_tape_fixed_episodes(torch_cuda):
     env.rollout(acts, horizon=L)
     env.check()
     assert torch.equal(env.obs, ref.obs) and _same_state(_state(env), _state(ref))
-    bad = _make('multi', U, B, E, rand_episodes=True, L=L, rng='reference')
-    bad.reset()
-    with pytest.raises(NotImplementedError):
-        bad.rollout(acts, horizon=L)
+    # streams that continue across episodes (rand_episodes): the host draws every episode's tape, rollout() cuts itself at the
+    # episode boundaries (round 2 raised NotImplementedError here)
+    ref = _make('multi', U, B, E, rand_episodes=True, L=L, rng='reference')
+    env = _make('multi', U, B, E, rand_episodes=True, L=L, rng='reference')
+    ref.reset(); env.reset()
+    want = torch.zeros((T,) + tuple(ref.obs.shape), device='cuda')
+    for t in range(T):
+        if ref.time == L:
+            ref.reset()
+        ref.step(acts[t])
+        want[t] = ref.obs
+    out = {'obs': torch.zeros_like(want), 'reward': torch.zeros((T,) + tuple(env.reward.shape), device='cuda')}
+    env.rollout(acts[:7], out={k: v[:7] for k, v in out.items()}, horizon=L)          # two calls: the boundary logic carries over
+    env.rollout(acts[7:], out={k: v[7:] for k, v in out.items()}, horizon=L)
+    env.check()
+    assert torch.equal(out['obs'], want) and _same_state(_state(env), _state(ref)) and env.time == ref.time
 
 
 def test_fused_rollout_against_the_oracle(torch_cuda):
@@ -179,7 +191,8 @@ def test_fused_rollout_against_the_oracle(torch_cuda):
     parity.assert_rates(env, ob, 'final state', ue_dr=got_dr[-1], ue_utility=got_ut[-1])          # incl. the EWMA the kernel stored
 
 
-@pytest.mark.parametrize('kind,rng,L', [('multi', 'philox', 30), ('central', 'philox', 30), ('multi', 'reference', 0), ('central', 'philox', 0)])
+@pytest.mark.parametrize('kind,rng,L', [('multi', 'philox', 30), ('central', 'philox', 30), ('multi', 'reference', 0), ('central', 'philox', 0),
+                                        ('central', 'reference', 30)])
 def test_rollout_with_ue_arrival_and_departure(torch_cuda, kind, rng, L):
     """rollout() of an env whose UE list changes (base.py:433-443, 592-618): the schedule is fed to dcomp_rollout_ex per step
     (counts; in rng='reference' mode also the host-drawn list positions / border points), resets at the horizon included.
@@ -225,9 +238,6 @@ def test_rollout_with_ue_arrival_and_departure(torch_cuda, kind, rng, L):
     last.reset()
     last.rollout(acts[:cut])
     assert torch.equal(last.obs, want['obs'][cut - 1]) and torch.equal(last.reward, want['reward'][cut - 1])
-    if rng == 'reference':
-        with pytest.raises(NotImplementedError):
-            last.rollout(acts[:2], horizon=30)               # a fresh host-drawn tape per episode: reset() between rollouts
 
 
 def test_rollout_argument_validation(torch_cuda):
