@@ -478,11 +478,21 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
         // the kernel addresses step t's outputs as (idx + t * E * U) on the caller's base pointers with 32-bit row indices
         if (every && (uint64_t)T * EU >= ((uint64_t)1 << 31)) return fail(DCOMP_EINVAL, "rollout fragment too long: num_steps * num_envs * num_ue must stay below 2^31 (split the rollout)");
         // with a registered policy: the variant that carries the rules; tape-driven central envs: the central-only instantiation
-        const dcomp::KernelFn kern = kp.next_act ? env->kern.rollout_pol : (!multi && env->kern.rollout_central) ? env->kern.rollout_central : env->kern.rollout;
+        dcomp::KernelFn kern = kp.next_act ? env->kern.rollout_pol : (!multi && env->kern.rollout_central) ? env->kern.rollout_central : env->kern.rollout;
+        int grid = env->grid;
+        // A batch dcomp_create packs tightly for dcomp_step (throughput-bound: >= 4 padded waves per SIMD, >= 1.4x the lanes in use) runs
+        // its tape-driven central rollouts tightly packed too: the fused kernel is bound by its VALU work there, and a third fewer
+        // waves do the same steps (65 536 x 10 x 5: six envs per wavefront instead of four).  Same packing, same summation order as
+        // dcomp_step uses for this env.
+        if (env->tight_g && !multi && !kp.next_act && env->kern.rollout_tight_central && !getenv("DCOMP_NO_TIGHT_ROLLOUT")) {
+            kern = env->kern.rollout_tight_central;
+            grid = env->tight_grid;
+            kp.tight_g = env->tight_g; kp.tight_gpw = env->tight_gpw; kp.tight_magic = env->tight_magic;
+        }
         if (!loop || L == 0 || env->time + T <= L) {
             // ONE launch; resets at the horizon of a tape-driven rollout happen inside the kernel
             kp.action = actions; kp.num_steps = T; kp.out_every_step = every; kp.horizon = L; kp.episode_inc = inc; kp.policy_loop = loop;
-            hipLaunchKernelGGL(kern, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
             int time = env->time;
             int64_t episode = env->episode;
             for (int t = 0; t < T; t++) {
@@ -505,7 +515,7 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
                 out_slice(kp, t);
                 kp.action = act_src; kp.num_steps = n; kp.out_every_step = every; kp.horizon = 0; kp.episode_inc = 0; kp.policy_loop = 1;
                 kp.time = (uint32_t)env->time; kp.episode = (uint32_t)env->episode;
-                hipLaunchKernelGGL(kern, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
                 env->time += n;
                 t += n;
                 act_src = kp.next_act;                             // (a lane reads its slot before it writes it)

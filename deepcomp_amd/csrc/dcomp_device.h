@@ -1505,6 +1505,15 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void rollout_kernel(const KParams p)
     step_kernel_body<B, UPAD, MP, true, false, POL, KIND>(p, sh);
 }
 
+// The tape-driven central rollout with envs packed tightly (SegT<true>): for the batches dcomp_create packs tightly -- many waves
+// per SIMD, where the fused kernel is bound by its VALU work and 37.5 % of a padded 10-UE wave is idle lanes.
+template <int B, int UPAD, int MP>
+__global__ __launch_bounds__(DCOMP_BLOCK) void rollout_kernel_tight(const KParams p)
+{
+    __shared__ BlockSharedT<B, UPAD> sh;
+    step_kernel_body<B, UPAD, MP, true, true, 0, DCOMP_CENTRAL>(p, sh);
+}
+
 // MobileEnv.reset (base.py:169-189): user.py:98-116 + movement.py:110-122 + first observation.
 template <int B, int UPAD>
 __global__ __launch_bounds__(DCOMP_BLOCK) void reset_kernel(const KParams p)
@@ -1558,7 +1567,7 @@ namespace dcomp {
 using KernelFn = void (*)(const KParams);
 // step_wide: organisation for envs of >= 64 lanes (dcomp_wide.h); nullptr for narrower envs.  It has no max-cap
 // path, the host falls back to `step` when a BS is max-cap.
-struct KernelPair { KernelFn step, reset, step_wide, step_dyn, rollout, step_tight, rollout_pol, rollout_central, tight_central; };   // step_dyn: UEs arrive / depart (dcomp_dyn.h), UPAD <= 64
+struct KernelPair { KernelFn step, reset, step_wide, step_dyn, rollout, step_tight, rollout_pol, rollout_central, tight_central, rollout_tight_central; };   // step_dyn: UEs arrive / depart (dcomp_dyn.h), UPAD <= 64
 
 template <int B, int UPAD, int MP>
 inline KernelFn wide_or_null()
@@ -1586,6 +1595,14 @@ inline KernelFn tight_or_null()
     else return nullptr;
 }
 
+template <int B, int UPAD, int MP>
+inline KernelFn rollout_tight_or_null()
+{
+    // only where dcomp_create takes long central rollouts to the fused kernel at any batch size (B <= 8) and packs tightly
+    if constexpr ((UPAD == 8 || UPAD == 16 || UPAD == 32) && B <= 8) return rollout_kernel_tight<B, UPAD, MP>;
+    else return nullptr;
+}
+
 template <int B, int UPAD>
 inline KernelFn dyn_or_null()
 {
@@ -1600,11 +1617,11 @@ inline KernelPair make_pair_(int mp)
     // narrow variants would never be launched there and are the most expensive instantiations of the build: left out.
     if constexpr (UPAD >= 64 && B > DCOMP_WIDE_MIN_B) {
         const KernelFn w = mp == MP_RES_FAIR ? wide_or_null<B, UPAD, MP_RES_FAIR>() : mp == MP_MIXED ? wide_or_null<B, UPAD, MP_MIXED>() : wide_or_null<B, UPAD, MP_GENERIC>();
-        return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, w, dyn_or_null<B, UPAD>(), nullptr, nullptr, nullptr, nullptr, nullptr};
+        return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, w, dyn_or_null<B, UPAD>(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     } else {
-    if (mp == MP_RES_FAIR) return KernelPair{step_kernel<B, UPAD, MP_RES_FAIR>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_RES_FAIR>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_GENERIC>(), tight_or_null<B, UPAD, MP_GENERIC>(), rollout_or_null<B, UPAD, MP_GENERIC, 1>(), rollout_or_null<B, UPAD, MP_GENERIC, 0, DCOMP_CENTRAL>(), tight_or_null<B, UPAD, MP_GENERIC, DCOMP_CENTRAL>()};   // (all-resource-fair: the generic variants, run-time modes, serve the fused rollout and the tight packing -- build time)
-    if (mp == MP_MIXED) return KernelPair{step_kernel<B, UPAD, MP_MIXED>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_MIXED>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_MIXED>(), tight_or_null<B, UPAD, MP_MIXED>(), rollout_or_null<B, UPAD, MP_MIXED, 1>(), rollout_or_null<B, UPAD, MP_MIXED, 0, DCOMP_CENTRAL>(), tight_or_null<B, UPAD, MP_MIXED, DCOMP_CENTRAL>()};
-    return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_GENERIC>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_GENERIC>(), tight_or_null<B, UPAD, MP_GENERIC>(), rollout_or_null<B, UPAD, MP_GENERIC, 1>(), rollout_or_null<B, UPAD, MP_GENERIC, 0, DCOMP_CENTRAL>(), tight_or_null<B, UPAD, MP_GENERIC, DCOMP_CENTRAL>()};
+    if (mp == MP_RES_FAIR) return KernelPair{step_kernel<B, UPAD, MP_RES_FAIR>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_RES_FAIR>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_GENERIC>(), tight_or_null<B, UPAD, MP_GENERIC>(), rollout_or_null<B, UPAD, MP_GENERIC, 1>(), rollout_or_null<B, UPAD, MP_GENERIC, 0, DCOMP_CENTRAL>(), tight_or_null<B, UPAD, MP_GENERIC, DCOMP_CENTRAL>(), rollout_tight_or_null<B, UPAD, MP_GENERIC>()};   // (all-resource-fair: the generic variants, run-time modes, serve the fused rollout and the tight packing -- build time)
+    if (mp == MP_MIXED) return KernelPair{step_kernel<B, UPAD, MP_MIXED>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_MIXED>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_MIXED>(), tight_or_null<B, UPAD, MP_MIXED>(), rollout_or_null<B, UPAD, MP_MIXED, 1>(), rollout_or_null<B, UPAD, MP_MIXED, 0, DCOMP_CENTRAL>(), tight_or_null<B, UPAD, MP_MIXED, DCOMP_CENTRAL>(), rollout_tight_or_null<B, UPAD, MP_MIXED>()};
+    return KernelPair{step_kernel<B, UPAD, MP_GENERIC>, reset_kernel<B, UPAD>, wide_or_null<B, UPAD, MP_GENERIC>(), dyn_or_null<B, UPAD>(), rollout_or_null<B, UPAD, MP_GENERIC>(), tight_or_null<B, UPAD, MP_GENERIC>(), rollout_or_null<B, UPAD, MP_GENERIC, 1>(), rollout_or_null<B, UPAD, MP_GENERIC, 0, DCOMP_CENTRAL>(), tight_or_null<B, UPAD, MP_GENERIC, DCOMP_CENTRAL>(), rollout_tight_or_null<B, UPAD, MP_GENERIC>()};
     }
 }
 
@@ -1623,7 +1640,7 @@ inline KernelPair kernels_for_upad(int upad, int mp)
     case 64: return make_pair_<B, 64>(mp);
     case 128: return make_pair_<B, 128>(mp);
     case 256: return make_pair_<B, 256>(mp);
-    default: return KernelPair{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    default: return KernelPair{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     }
 #endif
 }

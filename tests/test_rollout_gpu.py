@@ -146,9 +146,11 @@ def test_rollout_reference_tape_fixed_episodes(torch_cuda):
     assert torch.equal(out['obs'], want) and _same_state(_state(env), _state(ref)) and env.time == ref.time
 
 
-def test_fused_rollout_against_the_oracle(torch_cuda):
+@pytest.mark.parametrize('tight', [False, True])
+def test_fused_rollout_against_the_oracle(torch_cuda, tight, monkeypatch):
     """The fused kernel directly against the CPU oracle (not only against single steps): 4 096 x 10 x 5 central -- BASELINE
-    config 2 -- 40 steps with a reset at the horizon, every step's observation and reward compared."""
+    config 2 -- 40 steps with a reset at the horizon, every step's observation and reward compared.  tight: the tightly
+    packed instantiation (rollout_kernel_tight: six 10-UE envs per wavefront) that throughput-bound central batches take."""
     torch = torch_cuda
     from deepcomp_amd import scenarios
     from deepcomp_amd.entities import build_from_scenario
@@ -157,8 +159,9 @@ def test_fused_rollout_against_the_oracle(torch_cuda):
     E, U, B, L, T = 4096, 10, 5, 25, 40
     scn = scenarios.grid_map(B, 'mixed').with_ues(num_slow=U)
     m, bs, ues = build_from_scenario(scn)
+    monkeypatch.setenv('DCOMP_TIGHT', '1' if tight else '0')
     env = BatchedMobileEnv(m, bs, ues, 'central', num_envs=E, seed=42, rng='philox', rand_episodes=True, episode_length=L)
-    assert env.fused_rollout
+    assert env.fused_rollout and env.lanes_per_env == (U if tight else 16)
     oenvs = []
     for e in range(E):
         o = orc.OracleEnv(int(scn.width), int(scn.height), scn.bs_pos, scn.bs_sharing, ['slow'] * U, kind=orc.CENTRAL)
@@ -238,6 +241,42 @@ def test_rollout_with_ue_arrival_and_departure(torch_cuda, kind, rng, L):
     last.reset()
     last.rollout(acts[:cut])
     assert torch.equal(last.obs, want['obs'][cut - 1]) and torch.equal(last.reward, want['reward'][cut - 1])
+
+
+@pytest.mark.parametrize('U,B,E,sharing', [(10, 5, 333, 'mixed'), (5, 3, 500, 'mixed'), (20, 8, 100, 'rate-fair'), (9, 4, 77, 'proportional-fair'),
+                                           (17, 7, 40, 'mixed'), (21, 2, 64, 'resource-fair')])
+def test_tight_rollout_equals_tight_steps(torch_cuda, U, B, E, sharing, monkeypatch):
+    """rollout_kernel_tight (central envs packed G = U lanes each, the fused kernel of throughput-bound batches) against the
+    tightly packed step kernel launched once per step -- the same packing and summation order: every step's outputs and the
+    final state, resets at the horizon included; positions / masks / movement words bit-identical, floats to the last bits."""
+    torch = torch_cuda
+    monkeypatch.setenv('DCOMP_TIGHT', '1')
+    L, T = 9, 23
+    ref = _make('central', U, B, E, sharing=sharing, L=L)
+    env = _make('central', U, B, E, sharing=sharing, L=L)
+    assert env.lanes_per_env == U and env.fused_rollout
+    g = torch.Generator(device='cuda').manual_seed(11)
+    acts = torch.randint(0, B + 1, (T, E, U), generator=g, device='cuda', dtype=torch.uint8)
+    keys = ('obs', 'reward', 'sum_utility', 'ue_dr', 'ue_utility')
+    want = {k: [] for k in keys}
+    ref.reset(); env.reset()
+    for t in range(T):
+        if ref.time == L:
+            ref.reset()
+        ref.step(acts[t])
+        for k in keys:
+            want[k].append(getattr(ref, k).clone())
+    want = {k: torch.stack(v) for k, v in want.items()}
+    out = {k: torch.full_like(v, float('nan')) for k, v in want.items()}
+    env.rollout(acts[:6], out={k: v[:6] for k, v in out.items()}, horizon=L)
+    env.rollout(acts[6:], out={k: v[6:] for k, v in out.items()}, horizon=L)
+    env.check(); ref.check()
+    for k in ('pos', 'mv', 'conn'):
+        assert torch.equal(getattr(env, k), getattr(ref, k)), k
+    assert env.time == ref.time and env.episode == ref.episode
+    for k in keys:
+        torch.testing.assert_close(out[k], want[k], rtol=2e-6, atol=2e-6, msg=lambda m_, k=k: f'{k}: {m_}')
+    torch.testing.assert_close(env.ewma, ref.ewma, rtol=2e-6, atol=1e-30)
 
 
 def test_rollout_argument_validation(torch_cuda):

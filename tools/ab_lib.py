@@ -59,7 +59,7 @@ def build(a):
     print(so, os.path.getsize(so) >> 20, 'MiB')
 
 
-WORKLOADS = ['c3', 'c2roll', 'c5', 'c5big', 'c4share', 'central10x5', 'central10x5f', 'central32x10', 'c2policy', 'c3rf', 'c3roll']
+WORKLOADS = ['c3', 'c2roll', 'c5', 'c5big', 'c4share', 'central10x5', 'central10x5roll', 'central10x5f', 'central32x10', 'c2policy', 'c3rf', 'c3roll']
 
 
 def measure(a):
@@ -110,6 +110,8 @@ def measure(a):
             torch.cuda.synchronize()
             env.check()
             out[w] = e0.elapsed_time(e1) / 300
+        elif w == 'central10x5roll':     # the 65 536-env central batch through rollout(T = 50): fused at any batch size
+            out[w] = bench.measure_rollout(*mk, 65536, 10, 5, 'central', T=50, steps=1500)['ms_per_step']
         elif w == 'c2roll':
             out[w] = bench.measure_rollout(*mk, 4096, 10, 5, 'central', T=100, steps=6000)['ms_per_step']
         elif w == 'c2policy':
