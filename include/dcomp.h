@@ -162,8 +162,10 @@ int dcomp_num_ue(const dcomp_env *env);               /* UEs currently in every 
  * steps in ONE launch with the UE state in registers in between; envs of >= 64 lanes with more than 20 BSs and envs with UE
  * arrival / departure are launched once per step.  Fused: batches of up to 3 waves per SIMD, and central envs of <= 8 stations
  * at any batch size when num_steps >= 4.  Connection masks, positions and movement state are identical to T dcomp_step calls
- * either way; the floats are bit-identical too unless dcomp_step packs the envs tightly (dcomp_lanes_per_env: UE lists of 5, 9,
- * 10, 17-21 in batches of >= 4 096 waves), whose per-env sums run in scan order instead of butterfly order (<= 2e-6 relative). */
+ * either way.  A batch that dcomp_step packs tightly (dcomp_lanes_per_env: UE lists of 5, 9, 10, 17-21 in batches of >= 4 096
+ * waves; per-env sums in scan order instead of butterfly order) is packed the same way by the fused kernel of its tape-driven
+ * central rollouts: same summation order as its dcomp_step; with a registered policy (dcomp_set_policy) the fused kernel keeps
+ * the padded groups and the floats may differ from dcomp_step's in the last bits (<= 2e-6 relative). */
 int dcomp_rollout(dcomp_env *env, const dcomp_state *st, const uint8_t *actions, int32_t num_steps,
                   const dcomp_out *out, void *stream);
 
