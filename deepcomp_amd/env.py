@@ -319,7 +319,7 @@ class BatchedMobileEnv:
             if not live:
                 return
             self._live = (seeds, cursor)
-            spliced = self._live_fixed_tape(self._tape_depth_now)
+            spliced = self._live_fixed_tape(max(self._tape_depth_now, self.tape_depth))
         pos0, trip = spliced
         torch.cuda.current_stream(self.device).synchronize()       # steps in flight still read the old tape
         old = self._tape_dev
@@ -374,7 +374,8 @@ class BatchedMobileEnv:
                 consumed = ((self.mv >> 48) & 0xFFFF).cpu().numpy()
             return self._streams.draw_episode(reseed=False, consumed=consumed)
         self._live = None
-        if self._fixed_tape is None:          # re-seeded at every reset (base.py:171-173): same tape every episode
+        if self._fixed_tape is None or self._fixed_tape[1].shape[1] < self.tape_depth:   # (a live re-seed extended only the spliced tape)
+            # re-seeded at every reset (base.py:171-173): same tape every episode
             self._fixed_tape = _rng.mt_tape(self._cfg, self.env_seeds, self.tape_depth)
         return self._fixed_tape
 

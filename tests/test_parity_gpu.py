@@ -892,6 +892,8 @@ def test_tape_is_extended_for_episodes_that_outlive_it(torch_cuda, rand_episodes
         short.reset(); long_.reset()
         assert torch.equal(short.obs, long_.obs)
         for t in range(150 if not dyn else 19):
+            if t in (4, 11):                                     # seed() on the live env (base.py:132-143): the spliced tape is extended like any other
+                short.seed(900 + t + ep, immediate=True); long_.seed(900 + t + ep, immediate=True)
             a = torch.randint(0, len(bs) + 1, (3, short.U), generator=g, device='cuda', dtype=torch.uint8)
             short.step(a); long_.step(a)
         short.check(); long_.check()
