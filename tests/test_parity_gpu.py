@@ -1045,6 +1045,33 @@ def test_seed_on_a_live_env_like_the_reference(torch_cuda, name, surface):
         core.check()
 
 
+@pytest.mark.parametrize('dyn', [False, True])
+def test_seed_before_the_first_reset_like_the_reference(torch_cuda, dyn):
+    """MobileEnv.seed(s) on an env that has not been reset yet (base.py:132-143, 171-173): a rand_episodes=True env starts its
+    first episode on the new streams (= an env constructed with seed s); a rand_episodes=False env re-seeds with the CONFIGURED
+    seed at reset(), so the call changes nothing."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    m, bs, ues = build_from_scenario(scenarios.medium_map('mixed').with_ues(num_slow=2, num_fast=2))
+    kw = dict(num_envs=3, rng='reference', episode_length=12)
+    if dyn:
+        kw.update(ue_arrival={2: 1, 5: -1, 7: 2})
+    acts = torch.randint(0, len(bs) + 1, (12, 3, 8), device='cuda', dtype=torch.uint8)
+    for rand, same_as in ((True, 977), (False, 5)):
+        a = BatchedMobileEnv(m, bs, ues, 'multi', seed=5, rand_episodes=rand, **kw)
+        b = BatchedMobileEnv(m, bs, ues, 'multi', seed=same_as, rand_episodes=rand, **kw)
+        a.seed(977, immediate=True)
+        for ep in range(2):
+            a.reset(); b.reset()
+            assert torch.equal(a.obs, b.obs), (rand, ep)
+            for t in range(12):
+                a.step(acts[t][:, :a.U].contiguous()); b.step(acts[t][:, :b.U].contiguous())
+            assert torch.equal(a.pos, b.pos) and torch.equal(a.mv, b.mv) and torch.equal(a.obs, b.obs), (rand, ep)
+        a.check(); b.check()
+
+
 def test_rollout_buffer_and_unaligned_outputs(torch_cuda):
     """step_into() writes rows into arbitrary (4-byte aligned) slices of a rollout buffer: odd sizes exercise the
     alignment phase of the LDS copy-out; rollout() == the same steps issued one by one."""
