@@ -775,12 +775,18 @@ class BatchedMobileEnv:
                     'util_at_bs': o[..., 3 * B:4 * B], 'utility': o[..., 4 * B:4 * B + 1]}
         return {'connected': o[..., 0:U * B], 'dr': o[..., U * B:2 * U * B], 'utility': o[..., 2 * U * B:]}
 
-    def _vel_host(self, vel):
-        """Velocities as numbers: the movement word's integer, or the configured number of a UE whose velocity is not one."""
-        if self._vel_num is not None and not self.dynamic:
+    def _vel_host(self, vel, uid=None):
+        """Velocities as numbers: the movement word's integer, or the configured number of a UE whose velocity is not one
+        (uid: the id words per slot of an env whose UE list changes -- arrived UEs are always 'slow')."""
+        if self._vel_num is None:
+            return vel
+        if uid is None:
             fixed = self._vel_num >= 0
             vel[:, fixed] = self._vel_num[fixed]
-        return vel
+            return vel
+        ids, born = (uid & 0x7FFF).astype(np.int64), (uid & 0x8000) != 0
+        num = np.where((ids >= 1) & (ids <= self.U0) & ~born, self._vel_num[np.clip(ids - 1, 0, self.U0 - 1)], -1.0)
+        return np.where(num >= 0, num, vel)
 
     def state_host(self):
         """Host copy of the raw state (parity dumps)."""
@@ -789,7 +795,8 @@ class BatchedMobileEnv:
         return {
             'pos': self.pos.cpu().numpy().reshape(E, U, 2),
             'wp': np.stack([(mv & 0xFFFF).astype(np.float64), ((mv >> 16) & 0xFFFF).astype(np.float64)], -1).reshape(E, U, 2),
-            'vel': self._vel_host(((mv >> 32) & 0xFF).astype(np.float64).reshape(E, U)),
+            'vel': self._vel_host(((mv >> 32) & 0xFF).astype(np.float64).reshape(E, U),
+                                  self.uid.cpu().numpy().astype(np.uint16).reshape(E, U) if self.dynamic else None),
             'pausing': ((mv >> 47) & 1).astype(np.int32).reshape(E, U),
             'curr_pause': ((mv >> 40) & 0x7F).astype(np.int32).reshape(E, U),
             'cursor': ((mv >> 48) & 0xFFFF).astype(np.int32).reshape(E, U),

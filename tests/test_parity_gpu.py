@@ -522,6 +522,7 @@ def test_oracle_parity_dynamic_philox(torch_cuda, kind, reward):
     E, U0, B, L = 333, 6, 7, 60
     arrival = {2: 3, 5: -2, 9: 4, 14: -3, 20: 2, 21: 2, 30: -4, 41: 5, 50: -6}
     scn = scenarios.large_map('mixed').with_ues(num_static=1, num_slow=3, num_fast=2)
+    scn.ue_specs[0]['velocity'], scn.ue_specs[5]['velocity'] = 2.5, 11.7          # fixed velocities that are no integers (movement.py:116-117)
     m, bs, ues = build_from_scenario(scn)
     core = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=5, episode_length=L, reward=reward, rng='philox', rand_episodes=True,
                             ue_arrival=arrival)
@@ -557,6 +558,8 @@ def test_oracle_parity_dynamic_philox(torch_cuda, kind, reward):
             assert core.num_ue == oenvs[0].num_ue()
             assert np.array_equal(st['uid'], np.stack([o.uids() for o in oenvs])), f'step {t}: UE ids differ'
             assert np.array_equal(st['conn'], o_conn) and np.array_equal(st['pos'], o_pos), f'step {t}'
+            n0 = core.num_ue
+            assert np.array_equal(st['vel'][0][:n0], oenvs[0].state()['vel'][:n0]), f'step {t}: velocities (slots shift when UEs leave)'
             got = core.obs.cpu().numpy()
             want = o_obs if kind == 'multi' else np.concatenate([o_obs[:, :, :B].reshape(E, -1), o_obs[:, :, B:2 * B].reshape(E, -1), o_obs[:, :, 2 * B]], axis=1)
             np.testing.assert_allclose(got, want, rtol=RTOL_RATE, atol=ATOL_OBS)
