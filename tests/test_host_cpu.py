@@ -112,6 +112,71 @@ def test_stdlib_streams_continue_across_episodes():
     assert p0[0].tolist() == first and p1[0].tolist() == second
 
 
+def test_live_reseed_splices_the_new_streams_behind_each_cursor():
+    """MobileEnv.seed() on a live env (base.py:132-143), host side of the product: both streams of every UE restart from the new
+    seed, the running episode's tape continues behind each UE's cursor with the START of the new movement stream, and a
+    rand_episodes=True env carries the new streams into the next episode (positions from the fresh position stream, movement
+    from where the spliced stream was consumed)."""
+    from deepcomp_amd import rng
+    w, h, D = 194, 120, 7
+    st = rng.StdlibStreams([42, 20042], w, h, ['slow', 5], [(-1, -1), (3, -1)], D, border=[10, 20])
+    p0, t0 = st.draw_episode(reseed=False)
+    cur = np.array([2, 1, 4, 3])                       # triples consumed so far, per (env, UE)
+    _, t1 = st.reseed_live([977, 20977], cur)
+    for e, base in enumerate((977, 20977)):
+        for i, (vr, bb) in enumerate((((1, 3), 10), ((5, 5), 20))):
+            row, c = e * 2 + i, int(cur[e * 2 + i])
+            assert t1[row, :c].tolist() == t0[row, :c].tolist()                      # what was consumed stays
+            r = random.Random(base + 100 * (i + 1))
+            want = [[r.randint(*vr) if vr[0] != vr[1] else vr[0], r.randint(bb, w - bb), r.randint(bb, h - bb)] for _ in range(D - c + 3)]
+            assert t1[row, c:, :3].tolist() == want[:D - c]
+    # next episode: UE (0, 0) consumed 3 more triples of the spliced stream (cursor 5), the others none
+    p2, t2 = st.draw_episode(reseed=False, consumed=np.array([5, 1, 4, 3]))
+    r = random.Random(977 + 100)
+    seq = [[r.randint(1, 3), r.randint(10, w - 10), r.randint(10, h - 10)] for _ in range(3 + D + 2)]
+    assert t2[0, :, :3].tolist() == seq[3:3 + D]
+    pr = random.Random(977 + 100)
+    assert p2[0].tolist() == [pr.randint(0, w), pr.randint(0, h)]                     # the position stream started over too
+    st.extend(D + 2)                                                                  # episodes that outlive the tape keep drawing
+    assert st._trip[0, :, :3].tolist() == seq[3:3 + D + 2]
+
+
+def test_live_reseed_with_a_changing_ue_list_matches_the_oracles_reading():
+    """The product's DynamicStdlibStreams.reseed_live and the oracle's DynRefStreams / RefEventDraws (which the reference-run
+    reseeddyn_* fixtures pin) splice the same tapes and restart the same event generators."""
+    from deepcomp_amd import rng
+    from oracle import oracle as orc
+    w, h, D, U0, max_id = 300, 200, 9, 3, 6
+    vel = ['slow', 'fast', 4]
+    prod = rng.DynamicStdlibStreams([42], w, h, vel, [(-1, -1)] * U0, D, True, max_id)
+    init, new, ev = orc.DynRefStreams(42, w, h, vel, depth=D, rand_episodes=True), orc.RefRngTape(42, w, h, ['slow'] * max_id, depth=D), \
+        orc.RefEventDraws(42, w, h, rand_episodes=True)
+    pp, pt = prod.draw_episode()
+    op0, ot0 = init.draw_episode()
+    _, ot1 = new.draw_episode()
+    trip_all = np.concatenate([ot0, ot1])
+    assert np.array_equal(pt[:, :, :3], trip_all) and np.array_equal(pp, op0)
+    assert prod.departures(1, 3)[0].tolist() == ev.departures(1, 3) and prod.arrivals(2)[0].tolist() == [list(x) for x in ev.arrivals(2)]
+    lists = [[(1, False), (3, False), (4, True), (5, True)]]                          # UE 2 has left, ids 4 and 5 arrived
+    cursors = [[3, 2, 1, 2]]
+    _, pt2 = prod.reseed_live([977], lists, cursors)
+    ot2 = init.reseed_live(977, trip_all, [(u, b, c) for (u, b), c in zip(lists[0], cursors[0])])
+    ev.reseed_live(977)
+    assert np.array_equal(pt2[:, :, :3], ot2)
+    assert prod.departures(2, 4)[0].tolist() == ev.departures(2, 4) and prod.arrivals(1)[0].tolist() == [list(x) for x in ev.arrivals(1)]
+    _, pt3 = prod.extend(D + 4)                                                       # the spliced rows of arrived UEs survive an extension
+    assert np.array_equal(pt3[:, :D, :3], ot2)
+    r = random.Random(977 + 100 * 3)                                                  # id 4 sits at list position 3 (1-based): cursor 1
+    want = [[r.randint(1, 3), r.randint(10, w - 10), r.randint(10, h - 10)] for _ in range(D + 3)]
+    assert pt3[U0 + 3, 1:, :3].tolist() == want
+    # next episode (streams continue): same draws on both sides
+    consumed = [[5, 2, 4]]                                                            # UE 2 left at 2 triples (before the re-seed)
+    end_list = [(1, False), (3, False), (5, True)]
+    pp4, pt4 = prod.draw_episode([end_list], consumed)
+    op4, ot4 = init.draw_episode(end_list, consumed[0])
+    assert np.array_equal(pp4, op4) and np.array_equal(pt4[:U0, :D, :3], ot4)
+
+
 def test_create_rejects_bad_config_without_gpu(lib):
     from deepcomp_amd import _lib
     c, keep = _cfg(3, 10, 10, [1, 1, 1], [3, 3, 3])          # map too small for the 10 m waypoint border
