@@ -300,12 +300,12 @@ def test_rollout_argument_validation(torch_cuda):
 def test_long_rollouts_of_small_central_envs_are_fused_at_any_batch_size(torch_cuda):
     """Central envs of <= 8 stations go through the fused kernel for rollouts of >= 4 steps however large the batch (short rows
     stream well from registers and the kernel boundary is a quarter of such a step); shorter rollouts and multi-agent envs of
-    that size keep one launch per step.  Same masks / positions as step() -- the floats too, except for the summation order of
-    the tightly packed step kernel this batch size selects (<= 2e-6)."""
+    that size keep one launch per step.  Same masks / positions as step(); a batch of this size is packed tightly by step() AND by
+    the fused kernel (rollout_kernel_tight, picked by the library's own dispatch here), floats to the last bits (<= 2e-6)."""
     torch = torch_cuda
     E, U, B, T = 20000, 10, 5, 12
     big = _make('central', U, B, E)
-    assert big.fused_rollout and big.lanes_per_env == U              # step(): tight packing; rollout(): fused
+    assert big.fused_rollout and big.lanes_per_env == U              # step(): tight packing; rollout(): fused, tightly packed too
     multi = _make('multi', U, B, E)
     assert not multi.fused_rollout
     ref = _make('central', U, B, E)
