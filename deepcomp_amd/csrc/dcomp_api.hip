@@ -252,8 +252,10 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
         // trip, pairs carried from step to step -- 65 536 x 10 x 5: 16.3 vs 19-20 us per step, 16 384: 4.2 vs 11.2, 262 144: 58 vs
         // 63 (T = 50).  Rows of the multi-agent layout (4B + 1 floats per lane, stored straight from registers) stream too
         // badly for that: 65 536 x 32 x 10: 129 vs 77 us.
+        // Multi-agent rows (4B + 1 floats per lane) are short enough up to three stations -- the reference's stock small and medium
+        // maps: 65 536 x 5 x 3 multi 8.1 vs 12.1 us per step (T = 50); at 10 x 5 it is a draw (23.4 vs 23.3), at 16 x 8 a loss (51.8 vs 38.2).
         env->fused_long = !DYN && env->kern.step != env->kern.step_wide && env->kern.rollout != nullptr &&
-                          cfg->env_kind == DCOMP_CENTRAL && B <= 8 && !getenv("DCOMP_NO_FUSED_LONG");
+                          ((cfg->env_kind == DCOMP_CENTRAL && B <= 8) || (cfg->env_kind == DCOMP_MULTI && B <= 3)) && !getenv("DCOMP_NO_FUSED_LONG");
         // Tight packing of UE lists whose length is not a power of two (dcomp_device.h, struct Seg): G = U lanes per env,
         // 64 / G envs per wavefront, segmented ds_bpermute reductions (~13 instead of 4 instructions each).  It pays where the
         // launch is throughput-bound and the padding wastes many lanes: >= 4 padded waves per SIMD and >= 1.4x the lanes in use

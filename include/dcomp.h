@@ -160,8 +160,8 @@ int dcomp_num_ue(const dcomp_env *env);               /* UEs currently in every 
 /* T consecutive steps from an action tape actions[T][E][U] with no host work in between; outputs of the LAST step only.
  * Replaces the per-step Python loop of simulation.py:512-541.  The narrow kernel (dcomp_rollout_is_fused() == 1) runs all T
  * steps in ONE launch with the UE state in registers in between; envs of >= 64 lanes with more than 20 BSs and envs with UE
- * arrival / departure are launched once per step.  Fused: batches of up to 3 waves per SIMD, and central envs of <= 8 stations
- * at any batch size when num_steps >= 4.  Connection masks, positions and movement state are identical to T dcomp_step calls
+ * arrival / departure are launched once per step.  Fused: batches of up to 3 waves per SIMD, and -- at any batch size when
+ * num_steps >= 4 -- central envs of <= 8 stations and multi-agent envs of <= 3 stations (short observation rows).  Connection masks, positions and movement state are identical to T dcomp_step calls
  * either way.  A batch that dcomp_step packs tightly (dcomp_lanes_per_env: UE lists of 5, 9, 10, 17-21 in batches of >= 4 096
  * waves; per-env sums in scan order instead of butterfly order) is packed the same way by the fused kernel of its tape-driven
  * central rollouts: same summation order as its dcomp_step; with a registered policy (dcomp_set_policy) the fused kernel keeps

@@ -297,6 +297,31 @@ def test_rollout_argument_validation(torch_cuda):
         env.step_into(good[0].to(torch.int64), env.obs, env.reward)
 
 
+@pytest.mark.parametrize('reward', ['avg', 'sum'])
+def test_long_rollouts_of_multi_agent_envs_with_up_to_three_stations_are_fused(torch_cuda, reward):
+    """Multi-agent rows are 4B + 1 floats per UE: up to three stations (the reference's stock small / medium maps) they stream
+    well enough from registers that rollouts of >= 4 steps take the fused kernel at any batch size (65 536 x 5 x 3: 8.1 vs 12.1 us
+    per step).  Same masks / positions as step(); floats to the last bits (step() packs this batch tightly)."""
+    torch = torch_cuda
+    E, U, B, T, L = 30000, 5, 3, 14, 9
+    big, ref = _make('multi', U, B, E, reward=reward, L=L), _make('multi', U, B, E, reward=reward, L=L)
+    assert big.fused_rollout and not _make('multi', U, 4, E).fused_rollout
+    g = torch.Generator(device='cuda').manual_seed(4)
+    acts = torch.randint(0, B + 1, (T, E, U), generator=g, device='cuda', dtype=torch.uint8)
+    big.reset(); ref.reset()
+    out = {'obs': torch.empty((T,) + tuple(big.obs.shape), device='cuda'), 'reward': torch.empty((T, E, U), device='cuda')}
+    big.rollout(acts, out=out, horizon=L)
+    for t in range(T):
+        if ref.time == L:
+            ref.reset()
+        ref.step(acts[t])
+        torch.testing.assert_close(out['obs'][t], ref.obs, rtol=2e-6, atol=2e-6)
+        torch.testing.assert_close(out['reward'][t], ref.reward, rtol=0, atol=2e-5 * (U if reward == 'sum' else 1))
+    big.check(); ref.check()
+    assert torch.equal(big.pos, ref.pos) and torch.equal(big.conn, ref.conn) and torch.equal(big.mv, ref.mv) and big.time == ref.time
+    torch.testing.assert_close(big.ewma, ref.ewma, rtol=1e-5, atol=1e-30)
+
+
 def test_long_rollouts_of_small_central_envs_are_fused_at_any_batch_size(torch_cuda):
     """Central envs of <= 8 stations go through the fused kernel for rollouts of >= 4 steps however large the batch (short rows
     stream well from registers and the kernel boundary is a quarter of such a step); shorter rollouts and multi-agent envs of
