@@ -112,11 +112,26 @@ def measure_rollout(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev
     # the fused kernel reads / writes the UE state once per LAUNCH, not per step: its own traffic per env-step
     state_b = U * (33 + 32 - 1)
     fused_bpe = bytes_per_env_step(U, B, kind) - state_b + state_b / T
+    ksec = a.elapsed_time(b) * 1e-3
+    fused = bool(env.rollout_is_fused(T))
     out = {'value': E * n / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / n * 1e3, 'steps': n, 'steps_per_launch': T,
-           'fused_one_launch': bool(env.fused_rollout), 'kernel_ms_per_launch': a.elapsed_time(b) / n_calls,
-           'algorithmic_bytes_per_env_step': bpe, 'achieved_GBps_algorithmic': bpe * E * n / (a.elapsed_time(b) * 1e-3) / 1e9,
-           'kernel_bytes_per_env_step': fused_bpe, 'achieved_GBps_kernel_traffic': fused_bpe * E * n / (a.elapsed_time(b) * 1e-3) / 1e9,
+           'fused_one_launch': fused, 'kernel_ms_per_launch': a.elapsed_time(b) / n_calls,
+           # TWO figures, never one alone: SURVEY 8(d)'s per-step bytes / time is an ALGORITHMIC throughput (a fused kernel keeps
+           # the UE state in registers and never moves those bytes); the HBM fraction proper uses the bytes the kernel moves.
+           'algorithmic_bytes_per_env_step': bpe, 'achieved_GBps_algorithmic': bpe * E * n / ksec / 1e9,
+           'frac_of_hbm_peak_algorithmic': bpe * E * n / ksec / 1e9 / HBM_PEAK_GBS,
+           'kernel_bytes_per_env_step': fused_bpe if fused else bytes_per_env_step(U, B, kind),
+           'kernel_bytes_how': 'layout bytes the launch must move: outputs of every step + actions, UE state once per launch',
            'outputs': 'every step ([T, ...] fragment buffers), reset at the horizon inside the kernel'}
+    out['achieved_GBps_kernel_traffic'] = out['kernel_bytes_per_env_step'] * E * n / ksec / 1e9
+    out['frac_of_hbm_peak_kernel_traffic'] = out['achieved_GBps_kernel_traffic'] / HBM_PEAK_GBS
+    ent, src = traffic_from_profile(f'{E}x{U}x{B}_{kind}_mixed_rollout_T{T}', want_entry=True)
+    if ent:                                         # rocprofv3 --pmc bytes of the same launch shape (tracked profile, current kernels)
+        pmc = (2.0 * ent['fetch_kib'] + ent['write_kib']) * 1024.0
+        out['pmc_bytes_per_launch'] = pmc
+        out['achieved_GBps_pmc_traffic'] = pmc / (a.elapsed_time(b) / n_calls * 1e-3) / 1e9
+        out['frac_of_hbm_peak_pmc_traffic'] = out['achieved_GBps_pmc_traffic'] / HBM_PEAK_GBS
+    out['traffic_source'] = src
     if launches_too:                                # the same workload as one launch per step (what round 1 measured)
         acts = tape[0]
         k_total = max(T, steps)
@@ -168,16 +183,19 @@ def measure_steps(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev, 
             'lanes_per_env': env.lanes_per_env, 'how': f'{n} back-to-back launches after 300 untimed ones, HIP events'}
 
 
-def measure_sharded(torch, dist, BatchedMobileEnv, scenarios, build_from_scenario, dev, rank, world, backend, E, U, B, kind, steps=200, warm=100, L=100):
-    """N > 1, EVERY rank calls this: one GPU's share of a BASELINE multi-GPU configuration (config 4: 32 768 x 32 x 10 per GPU,
-    config 5: 4 096 x 128 x 32 per GPU) stepped by all ranks at once -- global env ids, no collective on the data path, barrier +
-    synchronize on both sides, MAX over ranks.  With world = 8 the job IS the BASELINE configuration."""
+def measure_sharded(torch, dist, BatchedMobileEnv, scenarios, build_from_scenario, dev, rank, world, backend, total_envs, U, B, kind, steps=200, warm=100, L=100):
+    """EVERY rank calls this, at every N (N = 1: the whole job on one GPU = the base of the strong-scaling curve): a BASELINE
+    multi-GPU configuration of FIXED total size (config 4: 262 144 x 32 x 10, config 5: 32 768 x 128 x 32) split over the ranks --
+    total_envs / N envs per GPU, global env ids, no collective on the data path, barrier + synchronize on both sides, MAX over
+    ranks.  With world = 8 the job IS the BASELINE configuration (32 768 resp. 4 096 envs per GPU)."""
+    E = total_envs // world
     scn = scenarios.grid_map(B, 'mixed').with_ues(num_slow=U)
     m, bs, ues = build_from_scenario(scn)
     env = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=42, episode_length=L, rng='philox', rand_episodes=True, device=dev,
                            env_id_base=rank * E)
     g = torch.Generator(device=dev).manual_seed(11 + rank)
     pool = torch.randint(0, B + 1, (4, E, U), generator=g, device=dev, dtype=torch.uint8)
+    use_dist = dist is not None and dist.is_initialized()
 
     def run(n, t=0):
         for i in range(n):
@@ -189,38 +207,57 @@ def measure_sharded(torch, dist, BatchedMobileEnv, scenarios, build_from_scenari
 
     def fence():
         torch.cuda.synchronize(dev)
-        dist.barrier()
+        if use_dist:
+            dist.barrier()
         torch.cuda.synchronize(dev)
     t = run(warm)
     fence()
     t0 = time.perf_counter()
     run(steps, t)
     fence()
-    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
     env.check()
-    dt = float(tt.item())
     bpe = survey_bytes_per_env_step(U, B, kind)
     return {'value': world * E * steps / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'total_envs': world * E,
-            'envs_per_gpu': E, 'num_ue': U, 'num_bs': B, 'n_gpus': world,
+            'envs_per_gpu': E, 'num_ue': U, 'num_bs': B, 'n_gpus': world, 'scaling': 'strong', 'kernel': 'dcomp::' + (env.step_kernel_name or '?'),
             'achieved_GBps_per_gpu': bpe * E * steps / dt / 1e9, 'frac_of_hbm_peak_per_gpu': bpe * E * steps / dt / 1e9 / HBM_PEAK_GBS,
-            'how': 'host clock over the step loop (resets included), barrier + synchronize on both sides, MAX over ranks'}
+            'how': f'host clock over the step loop after {warm} untimed steps (resets included), barrier + synchronize on both sides, MAX over ranks'}
+
+
+STRONG = (('config4_strong_262144x32x10', (262144, 32, 10, 'multi')), ('config5_strong_32768x128x32', (32768, 128, 32, 'multi')))
 
 
 def measure_also(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev):
-    """The other BASELINE configurations that fit one GPU, next to the headline (secondary figures)."""
+    """The other BASELINE configurations that fit one GPU, next to the headline (secondary figures).  Runs on EVERY rank at every N
+    before the headline's warm-up (the same ~3 s of launches: the same warm state for every point of a scaling curve)."""
     mk = (torch, BatchedMobileEnv, scenarios, build_from_scenario, dev)
     central = measure_steps(*mk, 65536, 10, 5, 'central')
     # the same batch through rollout(): short central rows take the fused kernel at every batch size once a rollout is >= 4 steps
     # long (no kernel boundary: the 5.4 us per-launch constant is a quarter of this shape's step; DESIGN.md section 4)
     r = measure_rollout(*mk, 65536, 10, 5, 'central', T=50, steps=1500)
-    central['through_rollout_T50'] = {'ms_per_step': r['ms_per_step'], 'fused_one_launch': r['fused_one_launch'],
-                                      'achieved_GBps': r['achieved_GBps_algorithmic'], 'frac_of_hbm_peak': r['achieved_GBps_algorithmic'] / HBM_PEAK_GBS,
-                                      'how': '50 steps per launch, every step\'s outputs into [T, ...] buffers, resets at the horizon inside the kernel'}
-    return {'config2_4096x10x5_central_fused_rollout': measure_rollout(*mk, 4096, 10, 5, 'central', T=100, steps=4000, launches_too=True),
-            'config5_share_4096x128x32_multi': measure_steps(*mk, 4096, 128, 32, 'multi'),
-            'central_65536x10x5': central,
-            'config4_share_32768x32x10_multi': measure_steps(*mk, 32768, 32, 10, 'multi')}      # last: the headline's own kernel
+    central['through_rollout_T50'] = {k: r[k] for k in ('ms_per_step', 'fused_one_launch', 'achieved_GBps_algorithmic', 'frac_of_hbm_peak_algorithmic',
+                                                        'achieved_GBps_kernel_traffic', 'frac_of_hbm_peak_kernel_traffic', 'kernel_bytes_per_env_step',
+                                                        'algorithmic_bytes_per_env_step', 'traffic_source') if k in r}
+    central['through_rollout_T50'].update({k: r[k] for k in ('achieved_GBps_pmc_traffic', 'frac_of_hbm_peak_pmc_traffic') if k in r})
+    central['through_rollout_T50']['how'] = ('50 steps per launch, every step\'s outputs into [T, ...] buffers, resets at the horizon inside the kernel; '
+                                             '`algorithmic` = SURVEY 8(d) per-step bytes / time (a throughput: the fused kernel never moves the per-step state '
+                                             'bytes), `kernel_traffic` = the bytes the launch really moves / time (the HBM fraction proper)')
+    out = {'config2_4096x10x5_central_fused_rollout': measure_rollout(*mk, 4096, 10, 5, 'central', T=100, steps=4000, launches_too=True),
+           'central_65536x10x5': central,
+           # SURVEY 8(d): "report both resource-fair everywhere and mixed" -- the headline workload with every BS resource-fair
+           'config3_65536x32x10_multi_resource_fair': measure_steps(*mk, 65536, 32, 10, 'multi', sharing='resource-fair')}
+    # one GPU's share of the two multi-GPU BASELINE configurations at N = 1 / 2 / 4 / 8 (strong scaling: total size fixed), kernel
+    # time by HIP events -- the per-GPU roofline of every point of the curve a multi-GPU node will draw
+    for name, total, U, B in (('config5_per_gpu_share_of_32768x128x32', 32768, 128, 32), ('config4_per_gpu_share_of_262144x32x10', 262144, 32, 10)):
+        out[name] = {f'N{n}_{total // n}_envs': measure_steps(*mk, total // n, U, B, 'multi', steps=200 if total // n * U * B > 6e7 else 300)
+                     for n in (1, 2, 4, 8)}
+    out['config5_share_4096x128x32_multi'] = out['config5_per_gpu_share_of_32768x128x32']['N8_4096_envs']
+    out['config4_share_32768x32x10_multi'] = out['config4_per_gpu_share_of_262144x32x10']['N8_32768_envs']      # last: the headline's own kernel
+    return out
 
 
 def stream_ceiling(torch, dev, write_bytes, rw_bytes, iters=100):
@@ -362,6 +399,12 @@ def main():
                          "episode (default); 'obs' = every fragment of --fragment steps of observations + rewards, all-gathered on a side stream "
                          "while the next fragment is being stepped")
     ap.add_argument('--fragment', type=int, default=4, help='steps per rollout fragment for --gather obs and for the post-run obs hand-off probe')
+    ap.add_argument('--gather-every', type=int, default=0,
+                    help="--gather summary: steps between two hand-offs (all-gather of the per-env reward + sum_utility since the last one). "
+                         "0 = min(episode length, max(4, steps // 2)): at least one collective falls inside ANY timed region")
+    ap.add_argument('--prewarm', type=int, default=300,
+                    help='untimed launches of the headline kernel on every rank before the warm-up steps (clock / power management settles over '
+                         'the first ~300 launches after idle; identical at every N so that the points of a scaling curve share one warm state)')
     ap.add_argument('--no-also', action='store_true', help='skip the secondary BASELINE config 2 measurement')
     ap.add_argument('--no-stream', action='store_true', help='skip the measured fill/copy bandwidth (roofline.measured_stream)')
     ap.add_argument('--no-check', action='store_true', help='skip the device error-flag check (ablation builds)')
@@ -440,7 +483,13 @@ def main():
     # --gather obs: the rollout hand-off north_star describes.  Steps write into a fragment buffer [F, E, U, 4B+1] (two of
     # them, alternating); a finished fragment is all-gathered on the side stream while the next one is being stepped.
     F = args.fragment
-    frag_bufs, frag_pending, gather_stats = None, [None, None], {'wait_s': 0.0, 'fragments': 0}
+    G = args.gather_every or min(L, max(4, K // 2))         # summary hand-off period: >= 1 collective inside any timed region of >= 4 steps
+    frag_bufs, frag_pending, gather_stats = None, [None, None], {'wait_s': 0.0, 'fragments': 0, 'collectives': 0, 'bytes_sent': 0, 'since': 0}
+
+    def count_collectives(frag):
+        """RolloutGather issues ONE all_gather_into_tensor per tensor of the fragment."""
+        gather_stats['collectives'] += len(frag)
+        gather_stats['bytes_sent'] += sum(v.numel() * v.element_size() for v in frag.values())
     if gather is not None and args.gather == 'obs':
         assert L % F == 0 and K % F == 0 and W % F == 0, "--fragment must divide the episode length, steps and warmup"
         frag_bufs = [{'obs': torch.empty((F,) + tuple(env.obs.shape), device=dev), 'reward': torch.empty((F,) + tuple(env.reward.shape), device=dev)}
@@ -470,17 +519,21 @@ def main():
         if f == F - 1:
             frag = frag_bufs[k] if args.backend == 'nccl' else {n: v.cpu() for n, v in frag_bufs[k].items()}
             frag_pending[k] = gather.all_gather_async(frag)
+            count_collectives(frag)
             gather_stats['fragments'] += 1
 
-    def end_of_episode():
+    def hand_off_summary():
+        """The default hand-off: every G steps each rank all-gathers its envs' current reward + sum_utility (the per-env summary a
+        data-parallel learner's logging / early stopping needs from the other shards), asynchronously on the side stream."""
         if gather is None:
             return
-        frag = {'reward': env.reward.clone(), 'sum_utility': env.sum_utility.clone()}    # end-of-episode state of every env
+        frag = {'reward': env.reward.clone(), 'sum_utility': env.sum_utility.clone()}
         if args.backend != 'nccl':
             frag = {k: v.cpu() for k, v in frag.items()}
         pending.append(gather.all_gather_async(frag))
+        count_collectives(frag)
         if len(pending) > 2:
-            pending.pop(0).wait()
+            timed_wait(pending.pop(0))
 
     def run(nsteps, t_start, spans=None):
         """spans: list that receives one HIP-event pair per run of back-to-back step launches between two resets -- the
@@ -522,9 +575,12 @@ def main():
             else:
                 env.step(pool[t & 15])
             t += 1
-            if gather is not None and frag_bufs is None and t % L == 0:
-                close()
-                end_of_episode()
+            if gather is not None and frag_bufs is None:
+                gather_stats['since'] += 1
+                if gather_stats['since'] >= G:         # every G steps, phase-shifted by G // 2 against the start of the timed region
+                    gather_stats['since'] = 0
+                    close()
+                    hand_off_summary()
         close()
         return t
 
@@ -543,23 +599,35 @@ def main():
     # The box's measured streaming rate is taken BEFORE the warm-up steps: it is part of the output anyway, and a
     # GPU that has just streamed for ~20 ms starts the step launches closer to its steady clocks than one that sat idle
     # through the set-up (the first launches after idle run 5-15 % slower, see roofline.steady_state).
+    # EVERYTHING before the warm-up steps runs on EVERY rank at EVERY N (rank 0's figures are printed): the N = 1 point and the N = 8
+    # point of a scaling curve enter their timed regions from the same warm state.
     stream_probe = None
-    if world == 1 and not args.no_stream:
+    if not args.no_stream:
         bpe0 = bytes_per_env_step(U, B, args.kind)
         stream_probe = stream_ceiling(torch, dev, E * (bpe0 - U * 33) // 4 * 4, E * U * 33 // 4 * 4)
-        stream_probe['when'] = 'before the warm-up steps'
+        stream_probe['when'] = 'before the warm-up steps, on every rank'
     # The secondary figures (the other BASELINE configurations on this GPU: ~2 s of back-to-back launches of the same kernels)
     # are measured BEFORE the headline: they are part of the output anyway, and the GPU then enters the W warm-up + K timed steps
     # at the clocks a running job has, instead of inside the 5-15 % slower transient of the first ~300 launches after idle
     # (tools/kprobe.py) that a 25-launch run would otherwise never leave.  `--also-after` restores the old order (A/B).
     default_workload = (E, U, B, args.kind, args.sharing) == (65536, 32, 10, 'multi', 'mixed')
     also_first = None
-    if world == 1 and not args.no_also and default_workload and not args.also_after:
+    if not args.no_also and default_workload and not args.also_after:
         also_first = measure_also(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev)
+    if args.prewarm > 0:                        # >= 300 untimed launches of the headline kernel itself (no hand-off, no events)
+        tp = 0
+        while tp < args.prewarm:
+            env.reset()
+            for i in range(min(L, args.prewarm - tp)):
+                env.step(pool[i & 15])
+            tp += min(L, args.prewarm - tp)
+        torch.cuda.synchronize(dev)
     t_env = run(W, 0)
     drain()
     fence()
-    gather_stats.update(wait_s=0.0, fragments=0, stall_events=[])
+    # the hand-offs of the timed region fall on its steps G/2, 3G/2, ...: every one has G/2 steps of stepping to overlap with (a
+    # hand-off issued at the region's last step could only be waited for), and K >= 4 steps always contain at least one
+    gather_stats.update(wait_s=0.0, fragments=0, stall_events=[], collectives=0, bytes_sent=0, since=G // 2)
     spans = []
     ev_pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (K // L + 3) + 8)]
     for e in ev_pool[:2]:
@@ -583,14 +651,18 @@ def main():
         per_frag = F * (env.obs.numel() + env.reward.numel()) * 4
         handoff = {'mode': args.gather, 'backend': 'rccl' if args.backend == 'nccl' else args.backend, 'rccl_ranks': dist.get_world_size(),
                    'overlapped_on_side_stream': args.backend == 'nccl',
+                   # counted where the collectives are ISSUED (count_collectives), reset after the warm-up: what really ran between t0
+                   # and the closing fence of the timed region (drain() waits for all of them before the fence)
+                   'collectives_in_timed_region': gather_stats['collectives'],
+                   'bytes_in_timed_region': {'sent_per_rank': gather_stats['bytes_sent'], 'received_per_rank': gather_stats['bytes_sent'] * world},
                    'compute_stream_stall_ms_total': stall_ms, 'host_blocked_ms_total': gather_stats['wait_s'] * 1e3}
         if args.gather == 'obs':
             handoff.update(fragment_steps=F, fragments=gather_stats['fragments'], bytes_sent_per_rank_per_fragment=per_frag,
                            bytes_received_per_rank_per_fragment=per_frag * world,
                            compute_stream_stall_ms_per_fragment=stall_ms / max(1, gather_stats['fragments']))
         else:
-            handoff.update(what=f'end-of-episode reward + sum_utility of every env, once per {L} steps',
-                           bytes_sent_per_rank=4 * (env.reward.numel() + E))
+            handoff.update(what=f'reward + sum_utility of every env, all-gathered every {G} steps (one collective per tensor), asynchronous',
+                           period_steps=G, bytes_sent_per_rank_per_handoff=4 * (env.reward.numel() + E))
 
     def probe_obs_handoff(nfrag=4):
         """The rollout hand-off north_star names, measured next to the headline (never part of `value`): fragments of F steps
@@ -644,14 +716,14 @@ def main():
             obs_probe = {'error': f'{type(ex).__name__}: {ex}'[:300]}
             torch.cuda.synchronize(dev)
 
-    # N > 1: the multi-GPU BASELINE configurations next to the weak-scaling headline -- config 4's split (32 768 x 32 x 10 per
-    # GPU: at N = 8 exactly the 262 144-env job) and config 5's (4 096 x 128 x 32 per GPU).  Every rank takes part.
+    # The multi-GPU BASELINE configurations next to the weak-scaling headline, as STRONG scaling (total size fixed: config 4 =
+    # 262 144 x 32 x 10, config 5 = 32 768 x 128 x 32; total / N envs per GPU).  Every rank takes part, at every N: the N = 1 run
+    # records the base of the curve (the whole job on one GPU), the N = 8 run IS the BASELINE configuration.
     sharded = None
-    if world > 1 and not args.no_also:
+    if not args.no_also:
         sharded = {}
-        mk = (torch, dist, BatchedMobileEnv, scenarios, build_from_scenario, dev, rank, world, args.backend)
-        for name, shape in (('config4_split_32768x32x10_per_gpu', (32768, 32, 10, 'multi')),
-                            ('config5_split_4096x128x32_per_gpu', (4096, 128, 32, 'multi'))):
+        mk = (torch, dist if use_dist else None, BatchedMobileEnv, scenarios, build_from_scenario, dev, rank, world, args.backend)
+        for name, shape in STRONG:
             try:
                 sharded[name] = measure_sharded(*mk, *shape)
             except Exception as ex:            # noqa: BLE001 -- a side measurement must never cost the headline line
@@ -667,7 +739,7 @@ def main():
     # launch over 300 launches on a cold MI355X, tools/kprobe.py): with the driver's --steps 20 the timed region lies inside
     # that transient.  The steady state is reported NEXT to it, never instead of it: >= 300 further launches untimed, then 200 timed.
     steady_ms = None
-    if world == 1 and not T and frag_bufs is None:
+    if world == 1 and not T and frag_bufs is None and gather is None:
         t = run(max(0, 300 - K), t_env)
         sp2 = []
         ev_pool.extend(torch.cuda.Event(enable_timing=True) for _ in range(2 * (200 // L + 3)))
@@ -675,6 +747,9 @@ def main():
         torch.cuda.synchronize(dev)
         steady_ms = sum(a.elapsed_time(b) for a, b, _ in sp2) / sum(n for _, _, n in sp2)
     resets_timed = sum(1 for s in range(t_env - K, t_env) if s % L == 0)
+    also_late = None
+    if not args.no_also and default_workload and args.also_after:
+        also_late = measure_also(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev)
 
     if rank == 0:
         bpe = bytes_per_env_step(U, B, args.kind)
@@ -692,7 +767,11 @@ def main():
                        'collective': ('none on the data path' if gather is None else
                                       f'all-gather of {F}-step observation + reward fragments ({F * (env.obs.numel() + env.reward.numel()) * 4 * world / 1e6:.0f} MB received per rank), side stream, overlapped'
                                       if args.gather == 'obs' else
-                                      f'all-gather of end-of-episode rewards + sum_utility ({4 * E * (env.reward.numel() // E + 1) * world / 1e6:.1f} MB) every {L} steps, async')},
+                                      f'all-gather of per-env rewards + sum_utility ({4 * E * (env.reward.numel() // E + 1) * world / 1e6:.1f} MB received per rank) every {G} steps, async, '
+                                      f'{gather_stats["collectives"]} collective(s) inside the timed region'),
+                       'prewarm': (('secondary configurations (`also`), then ' if also_first is not None else '') +
+                                   f'{args.prewarm} untimed launches of the headline kernel, then the {W} warm-up steps -- on every rank, identical at every N '
+                                   '(methodology: rounds 1-2 entered the timed region cold, round 3 after `also` at N = 1 only; `--prewarm 0 --also-after` = the round-2 order)')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,
                          'traffic': args.traffic_bytes, 'kernel': 'dcomp::' + (env.step_kernel_name or 'step_kernel'), 'kernel_ms': kern_ms,
@@ -718,15 +797,17 @@ def main():
                 out['roofline']['valu'] = valu_bound(ent, kern_ms)
         else:
             out['roofline']['traffic_source'] = '--traffic-bytes'
-        if world == 1 and not args.no_stream:
+        if not args.no_stream:
             # the launch writes (obs + reward + info + state) and reads (state + actions); ceiling for that mix
             sc = stream_probe
             sc['frac_of_fill'] = achieved / sc['fill_GBps']
             out['roofline']['measured_stream'] = sc
-        if world == 1 and not args.no_also and default_workload:
-            also = also_first if also_first is not None else measure_also(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev)
-            out.setdefault('also', {}).update(also)
-            out['also']['measured'] = 'before the warm-up steps of the headline' if also_first is not None else 'after the timed region'
+        if also_first is not None:
+            out.setdefault('also', {}).update(also_first)
+            out['also']['measured'] = 'before the warm-up steps of the headline, on every rank'
+        if also_late is not None:
+            out.setdefault('also', {}).update(also_late)
+            out['also']['measured'] = 'after the timed region (round-2 order)'
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(scn, args.kind, U, B)
     if use_dist:

@@ -66,7 +66,7 @@ POLICY = {'3gpp': 0, 'fullcomp': 1, 'dynamic': 2, 'cluster': 3}
 
 EXPORTS = ['dcomp_create', 'dcomp_destroy', 'dcomp_state_sizes', 'dcomp_obs_dim', 'dcomp_reset', 'dcomp_step',
            'dcomp_step_dyn', 'dcomp_num_ue',
-           'dcomp_rollout', 'dcomp_rollout_ex', 'dcomp_rollout_is_fused', 'dcomp_lanes_per_env', 'dcomp_step_kernel_name', 'dcomp_check', 'dcomp_time', 'dcomp_episode', 'dcomp_set_episode', 'dcomp_set_seed', 'dcomp_set_tape', 'dcomp_get_counters', 'dcomp_set_counters', 'dcomp_mt_draw_tape',
+           'dcomp_rollout', 'dcomp_rollout_ex', 'dcomp_rollout_is_fused', 'dcomp_rollout_fused_for', 'dcomp_lanes_per_env', 'dcomp_step_kernel_name', 'dcomp_check', 'dcomp_time', 'dcomp_episode', 'dcomp_set_episode', 'dcomp_set_seed', 'dcomp_set_tape', 'dcomp_get_counters', 'dcomp_set_counters', 'dcomp_mt_draw_tape',
            'dcomp_connect_threshold', 'dcomp_last_error', 'dcomp_version', 'dcomp_selftest', 'dcomp_heuristic_actions', 'dcomp_set_policy']
 
 _lib = None
@@ -104,6 +104,8 @@ def load():
     else:
         L.dcomp_rollout_ex.argtypes = [vp, ctypes.POINTER(DcompState), vp, i32, ctypes.POINTER(DcompOut), ctypes.POINTER(DcompRolloutOpts), vp]
         L.dcomp_rollout_is_fused.argtypes = [vp]
+        if hasattr(L, 'dcomp_rollout_fused_for'):
+            L.dcomp_rollout_fused_for.argtypes = [vp, i32, i32, i32]
         if hasattr(L, 'dcomp_lanes_per_env'):
             L.dcomp_lanes_per_env.argtypes = [vp]
         if hasattr(L, 'dcomp_step_kernel_name'):

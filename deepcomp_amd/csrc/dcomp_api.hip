@@ -476,9 +476,28 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
         k.time = 0u;
         hipLaunchKernelGGL(env->kern.reset, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, k);
     };
-    if (env->fused || (env->fused_long && (T >= 4 || loop))) {
-        // the kernel addresses step t's outputs as (idx + t * E * U) on the caller's base pointers with 32-bit row indices
-        if (every && (uint64_t)T * EU >= ((uint64_t)1 << 31)) return fail(DCOMP_EINVAL, "rollout fragment too long: num_steps * num_envs * num_ue must stay below 2^31 (split the rollout)");
+    if (env->dyn) {
+        // The whole arrival / departure schedule of the T steps is validated BEFORE the first launch (it used to be checked step by
+        // step inside the loop below: an invalid entry at step t then left the env t steps advanced and the caller's host-side
+        // event streams consumed).  The call either enqueues all T steps or nothing.
+        int cur = env->cur_ue, time = env->time;
+        for (int t = 0; t < T; t++) {
+            if (L > 0 && time == L) { time = 0; cur = env->cfg.num_ue; }
+            const int nrem = ev_rem ? ev_rem[t] : 0, nadd = ev_add ? ev_add[t] : 0;
+            if (nrem < 0 || nadd < 0 || (nrem > 0 && nadd > 0)) return fail(DCOMP_EINVAL, "step %d: one step either adds or removes UEs (base.py:436-443)", t);
+            if (cur - nrem < 1) return fail(DCOMP_EINVAL, "step %d: cannot remove %d of %d UEs", t, nrem, cur);
+            if (cur + nadd > env->cap) return fail(DCOMP_EINVAL, "step %d: %d + %d UEs exceed max_ues = %d", t, cur, nadd, env->cap);
+            if (tape && ((nrem && !opts->ev_remove_idx) || (nadd && !opts->ev_add_xy)))
+                return fail(DCOMP_EINVAL, "tape mode: events need the host-drawn indices / border points");
+            cur += nadd - nrem;
+            time += 1;
+        }
+    }
+    // the fused kernel addresses step t's outputs as (idx + t * E * U) on the caller's base pointers with 32-bit row indices: a
+    // fragment beyond that takes the one-launch-per-step path below (same results), except the closed loop, which has no other path
+    const bool fits32 = !(every && (uint64_t)T * EU >= ((uint64_t)1 << 31));
+    if (loop && !fits32) return fail(DCOMP_EINVAL, "policy_loop fragment too long: num_steps * num_envs * num_ue must stay below 2^31 (split the rollout)");
+    if (fits32 && (env->fused || (env->fused_long && (T >= 4 || loop)))) {
         // with a registered policy: the variant that carries the rules; tape-driven central envs: the central-only instantiation
         dcomp::KernelFn kern = kp.next_act ? env->kern.rollout_pol : (!multi && env->kern.rollout_central) ? env->kern.rollout_central : env->kern.rollout;
         int grid = env->grid;
@@ -536,12 +555,7 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
         kp.time = (uint32_t)env->time;
         kp.n_remove = kp.n_add = 0;
         if (env->dyn) {                                            // base.py:433-443: this step's departures / arrivals
-            const int nrem = ev_rem ? ev_rem[t] : 0, nadd = ev_add ? ev_add[t] : 0;
-            if (nrem < 0 || nadd < 0 || (nrem > 0 && nadd > 0)) return fail(DCOMP_EINVAL, "step %d: one step either adds or removes UEs (base.py:436-443)", t);
-            if (env->cur_ue - nrem < 1) return fail(DCOMP_EINVAL, "step %d: cannot remove %d of %d UEs", t, nrem, env->cur_ue);
-            if (env->cur_ue + nadd > env->cap) return fail(DCOMP_EINVAL, "step %d: %d + %d UEs exceed max_ues = %d", t, env->cur_ue, nadd, env->cap);
-            if (tape && ((nrem && !opts->ev_remove_idx) || (nadd && !opts->ev_add_xy)))
-                return fail(DCOMP_EINVAL, "tape mode: events need the host-drawn indices / border points");
+            const int nrem = ev_rem ? ev_rem[t] : 0, nadd = ev_add ? ev_add[t] : 0;       // (validated above, all T steps)
             kp.cur_ue = env->cur_ue;
             kp.n_remove = nrem; kp.n_add = nadd;
             kp.ev_remove = (tape && nrem) ? opts->ev_remove_idx + rem_off : nullptr;
@@ -571,6 +585,15 @@ extern "C" int dcomp_rollout_ex(dcomp_env *env, const dcomp_state *st, const uin
 }
 
 extern "C" int dcomp_rollout_is_fused(const dcomp_env *env) { return env ? ((env->fused || env->fused_long) ? 1 : 0) : -1; }
+// Whether THIS rollout is one launch: fusion of the short-row shapes (fused_long) depends on the number of steps -- a rollout of
+// fewer than 4 tape-driven steps goes out as one launch per step, as does an every-step fragment of >= 2^31 rows.
+extern "C" int dcomp_rollout_fused_for(const dcomp_env *env, int32_t num_steps, int32_t every_step, int32_t policy_loop)
+{
+    if (!env || num_steps < 1) return -1;
+    const uint64_t EU = (uint64_t)env->cfg.num_envs * env->cap;
+    if (every_step && (uint64_t)num_steps * EU >= ((uint64_t)1 << 31)) return 0;
+    return (env->fused || (env->fused_long && (num_steps >= 4 || policy_loop))) ? 1 : 0;
+}
 extern "C" int dcomp_lanes_per_env(const dcomp_env *env) { return env ? (env->tight_g ? env->tight_g : env->upad) : -1; }
 
 // The instantiation dcomp_step launches for this env, spelled as rocprofv3 prints it ("step_kernel<10, 32, 2>"): bench.py ties a

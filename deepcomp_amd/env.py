@@ -154,6 +154,7 @@ class BatchedMobileEnv:
         # (UE offsets reach 100*U: with more than 199 UEs a stride of 20000 would make env e's UE i+200 replay env e+1's UE i)
         self._seed_stride = max(20000, 100 * (len(ue_list) + 1))
         self._reseeded = False
+        self._device_seed = self.seed_value    # the Philox key the DEVICE draws from (a seed() call stages a new one until reset())
         self.env_seeds = (np.asarray(env_seeds, dtype=np.int64) if env_seeds is not None
                           else self.seed_value + self._seed_stride * (self.env_id_base + np.arange(self.E, dtype=np.int64)))
 
@@ -421,6 +422,7 @@ class BatchedMobileEnv:
             else:
                 if self._reseeded:                        # seed() since the last reset: the new Philox key starts here
                     _lib.check(self._L.dcomp_set_seed(self._h, ctypes.c_uint64(int(self.seed_value) & 0xFFFFFFFFFFFFFFFF)))
+                    self._device_seed = self.seed_value
                 if not self.rand_episodes or self._reseeded:
                     self._L.dcomp_set_episode(self._h, 0)     # fixed episodes: same Philox counter word every reset
             self._reseeded = False
@@ -504,8 +506,10 @@ class BatchedMobileEnv:
         L = int(horizon or 0)
         if new_episode_draws is None:
             new_episode_draws = self.rand_episodes
-        if L and self.rng_mode == _lib.RNG_TAPE and (self.rand_episodes or new_episode_draws or self.dynamic) and not _policy_steps:
-            # rng='reference' with streams that continue across episodes (or UEs re-seeded by list position at reset): every episode
+        if L and self.rng_mode == _lib.RNG_TAPE and (self.rand_episodes or new_episode_draws or self.dynamic or self._live is not None) and not _policy_steps:
+            # rng='reference' with streams that continue across episodes (or UEs re-seeded by list position at reset, or a fixed-episode
+            # env whose RUNNING episode was re-seeded with seed(immediate=True): its tape is a splice that only reset() replaces with
+            # the configured seed's again, base.py:171-173): every episode
             # needs a tape the HOST draws from where the previous one stopped, so the rollout is cut at the episode boundaries --
             # one launch per stretch, reset() (cursors read back, new tape) in between.  Same sequence as `if time == L: reset()`
             # before every step, like the in-kernel reset of the other modes.
@@ -584,7 +588,7 @@ class BatchedMobileEnv:
         L = int(horizon or 0)
         T, t0 = int(num_steps), 0
         keys = ('obs', 'reward', 'sum_utility', 'ue_dr', 'ue_utility', 'reward_before')
-        host_resets = L and self.rng_mode == _lib.RNG_TAPE and self.rand_episodes      # a fresh host-drawn tape per episode
+        host_resets = L and self.rng_mode == _lib.RNG_TAPE and (self.rand_episodes or self._live is not None)   # a fresh host-drawn tape per episode
         if self.fused_rollout and not self.dynamic and not host_resets:
             return self.rollout(self.next_action.view(1, self.E, self.U), out=out, horizon=L, _policy_steps=T)
         while t0 < T:
@@ -687,12 +691,22 @@ class BatchedMobileEnv:
         """True when rollout() runs its T steps in one kernel launch."""
         return self._L.dcomp_rollout_is_fused(self._h) == 1
 
+    def rollout_is_fused(self, num_steps, every_step=True, policy_loop=False):
+        """True when a rollout of `num_steps` steps is ONE kernel launch (fusion of the short-row shapes needs >= 4 steps or a
+        policy loop; fragments of >= 2^31 rows go out one launch per step)."""
+        if not hasattr(self._L, 'dcomp_rollout_fused_for'):
+            return self.fused_rollout
+        return self._L.dcomp_rollout_fused_for(self._h, int(num_steps), 1 if every_step else 0, 1 if policy_loop else 0) == 1
+
     # ------------------------------------------------------------------ checkpoint / resume
     def _fingerprint(self):
-        return dict(E=self.E, U=self.U, U0=self.U0, B=self.B, kind=int(self.kind), reward=self.reward_agg, seed=int(self.seed_value),
+        # seed: the key the running episode draws from (a seed staged by seed() travels as 'pending_seed' next to it)
+        return dict(E=self.E, U=self.U, U0=self.U0, B=self.B, kind=int(self.kind), reward=self.reward_agg, seed=int(self._device_seed),
                     env_id_base=self.env_id_base, map=(self.map_w, self.map_h), rand_episodes=self.rand_episodes,
                     bs=self._bs_x.tolist() + self._bs_y.tolist() + self._bs_sh.tolist(), dynamic=self.dynamic,
-                    movement=self._pause.tolist() + self._border.tolist(), state_layout=2)
+                    movement=self._pause.tolist() + self._border.tolist(),
+                    velocity=self._vlo.tolist() + self._vhi.tolist() + ([] if self._vel_num is None else self._vel_num.tolist()),
+                    state_layout=3)
 
     def state_dict(self):
         """Everything needed to continue this env batch bit-identically in another process (the reference never checkpoints
@@ -703,7 +717,8 @@ class BatchedMobileEnv:
         c = (ctypes.c_int64 * 5)()
         _lib.check(self._L.dcomp_get_counters(self._h, c))
         torch.cuda.current_stream(self.device).synchronize()
-        sd = {'config': self._fingerprint(), 'counters': list(c), 'outbuf': self._outbuf.detach().cpu().clone()}
+        sd = {'config': self._fingerprint(), 'counters': list(c), 'outbuf': self._outbuf.detach().cpu().clone(),
+              'pending_seed': int(self.seed_value) if self._reseeded else None}      # seed() since the last reset(): in force from the next one
         for k in ('pos', 'mv', 'conn', 'ewma', 'conn_since', 'uid', 'orig_consumed'):
             t = getattr(self, k)
             sd[k] = None if t is None else t.detach().cpu().clone()
@@ -721,6 +736,12 @@ class BatchedMobileEnv:
         self.flags.zero_()
         c = (ctypes.c_int64 * 5)(*sd['counters'])
         _lib.check(self._L.dcomp_set_counters(self._h, c))
+        if sd.get('pending_seed') is not None:          # the checkpointed run had called seed(s) and not yet reset(): so has this one now
+            self.seed(sd['pending_seed'])
+        elif self._reseeded:                            # a seed staged in THIS env is not part of the checkpointed run
+            self.seed_value = self._device_seed
+            self.env_seeds = self.seed_value + self._seed_stride * (self.env_id_base + np.arange(self.E, dtype=np.int64))
+            self._reseeded = False
         if self._policy_key is not None:
             # next_action still holds the decision for the observation of BEFORE the restore: redo it on the restored one (the
             # stand-alone policy kernel gives what the in-step policy would have written -- tests/test_adapters_gpu.py holds the

@@ -208,6 +208,10 @@ typedef struct dcomp_rollout_opts {
 int dcomp_rollout_ex(dcomp_env *env, const dcomp_state *st, const uint8_t *actions, int32_t num_steps,
                      const dcomp_out *out, const dcomp_rollout_opts *opts, void *stream);
 int dcomp_rollout_is_fused(const dcomp_env *env);      /* 1: T steps = one launch */
+/* Whether a rollout of num_steps steps with these options is ONE launch: fusion of the short-row shapes depends on the number of
+ * steps (>= 4, or a policy loop), and an every-step fragment of >= 2^31 rows (num_steps * num_envs * num_ue) takes the
+ * one-launch-per-step path (same results).  1 / 0; -1: bad arguments. */
+int dcomp_rollout_fused_for(const dcomp_env *env, int32_t num_steps, int32_t every_step, int32_t policy_loop);
 int dcomp_lanes_per_env(const dcomp_env *env);         /* lanes an env occupies in dcomp_step: next power of two >= num_ue, or
                                                          * num_ue itself when envs are packed tightly (throughput-bound batches of
                                                          * UE lists that are not a power of two long; DCOMP_TIGHT=0/1 overrides) */

@@ -75,10 +75,48 @@ def test_bench_spawns_its_own_ranks_n2_gloo_same_device():
     assert j['handoff']['mode'] == 'obs' and j['handoff']['fragments'] == 4
     assert j['handoff']['bytes_received_per_rank_per_fragment'] == 2 * 5 * 2048 * 32 * (41 + 1) * 4
     assert j['value'] > 0 and j['config']['parallelism'] == 'env-shard x2'
-    c4 = j['also']['config4_split_32768x32x10_per_gpu']
-    c5 = j['also']['config5_split_4096x128x32_per_gpu']
-    assert c4['n_gpus'] == 2 and c4['total_envs'] == 65536 and c4['value'] > 0, c4
-    assert c5['n_gpus'] == 2 and c5['total_envs'] == 8192 and c5['value'] > 0, c5
+    assert j['handoff']['collectives_in_timed_region'] == 2 * 4        # obs + reward per fragment, 4 fragments in the timed 20 steps
+    assert j['handoff']['bytes_in_timed_region']['sent_per_rank'] == 4 * 5 * 2048 * 32 * (41 + 1) * 4
+    c4 = j['also']['config4_strong_262144x32x10']                      # strong scaling: the BASELINE totals split over the ranks
+    c5 = j['also']['config5_strong_32768x128x32']
+    assert c4['n_gpus'] == 2 and c4['total_envs'] == 262144 and c4['envs_per_gpu'] == 131072 and c4['value'] > 0, c4
+    assert c5['n_gpus'] == 2 and c5['total_envs'] == 32768 and c5['envs_per_gpu'] == 16384 and c5['value'] > 0, c5
+
+
+def test_driver_form_n2_has_a_collective_inside_the_timed_region():
+    """with the driver's exact `--steps 20 --warmup 5` and an episode of 100 steps NO collective fell inside the timed region,
+    while config.collective claimed one per episode.  The default hand-off now happens every min(L, max(4, K // 2)) = 10 steps, is
+    counted where it is issued, and every rank runs the same pre-warm at every N.  Two self-spawned ranks on one device (gloo: RCCL
+    refuses two ranks on one GPU), default workload, secondary configurations on -- the driver's command line otherwise."""
+    env_clean = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    cmd = [sys.executable, 'bench.py', '--gpus', '2', '--steps', '20', '--warmup', '5', '--backend', 'gloo', '--same-device']
+    r = subprocess.run(cmd, cwd=REPO, env=env_clean, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert r.returncode == 0 and lines, (r.stdout[-2000:], r.stderr[-3000:])
+    j = json.loads(lines[-1])
+    h = j['handoff']
+    assert j['n_gpus'] == 2 and j['steps'] == 20 and j['warmup'] == 5 and h['mode'] == 'summary' and h['rccl_ranks'] == 2
+    assert h['period_steps'] == 10 and h['collectives_in_timed_region'] == 2 * 2          # reward + sum_utility, after timed steps 5 and 15
+    assert h['bytes_in_timed_region']['sent_per_rank'] == 2 * 4 * 65536 * (32 + 1)
+    assert h['bytes_in_timed_region']['received_per_rank'] == 2 * h['bytes_in_timed_region']['sent_per_rank']
+    assert '4 collective(s) inside the timed region' in j['config']['collective'] and 'every rank' in j['config']['prewarm']
+    a = j['also']
+    assert a['measured'].startswith('before the warm-up') and 'config2_4096x10x5_central_fused_rollout' in a     # the pre-warm ran at N = 2 too
+    assert a['config4_strong_262144x32x10']['envs_per_gpu'] == 131072 and a['config5_strong_32768x128x32']['envs_per_gpu'] == 16384
+    assert set(a['config5_per_gpu_share_of_32768x128x32']) == {'N1_32768_envs', 'N2_16384_envs', 'N4_8192_envs', 'N8_4096_envs'}
+    r50 = a['central_65536x10x5']['through_rollout_T50']
+    assert r50['frac_of_hbm_peak_kernel_traffic'] < r50['frac_of_hbm_peak_algorithmic']   # both figures, the honest one is the smaller
+
+
+def test_single_rank_rccl_driver_form_counts_its_collectives():
+    """`--gpus 1 --spawn --steps 20 --warmup 5`: a real RCCL communicator (one rank); the summary hand-off runs inside the timed region."""
+    env_clean = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '1', '--spawn', '--steps', '20', '--warmup', '5', '--no-cpu-baseline', '--no-also'],
+                       cwd=REPO, env=env_clean, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    j = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    h = j['handoff']
+    assert h['backend'] == 'rccl' and h['rccl_ranks'] == 1 and h['collectives_in_timed_region'] == 4 and h['period_steps'] == 10
 
 
 def test_bench_spawns_its_own_ranks_summary_mode_probe():

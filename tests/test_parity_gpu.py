@@ -1185,6 +1185,56 @@ def test_checkpoint_resume_is_bit_identical(torch_cuda, dyn):
         BatchedMobileEnv(m, bs, ues, 'multi', **dict(kw, seed=12)).load_state_dict(sd)
 
 
+def test_checkpoint_between_seed_and_reset(torch_cuda):
+    """seed(s) on a Philox env is STAGED until reset(); a checkpoint taken in between must continue the running episode on
+    the OLD key and switch to the new one at the next reset -- the checkpoint carries the device's key and the pending seed apart."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    E, L = 65, 12
+    m, bs, ues = build_from_scenario(scenarios.medium_map('mixed').with_ues(num_slow=3, num_fast=2))
+    kw = dict(num_envs=E, seed=11, episode_length=L, rng='philox', rand_episodes=True)
+    acts = torch.randint(0, len(bs) + 1, (40, E, 5), device='cuda', dtype=torch.uint8)
+
+    def run(env, t0, t1, rec):
+        for t in range(t0, t1):
+            if t % L == 0:
+                env.reset()
+            env.step(acts[t])
+            rec.append(env.obs.clone())
+    a = BatchedMobileEnv(m, bs, ues, 'multi', **kw)
+    run(a, 0, 5, [])
+    a.seed(4242)
+    sd = a.state_dict()
+    assert sd['config']['seed'] == 11 and sd['pending_seed'] == 4242
+    want, got = [], []
+    run(a, 5, 30, want)
+    b = BatchedMobileEnv(m, bs, ues, 'multi', **kw)              # configured like the checkpointed env was
+    b.load_state_dict(sd)
+    run(b, 5, 30, got)
+    for i, (x, y) in enumerate(zip(want, got)):
+        assert torch.equal(x, y), f'step {5 + i}'
+    # the second episode runs on the new key: an env constructed with it agrees from its first reset on
+    c = BatchedMobileEnv(m, bs, ues, 'multi', **dict(kw, seed=4242))
+    c.reset()
+    c.step(acts[12])
+    assert torch.equal(c.obs, want[12 - 5])
+    # a seed staged in the RESTORING env is not part of the checkpointed run
+    d = BatchedMobileEnv(m, bs, ues, 'multi', **kw)
+    d.seed(5)
+    sd0 = BatchedMobileEnv(m, bs, ues, 'multi', **kw)
+    run(sd0, 0, 3, [])
+    d.load_state_dict(sd0.state_dict())
+    x, y = [], []
+    run(sd0, 3, 20, x); run(d, 3, 20, y)
+    assert all(torch.equal(p, q) for p, q in zip(x, y))
+    # velocities are part of the fingerprint now
+    m2, bs2, ues2 = build_from_scenario(scenarios.medium_map('mixed').with_ues(num_slow=2, num_fast=3))
+    with pytest.raises(ValueError):
+        BatchedMobileEnv(m2, bs2, ues2, 'multi', **kw).load_state_dict(sd)
+
+
 def test_episode_horizon_guard(torch_cuda):
     """The draw cursor and conn_since are 16-bit: a step beyond 65536 is refused (NotImplementedError), reset() clears it."""
     import ctypes as C

@@ -350,3 +350,77 @@ def test_long_rollouts_of_small_central_envs_are_fused_at_any_batch_size(torch_c
     ref.step(acts[0]); ref.step(acts[1])
     torch.testing.assert_close(big.obs, ref.obs, rtol=2e-6, atol=2e-6)   # (the EWMA history differs in its last bits; masks must not)
     assert torch.equal(big.conn, ref.conn) and torch.equal(big.pos, ref.pos)
+
+
+def test_rollout_with_a_horizon_after_a_live_reseed(torch_cuda):
+    """seed(s, immediate=True) on a rand_episodes=False env splices the new streams into the RUNNING episode's tape; the
+    reference re-seeds with the configured seed at the next reset (base.py:171-173).  rollout(horizon=L) used to reset inside the
+    kernel and replay the splice; it must take the reset() path.  Against the step-by-step sequence (which the reseed_* fixtures
+    pin on the reference)."""
+    torch = torch_cuda
+    E, U, B, L, T = 5, 6, 4, 10, 27
+    g = torch.Generator(device='cuda').manual_seed(3)
+    acts = torch.randint(0, B + 1, (T, E, U), generator=g, device='cuda', dtype=torch.uint8)
+
+    def start(kind):
+        env = _make(kind, U, B, E, rng='reference', rand_episodes=False, L=L)
+        env.reset()
+        for t in range(4):
+            env.step(acts[t])
+        env.seed(977, immediate=True)
+        return env
+    for kind in ('multi', 'central'):
+        a, b = start(kind), start(kind)
+        want = []
+        for t in range(4, T):
+            if a.time == L:
+                a.reset()
+            a.step(acts[t])
+            want.append((a.obs.clone(), a.reward.clone()))
+        frag = {'obs': torch.empty((T - 4,) + tuple(b.obs.shape), device='cuda'), 'reward': torch.empty((T - 4,) + tuple(b.reward.shape), device='cuda')}
+        b.rollout(acts[4:], out=frag, horizon=L)
+        a.check(); b.check()
+        for i, (o, r) in enumerate(want):
+            assert torch.equal(frag['obs'][i], o) and torch.equal(frag['reward'][i], r), (kind, i)
+        assert _same_state(_state(a), _state(b)) and a.time == b.time
+
+
+def test_rollout_event_schedule_is_validated_before_the_first_launch(torch_cuda):
+    """an invalid arrival / departure entry at step t of a rollout used to surface after steps 0..t-1 had been launched
+    (env.time advanced).  The call now does all T steps or nothing."""
+    import ctypes
+    torch = torch_cuda
+    from deepcomp_amd import _lib, scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    m, bs, ues = build_from_scenario(scenarios.medium_map('mixed').with_ues(num_slow=3))
+    env = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=8, seed=1, rng='philox', episode_length=20, ue_arrival={3: 1, 6: -1})
+    env.reset()
+    T = 6
+    acts = torch.zeros((T, 8, env.U), dtype=torch.uint8, device='cuda')
+    n_rem = np.zeros(T, dtype=np.int32); n_add = np.zeros(T, dtype=np.int32)
+    n_add[1] = 1                     # fine: 3 -> 4 = max_ues
+    n_add[4] = 1                     # 4 + 1 > max_ues: invalid, at step 4
+    opts = _lib.DcompRolloutOpts(0, 0, 0, 0)
+    opts.ev_n_remove, opts.ev_n_add = n_rem.ctypes.data, n_add.ctypes.data
+    before = _state(env)
+    rc = env._L.dcomp_rollout_ex(env._h, env._st_ref, ctypes.c_void_p(acts.data_ptr()), T, env._out_ref, ctypes.byref(opts), env._stream())
+    assert rc == _lib.EINVAL and 'step 4' in _lib.last_error()
+    torch.cuda.synchronize()
+    assert env.time == 0 and env.num_ue == 3 and _same_state(before, _state(env))
+    n_add[4] = 0
+    _lib.check(env._L.dcomp_rollout_ex(env._h, env._st_ref, ctypes.c_void_p(acts.data_ptr()), T, env._out_ref, ctypes.byref(opts), env._stream()))
+    assert env.time == T and env.num_ue == 4
+    env.check()
+
+
+def test_rollout_is_fused_depends_on_the_number_of_steps(torch_cuda):
+    """`fused_rollout` is a property of the env; whether ONE rollout is one launch also depends on its length."""
+    big = _make('central', 10, 5, 65536)
+    assert big.fused_rollout and big.rollout_is_fused(50) and big.rollout_is_fused(4) and not big.rollout_is_fused(3)
+    assert big.rollout_is_fused(1, policy_loop=True)
+    small = _make('central', 10, 5, 4096)
+    assert small.rollout_is_fused(1) and small.rollout_is_fused(100)
+    assert not _make('multi', 128, 32, 64).rollout_is_fused(100)
+    # an every-step fragment of >= 2^31 rows falls back to one launch per step instead of failing (64-bit offsets on the host)
+    assert not big.rollout_is_fused(4096, every_step=True) and big.rollout_is_fused(4096, every_step=False)
