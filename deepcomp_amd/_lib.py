@@ -67,7 +67,8 @@ POLICY = {'3gpp': 0, 'fullcomp': 1, 'dynamic': 2, 'cluster': 3}
 EXPORTS = ['dcomp_create', 'dcomp_destroy', 'dcomp_state_sizes', 'dcomp_obs_dim', 'dcomp_reset', 'dcomp_step',
            'dcomp_step_dyn', 'dcomp_num_ue',
            'dcomp_rollout', 'dcomp_rollout_ex', 'dcomp_rollout_is_fused', 'dcomp_rollout_fused_for', 'dcomp_lanes_per_env', 'dcomp_step_kernel_name', 'dcomp_check', 'dcomp_time', 'dcomp_episode', 'dcomp_set_episode', 'dcomp_set_seed', 'dcomp_set_tape', 'dcomp_get_counters', 'dcomp_set_counters', 'dcomp_mt_draw_tape',
-           'dcomp_connect_threshold', 'dcomp_last_error', 'dcomp_version', 'dcomp_selftest', 'dcomp_heuristic_actions', 'dcomp_set_policy']
+           'dcomp_connect_threshold', 'dcomp_last_error', 'dcomp_version', 'dcomp_selftest', 'dcomp_heuristic_actions', 'dcomp_set_policy',
+           'dcomp_fragment_words', 'dcomp_pack_fragment', 'dcomp_unpack_fragment']
 
 _lib = None
 
@@ -129,6 +130,10 @@ def load():
         L.dcomp_heuristic_actions.argtypes = [ctypes.POINTER(DcompPolicy), vp, vp, vp]
     if hasattr(L, 'dcomp_set_policy'):
         L.dcomp_set_policy.argtypes = [vp, ctypes.POINTER(DcompPolicy), vp]
+    if hasattr(L, 'dcomp_pack_fragment'):
+        L.dcomp_fragment_words.argtypes = [i32, i32]
+        L.dcomp_pack_fragment.argtypes = [vp, i64, i32, i32, vp, vp, vp]
+        L.dcomp_unpack_fragment.argtypes = [vp, i64, i32, i32, vp, vp]
     if os.environ.get('DCOMP_LIB'):              # timing variants built from older sources lack the newest entry points
         EXPORTS[:] = [n for n in EXPORTS if hasattr(L, n)]
     for name in EXPORTS:

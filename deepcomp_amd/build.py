@@ -34,8 +34,8 @@ def b_list():
 
 
 def _sources():
-    return [os.path.join(CSRC, f) for f in ('dcomp_device.h', 'dcomp_wide.h', 'dcomp_dyn.h', 'dcomp_blist.h', 'dcomp_inst.hip', 'dcomp_api.hip')] + \
-        [os.path.join(os.path.dirname(HERE), 'include', 'dcomp.h')]
+    return [os.path.join(CSRC, f) for f in ('dcomp_device.h', 'dcomp_wide.h', 'dcomp_dyn.h', 'dcomp_blist.h', 'dcomp_inst.hip', 'dcomp_api.hip', 'dcomp_fragment.h')] + \
+        [os.path.join(os.path.dirname(HERE), 'include', f) for f in ('dcomp.h', 'dcomp_types.h')]
 
 
 def _dev_flags():
@@ -112,10 +112,11 @@ def build(force=False, jobs=None, extra_flags=()):
 
     def obj_stamp(t):
         """An object is rebuilt when its command line or one of ITS inputs changed: the per-station-count objects do not
-        include dcomp_api.hip (an ABI-side edit recompiles one file and relinks, seconds instead of minutes)."""
+        include dcomp_api.hip, dcomp_fragment.h or include/dcomp.h -- the entry-point declarations; they see include/dcomp_types.h
+        only -- so an ABI-side edit recompiles one file and relinks, seconds instead of ten minutes."""
         h = hashlib.sha256(' '.join(t[1]).encode())
         for f in _sources():
-            if f.endswith('dcomp_api.hip') and not t[0].endswith('dcomp_api.o'):
+            if f.endswith(('dcomp_api.hip', 'dcomp_fragment.h', os.sep + 'dcomp.h')) and not t[0].endswith('dcomp_api.o'):
                 continue
             h.update(os.path.basename(f).encode())
             h.update(open(f, 'rb').read())

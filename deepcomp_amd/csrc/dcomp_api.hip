@@ -10,8 +10,10 @@
 #include <thread>
 #include <vector>
 
+#include "../../include/dcomp.h"
 #include "dcomp_blist.h"
 #include "dcomp_device.h"
+#include "dcomp_fragment.h"
 
 namespace dcomp {
 #define DCOMP_DECL(n) KernelPair kernels_b##n(int upad, int mp);
@@ -969,6 +971,50 @@ extern "C" int dcomp_selftest(int op, int width, const double *x, const double *
         default: return fail(DCOMP_EINVAL, "width must be 2..64 (power of two)");
         }
     } else return fail(DCOMP_EINVAL, "unknown op");
+    HIP_TRY(hipGetLastError());
+    return DCOMP_OK;
+}
+
+// ---- compact rollout fragments for the learner hand-off (dcomp_fragment.h) ----
+extern "C" int dcomp_fragment_words(int32_t num_ue, int32_t num_bs)
+{
+    if (num_ue < 1 || num_ue > DCOMP_MAX_UE || num_bs < 1 || num_bs > DCOMP_MAX_BS) return -1;
+    return dcomp_frag::env_words(num_ue, num_bs);
+}
+
+static int fragment_params(dcomp_frag::FragParams &p, int64_t n, int U, int B, int &grid, size_t &lds_pack, size_t &lds_unpack)
+{
+    if (n < 1 || U < 1 || U > DCOMP_MAX_UE || B < 1 || B > DCOMP_MAX_BS)
+        return fail(DCOMP_EINVAL, "fragment: need num_env_steps >= 1, 1 <= num_ue <= %d, 1 <= num_bs <= %d", DCOMP_MAX_UE, DCOMP_MAX_BS);
+    if (dcomp_frag::fill(p, n, U, B, grid, lds_pack, lds_unpack)) return fail(DCOMP_EINVAL, "fragment too long for one launch: split it (num_env_steps * chunks >= 2^31)");
+    return DCOMP_OK;
+}
+
+extern "C" int dcomp_pack_fragment(const float *obs, int64_t num_env_steps, int32_t num_ue, int32_t num_bs, uint32_t *packed, int32_t *flags,
+                                   void *stream)
+{
+    if (!obs || !packed || !flags) return fail(DCOMP_EINVAL, "null argument");
+    dcomp_frag::FragParams p{};
+    int grid;
+    size_t lp, lu;
+    const int rc = fragment_params(p, num_env_steps, num_ue, num_bs, grid, lp, lu);
+    if (rc) return rc;
+    p.obs_in = obs; p.packed_out = packed; p.flags = flags;
+    hipLaunchKernelGGL(dcomp_frag::pack_kernel, dim3(grid), dim3(dcomp_frag::BLOCK), lp, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return DCOMP_OK;
+}
+
+extern "C" int dcomp_unpack_fragment(const uint32_t *packed, int64_t num_env_steps, int32_t num_ue, int32_t num_bs, float *obs, void *stream)
+{
+    if (!obs || !packed) return fail(DCOMP_EINVAL, "null argument");
+    dcomp_frag::FragParams p{};
+    int grid;
+    size_t lp, lu;
+    const int rc = fragment_params(p, num_env_steps, num_ue, num_bs, grid, lp, lu);
+    if (rc) return rc;
+    p.packed_in = packed; p.obs_out = obs;
+    hipLaunchKernelGGL(dcomp_frag::unpack_kernel, dim3(grid), dim3(dcomp_frag::BLOCK), lu, (hipStream_t)stream, p);
     HIP_TRY(hipGetLastError());
     return DCOMP_OK;
 }

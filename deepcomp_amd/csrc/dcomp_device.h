@@ -16,7 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../include/dcomp.h"
+#include "../../include/dcomp_types.h"
 
 // Build switches.  The product build uses the defaults; tools/ablate.py builds timing-only variants.
 // DCOMP_ABLATE    bit mask of pipeline stages to leave out (results are wrong by construction; timing only)

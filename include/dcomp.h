@@ -35,106 +35,11 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "dcomp_types.h"      /* limits, enums, dcomp_cfg / dcomp_state / dcomp_out / dcomp_tape / dcomp_events */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
-
-#define DCOMP_MAX_BS 32          /* connection set is one 32-bit mask per UE */
-#define DCOMP_MAX_UE 256         /* one env never spans more than one 256-lane workgroup */
-
-enum { DCOMP_OK = 0, DCOMP_EINVAL = -1, DCOMP_EHIP = -2, DCOMP_EACTION = -3, DCOMP_ETAPE = -4, DCOMP_EPOS = -5,
-       DCOMP_EUNSUPPORTED = -6 };
-
-enum { DCOMP_CENTRAL = 0, DCOMP_MULTI = 1 };                    /* central.py:143-152 | multi_agent.py:6 */
-enum { DCOMP_REWARD_AVG = 0, DCOMP_REWARD_SUM = 1, DCOMP_REWARD_MIN = 2 };   /* constants.py:24 */
-enum { DCOMP_RES_FAIR = 0, DCOMP_RATE_FAIR = 1, DCOMP_MAX_CAP = 2, DCOMP_PROP_FAIR = 3 };  /* station.py:152-202 */
-enum { DCOMP_UTIL_LOG = 0, DCOMP_UTIL_STEP = 1 };                /* utility.py:23-54 */
-enum { DCOMP_RNG_TAPE = 0, DCOMP_RNG_PHILOX = 1 };
-
-/* device-side sticky flag bits (flags[0]) */
-#define DCOMP_FLAG_BAD_ACTION   1u   /* action outside [0, B]        (base.py:238, central.py:61 assert) */
-#define DCOMP_FLAG_TAPE_EMPTY   2u   /* waypoint tape exhausted                                           */
-#define DCOMP_FLAG_OUTSIDE_MAP  4u   /* UE left the map              (movement.py:165-166 assert)         */
-
-typedef struct dcomp_env dcomp_env;
-
-/* Immutable per-handle configuration.  Replaces the objects inside the reference's env_config dict
- * (env_setup.py:247-256): Map -> map_w/map_h (int()-truncated, map.py:20-21); bs_list -> bs_x/bs_y/
- * bs_sharing; ue_list -> ue_*; 'reward' -> reward_agg; 'seed' -> seed; 'episode_length'. */
-typedef struct dcomp_cfg {
-    int32_t num_envs;            /* E: envs owned by this handle (one GPU's shard) */
-    int32_t num_ue;              /* U <= DCOMP_MAX_UE: UEs in the configured ue_list (= after every reset) */
-    int32_t num_bs;              /* B <= DCOMP_MAX_BS */
-    int32_t map_w, map_h;
-    int32_t env_kind;            /* DCOMP_CENTRAL | DCOMP_MULTI */
-    int32_t reward_agg;          /* DCOMP_REWARD_* */
-    int32_t rng_mode;            /* DCOMP_RNG_TAPE (reference-exact draws supplied by the host) | DCOMP_RNG_PHILOX */
-    int32_t tape_depth;          /* movement triples per UE per episode in tape mode */
-    int32_t device;              /* HIP device ordinal */
-    int32_t max_ues;             /* slots per env when UEs arrive / depart (base.py:79-84), >= num_ue; 0 = fixed list */
-    uint64_t seed;               /* Philox key */
-    int64_t env_id_base;         /* global id of this shard's env 0 (results do not depend on the GPU count) */
-    const double *bs_x, *bs_y;   /* host [B] */
-    const int32_t *bs_sharing;   /* host [B] DCOMP_*_FAIR / MAX_CAP */
-    const int32_t *ue_util;      /* host [U] DCOMP_UTIL_* or NULL (= log) */
-    const float *ue_dr_req;      /* host [U] or NULL (= 1) -- step utility only (user.py:33) */
-    const int32_t *ue_vel_lo, *ue_vel_hi;  /* host [U] inclusive velocity draw range; lo==hi: fixed (movement.py:112-117) */
-    const int32_t *ue_init_x, *ue_init_y;  /* host [U] fixed start coordinate or -1 = 'random' (user.py:98-109); NULL = random */
-    const int32_t *ue_pause_duration;      /* host [U] RandomWaypoint.pause_duration, 0..127 (movement.py:87,172-176); NULL = 2 */
-    const int32_t *ue_border_buffer;       /* host [U] RandomWaypoint.border_buffer, 1..255 (movement.py:87,126-127); NULL = 10.
-                                            * UEs that arrive during an episode always get the defaults (base.py:597-599). */
-    const double *ue_velocity;             /* host [U] or NULL: fixed velocity of UE u as a number when it is not an integer in
-                                            * 0..255 (movement.py:116-117 takes whatever the caller passed, e.g. 2.5), >= 0;
-                                            * negative / NaN = use the integer range above.  Such a UE never draws a velocity. */
-} dcomp_cfg;
-
-typedef struct dcomp_state {     /* device, caller-allocated; sizes via dcomp_state_sizes() */
-    double *pos;
-    uint64_t *mv;
-    uint32_t *conn;
-    float *ewma;
-    uint32_t *flags;
-    uint16_t *conn_since;        /* NULL unless dcomp_state_sizes() reports since_bytes > 0 */
-    uint16_t *uid;               /* [E*max_ues] UE id per slot, bit 15 = arrived during the episode; only with max_ues > 0 */
-    uint16_t *orig_consumed;     /* [E*num_ue] optional: movement triples an initial UE had consumed when it left the
-                                  * list (0xFFFF = never left) -- lets a tape-mode host continue that UE's stream */
-} dcomp_state;
-
-/* Outputs of reset()/step().  obs layout = RLlib's flatten order of the reference's Dict spaces
- * (sorted keys; variants.py:255-269, central.py:147-151):
- *   MULTI   obs[E][U][4B+1] = connected[B] | dr[B] | ues_at_bs[B] | util_at_bs[B] | utility[1]
- *   CENTRAL obs[E][U*(2B+1)] = connected[U*B] | dr[U*B] | utility[U]
- * reward: MULTI [E][U] (multi_agent.py:39-95), CENTRAL [E] (central.py:65-73).
- * Optional info tensors (base.py:383-411): sum_utility[E], ue_dr[E][U], ue_utility[E][U]; NULL to skip. */
-typedef struct dcomp_out {
-    float *obs;
-    float *reward;
-    float *sum_utility;
-    float *ue_dr;
-    float *ue_utility;
-    float *reward_before;        /* optional [E][U]: clip(utility at the pre-move rates)/20 per UE (base.py:158-167, 446) --
-                                  * the reward the single-agent env hands out (base.py:358-369); NULL to skip */
-} dcomp_out;
-
-/* Tape-mode draws for one episode (device): pos0[E*U][2] int32 start positions and
- * triples[E*U][depth] of {velocity, wx, wy, 0} uint16 -- the values the reference's per-UE
- * random.Random streams hand out. */
-typedef struct dcomp_tape {
-    const int32_t *pos0;         /* [E*num_ue][2] */
-    const uint16_t *triples;     /* [E*num_ids][depth][4]; per env: the initial UEs by position, then (UE arrival) one
-                                  * 'slow' tape per id an arriving UE can get (seed + 100*id, base.py:602-604) */
-    int32_t num_ids;             /* tapes per env; 0 = num_ue */
-} dcomp_tape;
-
-/* UE departure / arrival applied by one step, after the actions and before the rates (base.py:433-443).  The counts
- * are the same in every env (the schedule is configuration).  Tape mode: remove_idx[E][n_remove] = the reference's
- * random.randint(0, num_ue-1) list positions (base.py:611), add_xy[E][n_add][2] = map.rand_border_point()
- * (map.py:52-65), both device arrays; Philox mode: NULL (keyed draws in the kernel). */
-typedef struct dcomp_events {
-    int32_t n_remove, n_add;
-    const int32_t *remove_idx;
-    const int32_t *add_xy;
-} dcomp_events;
 
 int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out);                 /* MobileEnv.__init__  base.py:27-84 */
 int dcomp_destroy(dcomp_env *env);
@@ -271,7 +176,6 @@ const char *dcomp_version(void);
  * Ties as numpy / sorted() resolve them: the first (lowest-index) maximum.  obs_kind = layout of `obs` (DCOMP_MULTI:
  * [E][num_ue][4B+1], DCOMP_CENTRAL: [E][num_ue(2B+1)]); UE slots >= num_active (zero-padded observations of a dynamic
  * env, central.py:46-55) get action 0.  action: uint8 [E][num_ue]. */
-enum { DCOMP_POLICY_3GPP = 0, DCOMP_POLICY_FULLCOMP = 1, DCOMP_POLICY_DYNAMIC = 2, DCOMP_POLICY_CLUSTER = 3 };
 typedef struct dcomp_policy {
     int32_t policy;              /* DCOMP_POLICY_* */
     int32_t obs_kind;            /* DCOMP_CENTRAL | DCOMP_MULTI */
@@ -291,6 +195,27 @@ int dcomp_heuristic_actions(const dcomp_policy *p, const float *obs, uint8_t *ac
  * shape fields must be 0 or match the env; p == NULL or next_action == NULL switches it off.
  * Every step kernel has it (narrow, tight, wide, dynamic); DCOMP_EUNSUPPORTED is reserved for kernels that might not. */
 int dcomp_set_policy(dcomp_env *env, const dcomp_policy *p, uint8_t *next_action);
+
+/* Compact rollout fragments for the learner hand-off (the RCCL all-gather of rollouts; in the reference the sample
+ * batches travel through Ray's object store, util/env_setup.py:266, util/simulation.py:143).  The multi-agent observation row
+ * of RelNormEnv.get_ue_obs (single_ue/variants.py:271-305) is connected[B] | dr[B] | ues_at_bs[B] | util_at_bs[B] | utility;
+ * ues_at_bs / util_at_bs are properties of the ENV replicated into every UE's row (variants.py:296-299) and `connected` is B
+ * bits (variants.py:273).  Compact record of one env-step, dcomp_fragment_words(U, B) = U (B + 2) + 2B 32-bit words:
+ *     U x { dr[B] f32 | utility f32 | connected bit mask u32 }  then  ues_at_bs[B] f32 | util_at_bs[B] f32
+ * (1 616 B instead of 5 248 B at 32 x 10; 17 664 B instead of 66 048 B at 128 x 32).
+ *   dcomp_pack_fragment    obs: device rows [num_env_steps][num_ue][4B+1] (any number of steps x envs, e.g. a [T][E][U][4B+1]
+ *                          fragment) -> packed: device words [num_env_steps][dcomp_fragment_words].  flags: device int32[1],
+ *                          OR-ed with 1 if a listed row's per-env columns differ from row 0's, 2 if a `connected` entry is
+ *                          neither 0 nor 1 -- i.e. if the input is not an observation tensor and the record would not be
+ *                          lossless.  Zero it before, read it whenever convenient.
+ *   dcomp_unpack_fragment  the inverse.  unpack(pack(obs)) is BIT-IDENTICAL to obs when flags stayed 0: floats are copied, not
+ *                          recomputed; rows of unlisted UE slots (all zeros, UE arrival / departure) are recognised by their
+ *                          all-zero dr block (a listed UE's best station has dr == 1, variants.py:279-284).
+ * Both only enqueue one streaming kernel on `stream`. */
+int dcomp_fragment_words(int32_t num_ue, int32_t num_bs);       /* words per env-step; -1: bad arguments */
+int dcomp_pack_fragment(const float *obs, int64_t num_env_steps, int32_t num_ue, int32_t num_bs, uint32_t *packed, int32_t *flags,
+                        void *stream);
+int dcomp_unpack_fragment(const uint32_t *packed, int64_t num_env_steps, int32_t num_ue, int32_t num_bs, float *obs, void *stream);
 
 int dcomp_selftest(int op, int width, const double *x, const double *y, double *out, int64_t n, void *stream);
 

@@ -1,0 +1,150 @@
+"""GPU tests of the lossless compact rollout fragment (dcomp_pack_fragment / dcomp_unpack_fragment, include/dcomp.h).
+
+Bar: unpack(pack(rows)) is BIT-identical to the rows -- on observation rows the REFERENCE produced (tests/golden/estack_*,
+traj_grid128x32*, dyn_* fixtures: RelNormEnv.get_ue_obs, single_ue/variants.py:271-305), on the HIP path's own tensors at
+BASELINE sizes (config 3, one GPU's share of config 5), through UE arrival / departure (zero rows of unlisted slots), and the
+packer must refuse -- loudly, by its flag word -- anything it could not restore."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+@pytest.fixture(scope='module')
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def _rows_from_fixture(g):
+    """[T+1, U, 4B+1] float32 rows in RLlib's sorted-key order from a reference-run fixture (reset + every step)."""
+    out = []
+    for pre in ('reset', 'step'):
+        c, d = g[f'{pre}_obs_connected'], g[f'{pre}_obs_dr']
+        out.append(np.concatenate([c, d, g[f'{pre}_obs_ues_at_bs'], g[f'{pre}_obs_util_at_bs'], g[f'{pre}_obs_utility'][..., None]], axis=-1))
+    return np.concatenate(out, axis=0).astype(np.float32)
+
+
+def _bits(t):
+    import torch
+    return t.contiguous().view(torch.int32)
+
+
+@pytest.mark.parametrize('pattern', ['estack_grid32x10_multi_e*.npz', 'traj_grid128x32_multi_s42.npz', 'traj_grid64x16_multi_s42.npz',
+                                     'traj_custom4x4_multi_s4*.npz', 'traj_large8x7_multi_*.npz', 'dyn_*_multi_*.npz'])
+def test_round_trip_on_rows_the_reference_produced(torch_cuda, pattern):
+    torch = torch_cuda
+    from deepcomp_amd.fragment import FragmentCodec
+    files = sorted(glob.glob(os.path.join(GOLDEN, pattern)))
+    assert files
+    for f in files:
+        rows = _rows_from_fixture(np.load(f))
+        T, U, row = rows.shape
+        B = (row - 1) // 4
+        x = torch.from_numpy(rows).cuda()
+        codec = FragmentCodec(U, B)
+        packed = codec.pack(x)
+        assert packed.shape == (T, U * (B + 2) + 2 * B) and packed.dtype == torch.int32
+        y = codec.unpack(packed)
+        codec.check()
+        assert torch.equal(_bits(x), _bits(y)), os.path.basename(f)
+        # the record holds what it says: dr and utility copied, connection bits, the per-env columns once
+        p = packed.cpu().numpy().view(np.uint32).reshape(T, -1)
+        per_ue = p[:, :U * (B + 2)].reshape(T, U, B + 2)
+        assert np.array_equal(per_ue[..., :B].view(np.float32), rows[..., B:2 * B])
+        assert np.array_equal(per_ue[..., B].view(np.float32), rows[..., 4 * B])
+        want_bits = (rows[..., :B] != 0).astype(np.uint64) @ (1 << np.arange(B, dtype=np.uint64))
+        assert np.array_equal(per_ue[..., B + 1].astype(np.uint64), want_bits)
+        assert np.array_equal(p[:, U * (B + 2):].view(np.float32), rows[:, 0, 2 * B:4 * B])
+
+
+@pytest.mark.parametrize('E,U,B,T', [(65536, 32, 10, 1), (4096, 128, 32, 1), (1024, 32, 10, 8), (333, 7, 3, 5), (77, 130, 6, 2), (50, 5, 32, 3),
+                                      (9, 256, 32, 2), (4096, 10, 5, 4), (100, 1, 1, 3)])
+def test_round_trip_on_the_hip_path_at_scale(torch_cuda, E, U, B, T):
+    """The step kernels' own observation tensors, stepped into a [T, E, U, 4B+1] fragment buffer."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    from deepcomp_amd.fragment import FragmentCodec
+    m, bs, ues = build_from_scenario(scenarios.grid_map(B, 'mixed').with_ues(num_slow=U - U // 4, num_fast=U // 4))
+    env = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=E, seed=3, rng='philox', rand_episodes=True)
+    g = torch.Generator(device='cuda').manual_seed(5)
+    frag = torch.empty((T,) + tuple(env.obs.shape), device='cuda')
+    rew = torch.empty((T,) + tuple(env.reward.shape), device='cuda')
+    env.reset()
+    for t in range(6 + T):
+        a = torch.randint(0, B + 1, (E, U), generator=g, device='cuda', dtype=torch.uint8)
+        if t < 6:
+            env.step(a)
+        else:
+            env.step_into(a, frag[t - 6], rew[t - 6])
+    env.check()
+    codec = FragmentCodec(U, B)
+    packed = codec.pack(frag)
+    back = codec.unpack(packed)
+    codec.check()
+    assert packed.shape == (T, E, codec.words) and back.shape == frag.shape
+    assert torch.equal(_bits(frag), _bits(back))
+    assert packed.numel() * 4 * 3 < frag.numel() * 4 or B < 3          # >= 3x smaller (B >= 3)
+    # into caller-provided buffers
+    p2, b2 = torch.empty_like(packed), torch.full_like(frag, 7.0)
+    codec.pack(frag, out=p2); codec.unpack(p2, out=b2)
+    assert torch.equal(p2, packed) and torch.equal(_bits(b2), _bits(frag))
+
+
+def test_round_trip_with_unlisted_ue_slots(torch_cuda):
+    """UE arrival / departure: slots beyond the current list are all-zero rows and must come back as such."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    from deepcomp_amd.fragment import FragmentCodec
+    m, bs, ues = build_from_scenario(scenarios.large_map('mixed').with_ues(num_slow=4, num_fast=2))
+    env = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=300, seed=11, episode_length=40, rng='philox', rand_episodes=True,
+                           ue_arrival={3: 2, 9: -3, 15: 4, 22: -2, 31: 1})
+    codec = FragmentCodec(env.U, env.B)
+    g = torch.Generator(device='cuda').manual_seed(5)
+    env.reset()
+    seen_dead = False
+    for t in range(38):
+        env.step(torch.randint(0, env.B + 1, (300, env.U), generator=g, device='cuda', dtype=torch.uint8))
+        back = codec.unpack(codec.pack(env.obs))
+        assert torch.equal(_bits(env.obs), _bits(back)), t
+        n = env.num_ue
+        if n < env.U:
+            seen_dead = True
+            assert not env.obs[:, n:].any() and env.obs[:, :n, env.B:2 * env.B].amax(-1).eq(1).all()
+    codec.check()
+    assert seen_dead
+
+
+def test_pack_refuses_what_it_could_not_restore(torch_cuda):
+    torch = torch_cuda
+    from deepcomp_amd.fragment import FragmentCodec, fragment_words
+    U, B = 32, 10
+    rows = _rows_from_fixture(np.load(os.path.join(GOLDEN, 'estack_grid32x10_multi_e0.npz')))
+    codec = FragmentCodec(U, B)
+    x = torch.from_numpy(rows).cuda()
+    codec.pack(x); codec.check()
+    bad = x.clone(); bad[3, 5, 2 * B + 1] += 0.25                 # a replica of ues_at_bs that differs from row 0's
+    codec.pack(bad)
+    with pytest.raises(ValueError, match='per-env columns'):
+        codec.check()
+    bad = x.clone(); bad[1, 0, 3] = 0.5                           # `connected` is 0 / 1
+    codec.pack(bad)
+    with pytest.raises(ValueError, match='connected'):
+        codec.check()
+    codec.pack(x); codec.check()                                  # the flag word was cleared
+    assert fragment_words(32, 10) == 32 * 12 + 20 == 404 and fragment_words(128, 32) * 4 == 17664
+    with pytest.raises(ValueError):
+        fragment_words(0, 10)
+    with pytest.raises(ValueError):
+        codec.pack(x[..., :-1].contiguous())
+    with pytest.raises(ValueError):
+        codec.unpack(torch.zeros((4, 403), dtype=torch.int32, device='cuda'))

@@ -1,0 +1,180 @@
+"""Distribution test of the counter-based draws (rng='philox'; SURVEY.md section 7: "statistically tested").
+
+bench.py and every at-scale parity test run in Philox mode: same integer grids and ranges as the reference, not the same
+stream.  HIP == oracle bit-exactly there and the generator itself is pinned on known answers, but nothing held the DRAWS to
+the distributions the reference draws from:
+
+* start position   x ~ randint(0, W), y ~ randint(0, H)                           deepcomp/env/entities/user.py:98-109
+* velocity         'slow' ~ randint(1, 3), 'fast' ~ randint(5, 10)                deepcomp/env/util/movement.py:110-117
+* waypoint         x ~ randint(bb, W - bb), y ~ randint(bb, H - bb)               deepcomp/env/util/movement.py:119-130
+* cadence          arrive -> pause `pause_duration` steps -> redraw and move on   deepcomp/env/util/movement.py:158-181
+
+Two kinds of checks, every one at p > 1e-3:
+(a) one-sample chi-square of each marginal against the exact uniform law of `randint` on its grid (65 536 envs x 32 UEs over
+    several resets and 200 steps: ~2e6 draws per marginal), plus joint / lag tables that a counter-based generator with a bad
+    counter layout would fail (x against y, UE u against UE u + 1, env e against env e + 1, episode k against episode k + 1);
+(b) two-sample chi-square (contingency tables) of the DERIVED statistics against the reference's own stdlib streams run through
+    the same kernels in tape mode (rng='reference': CPython-compatible MT19937 seeded seed + 100 (i + 1), base.py:138-143):
+    number of redraws per UE after 200 steps, the FSM state (pausing, curr_pause), and where the UEs stand after 200 steps.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+P_MIN = 1e-3
+
+
+@pytest.fixture(scope='module')
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def _env(E, rng, seed, L=200, rand_episodes=True, slow=16, fast=16):
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    scn = scenarios.grid_map(10, 'mixed').with_ues(num_slow=slow, num_fast=fast)
+    m, bs, ues = build_from_scenario(scn)
+    env = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=E, seed=seed, episode_length=L, rng=rng, rand_episodes=rand_episodes, log_metrics=False)
+    return env, int(scn.width), int(scn.height)
+
+
+def _uniform_p(values, lo, hi):
+    """One-sample chi-square of integer draws against the uniform law on lo..hi (what random.randint gives)."""
+    from scipy import stats
+    v = np.asarray(values).astype(np.int64).ravel()
+    assert v.min() >= lo and v.max() <= hi, (v.min(), v.max(), lo, hi)
+    cnt = np.bincount(v - lo, minlength=hi - lo + 1)
+    return float(stats.chisquare(cnt).pvalue)
+
+
+def _independence_p(a, b, na, nb):
+    """Chi-square test of independence of two small-integer variables (na x nb contingency table)."""
+    from scipy import stats
+    t = np.bincount(np.asarray(a).ravel().astype(np.int64) * nb + np.asarray(b).ravel().astype(np.int64), minlength=na * nb).reshape(na, nb)
+    return float(stats.chi2_contingency(t)[1])
+
+
+def _two_sample_p(x, y, nbins):
+    """Chi-square homogeneity test of two samples of small integers in [0, nbins); sparse bins (expected < 8) are pooled."""
+    from scipy import stats
+    a = np.bincount(np.asarray(x).ravel().astype(np.int64), minlength=nbins)[:nbins].astype(np.float64)
+    b = np.bincount(np.asarray(y).ravel().astype(np.int64), minlength=nbins)[:nbins].astype(np.float64)
+    tot = a + b
+    exp_min = np.minimum(tot * a.sum() / tot.sum(), tot * b.sum() / tot.sum())
+    keep = exp_min >= 8
+    t = np.stack([np.append(a[keep], a[~keep].sum()), np.append(b[keep], b[~keep].sum())])
+    t = t[:, t.sum(0) > 0]
+    return float(stats.chi2_contingency(t)[1])
+
+
+def test_philox_draws_have_the_reference_distributions(torch_cuda):
+    torch = torch_cuda
+    E, U, B, STEPS = 65536, 32, 10, 200
+    env, W, H = _env(E, 'philox', seed=20260930)
+    bb = 10
+    ps = {}
+    g = torch.Generator(device='cuda').manual_seed(1)
+    acts = torch.randint(0, B + 1, (4, E, U), generator=g, device='cuda', dtype=torch.uint8)
+    first = []
+    for ep in range(3):                                 # several resets: the episode word of the counter moves
+        env.reset()
+        s = env.state_host()
+        first.append(s)
+        x, y = s['pos'][..., 0], s['pos'][..., 1]
+        assert np.array_equal(x, np.floor(x)) and np.array_equal(y, np.floor(y))           # integer grid (user.py:103,107)
+        ps[f'ep{ep} start x'] = _uniform_p(x, 0, W)
+        ps[f'ep{ep} start y'] = _uniform_p(y, 0, H)
+        ps[f'ep{ep} velocity slow'] = _uniform_p(s['vel'][:, :16], 1, 3)
+        ps[f'ep{ep} velocity fast'] = _uniform_p(s['vel'][:, 16:], 5, 10)
+        ps[f'ep{ep} waypoint x'] = _uniform_p(s['wp'][..., 0], bb, W - bb)
+        ps[f'ep{ep} waypoint y'] = _uniform_p(s['wp'][..., 1], bb, H - bb)
+        assert (s['cursor'] == 1).all() and (s['pausing'] == 0).all()
+        if ep < 2:
+            for t in range(7):
+                env.step(acts[t & 3])
+    s0, s1 = first[0], first[1]
+    x0 = s0['pos'][..., 0].astype(np.int64)
+    y0 = s0['pos'][..., 1].astype(np.int64)
+    # joint / lag structure: a counter layout that reuses a word between coordinates, UEs, envs or episodes fails here
+    ps['start x vs y'] = _independence_p(x0 % 8, y0 % 8, 8, 8)
+    ps['start x: UE u vs u+1'] = _independence_p(x0[:, :-1] % 8, x0[:, 1:] % 8, 8, 8)
+    ps['start x: env e vs e+1'] = _independence_p(x0[:-1] % 8, x0[1:] % 8, 8, 8)
+    ps['start x: episode k vs k+1'] = _independence_p(x0 % 8, s1['pos'][..., 0].astype(np.int64) % 8, 8, 8)
+    ps['start x vs waypoint x'] = _independence_p(x0 % 8, s0['wp'][..., 0].astype(np.int64) % 8, 8, 8)
+    ps['waypoint x vs y'] = _independence_p(s0['wp'][..., 0].astype(np.int64) % 8, s0['wp'][..., 1].astype(np.int64) % 8, 8, 8)
+    ps['velocity vs waypoint x (slow)'] = _independence_p(s0['vel'][:, :16].astype(np.int64) - 1, s0['wp'][:, :16, 0].astype(np.int64) % 8, 3, 8)
+    # third episode: 200 steps.  EVERY later draw of the streams (draw number > 1) is counted once, in the step it is made (the
+    # cursor field of the movement word moves): looking at the waypoints "in force" at some step instead would be length-biased --
+    # legs to far waypoints last longer -- and fail for the reference's own streams too.  Histograms are accumulated on the device.
+    from scipy import stats
+    hx = torch.zeros(W + 1, dtype=torch.int64, device='cuda'); hy = torch.zeros(H + 1, dtype=torch.int64, device='cuda')
+    hv = torch.zeros(16, dtype=torch.int64, device='cuda'); hxy = torch.zeros(64, dtype=torch.int64, device='cuda')
+    hvx = torch.zeros(16 * 8, dtype=torch.int64, device='cuda'); hprev = torch.zeros(64, dtype=torch.int64, device='cuda')
+    prev_cur = (env.mv >> 48) & 0xFFFF
+    prev_wx = env.mv & 0xFFFF
+    for t in range(STEPS):
+        env.step(acts[t & 3])
+        mv = env.mv
+        cur = (mv >> 48) & 0xFFFF
+        fresh = cur > prev_cur
+        assert int((cur - prev_cur).max()) <= 1                     # at most one redraw per step (movement.py:158-181)
+        wx, wy, vel = (mv & 0xFFFF)[fresh], ((mv >> 16) & 0xFFFF)[fresh], ((mv >> 32) & 0xFF)[fresh]
+        hx += torch.bincount(wx, minlength=W + 1); hy += torch.bincount(wy, minlength=H + 1)
+        hv += torch.bincount(vel, minlength=16)
+        hxy += torch.bincount((wx % 8) * 8 + wy % 8, minlength=64)
+        hvx += torch.bincount(vel * 8 + wx % 8, minlength=128)
+        hprev += torch.bincount((prev_wx[fresh] % 8) * 8 + wx % 8, minlength=64)      # consecutive draws of one stream
+        prev_cur, prev_wx = cur, mv & 0xFFFF
+    env.check()
+    hx, hy, hv, hxy, hvx, hprev = (h.cpu().numpy() for h in (hx, hy, hv, hxy, hvx, hprev))
+    assert hx.sum() > 4_000_000 and hx[:bb].sum() == 0 and hx[W - bb + 1:].sum() == 0 and hy[:bb].sum() == 0 and hy[H - bb + 1:].sum() == 0
+    assert hv[0] == 0 and hv[4] == 0 and hv[11:].sum() == 0
+    ps['later waypoint x'] = float(stats.chisquare(hx[bb:W - bb + 1]).pvalue)
+    ps['later waypoint y'] = float(stats.chisquare(hy[bb:H - bb + 1]).pvalue)
+    ps['later velocity slow'] = float(stats.chisquare(hv[1:4]).pvalue)
+    ps['later velocity fast'] = float(stats.chisquare(hv[5:11]).pvalue)
+    ps['later waypoint x vs y'] = float(stats.chi2_contingency(hxy.reshape(8, 8))[1])
+    ps['later velocity vs waypoint x'] = float(stats.chi2_contingency(hvx.reshape(16, 8)[[1, 2, 3, 5, 6, 7, 8, 9, 10]])[1])
+    ps['waypoint x: draw k vs k+1'] = float(stats.chi2_contingency(hprev.reshape(8, 8))[1])
+    bad = {k: p for k, p in ps.items() if not p > P_MIN}
+    assert not bad, f'marginals off their reference distribution (p <= {P_MIN}): {bad}\nall: {ps}'
+
+
+def test_philox_movement_cadence_matches_the_stdlib_streams(torch_cuda):
+    """Derived statistics after 200 steps, Philox draws against the reference's own streams (tape mode) through the same kernels."""
+    torch = torch_cuda
+    E, U, B, STEPS = 16384, 32, 10, 200
+    ph, W, H = _env(E, 'philox', seed=7)
+    ref, _, _ = _env(E, 'reference', seed=42, rand_episodes=False)          # base.py:138-143 streams, drawn by the library's MT19937
+    g = torch.Generator(device='cuda').manual_seed(2)
+    acts = torch.randint(0, B + 1, (4, E, U), generator=g, device='cuda', dtype=torch.uint8)
+    out = {}
+    for name, env in (('philox', ph), ('stdlib', ref)):
+        env.reset()
+        for t in range(STEPS):
+            env.step(acts[t & 3])
+        env.check()
+        out[name] = env.state_host()
+    a, b = out['philox'], out['stdlib']
+    ps = {}
+    for grp, sl in (('slow', slice(0, 16)), ('fast', slice(16, 32))):
+        ps[f'redraws per UE after {STEPS} steps ({grp})'] = _two_sample_p(a['cursor'][:, sl], b['cursor'][:, sl], 80)
+        ps[f'FSM state ({grp})'] = _two_sample_p(a['pausing'][:, sl] * 4 + a['curr_pause'][:, sl], b['pausing'][:, sl] * 4 + b['curr_pause'][:, sl], 8)
+        ps[f'velocity in force ({grp})'] = _two_sample_p(a['vel'][:, sl], b['vel'][:, sl], 11)
+
+        def cell(s):
+            x = np.clip(s['pos'][:, sl, 0] / W * 8, 0, 7.999).astype(np.int64)
+            y = np.clip(s['pos'][:, sl, 1] / H * 8, 0, 7.999).astype(np.int64)
+            return x * 8 + y
+        ps[f'position after {STEPS} steps, 8 x 8 cells ({grp})'] = _two_sample_p(cell(a), cell(b), 64)
+        ps[f'connections per UE ({grp})'] = _two_sample_p(np.vectorize(lambda m: bin(int(m)).count('1'))(a['conn'][:, sl]),
+                                                          np.vectorize(lambda m: bin(int(m)).count('1'))(b['conn'][:, sl]), 11)
+    # the cadence itself, exactly: a UE that arrives pauses pause_duration = 2 steps and redraws in the step it moves on
+    # (movement.py:158-181) -- pausing UEs have curr_pause in 0..2, moving ones 0, in both modes
+    for s in (a, b):
+        assert ((s['pausing'] == 1) | (s['curr_pause'] == 0)).all() and s['curr_pause'].max() <= 2
+    bad = {k: p for k, p in ps.items() if not p > P_MIN}
+    assert not bad, f'Philox-mode statistics differ from the stdlib streams (p <= {P_MIN}): {bad}\nall: {ps}'

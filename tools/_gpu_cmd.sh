@@ -1,13 +1,29 @@
 mkdir -p gpurun_out
-python -m pytest tests/test_handoff_gpu.py tests/test_rollout_gpu.py tests/test_parity_gpu.py -m gpu -q -x -k "handoff or driver_form or single_rank or spawns or live_reseed or event_schedule or is_fused or checkpoint or two_ranks" 2>&1 | tail -15 > gpurun_out/r4_a_pytest.log
-tail -15 gpurun_out/r4_a_pytest.log
-python bench.py --steps 20 --warmup 5 2>gpurun_out/r4_a_bench.err | tail -1 > gpurun_out/r4_a_bench.json
-python bench.py --gpus 1 --spawn --steps 20 --warmup 5 --no-cpu-baseline 2>gpurun_out/r4_a_bench_spawn.err | tail -1 > gpurun_out/r4_a_bench_spawn.json
-python -c "
-import json
-for f in ('gpurun_out/r4_a_bench.json','gpurun_out/r4_a_bench_spawn.json'):
-    j=json.load(open(f)); r=j['roofline']
-    print(f, j['value'], j['ms_per_step'], r['kernel_ms'], r['frac'], j.get('handoff'))
-    for k,v in j['also'].items():
-        if isinstance(v, dict): print(' ', k, {a:(round(b,5) if isinstance(b,float) else b) for a,b in v.items() if a in ('value','ms_per_step','kernel_ms','frac_of_hbm_peak','frac_of_hbm_peak_per_gpu') or a.startswith('N')})
-"
+python -m pytest tests -m gpu -q 2>&1 | tail -30 > gpurun_out/r4_b_pytest.log
+tail -30 gpurun_out/r4_b_pytest.log
+python - <<'PY' 2>&1 | tee gpurun_out/r4_b_fragbench.txt
+import torch, time
+from deepcomp_amd.fragment import FragmentCodec
+for (E,U,B) in ((65536,32,10),(4096,128,32),(32768,128,32),(262144,32,10)):
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    m, bs, ues = build_from_scenario(scenarios.grid_map(B, 'mixed').with_ues(num_slow=U))
+    env = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=E, seed=3, rng='philox', rand_episodes=True)
+    env.reset()
+    a = torch.randint(0, B + 1, (E, U), device='cuda', dtype=torch.uint8)
+    for t in range(5): env.step(a)
+    c = FragmentCodec(U,B)
+    p = c.pack(env.obs); o = c.unpack(p)
+    for name, fn in (('pack', lambda: c.pack(env.obs, out=p)), ('unpack', lambda: c.unpack(p, out=o))):
+        for _ in range(20): fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200): fn()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)/200
+        byts = env.obs.numel()*4 + p.numel()*4
+        print(f'{E}x{U}x{B} {name}: {ms*1e3:.1f} us, {byts/1e6:.0f} MB moved, {byts/ms/1e6:.0f} GB/s = {byts/ms/1e6/8000:.3f} of 8 TB/s')
+    c.check()
+    del env
+PY
