@@ -399,6 +399,9 @@ def main():
                          "episode (default); 'obs' = every fragment of --fragment steps of observations + rewards, all-gathered on a side stream "
                          "while the next fragment is being stepped")
     ap.add_argument('--fragment', type=int, default=4, help='steps per rollout fragment for --gather obs and for the post-run obs hand-off probe')
+    ap.add_argument('--compact', action='store_true',
+                    help="--gather obs: hand the observations over as the lossless compact record (dcomp_pack_fragment: U (B + 2) + 2B words per "
+                         "env-step instead of U (4B + 1), 3.2x fewer bytes at 32 x 10); the pack kernel runs inside the timed region")
     ap.add_argument('--gather-every', type=int, default=0,
                     help="--gather summary: steps between two hand-offs (all-gather of the per-env reward + sum_utility since the last one). "
                          "0 = min(episode length, max(4, steps // 2)): at least one collective falls inside ANY timed region")
@@ -494,6 +497,15 @@ def main():
         assert L % F == 0 and K % F == 0 and W % F == 0, "--fragment must divide the episode length, steps and warmup"
         frag_bufs = [{'obs': torch.empty((F,) + tuple(env.obs.shape), device=dev), 'reward': torch.empty((F,) + tuple(env.reward.shape), device=dev)}
                      for _ in range(2)]
+    codec = None
+    if args.compact or (use_dist and not args.no_gather and args.kind == 'multi'):
+        from deepcomp_amd.fragment import FragmentCodec
+        codec = FragmentCodec(U, B, device=dev) if args.kind == 'multi' else None
+    if args.compact and codec is None:
+        sys.exit("bench.py: --compact packs multi-agent observation rows (--kind multi)")
+    if frag_bufs is not None and args.compact:
+        for fb in frag_bufs:
+            fb['packed'] = torch.empty((F, E, codec.words), dtype=torch.int32, device=dev)
 
     def timed_wait(h):
         """h.wait() makes the compute stream wait for the collective; the HIP events around it time that stall on the GPU
@@ -517,7 +529,11 @@ def main():
             frag_pending[k] = None
         env.step_into(pool[t & 15], frag_bufs[k]['obs'][f], frag_bufs[k]['reward'][f])
         if f == F - 1:
-            frag = frag_bufs[k] if args.backend == 'nccl' else {n: v.cpu() for n, v in frag_bufs[k].items()}
+            send = frag_bufs[k]
+            if args.compact:                          # the hand-off carries the compact record, packed here on the compute stream
+                codec.pack(send['obs'], out=send['packed'])
+                send = {'obs_compact': send['packed'], 'reward': send['reward']}
+            frag = send if args.backend == 'nccl' else {n: v.cpu() for n, v in send.items()}
             frag_pending[k] = gather.all_gather_async(frag)
             count_collectives(frag)
             gather_stats['fragments'] += 1
@@ -648,7 +664,7 @@ def main():
     if gather is not None:
         torch.cuda.synchronize(dev)
         stall_ms = sum(a.elapsed_time(b) for a, b in gather_stats.get('stall_events', []))
-        per_frag = F * (env.obs.numel() + env.reward.numel()) * 4
+        per_frag = F * ((E * codec.words if args.compact else env.obs.numel()) + env.reward.numel()) * 4
         handoff = {'mode': args.gather, 'backend': 'rccl' if args.backend == 'nccl' else args.backend, 'rccl_ranks': dist.get_world_size(),
                    'overlapped_on_side_stream': args.backend == 'nccl',
                    # counted where the collectives are ISSUED (count_collectives), reset after the warm-up: what really ran between t0
@@ -657,21 +673,31 @@ def main():
                    'bytes_in_timed_region': {'sent_per_rank': gather_stats['bytes_sent'], 'received_per_rank': gather_stats['bytes_sent'] * world},
                    'compute_stream_stall_ms_total': stall_ms, 'host_blocked_ms_total': gather_stats['wait_s'] * 1e3}
         if args.gather == 'obs':
-            handoff.update(fragment_steps=F, fragments=gather_stats['fragments'], bytes_sent_per_rank_per_fragment=per_frag,
+            handoff.update(fragment_steps=F, fragments=gather_stats['fragments'], compact=bool(args.compact), bytes_sent_per_rank_per_fragment=per_frag,
                            bytes_received_per_rank_per_fragment=per_frag * world,
                            compute_stream_stall_ms_per_fragment=stall_ms / max(1, gather_stats['fragments']))
         else:
             handoff.update(what=f'reward + sum_utility of every env, all-gathered every {G} steps (one collective per tensor), asynchronous',
                            period_steps=G, bytes_sent_per_rank_per_handoff=4 * (env.reward.numel() + E))
 
-    def probe_obs_handoff(nfrag=4):
+    def probe_obs_handoff(nfrag=4, compact=False):
         """The rollout hand-off north_star names, measured next to the headline (never part of `value`): fragments of F steps
         of observations + rewards all-gathered over RCCL on a side stream while the next fragment is stepped."""
         from deepcomp_amd.sharded import RolloutGather
         g2 = gather if gather is not None else RolloutGather(use_side_stream=(args.backend == 'nccl'))
         bufs = [{'obs': torch.empty((F,) + tuple(env.obs.shape), device=dev), 'reward': torch.empty((F,) + tuple(env.reward.shape), device=dev)}
                 for _ in range(2)]
+        if compact:
+            for b_ in bufs:
+                b_['packed'] = torch.empty((F, E, codec.words), dtype=torch.int32, device=dev)
         env.reset()
+
+        def outgoing(k):
+            if not compact:
+                return bufs[k] if args.backend == 'nccl' else {n: v.cpu() for n, v in bufs[k].items()}
+            codec.pack(bufs[k]['obs'], out=bufs[k]['packed'])
+            send = {'obs_compact': bufs[k]['packed'], 'reward': bufs[k]['reward']}
+            return send if args.backend == 'nccl' else {n: v.cpu() for n, v in send.items()}
 
         def steps(k):
             for f in range(F):
@@ -692,16 +718,16 @@ def main():
             if hs[k] is not None:
                 hs[k].wait()
             steps(k)
-            hs[k] = g2.all_gather_async(bufs[k] if args.backend == 'nccl' else {n: v.cpu() for n, v in bufs[k].items()})
+            hs[k] = g2.all_gather_async(outgoing(k))
         for h in hs:
             if h is not None:
                 h.wait()
         ev[3].record()
         fence()
         wall = time.perf_counter() - t0
-        per = F * (env.obs.numel() + env.reward.numel()) * 4
+        per = F * ((E * codec.words if compact else env.obs.numel()) + env.reward.numel()) * 4
         step_ms, both_ms = ev[0].elapsed_time(ev[1]) / nfrag, ev[2].elapsed_time(ev[3]) / nfrag
-        return {'fragment_steps': F, 'fragments': nfrag, 'rccl_ranks': dist.get_world_size(), 'backend': 'rccl' if args.backend == 'nccl' else args.backend,
+        return {'compact': compact, 'fragment_steps': F, 'fragments': nfrag, 'rccl_ranks': dist.get_world_size(), 'backend': 'rccl' if args.backend == 'nccl' else args.backend,
                 'bytes_sent_per_rank_per_fragment': per, 'bytes_received_per_rank_per_fragment': per * world,
                 'ms_per_fragment_stepping_only': step_ms, 'ms_per_fragment_with_overlapped_all_gather': both_ms,
                 'exposed_handoff_ms_per_fragment': max(0.0, both_ms - step_ms), 'wall_s': wall,
@@ -712,6 +738,8 @@ def main():
     if use_dist and args.gather != 'obs' and not args.no_gather:
         try:                                   # a side measurement: it must never cost the headline line
             obs_probe = probe_obs_handoff()
+            if codec is not None:                  # the same hand-off with the lossless compact record (pack kernel included)
+                obs_probe['compact_record'] = probe_obs_handoff(compact=True)
         except Exception as ex:                # noqa: BLE001
             obs_probe = {'error': f'{type(ex).__name__}: {ex}'[:300]}
             torch.cuda.synchronize(dev)

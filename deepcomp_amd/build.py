@@ -100,6 +100,7 @@ def build(force=False, jobs=None, extra_flags=()):
     if not force and up_to_date(extra_flags):
         return LIB
     hipcc = os.environ.get('HIPCC', 'hipcc')
+    stamp_at_start = _fingerprint(extra_flags)      # of the sources as they are NOW: an edit during the (long) build must not be stamped as built
     os.makedirs(OBJ, exist_ok=True)
     jobs = jobs or os.cpu_count() or 4
     tasks = []
@@ -136,7 +137,7 @@ def build(force=False, jobs=None, extra_flags=()):
                 sys.stderr.write(out)
     _run([hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + [t[0] for t in tasks] + ['-lpthread'])
     with open(STAMP, 'w') as f:
-        f.write(_fingerprint(extra_flags) + '\n')
+        f.write(stamp_at_start + '\n')
     return LIB
 
 

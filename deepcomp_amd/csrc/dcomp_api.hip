@@ -60,6 +60,7 @@ struct dcomp_env {
     bool fused;                // kern.step is step_kernel: T steps in one launch (the wide / dynamic kernels step once per launch)
     bool fused_long;           // ... for rollouts of >= 4 steps at ANY batch size (small central rows: see dcomp_create)
     int upad, grid;
+    int wide_grid = 0;         // step_kernel_wide is persistent: workgroups launched (<= what the GPU holds at once), each walks grid / wide_grid slots
     int tight_g, tight_gpw, tight_magic, tight_grid;   // step_kernel's tight packing of non-power-of-two UE lists (0 = off)
     int cap, cur_ue;            // slots per env; UEs currently listed
     uint32_t n_removed, n_arrived;   // this episode (Philox draw words)
@@ -234,7 +235,16 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
             kp.ue_velq = env->d_ue_velq;
         }
     }
-    if (env->kern.step_wide && !kp.any_maxcap && !getenv("DCOMP_NO_WIDE")) env->kern.step = env->kern.step_wide;
+    if (env->kern.step_wide && !kp.any_maxcap && !getenv("DCOMP_NO_WIDE")) {
+        env->kern.step = env->kern.step_wide;
+        // persistent launch: as many workgroups as are resident at once (LDS-bound: 4 per CU at B = 32), never more than there are slots
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(env->kern.step_wide), DCOMP_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || cus < 1) cus = 256;
+        long cap = DCOMP_WIDE_PERSIST ? (long)per_cu * cus : (long)env->grid;      // (one workgroup per slot unless the persistent experiment is built)
+        if (const char *e = getenv("DCOMP_WIDE_GRID")) cap = (DCOMP_WIDE_PERSIST && atol(e) > 0) ? atol(e) : env->grid;
+        env->wide_grid = (int)(cap < env->grid ? cap : env->grid);
+    }
     if (DYN) {
         if (!env->kern.step_dyn) { dcomp_destroy(env); return fail(DCOMP_EUNSUPPORTED, "no dynamic-UE kernel for this shape"); }
         env->kern.step = env->kern.step_dyn;
@@ -327,7 +337,8 @@ static void launch_step(dcomp_env *env, KParams &kp, void *stream)
         hipLaunchKernelGGL(k, dim3(env->tight_grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
         return;
     }
-    hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
+    const int grid = (env->wide_grid && env->kern.step == env->kern.step_wide) ? env->wide_grid : env->grid;
+    hipLaunchKernelGGL(env->kern.step, dim3(grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
 }
 
 static int check_horizon(const dcomp_env *env, int steps)

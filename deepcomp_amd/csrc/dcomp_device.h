@@ -77,6 +77,14 @@
 #define DCOMP_NT_STATE 0     // experiment: bit 0 non-temporal state loads, bit 1 non-temporal state stores
 #endif
 
+// A rarely taken branch that LOADS from global memory (draw tape, velocity table, cluster table) consumes the value inside the
+// branch: the compiler then waits for it (s_waitcnt vmcnt) inside the branch too.  Left to itself it puts the wait at the join,
+// where every wave executes it -- and vmcnt counts loads AND stores in order, so a persistent kernel (step_kernel_wide) would wait
+// there for the previous slot's observation rows to drain, in the middle of its compute phase.
+#define VM_ARRIVED1(a) asm volatile("" : "+v"(a))
+#define VM_ARRIVED2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#define VM_ARRIVED3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+
 namespace dcomp {
 
 // ---- channel constants (station.py:26-30, 110-127): snr = K * (d + 1e-16)^(-GAMMA) -------------------------
@@ -481,6 +489,7 @@ __device__ __forceinline__ void draw_triple(const KParams &p, int env, uint32_t 
         const uint32_t slot = born ? (uint32_t)p.U0 + id0 : id0;
         ushort4 t = p.tape_triples[((size_t)env * p.tape_ids + slot) * p.tape_depth + k];
         vel = t.x; wx = t.y; wy = t.z;
+        VM_ARRIVED3(vel, wx, wy);
     } else {
         uint32_t r[4] = {0x12345678u + k * 977u, 0x9abcdef0u ^ uidw * 2654435761u, 0x0fedcba9u + (uint32_t)env * 40503u, 0u};
         if (!(DCOMP_ABLATE & 128)) philox4x32_10(p.env_base + (uint32_t)env, id0 | (born ? UID_BORN : 0u), episode, k + 1, p.seed_lo, p.seed_hi, r);
@@ -579,7 +588,8 @@ __device__ __forceinline__ void advance_ue(const KParams &p, uint32_t uidw, uint
         velf = (double)vel;
     }
     if (TABLE) {
-        const double2 vq = (uidw & UID_BORN) ? make_double2(-1.0, 0.0) : p.ue_velq[(uidw & 0x7FFFu) - 1u];
+        double2 vq = (uidw & UID_BORN) ? make_double2(-1.0, 0.0) : p.ue_velq[(uidw & 0x7FFFu) - 1u];
+        VM_ARRIVED2(vq.x, vq.y);
         velf = vq.x < 0.0 ? velf : vq.x;
         qmax = vq.x < 0.0 ? qmax : vq.y;
     }
@@ -906,7 +916,7 @@ __device__ __forceinline__ int policy_action_fn(const KParams &p, uint32_t conn,
         sel = 0;
 #pragma unroll 4
         for (int b = 0; b < B; b++) sel |= (dr(b) >= thr ? 1u : 0u) << b;
-    } else if (p.policy == DCOMP_POLICY_CLUSTER) sel = p.policy_cluster[best];
+    } else if (p.policy == DCOMP_POLICY_CLUSTER) { sel = p.policy_cluster[best]; VM_ARRIVED1(sel); }
     const uint32_t drop = conn & ~sel;
     if (drop) return __builtin_ffs((int)drop);
     const uint32_t cand = sel & ~conn;
@@ -934,7 +944,7 @@ __device__ __forceinline__ int policy_action(const KParams &p, uint32_t conn, co
         sel = 0;
 #pragma unroll
         for (int b = 0; b < B; b++) sel |= (dr[b] >= thr ? 1u : 0u) << b;
-    } else if (p.policy == DCOMP_POLICY_CLUSTER) sel = p.policy_cluster[best];      // heuristics.py:172-176
+    } else if (p.policy == DCOMP_POLICY_CLUSTER) { sel = p.policy_cluster[best]; VM_ARRIVED1(sel); }      // heuristics.py:172-176
     const uint32_t drop = conn & ~sel;
     if (drop) return __builtin_ffs((int)drop);                                      // cells outside the set first, index order
     const uint32_t cand = sel & ~conn;

@@ -15,8 +15,8 @@
 // `connected` entry against {0, 1} -- and raises a flag word otherwise, so "lossless" is checked, not assumed.
 //
 // Both kernels are pure streaming kernels (HBM-bound: pack reads 4B + 1 floats per UE and writes B + 2, unpack the reverse):
-// a workgroup moves a chunk of R rows of one env through LDS, global accesses are 16-byte pieces of contiguous spans (global
-// memory needs dword alignment only), the per-row work is a few LDS reads and selects.
+// a wavefront moves a chunk of R <= 32 rows of one env through its own LDS slice, global accesses are 16-byte pieces of
+// contiguous spans (global memory needs dword alignment only), the per-row work is a few LDS reads and selects.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -30,13 +30,18 @@ constexpr int BLOCK = 256;
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));        // 16-byte access at dword alignment
 typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(4)));
 
+__device__ __forceinline__ float4 as_f4(f4u v) { return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint4 as_u4(u4u v) { return make_uint4(v.x, v.y, v.z, v.w); }
+
 struct FragParams {
     const float *obs_in;        // pack: rows in;   unpack: unused
     float *obs_out;             // unpack: rows out
     const uint32_t *packed_in;  // unpack
     uint32_t *packed_out;       // pack
     int32_t *flags;             // pack: bit 0 = a listed row's per-env columns differ from row 0's, bit 1 = `connected` entry not 0 / 1
-    int32_t U, B, R, chunks;    // R rows per chunk, chunks per env
+    int32_t U, B, R, chunks;    // R rows per chunk (one wavefront each), chunks per env
+    int64_t units;              // chunks in all
+    int32_t rows_words, lw_pack, cw_words, lw_unpack;   // LDS words per wave: the rows / all of pack's; the compact words / all of unpack's
     uint32_t magic_row;         // ceil(2^32 / (4B + 1)): f / (4B + 1) = umulhi(f, magic) for f < 2^16 (exact: f (4B + 1) < 2^32)
     uint32_t magic_cw;          // ceil(2^32 / (B + 2))
 };
@@ -44,94 +49,100 @@ struct FragParams {
 // words of one env-step record
 __host__ __device__ inline int env_words(int U, int B) { return U * (B + 2) + 2 * B; }
 
-// LDS: rows of the chunk as they lie in memory (R (4B + 1) floats) | row 0's per-env columns (2B) | per row {conn word, listed}
+// LDS ops of one wave execute in order; this only stops the compiler from moving LDS accesses across it.
+__device__ __forceinline__ void wave_fence()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// One WAVEFRONT moves one chunk (R <= 32 rows of one env) and shares nothing with the other three waves of its workgroup: no
+// workgroup barriers, every wave has its loads in flight on its own (a first version with one 256-thread workgroup per env and
+// four __syncthreads-separated phases ran at 0.38 of the HBM peak at 32 x 10: latency-bound).
+// Per-wave LDS (LW words): the chunk's rows as they lie in memory (R (4B + 1) floats, 16-byte aligned) | row 0's per-env columns (2B).
 __global__ __launch_bounds__(BLOCK) void pack_kernel(const FragParams p)
 {
-    extern __shared__ float lds[];
+    extern __shared__ float4 lds4[];
     const int B = p.B, U = p.U, ROW = 4 * B + 1, CW = B + 2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t env = (int64_t)blockIdx.x / p.chunks;
-    const int chunk = (int)((int64_t)blockIdx.x - env * p.chunks);
-    const int r0 = chunk * p.R, nr = min(p.R, U - r0);
-    const int nf = nr * ROW;
-    float *rows = lds, *t0 = lds + p.R * ROW;
-    uint32_t *connw = reinterpret_cast<uint32_t *>(t0 + 2 * B);          // [R]: bit mask; bit 31 of listed[] below
-    uint32_t *listed = connw + p.R;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t unit = (int64_t)blockIdx.x * (BLOCK / 64) + wave;
+    if (unit >= p.units) return;
+    const int64_t env = unit / p.chunks;
+    const int chunk = (int)(unit - env * p.chunks);
+    const int r0 = chunk * p.R, nr = min(p.R, U - r0), nf = nr * ROW;
+    float *rows = reinterpret_cast<float *>(lds4) + (size_t)wave * p.lw_pack, *t0 = rows + p.rows_words;
     const float *src = p.obs_in + ((size_t)env * U + r0) * ROW;
-    for (int i = tid * 4; i + 3 < nf; i += BLOCK * 4) {
-        const f4u v = __builtin_nontemporal_load(reinterpret_cast<const f4u *>(src + i));     // read once, never again
-        rows[i] = v.x; rows[i + 1] = v.y; rows[i + 2] = v.z; rows[i + 3] = v.w;
-    }
-    if (tid < (nf & 3)) rows[(nf & ~3) + tid] = src[(nf & ~3) + tid];
-    if (tid < 2 * B) t0[tid] = p.obs_in[(size_t)env * U * ROW + 2 * B + tid];                 // row 0 of the env: the per-env columns
-    __syncthreads();
-    // per row: connection bit mask and "listed" (some dr entry is non-zero), two rows per wave pass (B <= 32 lanes each)
+    for (int i = lane * 4; i + 3 < nf; i += 64 * 4)
+        *reinterpret_cast<float4 *>(rows + i) = as_f4(__builtin_nontemporal_load(reinterpret_cast<const f4u *>(src + i)));     // read once, never again
+    if (lane < (nf & 3)) rows[(nf & ~3) + lane] = src[(nf & ~3) + lane];
+    if (lane < 2 * B) t0[lane] = p.obs_in[(size_t)env * U * ROW + 2 * B + lane];              // row 0 of the env: the per-env columns
+    wave_fence();
+    // lane r < 32: row r's `connected` block -> bit mask (and: every entry is 0 or 1), then its ues_at_bs replicas against row 0's;
+    // lane 32 + r: row r's dr block -> "listed" (some entry is non-zero), then its util_at_bs replicas.  Row stride 4B + 1 is odd:
+    // the 32 lanes of a half walk their rows conflict-free.
+    const int r = lane & 31, hi = lane >> 5;
+    const bool mine = r < nr;
+    const float *blk = rows + (mine ? r : 0) * ROW + hi * B;
+    uint32_t mask = 0;
     int bad = 0;
-    for (int r = wave * 2; r < nr; r += (BLOCK / 64) * 2) {
-        const int rr = r + (lane >> 5), b = lane & 31;
-        const bool in = rr < nr && b < B;
-        const float c = in ? rows[rr * ROW + b] : 0.f;
-        const float d = in ? rows[rr * ROW + B + b] : 0.f;
-        if (in && c != 0.f && c != 1.f) bad |= 2;
-        const unsigned long long mc = __ballot(c != 0.f), md = __ballot(d != 0.f);
-        if (b == 0 && rr < nr) {
-            connw[rr] = (uint32_t)(mc >> (lane & 32));
-            listed[rr] = (uint32_t)(md >> (lane & 32)) != 0u;
-        }
+    for (int b = 0; b < B; b++) {
+        const float c = blk[b];
+        mask |= (c != 0.f ? 1u : 0u) << b;
+        bad |= (!hi && c != 0.f && c != 1.f) ? 2 : 0;
     }
-    __syncthreads();
-    // every listed row carries row 0's per-env columns (what unpack will write back)
-    for (int i = tid; i < nr * 2 * B; i += BLOCK) {
-        const int r = i / (2 * B), j = i - r * 2 * B;
-        const uint32_t have = __float_as_uint(rows[r * ROW + 2 * B + j]);
-        const uint32_t want = listed[r] ? __float_as_uint(t0[j]) : 0u;
-        if (have != want) bad |= 1;
+    const uint32_t dmask = (uint32_t)__shfl((int)mask, r + 32, 64);                          // the dr mask of my row (held by lane 32 + r)
+    const bool listed = dmask != 0u;
+    {
+        const float *rep = blk + 2 * B, *want = t0 + hi * B;                                   // ues_at_bs (lanes < 32) | util_at_bs (lanes >= 32)
+        for (int b = 0; b < B; b++) bad |= (__float_as_uint(rep[b]) != (listed ? __float_as_uint(want[b]) : 0u)) ? 1 : 0;
     }
-    if (bad) atomicOr(p.flags, bad);
-    // compact words of this chunk, written as one contiguous span
+    if (mine && bad) atomicOr(p.flags, bad);
+    // the connection words go where the per-row utility float sits in the compact record's neighbour: write them into the rows
+    // buffer's `connected[0]` cell (dead from here on), so that word() below reads everything from one place
+    wave_fence();
+    if (mine && !hi) rows[r * ROW] = __uint_as_float(mask);
+    wave_fence();
     uint32_t *dst = p.packed_out + (size_t)env * env_words(U, B) + (size_t)r0 * CW;
     const int nw = nr * CW;
     auto word = [&](int w) -> uint32_t {
-        const int r = (int)__umulhi((uint32_t)w, p.magic_cw), k = w - r * CW;
-        if (k < B) return __float_as_uint(rows[r * ROW + B + k]);
-        if (k == B) return __float_as_uint(rows[r * ROW + 4 * B]);
-        return connw[r];
+        const int rr = (int)__umulhi((uint32_t)w, p.magic_cw), k = w - rr * CW;
+        const int at = k < B ? B + k : k == B ? 4 * B : 0;                                    // dr[k] | utility | connection mask
+        return __float_as_uint(rows[rr * ROW + at]);
     };
-    for (int w = tid * 4; w + 3 < nw; w += BLOCK * 4) {
+    for (int w = lane * 4; w + 3 < nw; w += 64 * 4) {
         u4u v;
         v.x = word(w); v.y = word(w + 1); v.z = word(w + 2); v.w = word(w + 3);
         *reinterpret_cast<u4u *>(dst + w) = v;
     }
-    if (tid < (nw & 3)) dst[(nw & ~3) + tid] = word((nw & ~3) + tid);
-    if (chunk == 0 && tid < 2 * B) p.packed_out[(size_t)env * env_words(U, B) + (size_t)U * CW + tid] = __float_as_uint(t0[tid]);
+    if (lane < (nw & 3)) dst[(nw & ~3) + lane] = word((nw & ~3) + lane);
+    if (chunk == 0 && lane < 2 * B) p.packed_out[(size_t)env * env_words(U, B) + (size_t)U * CW + lane] = __float_as_uint(t0[lane]);
 }
 
-// LDS: compact words of the chunk (R (B + 2)) | per-env columns (2B) | listed[R]
+// Per-wave LDS: the chunk's compact words (R (B + 2), 16-byte aligned) | per-env columns (2B) | listed[R]
 __global__ __launch_bounds__(BLOCK) void unpack_kernel(const FragParams p)
 {
-    extern __shared__ float lds[];
+    extern __shared__ float4 lds4[];
     const int B = p.B, U = p.U, ROW = 4 * B + 1, CW = B + 2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t env = (int64_t)blockIdx.x / p.chunks;
-    const int chunk = (int)((int64_t)blockIdx.x - env * p.chunks);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t unit = (int64_t)blockIdx.x * (BLOCK / 64) + wave;
+    if (unit >= p.units) return;
+    const int64_t env = unit / p.chunks;
+    const int chunk = (int)(unit - env * p.chunks);
     const int r0 = chunk * p.R, nr = min(p.R, U - r0);
-    uint32_t *cw = reinterpret_cast<uint32_t *>(lds), *t0 = cw + p.R * CW, *listed = t0 + 2 * B;
+    uint32_t *cw = reinterpret_cast<uint32_t *>(lds4) + (size_t)wave * p.lw_unpack, *t0 = cw + p.cw_words, *listed = t0 + 2 * B;
     const uint32_t *src = p.packed_in + (size_t)env * env_words(U, B) + (size_t)r0 * CW;
     const int nw = nr * CW;
-    for (int i = tid * 4; i + 3 < nw; i += BLOCK * 4) {
-        const u4u v = __builtin_nontemporal_load(reinterpret_cast<const u4u *>(src + i));
-        cw[i] = v.x; cw[i + 1] = v.y; cw[i + 2] = v.z; cw[i + 3] = v.w;
+    for (int i = lane * 4; i + 3 < nw; i += 64 * 4)
+        *reinterpret_cast<uint4 *>(cw + i) = as_u4(__builtin_nontemporal_load(reinterpret_cast<const u4u *>(src + i)));
+    if (lane < (nw & 3)) cw[(nw & ~3) + lane] = src[(nw & ~3) + lane];
+    if (lane < 2 * B) t0[lane] = p.packed_in[(size_t)env * env_words(U, B) + (size_t)U * CW + lane];
+    wave_fence();
+    if (lane < nr) {                                                                          // listed <=> some dr entry is non-zero
+        uint32_t any = 0;
+        for (int b = 0; b < B; b++) any |= cw[lane * CW + b] & 0x7FFFFFFFu;                   // (+0 and -0 are both "zero")
+        listed[lane] = any != 0u;
     }
-    if (tid < (nw & 3)) cw[(nw & ~3) + tid] = src[(nw & ~3) + tid];
-    if (tid < 2 * B) t0[tid] = p.packed_in[(size_t)env * env_words(U, B) + (size_t)U * CW + tid];
-    __syncthreads();
-    for (int r = wave * 2; r < nr; r += (BLOCK / 64) * 2) {
-        const int rr = r + (lane >> 5), b = lane & 31;
-        const bool in = rr < nr && b < B;
-        const unsigned long long md = __ballot(in && __uint_as_float(cw[rr * CW + b]) != 0.f);
-        if (b == 0 && rr < nr) listed[rr] = (uint32_t)(md >> (lane & 32)) != 0u;
-    }
-    __syncthreads();
+    wave_fence();
     float *dst = p.obs_out + ((size_t)env * U + r0) * ROW;
     const int nf = nr * ROW;
     auto val = [&](int f) -> float {
@@ -142,20 +153,20 @@ __global__ __launch_bounds__(BLOCK) void unpack_kernel(const FragParams p)
         if (c < 4 * B) return listed[r] ? __uint_as_float(t0[c - 2 * B]) : 0.f;     // ues_at_bs | util_at_bs   variants.py:296-299
         return __uint_as_float(q[B]);                                               // utility            variants.py:287
     };
-    for (int f = tid * 4; f + 3 < nf; f += BLOCK * 4) {
+    for (int f = lane * 4; f + 3 < nf; f += 64 * 4) {
         f4u v;
         v.x = val(f); v.y = val(f + 1); v.z = val(f + 2); v.w = val(f + 3);
         __builtin_nontemporal_store(v, reinterpret_cast<f4u *>(dst + f));           // write-once stream for the learner
     }
-    if (tid < (nf & 3)) dst[(nf & ~3) + tid] = val((nf & ~3) + tid);
+    if (lane < (nf & 3)) dst[(nf & ~3) + lane] = val((nf & ~3) + lane);
 }
 
 static int rows_per_chunk(int U, int B)
 {
-    // <= 24 KB of rows per workgroup: six workgroups per CU keep enough loads in flight; whole envs where they fit
-    const int cap = (24 * 1024) / ((4 * B + 1) * 4);
+    // <= 8 KB of rows per wave (five 4-wave workgroups per CU), <= 32 rows (one lane per row in each half-wave); whole envs where they fit
+    const int cap = (8 * 1024) / ((4 * B + 1) * 4);
     int R = U < cap ? U : cap;
-    if (R > 1) R &= ~1;                                       // (two rows per wave pass)
+    if (R > 32) R = 32;
     return R < 1 ? 1 : R;
 }
 
@@ -165,12 +176,18 @@ static int fill(FragParams &p, int64_t n, int U, int B, int &grid, size_t &lds_p
     p.U = U; p.B = B;
     p.R = rows_per_chunk(U, B);
     p.chunks = (U + p.R - 1) / p.R;
-    if (n * p.chunks > 0x7FFFFFFFll) return DCOMP_EINVAL;
-    grid = (int)(n * p.chunks);
+    p.units = n * p.chunks;
+    const int64_t blocks = (p.units + BLOCK / 64 - 1) / (BLOCK / 64);
+    if (blocks > 0x7FFFFFFFll) return DCOMP_EINVAL;
+    grid = (int)blocks;
     p.magic_row = (uint32_t)(0x100000000ull / (uint32_t)(4 * B + 1)) + 1u;
     p.magic_cw = (uint32_t)(0x100000000ull / (uint32_t)(B + 2)) + 1u;
-    lds_pack = ((size_t)p.R * (4 * B + 1) + 2 * B + 2 * p.R) * 4;
-    lds_unpack = ((size_t)p.R * (B + 2) + 2 * B + p.R) * 4;
+    p.rows_words = (p.R * (4 * B + 1) + 3) & ~3;
+    p.lw_pack = (p.rows_words + 2 * B + 3) & ~3;
+    p.cw_words = (p.R * (B + 2) + 3) & ~3;
+    p.lw_unpack = (p.cw_words + 2 * B + p.R + 3) & ~3;
+    lds_pack = (size_t)p.lw_pack * 4 * (BLOCK / 64);
+    lds_unpack = (size_t)p.lw_unpack * 4 * (BLOCK / 64);
     return DCOMP_OK;
 }
 

@@ -29,6 +29,21 @@ namespace dcomp {
 #ifndef DCOMP_WIDE_PC
 #define DCOMP_WIDE_PC 8          // stations per trip of the dense post-move pair evaluation (BS positions: one s_load burst per trip)
 #endif
+#ifndef DCOMP_WIDE_QUAD_ROWS
+#define DCOMP_WIDE_QUAD_ROWS 1   // B % 4 == 0: observation rows leave as 16-byte pieces, a half-wave per row (0: round-3 form, 4-byte columns; A/B)
+#endif
+#ifndef DCOMP_WIDE_NT_ROWS
+#define DCOMP_WIDE_NT_ROWS 0     // non-temporal 16-byte row stores (A/B)
+#endif
+#ifndef DCOMP_WIDE_UTIL_EACH
+#define DCOMP_WIDE_UTIL_EACH 1   // the utility float of a row (its last) is stored in the trip that stores the row, not every other trip: the
+#endif                           // line it completes leaves L2 whole (32 768 envs: -3 %; tools/micro/store_patterns.hip pattern 5 vs 1)
+#ifndef DCOMP_WIDE_PERSIST
+#define DCOMP_WIDE_PERSIST 0     // experiment (round 4): persistent workgroups that request the next slot's state before they store this one's rows
+#endif
+#ifndef DCOMP_WIDE_STORE_PRIO
+#define DCOMP_WIDE_STORE_PRIO 0  // A/B: the row-store loop (1) / everything behind the step's last barrier (2) at raised issue priority: +-0.2 %
+#endif
 #ifndef DCOMP_WIDE_K
 #define DCOMP_WIDE_K 4           // connections per UE the register fast paths hold; a wave with a busier UE takes the LDS detours
 #endif
@@ -46,9 +61,10 @@ struct alignas(16) WideShared {
         float nb_rb[256];                 // 'sum' reward: reward_before of the block's UEs (after part_b's last reader)
     };
     double2 bs[32];                       // BS positions, indexed PER LANE in the sparse passes
+    float4 nib[16];                       // `connected` pieces of the observation rows: entry n = the four floats of nibble n
     float xw[2][4];                       // central reward: per-wave partials
 };
-// (39.6 KB at B = 32: four workgroups per CU, as before)
+// (39.8 KB at B = 32: four workgroups per CU, as before -- the limit is 40 KB)
 
 template <int B>
 __device__ __forceinline__ int wide_col(int row, int c) { return row * (B + 1) + c; }
@@ -95,45 +111,57 @@ __device__ __forceinline__ float2 wide_rate_sums(SH &sh, int wave, int lane)
     return make_float2(nf, a);
 }
 
-template <int B, int UPAD, int MP>
-__global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
+// State of one UE as the step reads it, and the per-UE configuration (the same in every env).
+struct WideIn { double px, py; unsigned long long mv; uint32_t conn; float ewma; uint32_t act; };
+struct WideCfg { bool step_util; float dr_req; int vrange; };
+
+// The state of this lane's UE in the envs of workgroup-slot g (the loads are issued here; whoever reads the fields waits for them).
+template <int UPAD>
+__device__ __forceinline__ WideIn wide_load(const KParams &p, int g)
 {
-    static_assert(UPAD >= 64, "wide kernel: one wavefront holds UEs of a single env");
+    constexpr int NW = UPAD / 64, GPB = 256 / UPAD;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int env = g * GPB + wave / NW, u = (wave % NW) * 64 + lane;
+    WideIn in{0.0, 0.0, 0ull, 0u, 0.f, 0u};
+    if (env < p.E && u < p.U) {
+        const int idx = env * p.U + u;
+        const double2 q = p.pos[idx];
+        in.px = q.x; in.py = q.y;
+        in.mv = p.mv[idx];
+        in.conn = p.conn[idx];
+        in.ewma = p.ewma[idx];
+        in.act = p.action[idx];
+    }
+    return in;
+}
+
+// One MobileEnv.step of the GPB envs of workgroup-slot g.  `in`: their state (already requested); on return it holds the state of
+// slot g_next when has_next -- requested before this slot's observation rows are stored, see step_kernel_wide.
+template <int B, int UPAD, int MP>
+__device__ __forceinline__ void wide_step_one(const KParams &p, WideShared<B, UPAD> &sh, const int32_t *lds_modes, const WideCfg cfg,
+                                              const int g, WideIn &in, const bool has_next, const int g_next)
+{
     constexpr int NW = UPAD / 64, GPB = 256 / UPAD, ROW = 4 * B + 1, K = DCOMP_WIDE_K, PC = DCOMP_WIDE_PC;
     using SH = WideShared<B, UPAD>;
-    __shared__ SH sh;
-    __shared__ int32_t lds_modes[32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (the thread index is hidden from the optimiser once per slot: everything derived from it -- lane constants, table addresses,
+    // output offsets -- would otherwise be hoisted out of step_kernel_wide's slot loop and live in ~100 extra VGPRs across it)
+    int tid = threadIdx.x;
+    if (DCOMP_WIDE_PERSIST) asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const int env_local = wave / NW, u = (wave % NW) * 64 + lane;
-    const int env = blockIdx.x * GPB + env_local;
+    const int env = g * GPB + env_local;
     const bool active = (env < p.E) && (u < p.U);
     const int idx = env * p.U + u;
     const int w0 = (wave / NW) * NW;                               // first wave of my env
-    if (tid < B) { sh.bs[tid] = make_double2(p.bs_x[tid], p.bs_y[tid]); lds_modes[tid] = p.bs_mode[tid]; }
 
-    double px = 0.0, py = 0.0;
-    unsigned long long mv = 0;
-    uint32_t conn = 0, act = 0;
-    float ewma = 0.f;
-    bool step_util = false;
-    float dr_req = 1.f;
-    int vrange = MV_CFG_ARRIVED;
-    if (active) {
-        double2 q = p.pos[idx];
-        px = q.x; py = q.y;
-        mv = p.mv[idx];
-        conn = p.conn[idx];
-        ewma = p.ewma[idx];
-        act = p.action[idx];
-        {                                                            // loaded here, next to the state, not in the middle of the move
-            const UeCfg c = p.ue_cfg[u];
-            step_util = c.util == DCOMP_UTIL_STEP; dr_req = c.dr_req;
-            vrange = mv_cfg_pack(c.vel_lo, c.vel_hi, c.pause, c.border);
-        }
-    }
+    double px = in.px, py = in.py;
+    unsigned long long mv = in.mv;
+    uint32_t conn = in.conn, act = in.act;
+    float ewma = in.ewma;
+    const bool step_util = cfg.step_util;
+    const float dr_req = cfg.dr_req;
+    const int vrange = cfg.vrange;
     if (act > (uint32_t)B) { atomicOr(p.flags, DCOMP_FLAG_BAD_ACTION); act = 0; }
-
-    __syncthreads();                                                              // BS table
 
     float *const st = sh.drst[wave];
     float *const myrow = st + wide_col<B>(lane, 0);
@@ -363,6 +391,21 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
         p.conn[idx] = conn;
         p.ewma[idx] = ewma;
     }
+    // The next slot's state is requested HERE, before this slot's observation rows are stored, and its arrival is awaited right
+    // before the first row store (wide_arrived): vmcnt counts loads and stores in one in-order counter, so a load issued after
+    // the 40 row stores could only be waited for together with them -- the wave would sit out the drain of its own stores before
+    // it could compute again.  This way the rows of slot g drain while the wave computes slot g + grid (step_kernel_wide).
+    // (Unconditional on purpose -- the last slot of a workgroup requests its own state again and drops it: the compiler does not
+    // see that a conditional request and a conditional wait share their condition, and would guard every later write of these
+    // registers, and the top of the slot loop, with a wait for "the request that was never awaited".)
+    WideIn nx{0.0, 0.0, 0ull, 0u, 0.f, 0u};
+    if (DCOMP_WIDE_PERSIST) nx = wide_load<UPAD>(p, has_next ? g_next : g);
+    auto wide_arrived = [&]() {
+        if (DCOMP_WIDE_PERSIST) {
+            asm volatile("" : "+v"(nx.px), "+v"(nx.py), "+v"(nx.mv), "+v"(nx.conn), "+v"(nx.ewma), "+v"(nx.act));   // a use: the compiler's s_waitcnt goes here
+            in = nx;
+        }
+    };
 
     // ---- 7. per-BS utility aggregates (station.py:63-83), transposed like the rate sums: what a station needs -- |S_b|, sum and
     // min of the utilities of its UEs -- is a function of just TWO words per UE (connection mask, utility).
@@ -396,6 +439,9 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
         if (lane < 32) sh.part_a[wave][sb] = make_float4(my_cnt, t, mn, ta);     // (the pre-move sums in part_a were consumed before the barrier of step 6)
     }
     __syncthreads();                                                              // per-wave tables (and nb_*) visible to the block
+#if DCOMP_WIDE_STORE_PRIO == 2
+    __builtin_amdgcn_s_setprio(3);                 // (A/B: everything behind the last barrier of the step at raised priority)
+#endif
     auto station = [&](int b) -> float4 {                                         // totals of station b over the env's waves
         float4 a = sh.part_a[w0][b];
 #pragma unroll
@@ -458,6 +504,7 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
     const float util_n = util * (1.0f / MAX_UTIL);
 
     // ---- observation
+    wide_arrived();
     if (!multi) {                                                                 // central.py:31-57: connected | dr | utility blocks
         if (active) {
             float *base = p.obs + (size_t)env * p.U * (2 * B + 1);
@@ -470,6 +517,100 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
             if (p.next_act)                                                       // dcomp_set_policy: the rules on the entries just stored
                 p.next_act[idx] = (uint8_t)policy_action_fn<B>(p, conn, [&](int b) { return fast_exp2(cell(b) - l2max); });
         }
+        return;
+    }
+    if constexpr (B % 4 == 0 && DCOMP_WIDE_QUAD_ROWS) {
+        // ---- rows leave as 16-BYTE pieces, a half-wave per row (round 4).  With B a multiple of 4 the four blocks of a row start at
+        // multiples of 4 floats, so piece j (floats 4j .. 4j+3, j < B) of a row lies inside ONE block: lanes 0 .. B-1 of a half-wave
+        // take the B pieces of one row -- a lane's kind of column is a constant of the whole loop -- and one store instruction
+        // covers two whole rows (2 x 4B floats contiguous but for the utility float in between): 32 + 8 store instructions per
+        // wave instead of 128 + 16 four-byte ones.  Global memory needs dword alignment only.  EVERY piece comes out of LDS with one
+        // ds_read_b128, so the loop has no per-kind branches: `dr` pieces from the re-laid rows, the per-env columns from a 16-piece
+        // table the wave builds once, `connected` from a constant table of the 16 possible nibbles (sh.nib).
+        constexpr int QPR = B / 4;                                                // 16-byte pieces per block of a row
+        float drv[B];
+#pragma unroll
+        for (int b = 0; b < B; b++) drv[b] = fast_exp2(cell(b) - l2max);                          // variants.py:276-284
+        if (p.next_act) {                                                         // dcomp_set_policy (uniform): the rules on this UE's dr row
+            const int a = policy_action<B>(p, conn, drv);
+            if (active) p.next_act[idx] = (uint8_t)a;
+        }
+        // The dr entries are read back by OTHER lanes, 16 bytes at a time: rows at stride B words, the pieces of row l rotated by l
+        // (piece q in slot (q + l) mod QPR): eight consecutive lanes writing their piece q -- and the QPR lanes reading one row --
+        // touch every bank once.  The rows overlap the old stride-(B + 1) layout: every lane has read its row before any is rewritten.
+        wave_lds_fence();
+        float4 *const qst = reinterpret_cast<float4 *>(st);
+        {
+            const int rot = lane % QPR;
+#pragma unroll
+            for (int q = 0; q < QPR; q++) {
+                int s = q + rot;
+                s -= s >= QPR ? QPR : 0;
+                qst[lane * QPR + s] = make_float4(drv[4 * q], drv[4 * q + 1], drv[4 * q + 2], drv[4 * q + 3]);
+            }
+        }
+        const int h = lane >> 5, j = lane & 31;
+        const int kind = j / QPR, q = j - kind * QPR;                             // 0 connected | 1 dr | 2 ues_at_bs | 3 util_at_bs (j < B)
+        // the per-env columns, 2 QPR pieces, in the 64 words the re-laid rows leave free at the end of the wave's region
+        float4 *const envq = qst + 64 * QPR;
+        static_assert(64 * (B + 1) - 64 * B >= 8 * QPR, "the per-env pieces live behind the re-laid rows");
+        if (kind >= 2 && j < B && h == 0) {
+            float e[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float4 t = station(4 * q + k);
+                e[k] = kind == 2 ? t.x * inv_u                                                          // variants.py:296
+                                 : (t.x > 0.f ? t.y * fast_rcp(t.x) * (1.0f / MAX_UTIL) : 0.f);         // variants.py:299
+            }
+            envq[j - 2 * QPR] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+        wave_lds_fence();                                                         // the re-laid rows and the table are this wave's own
+        const unsigned long long am = __ballot(active);
+        const int nrows = group_popcount<64>(am, 0);                              // active lanes are lanes [0, nrows)
+        const size_t row0 = (size_t)env * p.U + (size_t)(wave % NW) * 64;
+        float *const out0 = p.obs + (row0 + h) * ROW + 4 * j;                     // this lane's piece of row 2i + h, at i = 0
+        const int npairs = (DCOMP_ABLATE & 8) ? 0 : (nrows + 1) >> 1;
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        // where this lane's piece of row 2i + h waits
+        auto piece = [&](int i) -> const float4 * {
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)conn, 2 * i);
+            const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)conn, 2 * i + 1);
+            const uint32_t nib = ((h ? c1 : c0) >> (4 * q)) & 15u;
+            int slot = (q + h + 2 * i) % QPR;                                     // (q + r) mod QPR, r = 2i + h   (QPR = 8: an AND)
+            const float4 *a = kind == 1 ? qst + (2 * i + h) * QPR + slot : envq + (j - 2 * QPR);
+            return kind == 0 ? sh.nib + nib : a;
+        };
+        auto put = [&](int i, const float4 v) {
+            if (j < B && 2 * i + h < nrows) {
+                f4u w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+                f4u *dst = reinterpret_cast<f4u *>(out0 + (size_t)i * (2 * ROW));
+#if DCOMP_WIDE_NT_ROWS
+                __builtin_nontemporal_store(w, dst);
+#else
+                *dst = w;
+#endif
+            }
+        };
+#if DCOMP_WIDE_STORE_PRIO == 1
+        __builtin_amdgcn_s_setprio(3);             // see step_kernel_wide: a wave that has rows to store goes first
+#endif
+        for (int i = 0; i < npairs; i += 2) {                                     // two row pairs per trip: both LDS reads in flight
+            const int i1 = min(i + 1, 31);
+            const float4 *a0 = piece(i), *a1 = piece(i1);
+            const float4 v0 = *a0, v1 = *a1;
+            put(i, v0);
+            if (i + 1 < npairs) put(i + 1, v1);
+            // the utility column (the row's last float) of the eight rows just completed: their own lanes store it, right behind
+#if DCOMP_WIDE_UTIL_EACH
+            if ((lane >> 2) == (i >> 1) && active) p.obs[(row0 + lane) * ROW + 4 * B] = util_n;      // the four rows of this trip, at once
+#else
+            if (((i & 2) || i + 2 >= npairs) && (lane >> 3) == (i >> 2) && active)
+                p.obs[(row0 + lane) * ROW + 4 * B] = util_n;
+#endif
+        }
+#if DCOMP_WIDE_STORE_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         return;
     }
     // the per-UE dr columns: normalise in place, the row loop reads them column-wise (lane r's row -> output row r)
@@ -539,6 +680,55 @@ __global__ __launch_bounds__(256) void step_kernel_wide(const KParams p)
         }
         if (lane < 4 && r0 + lane < nrows)
             p.obs[(row0 + r0 + lane) * ROW + 4 * B] = __uint_as_float(sh.row_ci[wave * 64 + r0 + lane].y) * (1.0f / MAX_UTIL);
+    }
+}
+
+// One workgroup per slot (GPB envs).  DCOMP_WIDE_PERSIST = 1 is the round-4 experiment that did NOT pay: persistent workgroups
+// (at most as many as the GPU holds at once, each walking the slots g, g + grid, ...) that request the next slot's state before
+// they store this slot's rows, so that a wave computes while its own rows drain -- vmcnt counts loads and stores in one in-order
+// counter, so every wait for a load inside the slot loop had to go (VM_ARRIVED in the rare branches, the unconditional request).
+// Same-box A/B: 4 096 x 128 x 32 54.5 -> 60.2 us, 32 768 envs 515 -> 541 us.  The slot loop costs 67 scalar spills and the
+// 128-VGPR cap, and the overlap it was built for does not come from a wave's own stores draining: a wave in its store loop is
+// held at ISSUE while the CU's memory pipe is backed up (tools/micro/store_patterns.hip: the rows alone take 39.5 us at 4 096
+// envs, 410-450 us at 32 768), and while it is held its SIMD can only run the OTHER waves.  What helps is that the storing wave
+// never waits for an issue slot behind computing waves: DCOMP_WIDE_STORE_PRIO.
+template <int B, int UPAD, int MP>
+__global__ __launch_bounds__(256, DCOMP_WIDE_PERSIST ? 4 : 1) void step_kernel_wide(const KParams p)
+{
+    static_assert(UPAD >= 64, "wide kernel: one wavefront holds UEs of a single env");
+    constexpr int NW = UPAD / 64, GPB = 256 / UPAD;
+    using SH = WideShared<B, UPAD>;
+    __shared__ SH sh;
+    __shared__ int32_t lds_modes[32];
+    const int tid = threadIdx.x;
+    const int total = (p.E + GPB - 1) / GPB;
+    WideIn in = wide_load<UPAD>(p, blockIdx.x);
+    WideCfg cfg{false, 1.f, MV_CFG_ARRIVED};
+    {
+        const int u = ((tid >> 6) % NW) * 64 + (tid & 63);
+        if (u < p.U) {
+            const UeCfg c = p.ue_cfg[u];
+            cfg.step_util = c.util == DCOMP_UTIL_STEP; cfg.dr_req = c.dr_req;
+            cfg.vrange = mv_cfg_pack(c.vel_lo, c.vel_hi, c.pause, c.border);
+        }
+    }
+    if (DCOMP_WIDE_PERSIST) {
+        // the first slot's state has ARRIVED before the slot loop: inside it no wait for a load may remain
+        asm volatile("" : "+v"(in.px), "+v"(in.py), "+v"(in.mv), "+v"(in.conn), "+v"(in.ewma), "+v"(in.act));
+        asm volatile("" : "+v"(cfg.dr_req), "+v"(cfg.vrange));
+    }
+    if (tid < B) { sh.bs[tid] = make_double2(p.bs_x[tid], p.bs_y[tid]); lds_modes[tid] = p.bs_mode[tid]; }
+    if (tid >= 64 && tid < 80) { const int n = tid - 64; sh.nib[n] = make_float4((float)(n & 1), (float)((n >> 1) & 1), (float)((n >> 2) & 1), (float)(n >> 3)); }
+    __syncthreads();                                                              // BS table, nibble table
+    if (!DCOMP_WIDE_PERSIST) {
+        wide_step_one<B, UPAD, MP>(p, sh, lds_modes, cfg, (int)blockIdx.x, in, false, 0);
+        return;
+    }
+#pragma unroll 1
+    for (int g = blockIdx.x; g < total; g += gridDim.x) {
+        const int gn = g + gridDim.x;
+        wide_step_one<B, UPAD, MP>(p, sh, lds_modes, cfg, g, in, gn < total, gn);
+        if (gn < total) __syncthreads();                  // this slot's per-station tables are read until its waves have built their pieces
     }
 }
 

@@ -422,10 +422,10 @@ class BatchedMobileEnv:
             else:
                 if self._reseeded:                        # seed() since the last reset: the new Philox key starts here
                     _lib.check(self._L.dcomp_set_seed(self._h, ctypes.c_uint64(int(self.seed_value) & 0xFFFFFFFFFFFFFFFF)))
-                    self._device_seed = self.seed_value
                 if not self.rand_episodes or self._reseeded:
                     self._L.dcomp_set_episode(self._h, 0)     # fixed episodes: same Philox counter word every reset
             self._reseeded = False
+            self._device_seed = self.seed_value            # the seed this episode's draws come from (tape drawn / key installed above)
             _lib.check(self._L.dcomp_reset(self._h, ctypes.byref(self._st), ctypes.byref(tape) if tape else None,
                                            ctypes.byref(self._out), self._stream()))
         if self._policy_key is not None:

@@ -106,6 +106,9 @@ def test_philox_draws_have_the_reference_distributions(torch_cuda):
     ps['start x vs waypoint x'] = _independence_p(x0 % 8, s0['wp'][..., 0].astype(np.int64) % 8, 8, 8)
     ps['waypoint x vs y'] = _independence_p(s0['wp'][..., 0].astype(np.int64) % 8, s0['wp'][..., 1].astype(np.int64) % 8, 8, 8)
     ps['velocity vs waypoint x (slow)'] = _independence_p(s0['vel'][:, :16].astype(np.int64) - 1, s0['wp'][:, :16, 0].astype(np.int64) % 8, 3, 8)
+    xs, vs = x0[:, :16].ravel(), s0['vel'][:, :16].astype(np.int64).ravel()
+    ps['start x block vs velocity (slow)'] = _independence_p(xs[xs < 384] // 128, vs[xs < 384] - 1, 3, 3)      # (the reference's own streams FAIL this one, below)
+    ps['start y vs waypoint x'] = _independence_p(y0 % 8, (s0['wp'][..., 0].astype(np.int64) - bb) % 8, 8, 8)
     # third episode: 200 steps.  EVERY later draw of the streams (draw number > 1) is counted once, in the step it is made (the
     # cursor field of the movement word moves): looking at the waypoints "in force" at some step instead would be length-biased --
     # legs to far waypoints last longer -- and fail for the reference's own streams too.  Histograms are accumulated on the device.
@@ -147,8 +150,19 @@ def test_philox_movement_cadence_matches_the_stdlib_streams(torch_cuda):
     """Derived statistics after 200 steps, Philox draws against the reference's own streams (tape mode) through the same kernels."""
     torch = torch_cuda
     E, U, B, STEPS = 16384, 32, 10, 200
+    from deepcomp_amd import rng as _rng
     ph, W, H = _env(E, 'philox', seed=7)
     ref, _, _ = _env(E, 'reference', seed=42, rand_episodes=False)          # base.py:138-143 streams, drawn by the library's MT19937
+
+    # The reference seeds a UE's position stream and its movement stream with the SAME number (base.py:138-143), so the first
+    # draws of the two are functions of the same generator outputs (test_reference_streams_share_their_first_draws below): a slow
+    # UE's first velocity is its start x // 128 + 1.  That accident is not a property of the distributions; the comparison here is
+    # with stdlib streams drawn as user.py:98-109 and movement.py:110-130 draw them, the two streams seeded apart.
+    def independent_streams():
+        pos0, _ = _rng.mt_tape(ref._cfg, ref.env_seeds, ref.tape_depth)
+        _, trip = _rng.mt_tape(ref._cfg, ref.env_seeds + 7, ref.tape_depth)       # base + 100 (i + 1) + 7: no stream of the first set
+        return pos0, trip
+    ref._draw_tape = independent_streams
     g = torch.Generator(device='cuda').manual_seed(2)
     acts = torch.randint(0, B + 1, (4, E, U), generator=g, device='cuda', dtype=torch.uint8)
     out = {}
@@ -178,3 +192,22 @@ def test_philox_movement_cadence_matches_the_stdlib_streams(torch_cuda):
         assert ((s['pausing'] == 1) | (s['curr_pause'] == 0)).all() and s['curr_pause'].max() <= 2
     bad = {k: p for k, p in ps.items() if not p > P_MIN}
     assert not bad, f'Philox-mode statistics differ from the stdlib streams (p <= {P_MIN}): {bad}\nall: {ps}'
+
+
+def test_reference_streams_share_their_first_draws(torch_cuda):
+    """A property of the REFERENCE that the distribution tests had to know about (found by the cadence test above): base.py:138-143
+    seeds a UE's position generator and its movement generator with the same number, so `randint(0, W)` (user.py:103) and the first
+    `randint(1, 3)` (movement.py:112) read the same 32-bit output -- start x in 0..127 / 128..255 / 256..383 ALWAYS comes with a
+    first velocity of 1 / 2 / 3 on a 400 m map -- and start y / first waypoint x likewise share one.  rng='reference' reproduces it
+    (it replays the reference's streams bit for bit); rng='philox' draws every quantity independently."""
+    env, W, H = _env(256, 'reference', seed=42, rand_episodes=False, L=20)
+    assert W == 400
+    env.reset()
+    s = env.state_host()
+    x = s['pos'][:, :16, 0].astype(np.int64).ravel()
+    v = s['vel'][:, :16].astype(np.int64).ravel()
+    sel = x < 384
+    assert sel.sum() > 3000 and np.array_equal(v[sel], 1 + x[sel] // 128)
+    y = s['pos'][..., 1].astype(np.int64).ravel()
+    wx = s['wp'][..., 0].astype(np.int64).ravel()
+    assert (wx == y + 10).mean() > 0.7            # both are the top 9 bits of one output word whenever neither draw rejects it

@@ -1,29 +1,5 @@
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -q 2>&1 | tail -30 > gpurun_out/r4_b_pytest.log
-tail -30 gpurun_out/r4_b_pytest.log
-python - <<'PY' 2>&1 | tee gpurun_out/r4_b_fragbench.txt
-import torch, time
-from deepcomp_amd.fragment import FragmentCodec
-for (E,U,B) in ((65536,32,10),(4096,128,32),(32768,128,32),(262144,32,10)):
-    from deepcomp_amd import scenarios
-    from deepcomp_amd.entities import build_from_scenario
-    from deepcomp_amd.env import BatchedMobileEnv
-    m, bs, ues = build_from_scenario(scenarios.grid_map(B, 'mixed').with_ues(num_slow=U))
-    env = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=E, seed=3, rng='philox', rand_episodes=True)
-    env.reset()
-    a = torch.randint(0, B + 1, (E, U), device='cuda', dtype=torch.uint8)
-    for t in range(5): env.step(a)
-    c = FragmentCodec(U,B)
-    p = c.pack(env.obs); o = c.unpack(p)
-    for name, fn in (('pack', lambda: c.pack(env.obs, out=p)), ('unpack', lambda: c.unpack(p, out=o))):
-        for _ in range(20): fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(200): fn()
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1)/200
-        byts = env.obs.numel()*4 + p.numel()*4
-        print(f'{E}x{U}x{B} {name}: {ms*1e3:.1f} us, {byts/1e6:.0f} MB moved, {byts/ms/1e6:.0f} GB/s = {byts/ms/1e6/8000:.3f} of 8 TB/s')
-    c.check()
-    del env
-PY
+export DCOMP_BUILD_B=32
+V=$GRAFT_REPO_ROOT/deepcomp_amd/csrc/variants
+DCOMP_LIB=$V/libdcomp_hip_sp1.so python tools/check_wide.py 2>&1 | tail -2
+python tools/ab_lib.py run sp0 sp1 sp2 --rounds 2 --only c5,c5big 2>&1 | tail -6 | tee gpurun_out/r4_i_ab.txt
