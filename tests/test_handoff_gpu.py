@@ -139,3 +139,17 @@ def test_bench_self_spawn_single_rank_rccl():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     j = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
     assert j['n_gpus'] == 1 and j['handoff']['rccl_ranks'] == 1 and j['handoff']['backend'] == 'rccl'
+
+
+def test_bench_compact_observation_handoff_single_rank_rccl():
+    """`--gather obs --compact`: the fragment crosses the collective as the lossless compact record (dcomp_pack_fragment inside the
+    timed region): U (B + 2) + 2B words per env-step instead of U (4B + 1)."""
+    rc, out, j = _run([sys.executable, 'bench.py', '--gpus', '1', '--force-dist', '--gather', 'obs', '--compact', '--fragment', '5'] + COMMON)
+    assert rc == 0 and j is not None, out[-3000:]
+    h = j['handoff']
+    assert h['mode'] == 'obs' and h['compact'] is True and h['fragments'] == 4
+    words = 32 * (10 + 2) + 2 * 10
+    assert h['bytes_sent_per_rank_per_fragment'] == 5 * 2048 * (words + 32) * 4
+    assert h['bytes_in_timed_region']['sent_per_rank'] == 4 * h['bytes_sent_per_rank_per_fragment']
+    raw = 5 * 2048 * 32 * (41 + 1) * 4
+    assert raw / h['bytes_sent_per_rank_per_fragment'] > 3.0

@@ -1,5 +1,12 @@
 mkdir -p gpurun_out
-export DCOMP_BUILD_B=32
-V=$GRAFT_REPO_ROOT/deepcomp_amd/csrc/variants
-DCOMP_LIB=$V/libdcomp_hip_sp1.so python tools/check_wide.py 2>&1 | tail -2
-python tools/ab_lib.py run sp0 sp1 sp2 --rounds 2 --only c5,c5big 2>&1 | tail -6 | tee gpurun_out/r4_i_ab.txt
+python -m pytest tests -m gpu -q 2>&1 | tail -25 > gpurun_out/r4_j_pytest.log
+tail -25 gpurun_out/r4_j_pytest.log
+python tools/fragment_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r4_j_fragment.txt
+python bench.py --steps 20 --warmup 5 2>gpurun_out/r4_j_bench.err | tail -1 > gpurun_out/r4_j_bench.json
+python bench.py --gpus 1 --spawn --steps 20 --warmup 5 --no-cpu-baseline 2>gpurun_out/r4_j_bench_spawn.err | tail -1 > gpurun_out/r4_j_bench_spawn.json
+python -c "
+import json
+for f in ('gpurun_out/r4_j_bench.json','gpurun_out/r4_j_bench_spawn.json'):
+    j=json.load(open(f)); r=j['roofline']
+    print(f, j['value'], j['ms_per_step'], r['kernel_ms'], r['frac'], j.get('handoff'))
+"
