@@ -481,7 +481,8 @@ def main():
     pending = []
     if use_dist and not args.no_gather:
         from deepcomp_amd.sharded import RolloutGather
-        gather = RolloutGather(use_side_stream=(args.backend == 'nccl'))
+        gather = RolloutGather(use_side_stream=(args.backend == 'nccl'), reuse_buffers=3)
+        summary_stage = [{'reward': torch.empty_like(env.reward), 'sum_utility': torch.empty_like(env.sum_utility)} for _ in range(3)]
 
     # --gather obs: the rollout hand-off north_star describes.  Steps write into a fragment buffer [F, E, U, 4B+1] (two of
     # them, alternating); a finished fragment is all-gathered on the side stream while the next one is being stepped.
@@ -543,7 +544,8 @@ def main():
         data-parallel learner's logging / early stopping needs from the other shards), asynchronously on the side stream."""
         if gather is None:
             return
-        frag = {'reward': env.reward.clone(), 'sum_utility': env.sum_utility.clone()}
+        frag = summary_stage[gather_stats['collectives'] // 2 % 3]         # (at most 3 hand-offs are in flight: `pending` below)
+        frag['reward'].copy_(env.reward); frag['sum_utility'].copy_(env.sum_utility)
         if args.backend != 'nccl':
             frag = {k: v.cpu() for k, v in frag.items()}
         pending.append(gather.all_gather_async(frag))
@@ -639,7 +641,9 @@ def main():
             tp += min(L, args.prewarm - tp)
         torch.cuda.synchronize(dev)
     t_env = run(W, 0)
-    drain()
+    if gather is not None and frag_bufs is None:
+        hand_off_summary()                      # one UNTIMED hand-off: the first collective of a communicator sets up its channels (milliseconds);
+    drain()                                     # with --warmup 5 no hand-off of the warm-up steps would have done that before the timed region
     fence()
     # the hand-offs of the timed region fall on its steps G/2, 3G/2, ...: every one has G/2 steps of stepping to overlap with (a
     # hand-off issued at the region's last step could only be waited for), and K >= 4 steps always contain at least one

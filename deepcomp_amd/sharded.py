@@ -60,12 +60,15 @@ class RolloutGather:
     ``shard_bounds(...)[r][0] + e``.  One flat collective per tensor (large messages: on the fully connected
     xGMI mesh every GPU pushes its shard to its 7 peers concurrently)."""
 
-    def __init__(self, group=None, use_side_stream=True):
+    def __init__(self, group=None, use_side_stream=True, reuse_buffers=0):
+        """reuse_buffers = k > 0: the gathered tensors come from k alternating sets of buffers instead of fresh allocations (a
+        hand-off every few steps should not pay the allocator): the tensors of a handle are valid until k further calls."""
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.use_side_stream = use_side_stream
         self._stream = None
+        self._reuse, self._sets, self._turn = int(reuse_buffers), {}, 0
 
     def all_gather_async(self, fragment):
         out, works = {}, []
@@ -80,9 +83,16 @@ class RolloutGather:
         with ctx:
             for name, t in fragment.items():
                 t = t.contiguous()
-                o = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+                if self._reuse:
+                    key = (name, tuple(t.shape), t.dtype, t.device, self._turn % self._reuse)
+                    o = self._sets.get(key)
+                    if o is None:
+                        o = self._sets[key] = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+                else:
+                    o = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
                 works.append(dist.all_gather_into_tensor(o.view(-1), t.view(-1), group=self.group, async_op=True))
                 out[name] = o
+        self._turn += 1
         return GatherHandle(out, works, stream)
 
     def all_gather(self, fragment):

@@ -91,7 +91,7 @@ def test_round_trip_on_the_hip_path_at_scale(torch_cuda, E, U, B, T):
     codec.check()
     assert packed.shape == (T, E, codec.words) and back.shape == frag.shape
     assert torch.equal(_bits(frag), _bits(back))
-    assert packed.numel() < frag.numel()
+    assert packed.numel() <= frag.numel()                              # (equal only at 1 UE x 1 station)
     if (U, B) in ((32, 10), (128, 32)):                                # the BASELINE shapes: 3.2x / 3.7x fewer bytes on the links
         assert packed.numel() * 3.2 <= frag.numel()
     # into caller-provided buffers
