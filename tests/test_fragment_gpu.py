@@ -150,3 +150,42 @@ def test_pack_refuses_what_it_could_not_restore(torch_cuda):
         codec.pack(x[..., :-1].contiguous())
     with pytest.raises(ValueError):
         codec.unpack(torch.zeros((4, 403), dtype=torch.int32, device='cuda'))
+
+
+def test_rollout_gather_hands_rows_over_as_the_compact_record(torch_cuda):
+    """RolloutGather(codec=...): the fragment's observations cross the collective as the compact record and come back from
+    GatherHandle.wait() as the rows, bit for bit (single-rank RCCL communicator on this GPU; the N > 1 indexing is covered by
+    tests/test_sharded_gloo.py)."""
+    import torch.distributed as dist
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    from deepcomp_amd.fragment import FragmentCodec
+    from deepcomp_amd.sharded import RolloutBuffer, RolloutGather
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29571')
+    own = not dist.is_initialized()
+    if own:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))      # RCCL, one rank
+    try:
+        E, U, B, T = 512, 32, 10, 4
+        m, bs, ues = build_from_scenario(scenarios.grid_map(B, 'mixed').with_ues(num_slow=U))
+        env = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=E, seed=9, rng='philox')
+        env.reset()
+        buf = RolloutBuffer(env, T)
+        g = torch.Generator(device='cuda').manual_seed(3)
+        frag = buf.collect(lambda obs: torch.randint(0, B + 1, (E, U), generator=g, device='cuda', dtype=torch.uint8))
+        codec = FragmentCodec(U, B)
+        gather = RolloutGather(use_side_stream=False, codec=codec)
+        sent = {'obs': frag['obs'], 'reward': frag['reward']}
+        h = gather.all_gather_async(sent)
+        got = h.wait()
+        codec.check()
+        assert got['obs_compact'].shape == (1, T, E, codec.words) and got['obs'].shape == (1, T, E, U, 4 * B + 1)
+        assert torch.equal(got['obs'][0].view(torch.int32), frag['obs'].view(torch.int32))
+        assert torch.equal(got['reward'][0], frag['reward'])
+    finally:
+        if own:
+            dist.destroy_process_group()
