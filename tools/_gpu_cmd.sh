@@ -1,2 +1,3 @@
 mkdir -p gpurun_out
-python -m pytest tests/test_fragment_gpu.py tests/test_handoff_gpu.py -m gpu -q 2>&1 | tail -8
+export DCOMP_BUILD_B=32
+python tools/ab_lib.py run cur fakep faken --rounds 2 --only c5,c5big 2>&1 | tail -5 | tee gpurun_out/r4_p_ab.txt
