@@ -151,14 +151,17 @@ def measure_rollout(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev
     return out
 
 
-def measure_steps(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev, E, U, B, kind, steps=300, L=100, sharing='mixed'):
+def measure_steps(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev, E, U, B, kind, steps=300, L=100, sharing='mixed', ring=0):
     """One launch per step on another shape (secondary figures): HIP events around back-to-back launches after 300 untimed
-    ones (steady state), SURVEY 8(d) bytes / launch duration."""
+    ones (steady state), SURVEY 8(d) bytes / launch duration.  ring = k > 0: the steps write their observations / rewards into k
+    DIFFERENT buffers in turn (a rollout fragment, step_into) instead of rewriting env.obs -- a buffer that is rewritten every step
+    partly never leaves the 256 MB Infinity Cache, a fragment does."""
     scn = scenarios.grid_map(B, sharing).with_ues(num_slow=U)
     m, bs, ues = build_from_scenario(scn)
     env = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=42, episode_length=L, rng='philox', rand_episodes=True, device=dev)
     g = torch.Generator(device=dev).manual_seed(7)
     pool = torch.randint(0, B + 1, (4, E, U), generator=g, device=dev, dtype=torch.uint8)
+    frag = [(torch.empty_like(env.obs), torch.empty_like(env.reward)) for _ in range(ring)]
     ms, n = 0.0, 0
     for phase, count in (('warm', 300), ('timed', steps)):
         t = 0
@@ -168,7 +171,10 @@ def measure_steps(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev, 
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for i in range(k):
-                env.step(pool[i & 3])
+                if ring:
+                    env.step_into(pool[i & 3], *frag[i % ring])
+                else:
+                    env.step(pool[i & 3])
             b.record()
             torch.cuda.synchronize(dev)
             if phase == 'timed':
@@ -249,7 +255,10 @@ def measure_also(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev):
     out = {'config2_4096x10x5_central_fused_rollout': measure_rollout(*mk, 4096, 10, 5, 'central', T=100, steps=4000, launches_too=True),
            'central_65536x10x5': central,
            # "report both resource-fair everywhere and mixed" -- the headline workload with every BS resource-fair
-           'config3_65536x32x10_multi_resource_fair': measure_steps(*mk, 65536, 32, 10, 'multi', sharing='resource-fair')}
+           'config3_65536x32x10_multi_resource_fair': measure_steps(*mk, 65536, 32, 10, 'multi', sharing='resource-fair'),
+           # the headline workload stepping into a ring of 8 fragment buffers (2.75 GB) instead of rewriting ONE 344 MB observation
+           # tensor, of which 256 MB can stay in the Infinity Cache from step to step: what a sampler that keeps every step sees
+           'config3_65536x32x10_multi_into_8_fragment_buffers': measure_steps(*mk, 65536, 32, 10, 'multi', ring=8)}
     # one GPU's share of the two multi-GPU BASELINE configurations at N = 1 / 2 / 4 / 8 (strong scaling: total size fixed), kernel
     # time by HIP events -- the per-GPU roofline of every point of the curve a multi-GPU node will draw
     for name, total, U, B in (('config5_per_gpu_share_of_32768x128x32', 32768, 128, 32), ('config4_per_gpu_share_of_262144x32x10', 262144, 32, 10)):
