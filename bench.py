@@ -491,7 +491,8 @@ def main():
     if use_dist and not args.no_gather:
         from deepcomp_amd.sharded import RolloutGather
         gather = RolloutGather(use_side_stream=(args.backend == 'nccl'), reuse_buffers=3)
-        summary_stage = [{'reward': torch.empty_like(env.reward), 'sum_utility': torch.empty_like(env.sum_utility)} for _ in range(3)]
+        # the summary of one hand-off is ONE tensor [E, reward columns + 1] (per-env rewards | sum_utility): one staging kernel, one collective
+        summary_stage = [torch.empty((E, env.reward.numel() // E + 1), device=dev) for _ in range(3)]
 
     # --gather obs: the rollout hand-off north_star describes.  Steps write into a fragment buffer [F, E, U, 4B+1] (two of
     # them, alternating); a finished fragment is all-gathered on the side stream while the next one is being stepped.
@@ -553,8 +554,9 @@ def main():
         data-parallel learner's logging / early stopping needs from the other shards), asynchronously on the side stream."""
         if gather is None:
             return
-        frag = summary_stage[gather_stats['collectives'] // 2 % 3]         # (at most 3 hand-offs are in flight: `pending` below)
-        frag['reward'].copy_(env.reward); frag['sum_utility'].copy_(env.sum_utility)
+        stage = summary_stage[gather_stats['collectives'] % 3]              # (at most 3 hand-offs are in flight: `pending` below)
+        torch.cat((env.reward.view(E, -1), env.sum_utility.view(E, 1)), dim=1, out=stage)
+        frag = {'reward_and_sum_utility': stage}
         if args.backend != 'nccl':
             frag = {k: v.cpu() for k, v in frag.items()}
         pending.append(gather.all_gather_async(frag))
@@ -690,7 +692,7 @@ def main():
                            bytes_received_per_rank_per_fragment=per_frag * world,
                            compute_stream_stall_ms_per_fragment=stall_ms / max(1, gather_stats['fragments']))
         else:
-            handoff.update(what=f'reward + sum_utility of every env, all-gathered every {G} steps (one collective per tensor), asynchronous',
+            handoff.update(what=f'reward + sum_utility of every env, all-gathered every {G} steps as one tensor [E, reward columns + 1] (one collective per hand-off), asynchronous',
                            period_steps=G, bytes_sent_per_rank_per_handoff=4 * (env.reward.numel() + E))
 
     def probe_obs_handoff(nfrag=4, compact=False):
@@ -776,6 +778,8 @@ def main():
     # queue: round 1's kernel_ms > ms_per_step).
     torch.cuda.synchronize(dev)
     kern_ms = sum(a.elapsed_time(b) for a, b, _ in spans) / max(1, sum(n for _, _, n in spans))
+    # what sits BETWEEN the runs of back-to-back step launches on the compute stream (reset launches, the copies of a hand-off, idle)
+    gaps_ms = sum(spans[i][1].elapsed_time(spans[i + 1][0]) for i in range(len(spans) - 1))
     # The first few hundred launches after idle run 5-15 % slower (clock / power management settling: 91 -> 115 -> 82 us per
     # launch over 300 launches on a cold MI355X, tools/kprobe.py): with the driver's --steps 20 the timed region lies inside
     # that transient.  The steady state is reported NEXT to it, never instead of it: >= 300 further launches untimed, then 200 timed.
@@ -817,6 +821,7 @@ def main():
                          'frac': achieved / HBM_PEAK_GBS,
                          'traffic': args.traffic_bytes, 'kernel': 'dcomp::' + (env.step_kernel_name or 'step_kernel'), 'kernel_ms': kern_ms,
                          'kernel_ms_how': f'HIP events over the timed region: {sum(n for _, _, n in spans)} launches in {len(spans)} back-to-back run(s) between resets',
+                         'between_runs_ms_total': gaps_ms,
                          'launch_bound': kern_ms < 0.02,
                          'algorithmic_bytes_per_env_step': sbpe, 'layout_bytes_per_env_step': bpe},
         }

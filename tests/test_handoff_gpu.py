@@ -96,10 +96,10 @@ def test_driver_form_n2_has_a_collective_inside_the_timed_region():
     j = json.loads(lines[-1])
     h = j['handoff']
     assert j['n_gpus'] == 2 and j['steps'] == 20 and j['warmup'] == 5 and h['mode'] == 'summary' and h['rccl_ranks'] == 2
-    assert h['period_steps'] == 10 and h['collectives_in_timed_region'] == 2 * 2          # reward + sum_utility, after timed steps 5 and 15
+    assert h['period_steps'] == 10 and h['collectives_in_timed_region'] == 2              # one [E, U + 1] tensor after timed steps 5 and 15
     assert h['bytes_in_timed_region']['sent_per_rank'] == 2 * 4 * 65536 * (32 + 1)
     assert h['bytes_in_timed_region']['received_per_rank'] == 2 * h['bytes_in_timed_region']['sent_per_rank']
-    assert '4 collective(s) inside the timed region' in j['config']['collective'] and 'every rank' in j['config']['prewarm']
+    assert '2 collective(s) inside the timed region' in j['config']['collective'] and 'every rank' in j['config']['prewarm']
     a = j['also']
     assert a['measured'].startswith('before the warm-up') and 'config2_4096x10x5_central_fused_rollout' in a     # the pre-warm ran at N = 2 too
     assert a['config4_strong_262144x32x10']['envs_per_gpu'] == 131072 and a['config5_strong_32768x128x32']['envs_per_gpu'] == 16384
@@ -116,7 +116,7 @@ def test_single_rank_rccl_driver_form_counts_its_collectives():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     j = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
     h = j['handoff']
-    assert h['backend'] == 'rccl' and h['rccl_ranks'] == 1 and h['collectives_in_timed_region'] == 4 and h['period_steps'] == 10
+    assert h['backend'] == 'rccl' and h['rccl_ranks'] == 1 and h['collectives_in_timed_region'] == 2 and h['period_steps'] == 10
 
 
 def test_bench_spawns_its_own_ranks_summary_mode_probe():

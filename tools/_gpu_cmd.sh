@@ -1,3 +1,8 @@
 mkdir -p gpurun_out
-for kb in 8 4 2 12 16; do echo "cap ${kb} KB"; DCOMP_FRAG_CAP_KB=$kb python tools/fragment_bench.py 2>&1 | grep -v amdgpu.ids | head -4; done | tee gpurun_out/r4_t_frag.txt
-echo noverify; DCOMP_FRAG_NOVERIFY=1 python tools/fragment_bench.py 2>&1 | grep "pack" | head -4 | tee -a gpurun_out/r4_t_frag.txt
+python -m pytest tests/test_handoff_gpu.py -m gpu -q 2>&1 | tail -3
+python bench.py --gpus 1 --spawn --steps 20 --warmup 5 --no-cpu-baseline --no-also 2>/dev/null | tail -1 | python -c "
+import sys,json; j=json.loads(sys.stdin.read()); r=j['roofline']; h=j.get('handoff') or {}
+print('spawn', round(j['ms_per_step'],4), round(r['kernel_ms'],4), 'gaps', round(r['between_runs_ms_total'],4), h.get('collectives_in_timed_region'), h.get('host_blocked_ms_total'))"
+python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-also 2>/dev/null | tail -1 | python -c "
+import sys,json; j=json.loads(sys.stdin.read()); r=j['roofline']
+print('plain', round(j['ms_per_step'],4), round(r['kernel_ms'],4))"
