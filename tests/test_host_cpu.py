@@ -45,6 +45,25 @@ def test_policy_entry_point_refuses_bad_arguments_on_the_host(lib):
     assert lib.dcomp_heuristic_actions(ctypes.byref(p), None, fake, None) == EINVAL
 
 
+def test_fragment_entry_points_on_the_host(lib):
+    """dcomp_fragment_words is pure arithmetic; dcomp_pack_fragment / dcomp_unpack_fragment validate before they launch."""
+    import ctypes
+    EINVAL = -1
+    assert lib.dcomp_fragment_words(32, 10) == 32 * 12 + 20                     # U (B + 2) + 2B words: 1 616 B instead of 5 248 B
+    assert lib.dcomp_fragment_words(128, 32) * 4 == 17664
+    assert lib.dcomp_fragment_words(1, 1) == 5 and lib.dcomp_fragment_words(256, 32) == 256 * 34 + 64
+    for bad in ((0, 10), (257, 10), (32, 0), (32, 33)):
+        assert lib.dcomp_fragment_words(*bad) == -1
+    fake = ctypes.c_void_p(4096)                       # never dereferenced: every case below fails validation first
+    assert lib.dcomp_pack_fragment(None, 4, 32, 10, fake, fake, None) == EINVAL
+    assert lib.dcomp_pack_fragment(fake, 4, 32, 10, fake, None, None) == EINVAL       # the flag word is not optional
+    assert lib.dcomp_pack_fragment(fake, 0, 32, 10, fake, fake, None) == EINVAL
+    assert lib.dcomp_pack_fragment(fake, 4, 32, 40, fake, fake, None) == EINVAL
+    assert lib.dcomp_unpack_fragment(fake, 4, 300, 10, fake, None) == EINVAL
+    assert lib.dcomp_unpack_fragment(None, 4, 32, 10, fake, None) == EINVAL
+    assert lib.dcomp_last_error()
+
+
 def test_connect_threshold_matches_reference_constant(lib):
     # SURVEY.md Appendix B: d_T(snr = 2e-8) = 68.92488308058013 m; "roughly 69 m" (station.py:9)
     assert lib.dcomp_connect_threshold() == pytest.approx(68.92488308058013, abs=1e-9)
