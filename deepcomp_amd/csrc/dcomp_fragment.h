@@ -65,17 +65,32 @@ __global__ __launch_bounds__(BLOCK) void pack_kernel(const FragParams p)
     extern __shared__ float4 lds4[];
     const int B = p.B, U = p.U, ROW = 4 * B + 1, CW = B + 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *rows = reinterpret_cast<float *>(lds4) + (size_t)wave * p.lw_pack, *t0 = rows + p.rows_words;
     const int64_t unit = (int64_t)blockIdx.x * (BLOCK / 64) + wave;
     if (unit >= p.units) return;
     const int64_t env = unit / p.chunks;
     const int chunk = (int)(unit - env * p.chunks);
     const int r0 = chunk * p.R, nr = min(p.R, U - r0), nf = nr * ROW;
-    float *rows = reinterpret_cast<float *>(lds4) + (size_t)wave * p.lw_pack, *t0 = rows + p.rows_words;
     const float *src = p.obs_in + ((size_t)env * U + r0) * ROW;
-    for (int i = lane * 4; i + 3 < nf; i += 64 * 4)
-        *reinterpret_cast<float4 *>(rows + i) = as_f4(__builtin_nontemporal_load(reinterpret_cast<const f4u *>(src + i)));     // read once, never again
-    if (lane < (nf & 3)) rows[(nf & ~3) + lane] = src[(nf & ~3) + lane];
-    if (lane < 2 * B) t0[lane] = p.obs_in[(size_t)env * U * ROW + 2 * B + lane];              // row 0 of the env: the per-env columns
+    // ALL loads of the unit are issued before the first one is used (registers, then LDS): a loop of "load 16 bytes, write them to
+    // LDS" waits for every load in turn and has one piece per lane in flight -- the kernel is bound by load latency x bytes in
+    // flight (this form: 95 -> 87 us at 65 536 x 32 x 10, 697 -> 484 us at 32 768 x 128 x 32).
+    constexpr int NQ = 8;                                         // 16-byte pieces per lane: 64 lanes x 8 x 16 B = the 8 KB slice
+    f4u q[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; k++) {                                // UNCONDITIONAL (a piece beyond the unit re-reads piece 0 and is dropped):
+        const int i = lane * 4 + k * 256;                         // behind a divergent `if` the compiler waits for each load at the join
+        q[k] = __builtin_nontemporal_load(reinterpret_cast<const f4u *>(src + (i + 3 < nf ? i : 0)));     // read once, never again (nf >= 5)
+    }
+    const float tail = lane < (nf & 3) ? src[(nf & ~3) + lane] : 0.f;
+    const float t0v = lane < 2 * B ? p.obs_in[(size_t)env * U * ROW + 2 * B + lane] : 0.f;     // row 0 of the env: the per-env columns
+#pragma unroll
+    for (int k = 0; k < NQ; k++) {
+        const int i = lane * 4 + k * 256;
+        if (i + 3 < nf) *reinterpret_cast<float4 *>(rows + i) = as_f4(q[k]);
+    }
+    if (lane < (nf & 3)) rows[(nf & ~3) + lane] = tail;
+    if (lane < 2 * B) t0[lane] = t0v;
     wave_fence();
     // lane r < 32: row r's `connected` block -> bit mask (and: every entry is 0 or 1), then its ues_at_bs replicas against row 0's;
     // lane 32 + r: row r's dr block -> "listed" (some entry is non-zero), then its util_at_bs replicas.  Row stride 4B + 1 is odd:
@@ -132,10 +147,24 @@ __global__ __launch_bounds__(BLOCK) void unpack_kernel(const FragParams p)
     uint32_t *cw = reinterpret_cast<uint32_t *>(lds4) + (size_t)wave * p.lw_unpack, *t0 = cw + p.cw_words, *listed = t0 + 2 * B;
     const uint32_t *src = p.packed_in + (size_t)env * env_words(U, B) + (size_t)r0 * CW;
     const int nw = nr * CW;
-    for (int i = lane * 4; i + 3 < nw; i += 64 * 4)
-        *reinterpret_cast<uint4 *>(cw + i) = as_u4(__builtin_nontemporal_load(reinterpret_cast<const u4u *>(src + i)));
-    if (lane < (nw & 3)) cw[(nw & ~3) + lane] = src[(nw & ~3) + lane];
-    if (lane < 2 * B) t0[lane] = p.packed_in[(size_t)env * env_words(U, B) + (size_t)U * CW + lane];
+    constexpr int NQ = 5;                                         // R (B + 2) <= 32 x 34 words = 4.25 KiB: at most 5 pieces per lane
+    u4u q[NQ];
+    if (nw >= 4) {                                                // (uniform; a unit of 1 UE x 1 station has 3 words: tail path only)
+#pragma unroll
+        for (int k = 0; k < NQ; k++) {                            // all loads in flight before the first LDS write, unconditional as in pack_kernel
+            const int i = lane * 4 + k * 256;
+            q[k] = __builtin_nontemporal_load(reinterpret_cast<const u4u *>(src + (i + 3 < nw ? i : 0)));
+        }
+    }
+    const uint32_t tail = lane < (nw & 3) ? src[(nw & ~3) + lane] : 0u;
+    const uint32_t t0v = lane < 2 * B ? p.packed_in[(size_t)env * env_words(U, B) + (size_t)U * CW + lane] : 0u;
+#pragma unroll
+    for (int k = 0; k < NQ; k++) {
+        const int i = lane * 4 + k * 256;
+        if (i + 3 < nw) *reinterpret_cast<uint4 *>(cw + i) = as_u4(q[k]);
+    }
+    if (lane < (nw & 3)) cw[(nw & ~3) + lane] = tail;
+    if (lane < 2 * B) t0[lane] = t0v;
     wave_fence();
     if (lane < nr) {                                                                          // listed <=> some dr entry is non-zero
         uint32_t any = 0;
@@ -153,10 +182,12 @@ __global__ __launch_bounds__(BLOCK) void unpack_kernel(const FragParams p)
         if (c < 4 * B) return listed[r] ? __uint_as_float(t0[c - 2 * B]) : 0.f;     // ues_at_bs | util_at_bs   variants.py:296-299
         return __uint_as_float(q[B]);                                               // utility            variants.py:287
     };
+    const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;           // (uniform) non-temporal only for whole 16-byte pieces
     for (int f = lane * 4; f + 3 < nf; f += 64 * 4) {
         f4u v;
         v.x = val(f); v.y = val(f + 1); v.z = val(f + 2); v.w = val(f + 3);
-        __builtin_nontemporal_store(v, reinterpret_cast<f4u *>(dst + f));           // write-once stream for the learner
+        if (aligned) __builtin_nontemporal_store(v, reinterpret_cast<f4u *>(dst + f));          // write-once stream for the learner
+        else *reinterpret_cast<f4u *>(dst + f) = v;
     }
     if (lane < (nf & 3)) dst[(nf & ~3) + lane] = val((nf & ~3) + lane);
 }
@@ -167,7 +198,8 @@ static int rows_per_chunk(int U, int B)
     const int cap = (8 * 1024) / ((4 * B + 1) * 4);
     int R = U < cap ? U : cap;
     if (R > 32) R = 32;
-    return R < 1 ? 1 : R;
+    if (R >= 4 && R < U) R &= ~3;          // chunks of a multiple of 4 rows start 16-byte aligned (a row is 4B + 1 floats): the row
+    return R < 1 ? 1 : R;                  // stores of unpack are then ALIGNED non-temporal stores (misaligned ones stream at 2.9 TB/s)
 }
 
 static int fill(FragParams &p, int64_t n, int U, int B, int &grid, size_t &lds_pack, size_t &lds_unpack)
