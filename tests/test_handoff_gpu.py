@@ -153,3 +153,19 @@ def test_bench_compact_observation_handoff_single_rank_rccl():
     assert h['bytes_in_timed_region']['sent_per_rank'] == 4 * h['bytes_sent_per_rank_per_fragment']
     raw = 5 * 2048 * 32 * (41 + 1) * 4
     assert raw / h['bytes_sent_per_rank_per_fragment'] > 3.0
+
+
+def test_bench_compact_handoff_two_gloo_ranks_same_device():
+    """Two self-spawned ranks (gloo, one device): every fragment is packed on the GPU, staged through the host as int32 words, gathered
+    and counted -- the N > 1 control flow of `--gather obs --compact`."""
+    env_clean = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    cmd = [sys.executable, 'bench.py', '--gpus', '2', '--backend', 'gloo', '--same-device', '--gather', 'obs', '--compact', '--fragment', '5',
+           '--no-also'] + COMMON
+    r = subprocess.run(cmd, cwd=REPO, env=env_clean, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    j = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    h = j['handoff']
+    words = 32 * 12 + 20
+    assert h['compact'] is True and h['rccl_ranks'] == 2 and h['fragments'] == 4 and h['collectives_in_timed_region'] == 8
+    assert h['bytes_sent_per_rank_per_fragment'] == 5 * 2048 * (words + 32) * 4
+    assert h['bytes_received_per_rank_per_fragment'] == 2 * h['bytes_sent_per_rank_per_fragment']
