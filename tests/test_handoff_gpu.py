@@ -169,3 +169,17 @@ def test_bench_compact_handoff_two_gloo_ranks_same_device():
     assert h['compact'] is True and h['rccl_ranks'] == 2 and h['fragments'] == 4 and h['collectives_in_timed_region'] == 8
     assert h['bytes_sent_per_rank_per_fragment'] == 5 * 2048 * (words + 32) * 4
     assert h['bytes_received_per_rank_per_fragment'] == 2 * h['bytes_sent_per_rank_per_fragment']
+
+
+def test_bench_under_torch_distributed_run_two_gloo_ranks():
+    """The driver's launcher form for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W`), with the process group on gloo because both ranks share this box's one
+    GPU: RANK / LOCAL_RANK / WORLD_SIZE come from the launcher, rank 0 prints the one JSON line."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), 'bench.py', '--gpus', '2', '--steps', '20', '--warmup', '5', '--backend', 'gloo', '--same-device',
+           '--envs', '4096', '--no-also', '--no-stream']
+    rc, out, j = _run(cmd)
+    assert rc == 0 and j is not None, out[-3000:]
+    assert j['n_gpus'] == 2 and j['steps'] == 20 and j['config']['parallelism'] == 'env-shard x2' and j['config']['envs_per_gpu'] == 4096
+    assert j['handoff']['rccl_ranks'] == 2 and j['handoff']['collectives_in_timed_region'] == 2
+    assert len([l for l in out.splitlines() if l.startswith('{"metric"')]) == 1

@@ -22,7 +22,7 @@ SHARING = ['resource-fair', 'rate-fair', 'max-cap', 'proportional-fair']
 def random_spec(rng):
     """A random configuration as plain data (JSON-able); build_case() turns it into entity objects."""
     U = int(rng.choice([1, 2, 3, 5, 8, 10, 17, 32, 33, 64, 70, 128, 130]))
-    B = int(rng.choice([1, 2, 3, 5, 7, 10, 12, 16, 19, 21, 23, 24, 25, 32]))
+    B = int(rng.choice([1, 2, 3, 5, 7, 10, 12, 16, 19, 21, 23, 24, 25, 28, 32]))
     if U * B > 2500 and rng.random() < 0.75:       # most cases small; a quarter keeps the big shapes (wide kernel, 256 lanes per env)
         U = max(1, 2500 // B)
     E = int(rng.choice([1, 3, 8, 21]))
