@@ -41,6 +41,7 @@ struct FragParams {
     int32_t *flags;             // pack: bit 0 = a listed row's per-env columns differ from row 0's, bit 1 = `connected` entry not 0 / 1
     int32_t U, B, R, chunks;    // R rows per chunk (one wavefront each), chunks per env
     int64_t units;              // chunks in all
+    int32_t step_r_cw, step_k_cw, step_r_row, step_c_row;       // 256 words / floats further on: rows and remainder (pack's / unpack's store walk)
     int32_t rows_words, lw_pack, cw_words, lw_unpack;   // LDS words per wave: the rows / all of pack's; the compact words / all of unpack's
     uint32_t magic_row;         // ceil(2^32 / (4B + 1)): f / (4B + 1) = umulhi(f, magic) for f < 2^16 (exact: f (4B + 1) < 2^32)
     uint32_t magic_cw;          // ceil(2^32 / (B + 2))
@@ -119,15 +120,31 @@ __global__ __launch_bounds__(BLOCK) void pack_kernel(const FragParams p)
     wave_fence();
     uint32_t *dst = p.packed_out + (size_t)env * env_words(U, B) + (size_t)r0 * CW;
     const int nw = nr * CW;
-    auto word = [&](int w) -> uint32_t {
+    auto word = [&](int w) -> uint32_t {                          // (generic form: the tail words)
         const int rr = (int)__umulhi((uint32_t)w, p.magic_cw), k = w - rr * CW;
         const int at = k < B ? B + k : k == B ? 4 * B : 0;                                    // dr[k] | utility | connection mask
         return __float_as_uint(rows[rr * ROW + at]);
     };
-    for (int w = lane * 4; w + 3 < nw; w += 64 * 4) {
-        u4u v;
-        v.x = word(w); v.y = word(w + 1); v.z = word(w + 2); v.w = word(w + 3);
-        *reinterpret_cast<u4u *>(dst + w) = v;
+    {
+        // a lane walks (row, word-in-row) incrementally -- one division when it starts, none per word (v_mul_hi_u32 issues at a
+        // quarter of the rate, and the profile had the kernels VALU-bound: 444 / 741 instructions per wave in pack / unpack)
+        int rr = (int)__umulhi((uint32_t)(lane * 4), p.magic_cw), k = lane * 4 - rr * CW;
+        for (int w = lane * 4; w + 3 < nw; w += 64 * 4) {
+            uint32_t o[4];
+            int r2 = rr, k2 = k;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int at = k2 < B ? B + k2 : k2 == B ? 4 * B : 0;
+                o[j] = __float_as_uint(rows[__umul24(r2, ROW) + at]);
+                k2++;
+                if (k2 == CW) { k2 = 0; r2++; }
+            }
+            u4u v;
+            v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
+            *reinterpret_cast<u4u *>(dst + w) = v;
+            rr += p.step_r_cw; k += p.step_k_cw;                  // 256 words on
+            if (k >= CW) { k -= CW; rr++; }
+        }
     }
     if (lane < (nw & 3)) dst[(nw & ~3) + lane] = word((nw & ~3) + lane);
     if (chunk == 0 && lane < 2 * B) p.packed_out[(size_t)env * env_words(U, B) + (size_t)U * CW + lane] = __float_as_uint(t0[lane]);
@@ -183,11 +200,30 @@ __global__ __launch_bounds__(BLOCK) void unpack_kernel(const FragParams p)
         return __uint_as_float(q[B]);                                               // utility            variants.py:287
     };
     const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;           // (uniform) non-temporal only for whole 16-byte pieces
-    for (int f = lane * 4; f + 3 < nf; f += 64 * 4) {
-        f4u v;
-        v.x = val(f); v.y = val(f + 1); v.z = val(f + 2); v.w = val(f + 3);
-        if (aligned) __builtin_nontemporal_store(v, reinterpret_cast<f4u *>(dst + f));          // write-once stream for the learner
-        else *reinterpret_cast<f4u *>(dst + f) = v;
+    {
+        int r = (int)__umulhi((uint32_t)(lane * 4), p.magic_row), c = lane * 4 - r * ROW;       // (row, column) of the lane's first float
+        for (int f = lane * 4; f + 3 < nf; f += 64 * 4) {
+            float o[4];
+            int r2 = r, c2 = c;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t *q = cw + __umul24(r2, CW);
+                const uint32_t w = q[c2 < B ? B + 1 : c2 < 2 * B ? c2 - B : B];               // connection mask | dr[c - B] | utility
+                const int e = c2 - 2 * B;
+                const uint32_t env = t0[e >= 0 && e < 2 * B ? e : 0];                         // ues_at_bs | util_at_bs of the env
+                const bool isenv = e >= 0 && e < 2 * B;
+                const uint32_t bits = c2 < B ? __float_as_uint((float)((w >> c2) & 1u)) : w;
+                o[j] = __uint_as_float(isenv ? (listed[r2] ? env : 0u) : bits);
+                c2++;
+                if (c2 == ROW) { c2 = 0; r2++; }
+            }
+            f4u v;
+            v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
+            if (aligned) __builtin_nontemporal_store(v, reinterpret_cast<f4u *>(dst + f));      // write-once stream for the learner
+            else *reinterpret_cast<f4u *>(dst + f) = v;
+            r += p.step_r_row; c += p.step_c_row;                 // 256 floats on
+            if (c >= ROW) { c -= ROW; r++; }
+        }
     }
     if (lane < (nf & 3)) dst[(nf & ~3) + lane] = val((nf & ~3) + lane);
 }
@@ -214,6 +250,8 @@ static int fill(FragParams &p, int64_t n, int U, int B, int &grid, size_t &lds_p
     grid = (int)blocks;
     p.magic_row = (uint32_t)(0x100000000ull / (uint32_t)(4 * B + 1)) + 1u;
     p.magic_cw = (uint32_t)(0x100000000ull / (uint32_t)(B + 2)) + 1u;
+    p.step_r_cw = 256 / (B + 2); p.step_k_cw = 256 % (B + 2);
+    p.step_r_row = 256 / (4 * B + 1); p.step_c_row = 256 % (4 * B + 1);
     p.rows_words = (p.R * (4 * B + 1) + 3) & ~3;
     p.lw_pack = (p.rows_words + 2 * B + 3) & ~3;
     p.cw_words = (p.R * (B + 2) + 3) & ~3;
