@@ -49,6 +49,17 @@ __global__ __launch_bounds__(256) void k(float *obs, int waves_total, int persis
     }
 }
 
+__global__ __launch_bounds__(256) void sweep(float *obs, size_t total_kib, int nt)
+{
+    const size_t waves = (size_t)gridDim.x * 4, w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    for (size_t k = w; k < total_kib; k += waves) {
+        f4u v; v.x = v.y = v.z = v.w = (float)k;
+        f4u *dst = reinterpret_cast<f4u *>(obs + k * 256 + 4 * lane);
+        if (nt) __builtin_nontemporal_store(v, dst); else *dst = v;
+    }
+}
+
 template <int PAT>
 static void run(const char *name, float *obs, int envs, int grid_cap)
 {
@@ -81,6 +92,24 @@ int main()
             run<2>("2 ... non-temporal", obs, envs, cap);
             run<3>("3 line-aligned 1 KiB per instruction", obs, envs, cap);
             run<4>("4 ... non-temporal", obs, envs, cap);
+        }
+    }
+    // How much of the sustained rate is DRAM locality?  The same bytes, line-aligned 1 KiB store instructions, but the resident waves
+    // write ADJACENT KiBs at the same time (a persistent grid sweeping the buffer front to back) instead of each wave its own 33 KB.
+    for (int envs : sizes) {
+        const size_t total_kib = (size_t)envs * 2 * 64 * ROW * 4 / 1024;
+        for (int nt = 0; nt < 2; nt++) {
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            for (int i = 0; i < 10; i++) hipLaunchKernelGGL(sweep, dim3(2048), dim3(256), 0, 0, obs, total_kib, nt);
+            (void)hipEventRecord(a);
+            for (int i = 0; i < 50; i++) hipLaunchKernelGGL(sweep, dim3(2048), dim3(256), 0, 0, obs, total_kib, nt);
+            (void)hipEventRecord(b);
+            (void)hipEventSynchronize(b);
+            float ms;
+            (void)hipEventElapsedTime(&ms, a, b);
+            printf("6 front-to-back sweep by a persistent grid%s       envs %6d: %8.1f us  %6.0f GB/s\n", nt ? ", non-temporal" : "               ", envs,
+                   ms / 50 * 1e3, (double)total_kib * 1024 / (ms / 50 * 1e-3) / 1e9);
         }
     }
     return 0;
