@@ -142,7 +142,6 @@ __device__ __forceinline__ void wide_step_one(const KParams &p, WideShared<B, UP
                                               const int g, WideIn &in, const bool has_next, const int g_next)
 {
     constexpr int NW = UPAD / 64, GPB = 256 / UPAD, ROW = 4 * B + 1, K = DCOMP_WIDE_K, PC = DCOMP_WIDE_PC;
-    using SH = WideShared<B, UPAD>;
     // (the thread index is hidden from the optimiser once per slot: everything derived from it -- lane constants, table addresses,
     // output offsets -- would otherwise be hoisted out of step_kernel_wide's slot loop and live in ~100 extra VGPRs across it)
     int tid = threadIdx.x;
