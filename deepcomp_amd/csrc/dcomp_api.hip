@@ -60,6 +60,7 @@ struct dcomp_env {
     bool fused;                // kern.step is step_kernel: T steps in one launch (the wide / dynamic kernels step once per launch)
     bool fused_long;           // ... for rollouts of >= 4 steps at ANY batch size (small central rows: see dcomp_create)
     int upad, grid;
+    int wide_pad_lds = 0;      // step_kernel_wide: extra dynamic LDS per workgroup = fewer resident workgroups per CU (see dcomp_create)
     int wide_grid = 0;         // step_kernel_wide is persistent: workgroups launched (<= what the GPU holds at once), each walks grid / wide_grid slots
     int tight_g, tight_gpw, tight_magic, tight_grid;   // step_kernel's tight packing of non-power-of-two UE lists (0 = off)
     int cap, cur_ue;            // slots per env; UEs currently listed
@@ -244,6 +245,13 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
         long cap = DCOMP_WIDE_PERSIST ? (long)per_cu * cus : (long)env->grid;      // (one workgroup per slot unless the persistent experiment is built)
         if (const char *e = getenv("DCOMP_WIDE_GRID")) cap = (DCOMP_WIDE_PERSIST && atol(e) > 0) ? atol(e) : env->grid;
         env->wide_grid = (int)(cap < env->grid ? cap : env->grid);
+        // Batches whose observation rows are >= 1 GB per step -- four times the Infinity Cache: every byte goes out at the sustained HBM
+        // write rate -- run with TWO workgroups per CU instead of the four the kernel's 39.8 KB of LDS allow (24 000 B of unused dynamic
+        // LDS per workgroup): 16 384 x 128 x 32 252-272 -> 251 us, 32 768 envs 517 -> 477 us (0.60 -> 0.65 of the HBM peak), repeatably;
+        // at 8 192 envs (0.54 GB) the same cap costs 6 %, at 4 096 envs (inside the cache) 25 %.  Fewer waves writing at once stream better.
+        const double row_bytes = (double)E * CAP * (cfg->env_kind == DCOMP_MULTI ? 4 * B + 1 : 2 * B + 1) * 4.0;
+        env->wide_pad_lds = row_bytes >= 1.0e9 ? 24000 : 0;
+        if (const char *e = getenv("DCOMP_WIDE_PAD_LDS")) env->wide_pad_lds = atoi(e);                 // A/B
     }
     if (DYN) {
         if (!env->kern.step_dyn) { dcomp_destroy(env); return fail(DCOMP_EUNSUPPORTED, "no dynamic-UE kernel for this shape"); }
@@ -337,8 +345,9 @@ static void launch_step(dcomp_env *env, KParams &kp, void *stream)
         hipLaunchKernelGGL(k, dim3(env->tight_grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
         return;
     }
-    const int grid = (env->wide_grid && env->kern.step == env->kern.step_wide) ? env->wide_grid : env->grid;
-    hipLaunchKernelGGL(env->kern.step, dim3(grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
+    const bool wide = env->wide_grid && env->kern.step == env->kern.step_wide;
+    const int grid = wide ? env->wide_grid : env->grid;
+    hipLaunchKernelGGL(env->kern.step, dim3(grid), dim3(DCOMP_BLOCK), wide ? env->wide_pad_lds : 0, (hipStream_t)stream, kp);
 }
 
 static int check_horizon(const dcomp_env *env, int steps)

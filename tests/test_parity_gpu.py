@@ -1271,6 +1271,31 @@ def test_checkpoint_across_the_packing_boundary(torch_cuda, monkeypatch):
     a.check(); b.check()
 
 
+def test_wide_kernel_with_capped_occupancy_is_the_same_kernel(torch_cuda, monkeypatch):
+    """Batches whose observation rows exceed 1 GB per step launch the wide kernel with 24 000 B of unused dynamic LDS per workgroup (two
+    resident workgroups per CU instead of four: dcomp_create).  Same code, same results: forced on for a small batch and compared bit for
+    bit with the default launch."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    E, U, B = 37, 128, 32
+    m, bs, ues = build_from_scenario(scenarios.grid_map(B, 'mixed').with_ues(num_slow=100, num_fast=28))
+    acts = torch.randint(0, B + 1, (12, E, U), device='cuda', dtype=torch.uint8)
+    outs = []
+    for pad in ('0', '24000'):
+        monkeypatch.setenv('DCOMP_WIDE_PAD_LDS', pad)
+        env = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=E, seed=3, rng='philox')
+        assert env.step_kernel_name == 'step_kernel_wide<32, 128, 2>'
+        env.reset()
+        for t in range(12):
+            env.step(acts[t])
+        env.check()
+        outs.append((env.obs.clone(), env.reward.clone(), env.pos.clone(), env.mv.clone(), env.conn.clone(), env.ewma.clone()))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+
+
 def test_episode_horizon_guard(torch_cuda):
     """The draw cursor and conn_since are 16-bit: a step beyond 65536 is refused (NotImplementedError), reset() clears it."""
     import ctypes as C
