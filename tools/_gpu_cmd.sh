@@ -1,6 +1,8 @@
-mkdir -p gpurun_out/profiles_r04
-bash tools/profile_gpu.sh r04_c5big --envs 32768 --ues 128 --bs 32 > /dev/null 2>&1
-cp gpurun_out/prof_r04_c5big/summary.txt gpurun_out/profiles_r04/r04_c5big_summary.txt
-f=$(find gpurun_out/prof_r04_c5big/trace -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f gpurun_out/profiles_r04/r04_c5big_kernel_stats.csv
-rm -rf gpurun_out/prof_r04_c5big/trace gpurun_out/prof_r04_c5big/pmc_*/
-grep "step_kernel_wide" gpurun_out/profiles_r04/r04_c5big_summary.txt | head -1 | cut -c1-230
+mkdir -p gpurun_out
+python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 | tee gpurun_out/r4_as_pytest.log
+python __graft_entry__.py smoke 2>&1 | grep "smoke ok"
+python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/r4_as_bench.json
+python -c "
+import json
+j=json.load(open('gpurun_out/r4_as_bench.json')); r=j['roofline']
+print(j['value'], j['ms_per_step'], r['kernel_ms'], r['frac'], r['traffic'], r['steady_state']['frac'], j['cpu_baseline']['value'])"
