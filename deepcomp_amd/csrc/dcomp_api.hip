@@ -250,7 +250,8 @@ extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
         // LDS per workgroup): 16 384 x 128 x 32 252-272 -> 251 us, 32 768 envs 517 -> 477 us (0.60 -> 0.65 of the HBM peak), repeatably;
         // at 8 192 envs (0.54 GB) the same cap costs 6 %, at 4 096 envs (inside the cache) 25 %.  Fewer waves writing at once stream better.
         const double row_bytes = (double)E * CAP * (cfg->env_kind == DCOMP_MULTI ? 4 * B + 1 : 2 * B + 1) * 4.0;
-        env->wide_pad_lds = row_bytes >= 1.0e9 ? 24000 : 0;
+        // Between 0.4 and 1 GB three per CU (13 000 B) are the best of the three: 8 192 envs 141 -> 134 us, 6 144 envs 101.5 -> 98.5 us.
+        env->wide_pad_lds = row_bytes >= 1.0e9 ? 24000 : row_bytes >= 4.0e8 ? 13000 : 0;
         if (const char *e = getenv("DCOMP_WIDE_PAD_LDS")) env->wide_pad_lds = atoi(e);                 // A/B
     }
     if (DYN) {
