@@ -701,7 +701,8 @@ __global__ __launch_bounds__(256, DCOMP_WIDE_PERSIST ? 4 : 1) void step_kernel_w
     __shared__ int32_t lds_modes[32];
     const int tid = threadIdx.x;
     const int total = (p.E + GPB - 1) / GPB;
-    WideIn in = wide_load<UPAD>(p, blockIdx.x);
+    const int slot0 = DCOMP_WIDE_PERSIST ? (int)blockIdx.x : xcd_contiguous_block();     // every XCD a contiguous eighth of the slots
+    WideIn in = wide_load<UPAD>(p, slot0);
     WideCfg cfg{false, 1.f, MV_CFG_ARRIVED};
     {
         const int u = ((tid >> 6) % NW) * 64 + (tid & 63);
@@ -720,7 +721,7 @@ __global__ __launch_bounds__(256, DCOMP_WIDE_PERSIST ? 4 : 1) void step_kernel_w
     if (tid >= 64 && tid < 80) { const int n = tid - 64; sh.nib[n] = make_float4((float)(n & 1), (float)((n >> 1) & 1), (float)((n >> 2) & 1), (float)(n >> 3)); }
     __syncthreads();                                                              // BS table, nibble table
     if (!DCOMP_WIDE_PERSIST) {
-        wide_step_one<B, UPAD, MP>(p, sh, lds_modes, cfg, (int)blockIdx.x, in, false, 0);
+        wide_step_one<B, UPAD, MP>(p, sh, lds_modes, cfg, slot0, in, false, 0);
         return;
     }
 #pragma unroll 1

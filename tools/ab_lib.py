@@ -59,7 +59,7 @@ def build(a):
     print(so, os.path.getsize(so) >> 20, 'MiB')
 
 
-WORKLOADS = ['c3', 'c2roll', 'c5', 'c5big', 'c4share', 'central10x5', 'central10x5roll', 'central10x5f', 'central32x10', 'c2policy', 'c3rf', 'c3roll']
+WORKLOADS = ['c3', 'c2roll', 'c5', 'c5mid', 'c5big', 'c4share', 'c4big', 'central10x5', 'central10x5roll', 'central10x5f', 'central32x10', 'c2policy', 'c3rf', 'c3roll']
 
 
 def measure(a):
@@ -82,6 +82,10 @@ def measure(a):
             out[w] = bench.measure_steps(*mk, 4096, 128, 32, 'multi')['kernel_ms']
         elif w == 'c5big':
             out[w] = bench.measure_steps(*mk, 32768, 128, 32, 'multi', steps=100)['kernel_ms']
+        elif w == 'c5mid':
+            out[w] = bench.measure_steps(*mk, 8192, 128, 32, 'multi', steps=200)['kernel_ms']
+        elif w == 'c4big':
+            out[w] = bench.measure_steps(*mk, 262144, 32, 10, 'multi', steps=200)['kernel_ms']
         elif w == 'c4share':
             out[w] = bench.measure_steps(*mk, 32768, 32, 10, 'multi')['kernel_ms']
         elif w == 'central10x5':

@@ -12,7 +12,12 @@ template <int PAT>
 __global__ __launch_bounds__(256) void k(float *obs, int waves_total, int persistent_stride)
 {
     const int lane = threadIdx.x & 63;
-    for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < waves_total; w += persistent_stride) {
+    int blk = blockIdx.x;
+    if (PAT == 7) {                          // XCD-aware: workgroup b runs on XCD b % 8; give every XCD one contiguous eighth of the buffer
+        const int per = gridDim.x / 8;
+        blk = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    }
+    for (int w = blk * 4 + (threadIdx.x >> 6); w < waves_total; w += persistent_stride) {
         float *base = obs + (size_t)w * 64 * ROW;
         const float val = (float)(w + lane);
         if (PAT == 0) {                       // round 3: row by row, 4-byte columns (two store instructions per row + utility)
@@ -38,7 +43,7 @@ __global__ __launch_bounds__(256) void k(float *obs, int waves_total, int persis
                     if (PAT == 4) __builtin_nontemporal_store(v, dst); else *dst = v;
                 }
             }
-        } else if (PAT == 5) {                // like 1, utility float right with its rows (2 lanes per iteration)
+        } else if (PAT == 5 || PAT == 7) {                // like 1, utility float right with its rows (2 lanes per iteration)
             const int h = lane >> 5, j = lane & 31;
             for (int i = 0; i < 32; i++) {
                 f4u v; v.x = v.y = v.z = v.w = val;
@@ -89,6 +94,7 @@ int main()
             run<0>("0 four-byte columns, row by row", obs, envs, cap);
             run<1>("1 16-byte pieces, half-wave per row", obs, envs, cap);
             run<5>("5 ... utility with its rows", obs, envs, cap);
+            if (cap == 0) run<7>("7 ... and every XCD a contiguous eighth of the buffer", obs, envs, cap);
             run<2>("2 ... non-temporal", obs, envs, cap);
             run<3>("3 line-aligned 1 KiB per instruction", obs, envs, cap);
             run<4>("4 ... non-temporal", obs, envs, cap);
