@@ -1,3 +1,2 @@
 mkdir -p gpurun_out
-python -m pytest tests/test_fragment_gpu.py -m gpu -q 2>&1 | grep -E "passed|failed"
-python tools/fragment_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r4_bb_fragment.txt
+DCOMP_BUILD_B=5 python tools/ab_lib.py run r0 r1 --rounds 2 --only central10x5roll,c2roll,central10x5 2>&1 | tail -5
