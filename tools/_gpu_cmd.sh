@@ -1,2 +1,10 @@
-mkdir -p gpurun_out
-DCOMP_BUILD_B=5 python tools/ab_lib.py run r0 r1 --rounds 2 --only central10x5roll,c2roll,central10x5 2>&1 | tail -5
+set -x
+for x in 0 1 0 1; do
+  echo "=== DCOMP_HEUR_XCD=$x"
+  DCOMP_HEUR_XCD=$x python tools/bench_policy.py --envs 65536 --ues 32 --bs 10 2>&1 | grep -E "kernel|alone"
+done
+for x in 0 1; do
+  echo "=== big DCOMP_HEUR_XCD=$x"
+  DCOMP_HEUR_XCD=$x python tools/bench_policy.py --envs 8192 --ues 128 --bs 32 2>&1 | grep -E "kernel|alone"
+done
+DCOMP_HEUR_XCD=1 python -m pytest tests/test_adapters_gpu.py tests/test_policy_gpu.py -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3
