@@ -13,7 +13,7 @@ __global__ __launch_bounds__(256) void k(float *obs, int waves_total, int persis
 {
     const int lane = threadIdx.x & 63;
     int blk = blockIdx.x;
-    if (PAT == 7) {                          // XCD-aware: workgroup b runs on XCD b % 8; give every XCD one contiguous eighth of the buffer
+    if (PAT >= 7) {                          // XCD-aware: workgroup b runs on XCD b % 8; give every XCD one contiguous eighth of the buffer
         const int per = gridDim.x / 8;
         blk = (blockIdx.x % 8) * per + blockIdx.x / 8;
     }
@@ -34,13 +34,13 @@ __global__ __launch_bounds__(256) void k(float *obs, int waves_total, int persis
                 if (PAT == 2) __builtin_nontemporal_store(v, dst); else *dst = v;
                 if ((i & 3) == 3 && (lane >> 3) == (i >> 2)) base[lane * ROW + 128] = val;
             }
-        } else if (PAT == 3 || PAT == 4) {    // line-aligned 1 KiB per store instruction (what LDS staging in memory layout would give)
+        } else if (PAT == 3 || PAT == 4 || PAT == 8 || PAT == 9) {    // line-aligned 1 KiB per store instruction (what LDS staging in memory layout would give)
             for (int i = 0; i < 33; i++) {
                 const int f = i * 256 + 4 * lane;
                 if (f < 64 * ROW) {
                     f4u v; v.x = v.y = v.z = v.w = val;
                     f4u *dst = reinterpret_cast<f4u *>(base + f);
-                    if (PAT == 4) __builtin_nontemporal_store(v, dst); else *dst = v;
+                    if (PAT == 4 || PAT == 9) __builtin_nontemporal_store(v, dst); else *dst = v;
                 }
             }
         } else if (PAT == 5 || PAT == 7) {                // like 1, utility float right with its rows (2 lanes per iteration)
@@ -98,6 +98,8 @@ int main()
             run<2>("2 ... non-temporal", obs, envs, cap);
             run<3>("3 line-aligned 1 KiB per instruction", obs, envs, cap);
             run<4>("4 ... non-temporal", obs, envs, cap);
+            if (cap == 0) run<8>("8 line-aligned 1 KiB, XCD-contiguous", obs, envs, cap);
+            if (cap == 0) run<9>("9 ... non-temporal", obs, envs, cap);
         }
     }
     // How much of the sustained rate is DRAM locality?  The same bytes, line-aligned 1 KiB store instructions, but the resident waves
