@@ -151,17 +151,20 @@ def measure_rollout(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev
     return out
 
 
-def measure_steps(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev, E, U, B, kind, steps=300, L=100, sharing='mixed', ring=0):
+def measure_steps(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev, E, U, B, kind, steps=300, L=100, sharing='mixed', ring=0, compact=False):
     """One launch per step on another shape (secondary figures): HIP events around back-to-back launches after 300 untimed
     ones (steady state), SURVEY 8(d) bytes / launch duration.  ring = k > 0: the steps write their observations / rewards into k
     DIFFERENT buffers in turn (a rollout fragment, step_into) instead of rewriting env.obs -- a buffer that is rewritten every step
-    partly never leaves the 256 MB Infinity Cache, a fragment does."""
+    partly never leaves the 256 MB Infinity Cache, a fragment does.  compact: the steps write the lossless compact record
+    (dcomp_out.obs_compact, U (B + 2) + 2B words per env-step) INSTEAD of the rows; its figure counts the bytes of THAT layout --
+    it is not a fraction of the SURVEY 8(d) roofline, whose bytes are the row format's."""
     scn = scenarios.grid_map(B, sharing).with_ues(num_slow=U)
     m, bs, ues = build_from_scenario(scn)
     env = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=42, episode_length=L, rng='philox', rand_episodes=True, device=dev)
     g = torch.Generator(device=dev).manual_seed(7)
     pool = torch.randint(0, B + 1, (4, E, U), generator=g, device=dev, dtype=torch.uint8)
     frag = [(torch.empty_like(env.obs), torch.empty_like(env.reward)) for _ in range(ring)]
+    packed = torch.empty((E, env.compact_words), dtype=torch.int32, device=dev) if compact else None
     ms, n = 0.0, 0
     for phase, count in (('warm', 300), ('timed', steps)):
         t = 0
@@ -171,7 +174,9 @@ def measure_steps(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev, 
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for i in range(k):
-                if ring:
+                if compact:
+                    env.step_compact(pool[i & 3], packed, env.reward)
+                elif ring:
                     env.step_into(pool[i & 3], *frag[i % ring])
                 else:
                     env.step(pool[i & 3])
@@ -184,6 +189,13 @@ def measure_steps(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev, 
     env.check()
     kms = ms / n
     bpe = survey_bytes_per_env_step(U, B, kind)
+    if compact:                                  # the row format's 4 (4B + 1) bytes of observation per UE become 4 (B + 2), + 8B per env
+        cb = bpe - U * 4 * (4 * B + 1) + 4 * env.compact_words
+        return {'kernel_ms': kms, 'env_steps_per_s_kernel_only': E / (kms * 1e-3), 'bytes_per_env_step_in_the_compact_layout': cb,
+                'bytes_per_env_step_in_the_row_format': bpe, 'achieved_GBps_by_the_bytes_it_moves': cb * E / (kms * 1e-3) / 1e9,
+                'frac_of_hbm_peak_by_the_bytes_it_moves': cb * E / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'observation': 'lossless compact record written by the step itself (dcomp_out.obs_compact); dcomp_unpack_fragment restores the rows bit for bit',
+                'how': f'{n} back-to-back launches after 300 untimed ones, HIP events'}
     return {'kernel_ms': kms, 'env_steps_per_s_kernel_only': E / (kms * 1e-3), 'algorithmic_bytes_per_env_step': bpe,
             'achieved_GBps': bpe * E / (kms * 1e-3) / 1e9, 'frac_of_hbm_peak': bpe * E / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             'lanes_per_env': env.lanes_per_env, 'how': f'{n} back-to-back launches after 300 untimed ones, HIP events'}
@@ -258,12 +270,15 @@ def measure_also(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev):
            'config3_65536x32x10_multi_resource_fair': measure_steps(*mk, 65536, 32, 10, 'multi', sharing='resource-fair'),
            # the headline workload stepping into a ring of 8 fragment buffers (2.75 GB) instead of rewriting ONE 344 MB observation
            # tensor, of which 256 MB can stay in the Infinity Cache from step to step: what a sampler that keeps every step sees
-           'config3_65536x32x10_multi_into_8_fragment_buffers': measure_steps(*mk, 65536, 32, 10, 'multi', ring=8)}
+           'config3_65536x32x10_multi_into_8_fragment_buffers': measure_steps(*mk, 65536, 32, 10, 'multi', ring=8),
+           'config3_65536x32x10_multi_compact_record': measure_steps(*mk, 65536, 32, 10, 'multi', compact=True)}
     # one GPU's share of the two multi-GPU BASELINE configurations at N = 1 / 2 / 4 / 8 (strong scaling: total size fixed), kernel
     # time by HIP events -- the per-GPU roofline of every point of the curve a multi-GPU node will draw
     for name, total, U, B in (('config5_per_gpu_share_of_32768x128x32', 32768, 128, 32), ('config4_per_gpu_share_of_262144x32x10', 262144, 32, 10)):
         out[name] = {f'N{n}_{total // n}_envs': measure_steps(*mk, total // n, U, B, 'multi', steps=200 if total // n * U * B > 6e7 else 300)
                      for n in (1, 2, 4, 8)}
+    # config 5 with the compact record: the whole job on one GPU and the N = 8 share (the launches the row format binds to the HBM write rate)
+    out['config5_compact_record'] = {f'N{n}_{32768 // n}_envs': measure_steps(*mk, 32768 // n, 128, 32, 'multi', steps=200, compact=True) for n in (1, 8)}
     out['config5_share_4096x128x32_multi'] = out['config5_per_gpu_share_of_32768x128x32']['N8_4096_envs']
     out['config4_share_32768x32x10_multi'] = out['config4_per_gpu_share_of_262144x32x10']['N8_32768_envs']      # last: the headline's own kernel
     return out
@@ -695,13 +710,13 @@ def main():
             handoff.update(what=f'reward + sum_utility of every env, all-gathered every {G} steps as one tensor [E, reward columns + 1] (one collective per hand-off), asynchronous',
                            period_steps=G, bytes_sent_per_rank_per_handoff=4 * (env.reward.numel() + E))
 
-    def probe_obs_handoff(nfrag=4, compact=False):
+    def probe_obs_handoff(nfrag=4, compact=False, direct=False):
         """The rollout hand-off north_star names, measured next to the headline (never part of `value`): fragments of F steps
         of observations + rewards all-gathered over RCCL on a side stream while the next fragment is stepped."""
         from deepcomp_amd.sharded import RolloutGather
         g2 = gather if gather is not None else RolloutGather(use_side_stream=(args.backend == 'nccl'))
-        bufs = [{'obs': torch.empty((F,) + tuple(env.obs.shape), device=dev), 'reward': torch.empty((F,) + tuple(env.reward.shape), device=dev)}
-                for _ in range(2)]
+        bufs = [{'obs': None if direct else torch.empty((F,) + tuple(env.obs.shape), device=dev),
+                 'reward': torch.empty((F,) + tuple(env.reward.shape), device=dev)} for _ in range(2)]
         if compact:
             for b_ in bufs:
                 b_['packed'] = torch.empty((F, E, codec.words), dtype=torch.int32, device=dev)
@@ -710,13 +725,17 @@ def main():
         def outgoing(k):
             if not compact:
                 return bufs[k] if args.backend == 'nccl' else {n: v.cpu() for n, v in bufs[k].items()}
-            codec.pack(bufs[k]['obs'], out=bufs[k]['packed'])
+            if not direct:
+                codec.pack(bufs[k]['obs'], out=bufs[k]['packed'])
             send = {'obs_compact': bufs[k]['packed'], 'reward': bufs[k]['reward']}
             return send if args.backend == 'nccl' else {n: v.cpu() for n, v in send.items()}
 
         def steps(k):
             for f in range(F):
-                env.step_into(pool[f & 15], bufs[k]['obs'][f], bufs[k]['reward'][f])
+                if direct:                                   # dcomp_out.obs_compact: the step writes the record itself, no rows, no pack pass
+                    env.step_compact(pool[f & 15], bufs[k]['packed'][f], bufs[k]['reward'][f])
+                else:
+                    env.step_into(pool[f & 15], bufs[k]['obs'][f], bufs[k]['reward'][f])
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         steps(0); steps(1)                                   # warm
         fence()
@@ -742,7 +761,8 @@ def main():
         wall = time.perf_counter() - t0
         per = F * ((E * codec.words if compact else env.obs.numel()) + env.reward.numel()) * 4
         step_ms, both_ms = ev[0].elapsed_time(ev[1]) / nfrag, ev[2].elapsed_time(ev[3]) / nfrag
-        return {'compact': compact, 'fragment_steps': F, 'fragments': nfrag, 'rccl_ranks': dist.get_world_size(), 'backend': 'rccl' if args.backend == 'nccl' else args.backend,
+        return {'compact': compact, 'written_by': ('the step itself (dcomp_out.obs_compact)' if direct else 'dcomp_pack_fragment after the steps') if compact else 'rows',
+                'fragment_steps': F, 'fragments': nfrag, 'rccl_ranks': dist.get_world_size(), 'backend': 'rccl' if args.backend == 'nccl' else args.backend,
                 'bytes_sent_per_rank_per_fragment': per, 'bytes_received_per_rank_per_fragment': per * world,
                 'ms_per_fragment_stepping_only': step_ms, 'ms_per_fragment_with_overlapped_all_gather': both_ms,
                 'exposed_handoff_ms_per_fragment': max(0.0, both_ms - step_ms), 'wall_s': wall,
@@ -755,6 +775,7 @@ def main():
             obs_probe = probe_obs_handoff()
             if codec is not None:                  # the same hand-off with the lossless compact record (pack kernel included)
                 obs_probe['compact_record'] = probe_obs_handoff(compact=True)
+                obs_probe['compact_record_from_the_step'] = probe_obs_handoff(compact=True, direct=True)
         except Exception as ex:                # noqa: BLE001
             obs_probe = {'error': f'{type(ex).__name__}: {ex}'[:300]}
             torch.cuda.synchronize(dev)

@@ -38,7 +38,8 @@ class DcompState(ctypes.Structure):
 
 class DcompOut(ctypes.Structure):
     _fields_ = [('obs', ctypes.c_void_p), ('reward', ctypes.c_void_p), ('sum_utility', ctypes.c_void_p),
-                ('ue_dr', ctypes.c_void_p), ('ue_utility', ctypes.c_void_p), ('reward_before', ctypes.c_void_p)]
+                ('ue_dr', ctypes.c_void_p), ('ue_utility', ctypes.c_void_p), ('reward_before', ctypes.c_void_p),
+                ('obs_compact', ctypes.c_void_p)]
 
 
 class DcompTape(ctypes.Structure):

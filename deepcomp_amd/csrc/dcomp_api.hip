@@ -348,7 +348,9 @@ static void launch_step(dcomp_env *env, KParams &kp, void *stream)
     }
     const bool wide = env->wide_grid && env->kern.step == env->kern.step_wide;
     const int grid = wide ? env->wide_grid : env->grid;
-    hipLaunchKernelGGL(env->kern.step, dim3(grid), dim3(DCOMP_BLOCK), wide ? env->wide_pad_lds : 0, (hipStream_t)stream, kp);
+    // (the occupancy cap is for launches that stream GBs of ROWS; with the compact record a launch is bound by its arithmetic and wants
+    // every wave it can get: 32 768 x 128 x 32 236 us with four workgroups per CU, 369 us with two)
+    hipLaunchKernelGGL(env->kern.step, dim3(grid), dim3(DCOMP_BLOCK), wide && !kp.obs_compact ? env->wide_pad_lds : 0, (hipStream_t)stream, kp);
 }
 
 static int check_horizon(const dcomp_env *env, int steps)
@@ -362,7 +364,12 @@ static int fill_params(dcomp_env *env, const dcomp_state *st, const dcomp_out *o
 {
     if (!env || !st || !out) return fail(DCOMP_EINVAL, "null argument");
     if (!st->pos || !st->mv || !st->conn || !st->ewma || !st->flags) return fail(DCOMP_EINVAL, "state pointers must all be set");
-    if (!out->obs) return fail(DCOMP_EINVAL, "out->obs is required");
+    if (!out->obs && !out->obs_compact) return fail(DCOMP_EINVAL, "out->obs (or out->obs_compact) is required");
+    if (out->obs_compact) {
+        if (out->obs) return fail(DCOMP_EINVAL, "out->obs and out->obs_compact are alternatives: set one, leave the other NULL");
+        if (env->cfg.env_kind != DCOMP_MULTI) return fail(DCOMP_EINVAL, "out->obs_compact: the compact record is defined for multi-agent observations (central observations carry no per-env columns)");
+        if (env->dyn) return fail(DCOMP_EUNSUPPORTED, "out->obs_compact with UE arrival / departure: write rows and use dcomp_pack_fragment");
+    }
     if (env->kp.any_maxcap && !st->conn_since) return fail(DCOMP_EINVAL, "a max-cap BS needs state.conn_since (see dcomp_state_sizes)");
     if (env->dyn && !st->uid) return fail(DCOMP_EINVAL, "UE arrival/departure needs state.uid");
     kp = env->kp;
@@ -372,7 +379,8 @@ static int fill_params(dcomp_env *env, const dcomp_state *st, const dcomp_out *o
     kp.conn_since = st->conn_since;
     kp.time = (uint32_t)env->time;
     kp.pos = (double2 *)st->pos; kp.mv = (unsigned long long *)st->mv; kp.conn = st->conn; kp.ewma = st->ewma; kp.flags = st->flags;
-    kp.obs = out->obs; kp.reward = out->reward; kp.sum_util = out->sum_utility; kp.ue_dr = out->ue_dr; kp.ue_util = out->ue_utility; kp.rb_out = out->reward_before;
+    kp.obs = out->obs_compact ? reinterpret_cast<float *>(out->obs_compact) : out->obs; kp.obs_compact = out->obs_compact ? 1 : 0;
+    kp.reward = out->reward; kp.sum_util = out->sum_utility; kp.ue_dr = out->ue_dr; kp.ue_util = out->ue_utility; kp.rb_out = out->reward_before;
     kp.episode = (uint32_t)(env->episode < 0 ? 0 : env->episode);
     kp.num_steps = 1; kp.out_every_step = 0; kp.horizon = 0; kp.episode_inc = 0;
     kp.tight_g = 0; kp.tight_gpw = 0; kp.tight_magic = 0;
@@ -483,7 +491,8 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
     const size_t obs_step = EU * (size_t)(multi ? 4 * env->cfg.num_bs + 1 : 2 * env->cfg.num_bs + 1);
     auto out_slice = [&](KParams &k, int t) {                  // where step t's outputs go
         if (!every) return;
-        k.obs = out->obs + obs_step * t;
+        k.obs = out->obs_compact ? reinterpret_cast<float *>(out->obs_compact) + E * (size_t)dcomp_frag::env_words(env->cfg.num_ue, env->cfg.num_bs) * t
+                                 : out->obs + obs_step * t;
         if (out->reward) k.reward = out->reward + (multi ? EU : E) * t;
         if (out->sum_utility) k.sum_util = out->sum_utility + E * t;
         if (out->ue_dr) k.ue_dr = out->ue_dr + EU * t;

@@ -127,6 +127,7 @@ struct KParams {
     // io (device)
     const uint8_t *action;
     float *obs, *reward, *sum_util, *ue_dr, *ue_util, *rb_out;
+    int32_t obs_compact;       // 1: `obs` is dcomp_out.obs_compact -- the step writes the compact record (dcomp_fragment.h) instead of the rows
     uint8_t *next_act;         // optional [E][U]: the heuristic policy's action on the observation this launch writes (dcomp_set_policy)
     const uint32_t *policy_cluster;   // DCOMP_POLICY_CLUSTER: [B] cluster masks
     int32_t policy;            // DCOMP_POLICY_*
@@ -904,7 +905,7 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
 // l2 / cnt are consumed (overwritten with the observation entries).
 // `active`: this lane owns a slot (row) of the env; `alive`: a UE currently sits in that slot (always the same unless
 // UEs arrive / depart, then dead slots produce zero rows: central.py:46-55); n_eff = UEs currently in the env.
-struct Outs { float *obs, *reward, *sum_util, *ue_dr, *ue_util, *rb_out; uint8_t *next_act; };   // where this step's outputs go
+struct Outs { float *obs, *reward, *sum_util, *ue_dr, *ue_util, *rb_out; uint8_t *next_act; int compact; };   // where this step's outputs go
 
 // The same rules with the dr entries behind a functor (the wide kernel keeps a UE's row in LDS, not in registers).
 template <int B, class F>
@@ -1074,7 +1075,22 @@ __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, B
         for (int b = 0; b < B; b++) acc += l2[b] + cnt[b] + tsum[b];
         if (active && acc == 123456.f) o.obs[idx] = acc;         // keeps the producers alive, writes nothing
     } else if (kind == DCOMP_MULTI && !STAGED) {
-        if (active) {
+        if (active && o.compact) {                              // (uniform) the compact record instead of the row, straight from registers
+            if (o.reward) o.reward[idx] = alive ? reward : 0.f;
+            float *rec = o.obs + (size_t)idx * (B + 2) + (size_t)env * (2 * B);     // word U (B + 2) env + (B + 2) u + 2B env
+            float recv[B + 2];
+#pragma unroll
+            for (int b = 0; b < B; b++) recv[b] = l2[b];
+            recv[B] = util_n;
+            recv[B + 1] = __uint_as_float(conn);
+            store_run<B + 2>(rec, recv);
+            if (u == U - 1) {                                   // the per-env columns once, behind the last UE's record
+                float tl[2 * B];
+#pragma unroll
+                for (int b = 0; b < B; b++) { tl[b] = cnt[b]; tl[B + b] = tsum[b]; }
+                store_run<2 * B>(rec + B + 2, tl);
+            }
+        } else if (active) {
             if (o.reward) o.reward[idx] = alive ? reward : 0.f;
             float rowv[SG::ROW];
 #pragma unroll
@@ -1086,6 +1102,61 @@ __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, B
             }
             rowv[4 * B] = util_n;
             store_run<SG::ROW>(o.obs + (size_t)idx * SG::ROW, rowv);       // the lane's 4B+1 consecutive floats
+        }
+    } else if (kind == DCOMP_MULTI && o.compact) {
+        // The compact record (dcomp_fragment.h: per UE dr[B] | utility | connection mask, then ues_at_bs[B] | util_at_bs[B] once
+        // per env) INSTEAD of the rows -- a third of the store traffic, and no pack pass for a learner hand-off.  The records of a
+        // wave's rows are one contiguous span (the per-env columns sit between the envs' records): staged in LDS as they lie in
+        // memory and copied out linearly, as the rows are; spans larger than the staging buffer go in windows.
+        if (active && o.reward) stream_store(&o.reward[idx], alive ? reward : 0.f);
+        const unsigned long long am = __ballot(active);
+        if (am != 0ull) {
+            constexpr int CW = B + 2;
+            const int first = __ffsll((long long)am) - 1, last = 63 - __clzll((long long)am);
+            const int idx0 = __builtin_amdgcn_readlane(idx, first), env0 = __builtin_amdgcn_readlane(env, first);
+            const size_t g0 = (size_t)idx0 * CW + (size_t)env0 * (2 * B);           // first word of the span
+            const int loc = (idx - idx0) * CW + (env - env0) * (2 * B);             // my record inside it
+            const bool tail = u == U - 1;                                           // the last UE's lane adds the per-env columns
+            const int n = __builtin_amdgcn_readlane(loc + CW + (tail ? 2 * B : 0), last);
+            const int ph = (int)((((size_t)o.obs >> 2) + g0) & 3);                  // 16-byte phase of the span start
+            uint32_t *st = reinterpret_cast<uint32_t *>(sh.stage[wave]);
+            constexpr int CH = (SG::WORDS - 4) & ~3;                                // window size (multiple of 4: constant phase)
+            const bool one = n <= CH;                                               // the usual case: everything in one window
+#pragma unroll 1
+            for (int w0 = 0; w0 < n; w0 += CH) {
+                const int cw = min(CH, n - w0);
+                if (active) {
+                    uint32_t *rec = st + ph - w0 + loc;
+                    const int at = loc - w0;
+#pragma unroll
+                    for (int b = 0; b < B; b++) if (one || (unsigned)(at + b) < (unsigned)cw) rec[b] = __float_as_uint(l2[b]);
+                    if (one || (unsigned)(at + B) < (unsigned)cw) rec[B] = __float_as_uint(util_n);
+                    if (one || (unsigned)(at + B + 1) < (unsigned)cw) rec[B + 1] = conn;
+                    if (tail) {
+#pragma unroll
+                        for (int b = 0; b < B; b++) {
+                            if (one || (unsigned)(at + CW + b) < (unsigned)cw) rec[CW + b] = __float_as_uint(cnt[b]);
+                            if (one || (unsigned)(at + CW + B + b) < (unsigned)cw) rec[CW + B + b] = __float_as_uint(tsum[b]);
+                        }
+                    }
+                }
+                wave_lds_fence();
+                const int n_end = ph + cw;
+                uint32_t *gbase_ptr = reinterpret_cast<uint32_t *>(o.obs) + g0 + w0 - ph;      // 16-byte aligned
+                for (int j = lane * 4; j < n_end; j += 256) {
+                    if (j >= ph && j + 4 <= n_end) {
+                        typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+#if DCOMP_NT_OBS
+                        __builtin_nontemporal_store(*reinterpret_cast<const u4v *>(st + j), reinterpret_cast<u4v *>(gbase_ptr + j));
+#else
+                        *reinterpret_cast<u4v *>(gbase_ptr + j) = *reinterpret_cast<const u4v *>(st + j);
+#endif
+                    } else {
+                        for (int k = max(j, ph); k < min(j + 4, n_end); k++) gbase_ptr[k] = st[k];
+                    }
+                }
+                wave_lds_fence();
+            }
         }
     } else if (kind == DCOMP_MULTI) {
         if (active && o.reward) stream_store(&o.reward[idx], alive ? reward : 0.f);
@@ -1441,7 +1512,7 @@ __device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<
             vrange = mv_cfg_pack(c.vel_lo, c.vel_hi, c.pause, c.border);
         }
     }
-    Outs o{p.obs, p.reward, p.sum_util, p.ue_dr, p.ue_util, p.rb_out, POL == 0 ? nullptr : p.next_act};
+    Outs o{p.obs, p.reward, p.sum_util, p.ue_dr, p.ue_util, p.rb_out, POL == 0 ? nullptr : p.next_act, p.obs_compact};
     if (!ROLLOUT) {
         step_once<B, UPAD, MP, true, S, -1, false, KIND>(p, sh, o, true, active, env, env_local, u, idx, wave, lane, gbase, act, p.time, p.episode,
                                                          step_util, dr_req, vrange, px, py, mv, conn, ewma, sg);
@@ -1584,7 +1655,7 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void reset_kernel(const KParams p)
 #pragma unroll
     for (int b = 0; b < B; b++) cnt[b] = 0.f;
     const float util = ue_utility(0.f, step_util, dr_req);
-    const Outs o{p.obs, p.reward, p.sum_util, p.ue_dr, p.ue_util, p.rb_out, p.next_act};
+    const Outs o{p.obs, p.reward, p.sum_util, p.ue_dr, p.ue_util, p.rb_out, p.next_act, p.obs_compact};
     write_outputs<B, UPAD, true, true>(p, o, sh, active, env, env_local, u, idx, wave, lane, gbase, 0u, in_range, l2, cnt, util, 0.f, 0.f, alive,
                                  p.U0);
 }

@@ -518,6 +518,51 @@ __device__ __forceinline__ void wide_step_one(const KParams &p, WideShared<B, UP
         }
         return;
     }
+    if (p.obs_compact) {                                                          // (uniform)
+        // ---- the compact record instead of the rows (dcomp_out.obs_compact; layout in dcomp_fragment.h): per UE dr[B] | utility |
+        // connection mask, then the per-env columns once.  A wave's records are ONE contiguous span of 64 (B + 2) words.  My row of the
+        // LDS table (stride B + 1) gets the utility in its spare word, so [dr | utility] are B + 1 consecutive words per row and the
+        // masks wait in row_ci: a lane walks (row, word) of its 16-byte pieces incrementally, one LDS read per word.
+        constexpr int CW = B + 2;
+#pragma unroll 4
+        for (int b = 0; b < B; b++) cell(b) = fast_exp2(cell(b) - l2max);                     // variants.py:276-284
+        myrow[B] = util_n;
+        if (p.next_act) {                                                         // dcomp_set_policy (uniform): the rules on this UE's dr row
+            const int a = policy_action_fn<B>(p, conn, [&](int b) { return cell(b); });
+            if (active) p.next_act[idx] = (uint8_t)a;
+        }
+        wave_lds_fence();
+        const unsigned long long am = __ballot(active);
+        const int nrows = group_popcount<64>(am, 0);                              // active lanes are lanes [0, nrows)
+        const size_t rec0 = ((size_t)env * p.U + (size_t)(wave % NW) * 64) * CW + (size_t)env * (2 * B);
+        uint32_t *const dst = reinterpret_cast<uint32_t *>(p.obs) + rec0;
+        const uint32_t *const stw = reinterpret_cast<const uint32_t *>(st);
+        const uint2 *const ci = sh.row_ci + wave * 64;
+        const int nw = nrows * CW;
+        typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(4)));
+        int r = (lane * 4) / CW, k = lane * 4 - r * CW;
+        for (int w = lane * 4; w < nw; w += 256) {
+            uint32_t o4[4];
+            int r2 = r, k2 = k;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int rr = min(r2, 63);
+                o4[j] = k2 == B + 1 ? ci[rr].x : stw[wide_col<B>(rr, k2)];
+                k2++;
+                if (k2 == CW) { k2 = 0; r2++; }
+            }
+            if (w + 3 < nw) { u4u v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3]; *reinterpret_cast<u4u *>(dst + w) = v; }
+            else for (int j = 0; j < 4; j++) if (w + j < nw) dst[w + j] = o4[j];
+            r += 256 / CW; k += 256 % CW;
+            if (k >= CW) { k -= CW; r++; }
+        }
+        if ((wave % NW) == 0 && nrows > 0 && lane < 2 * B) {                      // ues_at_bs | util_at_bs, once per env (variants.py:296-299)
+            const float4 t = station(lane < B ? lane : lane - B);
+            const float e = lane < B ? t.x * inv_u : (t.x > 0.f ? t.y * fast_rcp(t.x) * (1.0f / MAX_UTIL) : 0.f);
+            reinterpret_cast<float *>(p.obs)[((size_t)env * p.U + p.U) * CW + (size_t)env * (2 * B) + lane] = e;
+        }
+        return;
+    }
     if constexpr (B % 4 == 0 && DCOMP_WIDE_QUAD_ROWS) {
         // ---- rows leave as 16-BYTE pieces, a half-wave per row (round 4).  With B a multiple of 4 the four blocks of a row start at
         // multiples of 4 floats, so piece j (floats 4j .. 4j+3, j < B) of a row lies inside ONE block: lanes 0 .. B-1 of a half-wave

@@ -236,11 +236,12 @@ class BatchedMobileEnv:
         self._live = None                    # seed(immediate=True) in a running fixed episode: (new env seeds, cursors at that time)
 
     # ------------------------------------------------------------------ helpers
-    def _make_out(self, obs, reward):
+    def _make_out(self, obs, reward, packed=None):
         m = self.log_metrics
-        return _lib.DcompOut(obs.data_ptr(), reward.data_ptr(), self.sum_utility.data_ptr() if m else None,
+        return _lib.DcompOut(obs.data_ptr() if obs is not None else None, reward.data_ptr(), self.sum_utility.data_ptr() if m else None,
                              self.ue_dr.data_ptr() if m else None, self.ue_utility.data_ptr() if m else None,
-                             self.reward_before.data_ptr() if self.want_reward_before else None)
+                             self.reward_before.data_ptr() if self.want_reward_before else None,
+                             packed.data_ptr() if packed is not None else None)
 
     def _stream(self):
         try:                                   # raw handle of torch's current stream without building a Stream object (~4 us)
@@ -412,7 +413,7 @@ class BatchedMobileEnv:
         del old
 
     # ------------------------------------------------------------------ gym-like batched API
-    def reset(self):
+    def reset(self, _out=None):
         """MobileEnv.reset (base.py:169-189) for all envs -> first observation tensor."""
         with torch.cuda.device(self.device):
             tape = None
@@ -427,10 +428,10 @@ class BatchedMobileEnv:
             self._reseeded = False
             self._device_seed = self.seed_value            # the seed this episode's draws come from (tape drawn / key installed above)
             _lib.check(self._L.dcomp_reset(self._h, ctypes.byref(self._st), ctypes.byref(tape) if tape else None,
-                                           ctypes.byref(self._out), self._stream()))
+                                           ctypes.byref(self._out if _out is None else _out), self._stream()))
         if self._policy_key is not None:
             self._policy_launched()
-        return self.obs
+        return self.obs if _out is None else None
 
     def step(self, action):
         """MobileEnv.step (base.py:413-466).  action: uint8 tensor [E, U] on this device, values in [0, B]."""
@@ -487,6 +488,35 @@ class BatchedMobileEnv:
         with torch.cuda.device(self.device):
             self._launch_step(action, out)
 
+    @property
+    def compact_words(self):
+        """int32 words of one env-step in the compact record (deepcomp_amd.fragment: U (B + 2) + 2B); multi-agent envs only."""
+        from .fragment import fragment_words
+        return fragment_words(self.U, self.B)
+
+    def _require_compact(self, packed, steps=1):
+        if self.kind != _lib.MULTI or self.dynamic:
+            raise NotImplementedError("compact observation records exist for multi-agent envs with a fixed UE list "
+                                      "(write rows and use deepcomp_amd.fragment.FragmentCodec.pack otherwise)")
+        self._require(packed, torch.int32, steps * self.E * self.compact_words, 'packed')
+
+    def step_compact(self, action, packed, reward):
+        """step() that writes the observation as the lossless COMPACT record (int32 [E, U (B + 2) + 2B]: per UE dr[B] | utility |
+        connection mask, then ues_at_bs[B] | util_at_bs[B] once per env; variants.py:271-305) INSTEAD of the [E, U, 4B + 1] rows: a
+        third of the store traffic, and nothing to pack before a learner hand-off.  FragmentCodec(U, B).unpack(packed) is
+        bit-identical to the rows step() would have written.  self.obs is NOT updated by this call."""
+        self._require(action, torch.uint8, self.E * self.U, 'action')
+        self._require_compact(packed)
+        self._require(reward, torch.float32, self.reward.numel(), 'reward')
+        out = self._make_out(None, reward, packed)
+        with torch.cuda.device(self.device):
+            self._launch_step(action, out)
+
+    def reset_compact(self, packed):
+        """reset() whose first observation is written as the compact record (see step_compact)."""
+        self._require_compact(packed)
+        return self.reset(_out=self._make_out(None, self.reward, packed))
+
     def rollout(self, actions, out=None, horizon=None, new_episode_draws=None, _policy_steps=0):
         """T consecutive steps from an action tape [T, E, U] (uint8) in ONE host call -- and, for the narrow kernel
         (``fused_rollout``), ONE kernel launch with the UE state in registers in between (replaces the per-step loop of
@@ -513,7 +543,7 @@ class BatchedMobileEnv:
             # needs a tape the HOST draws from where the previous one stopped, so the rollout is cut at the episode boundaries --
             # one launch per stretch, reset() (cursors read back, new tape) in between.  Same sequence as `if time == L: reset()`
             # before every step, like the in-kernel reset of the other modes.
-            keys = ('obs', 'reward', 'sum_utility', 'ue_dr', 'ue_utility', 'reward_before')
+            keys = ('obs', 'obs_compact', 'reward', 'sum_utility', 'ue_dr', 'ue_utility', 'reward_before')
             t0 = 0
             while t0 < T:
                 if self.time >= L:
@@ -521,10 +551,16 @@ class BatchedMobileEnv:
                 n = min(T - t0, L - self.time)
                 self.rollout(actions[t0:t0 + n], out=None if out is None else {k: out[k][t0:t0 + n] for k in keys if out.get(k) is not None})
                 t0 += n
-            return (self.obs, self.reward) if out is None else (out['obs'], out['reward'])
+            return (self.obs, self.reward) if out is None else (out.get('obs', out.get('obs_compact')), out['reward'])
         o = self._out
         if out is not None:
-            self._require(out['obs'], torch.float32, T * self.obs.numel(), "out['obs']")
+            packed = out.get('obs_compact')          # the compact record of every step instead of the rows (see step_compact)
+            if packed is not None:
+                if out.get('obs') is not None:
+                    raise ValueError("out['obs'] and out['obs_compact'] are alternatives")
+                self._require_compact(packed, T)
+            else:
+                self._require(out['obs'], torch.float32, T * self.obs.numel(), "out['obs']")
             self._require(out['reward'], torch.float32, T * self.reward.numel(), "out['reward']")
             ptr = {}
             for k, n in (('sum_utility', self.E), ('ue_dr', self.E * self.U), ('ue_utility', self.E * self.U),
@@ -532,8 +568,9 @@ class BatchedMobileEnv:
                 if out.get(k) is not None:
                     self._require(out[k], torch.float32, T * n, f"out['{k}']")
                     ptr[k] = out[k].data_ptr()
-            o = _lib.DcompOut(out['obs'].data_ptr(), out['reward'].data_ptr(), ptr.get('sum_utility'), ptr.get('ue_dr'),
-                              ptr.get('ue_utility'), ptr.get('reward_before'))
+            o = _lib.DcompOut(None if packed is not None else out['obs'].data_ptr(), out['reward'].data_ptr(), ptr.get('sum_utility'),
+                              ptr.get('ue_dr'), ptr.get('ue_utility'), ptr.get('reward_before'),
+                              packed.data_ptr() if packed is not None else None)
         if self.rng_mode == _lib.RNG_TAPE:
             self._ensure_tape(min(T, L - self.time) if L else T)
         opts = _lib.DcompRolloutOpts(1 if out is not None else 0, L, 1 if new_episode_draws else 0, 1 if _policy_steps else 0)
@@ -544,7 +581,7 @@ class BatchedMobileEnv:
                                                 ctypes.byref(opts), self._stream()))
         if self._policy_key is not None:
             self._policy_launched()
-        return (self.obs, self.reward) if out is None else (out['obs'], out['reward'])
+        return (self.obs, self.reward) if out is None else (out.get('obs', out.get('obs_compact')), out['reward'])
 
     def _rollout_events(self, T, L, opts):
         """UE departures / arrivals of the next T steps (base.py:433-443) for dcomp_rollout_ex's event feed: the schedule is

@@ -28,6 +28,19 @@ def test_abi_exports_every_declared_symbol(lib):
     assert b'gfx950' in lib.dcomp_version()
 
 
+def test_ctypes_structs_list_the_headers_members_in_order():
+    """The Python layer passes dcomp_state / dcomp_out / dcomp_tape by pointer: a member added to include/dcomp_types.h (round 4:
+    dcomp_out.obs_compact) must appear in the ctypes mirror, in the same place."""
+    import re
+    from deepcomp_amd import _lib
+    txt = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'dcomp_types.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    for cname, mirror in (('dcomp_state', _lib.DcompState), ('dcomp_out', _lib.DcompOut), ('dcomp_tape', _lib.DcompTape)):
+        body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), txt, flags=re.S).group(1)
+        members = [re.split(r'[\s*]+', m.strip())[-1] for decl in body.split(';') if decl.strip() for m in decl.split(',')]
+        assert members == [f[0] for f in mirror._fields_], (cname, members)
+
+
 def test_policy_entry_point_refuses_bad_arguments_on_the_host(lib):
     """dcomp_heuristic_actions validates before it touches the device (raw pointers cross the ABI): no GPU needed."""
     import ctypes
