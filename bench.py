@@ -423,6 +423,9 @@ def main():
                          "episode (default); 'obs' = every fragment of --fragment steps of observations + rewards, all-gathered on a side stream "
                          "while the next fragment is being stepped")
     ap.add_argument('--fragment', type=int, default=4, help='steps per rollout fragment for --gather obs and for the post-run obs hand-off probe')
+    ap.add_argument('--compact-step', action='store_true',
+                    help="NOT the headline: the steps write the lossless compact observation record themselves (dcomp_out.obs_compact) instead of "
+                         "the rows; roofline.achieved then counts the bytes of THAT layout (profiling aid: tools/profile_gpu.sh ... --compact-step)")
     ap.add_argument('--compact', action='store_true',
                     help="--gather obs: hand the observations over as the lossless compact record (dcomp_pack_fragment: U (B + 2) + 2B words per "
                          "env-step instead of U (4B + 1), 3.2x fewer bytes at 32 x 10); the pack kernel runs inside the timed region")
@@ -533,6 +536,12 @@ def main():
         for fb in frag_bufs:
             fb['packed'] = torch.empty((F, E, codec.words), dtype=torch.int32, device=dev)
 
+    packed_main = None
+    if args.compact_step:
+        if args.kind != 'multi' or T or frag_bufs is not None:
+            sys.exit("bench.py: --compact-step is for multi-agent envs stepped one launch per step, without --gather obs")
+        packed_main = torch.empty((E, env.compact_words), dtype=torch.int32, device=dev)
+
     def timed_wait(h):
         """h.wait() makes the compute stream wait for the collective; the HIP events around it time that stall on the GPU
         (0 when the gather had finished long before), the host clock what the host itself blocked."""
@@ -616,6 +625,8 @@ def main():
             begin()
             if frag_bufs is not None:
                 step_into_fragment(t)
+            elif packed_main is not None:
+                env.step_compact(pool[t & 15], packed_main, env.reward)
             else:
                 env.step(pool[t & 15])
             t += 1
@@ -663,7 +674,10 @@ def main():
         while tp < args.prewarm:
             env.reset()
             for i in range(min(L, args.prewarm - tp)):
-                env.step(pool[i & 15])
+                if packed_main is not None:
+                    env.step_compact(pool[i & 15], packed_main, env.reward)
+                else:
+                    env.step(pool[i & 15])
             tp += min(L, args.prewarm - tp)
         torch.cuda.synchronize(dev)
     t_env = run(W, 0)
@@ -820,6 +834,9 @@ def main():
     if rank == 0:
         bpe = bytes_per_env_step(U, B, args.kind)
         sbpe = survey_bytes_per_env_step(U, B, args.kind)
+        if packed_main is not None:            # the compact layout's own bytes: 4 (B + 2) per UE + 8B per env instead of 4 (4B + 1) per UE
+            sbpe = sbpe - U * 4 * (4 * B + 1) + 4 * env.compact_words
+            bpe = bpe - U * 4 * (4 * B + 1) + 4 * env.compact_words
         # algorithmic bytes per env-step x the env-steps one launch processes / launch duration
         achieved = sbpe * E / (kern_ms * 1e-3) / 1e9
         out = {
@@ -827,7 +844,8 @@ def main():
             'warmup': W, 'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64 positions / f32 rates', 'data': 'synthetic',
             'config': {'workload': f'{E} envs/GPU x {U} UE x {B} BS, {args.kind}-agent obs, sharing={args.sharing}, '
-                                   f'log utility, reward avg, episode {L} ({resets_timed} reset launch(es) inside the timed {K} steps), random actions' + (f', rollout chunks of {T}' if T else ''),
+                                   f'log utility, reward avg, episode {L} ({resets_timed} reset launch(es) inside the timed {K} steps), random actions' + (f', rollout chunks of {T}' if T else '') +
+                                   (', observations written as the COMPACT record (dcomp_out.obs_compact; not the BASELINE output format -- roofline bytes are the compact layout\'s)' if packed_main is not None else ''),
                        'envs_per_gpu': E, 'num_ue': U, 'num_bs': B, 'pair_steps_per_s': world * E * K / elapsed * U * B,
                        'parallelism': f'env-shard x{world}',
                        'collective': ('none on the data path' if gather is None else
@@ -857,7 +875,7 @@ def main():
                                                'frac': sbpe * E / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                'how': f'200 launches timed after {max(300, K)} untimed ones (same HIP-event method)'}
         if args.traffic_bytes is None:
-            ent, src = traffic_from_profile(f'{E}x{U}x{B}_{args.kind}_{args.sharing}', env.step_kernel_name, want_entry=True)
+            ent, src = traffic_from_profile(f'{E}x{U}x{B}_{args.kind}_{args.sharing}' + ('_compact' if packed_main is not None else ''), env.step_kernel_name, want_entry=True)
             out['roofline']['traffic'] = (2.0 * ent['fetch_kib'] + ent['write_kib']) * 1024.0 if ent else None
             out['roofline']['traffic_source'] = src
             if ent and valu_bound(ent, kern_ms):

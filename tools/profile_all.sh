@@ -17,6 +17,8 @@ bash tools/profile_gpu.sh ${P}_c3 > /dev/null 2>&1; keep ${P}_c3
 bash tools/profile_gpu.sh ${P}_c4share --envs 32768 > /dev/null 2>&1; keep ${P}_c4share
 bash tools/profile_gpu.sh ${P}_c5 --envs 4096 --ues 128 --bs 32 > /dev/null 2>&1; keep ${P}_c5
 bash tools/profile_gpu.sh ${P}_c5big --envs 32768 --ues 128 --bs 32 > /dev/null 2>&1; keep ${P}_c5big
+bash tools/profile_gpu.sh ${P}_c3compact --compact-step > /dev/null 2>&1; keep ${P}_c3compact
+bash tools/profile_gpu.sh ${P}_c5bigcompact --envs 32768 --ues 128 --bs 32 --compact-step > /dev/null 2>&1; keep ${P}_c5bigcompact
 bash tools/profile_gpu.sh ${P}_central --envs 65536 --ues 10 --bs 5 --kind central > /dev/null 2>&1; keep ${P}_central
 bash tools/profile_rollout.sh ${P}_c2roll 4096 10 5 central 100 > /dev/null 2>&1; keep ${P}_c2roll
 bash tools/profile_rollout.sh ${P}_centralroll 65536 10 5 central 50 > /dev/null 2>&1; keep ${P}_centralroll

@@ -68,8 +68,8 @@ def main():
     path = os.path.join(REPO, 'profiles', 'traffic.json')
     db = json.load(open(path)) if os.path.exists(path) else {}
     old = db.get(key, {})
-    if old.get('tag') == tag:                      # the same profile registered again (new fields): it still belongs to the tree it was taken from
-        commit = old.get('commit', commit)
+    if old.get('tag') == tag and old.get('source_fingerprint') == (fp.group(1) if fp else None):
+        commit = old.get('commit', commit)         # the same profile registered again (new fields): it still belongs to the tree it was taken from
     db[key] = {'tag': tag, 'kernel': kern, 'fetch_kib': vals['FETCH_SIZE'], 'write_kib': vals['WRITE_SIZE'],
                'source_fingerprint': fp.group(1) if fp else None, 'kernel_fingerprint': kfp.group(1) if kfp else None, 'commit': commit,
                'bytes_per_launch': (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0,
