@@ -184,7 +184,32 @@ def run_case(c, torch):
             tol = (ATOL_UTIL if kind == 'multi' else ATOL_OBS) * (U if reward == 'sum' else 1)
             np.testing.assert_allclose(core.reward.cpu().numpy(), rew_o, atol=tol, rtol=0, err_msg=f'{tag}: reward')
 
+    # round 4: multi-agent envs with a fixed UE list also run a TWIN whose steps write the compact record themselves
+    # (dcomp_out.obs_compact): unpack of it must be the core env's rows bit for bit, pack of the rows the record word for word
+    twin = codec = packed = trew = None
+    if kind == 'multi' and not arrival:
+        from deepcomp_amd.fragment import FragmentCodec
+        os.environ['DCOMP_TIGHT'] = '1' if c.get('tight') else '0'
+        try:
+            twin = BatchedMobileEnv(c['m'], c['bs'], c['ues'], kind, num_envs=E, seed=c['seed'], reward=reward,
+                                    rng='reference' if tape else 'philox', rand_episodes=c.get('rand_episodes', True) if tape else True,
+                                    env_id_base=c['base'], episode_length=L, tape_depth=depth if tape else None)
+        finally:
+            os.environ.pop('DCOMP_TIGHT', None)
+        codec = FragmentCodec(U, B)
+        packed = torch.empty((E, codec.words), dtype=torch.int32, device='cuda')
+        trew = torch.empty_like(twin.reward)
+
+    def cmp_twin(tag):
+        rows = codec.unpack(packed)
+        assert torch.equal(rows.view(torch.int32), core.obs.view(torch.int32)), f'{tag}: unpack(compact record) differs from the rows'
+        assert torch.equal(codec.pack(core.obs), packed), f'{tag}: compact record differs from pack(rows)'
+        codec.check()
+
     core.reset()
+    if twin is not None:
+        twin.reset_compact(packed)
+        cmp_twin('reset')
     cmp('reset', oracle_reset(True), None, None, None)
     te = 0                                              # env.time inside the episode
     frag = int(c.get('rollout') or 0)                   # > 0: the HIP path goes through the fused rollout, `frag` steps per call
@@ -194,6 +219,9 @@ def run_case(c, torch):
             if pend:
                 core.rollout(torch.from_numpy(np.stack(pend)).cuda()); pend = []
             core.reset()
+            if twin is not None:
+                twin.reset_compact(packed)
+                cmp_twin('reset2')
             cmp('reset2', oracle_reset(False), None, None, None)
             te = 0
         a = arng.integers(0, B + 1, size=(E, U)).astype(np.uint8)
@@ -211,7 +239,13 @@ def run_case(c, torch):
             res = ob.step(a)
             te += 1
             if len(pend) == frag or t == c['steps'] - 1 or t + 1 == c['steps'] // 2:
-                core.rollout(torch.from_numpy(np.stack(pend)).cuda())
+                acts = torch.from_numpy(np.stack(pend)).cuda()
+                core.rollout(acts)
+                if twin is not None:                       # the twin's fragment: every step's record, the last one against the rows
+                    tp = torch.empty((len(pend), E, codec.words), dtype=torch.int32, device='cuda')
+                    twin.rollout(acts, out={'obs_compact': tp, 'reward': torch.empty((len(pend),) + tuple(twin.reward.shape), device='cuda')})
+                    packed.copy_(tp[-1])
+                    cmp_twin(f'step {t} (rollout x{frag})')
                 pend = []
                 cmp(f'step {t} (rollout x{frag})', *res)
             continue
@@ -224,9 +258,15 @@ def run_case(c, torch):
                     else:
                         o.set_event_counts(n_rem, n_add)
         core.step(torch.from_numpy(a).cuda())
+        if twin is not None:
+            twin.step_compact(torch.from_numpy(a).cuda(), packed, trew)
+            cmp_twin(f'step {t}')
+            assert torch.equal(trew.view(torch.int32), core.reward.view(torch.int32)), f'step {t}: reward of the compact twin'
         cmp(f'step {t}', *ob.step(a))
         te += 1
     core.check()
+    if twin is not None:
+        twin.check()
 
 
 def describe(c):
