@@ -427,8 +427,10 @@ def main():
                     help="NOT the headline: the steps write the lossless compact observation record themselves (dcomp_out.obs_compact) instead of "
                          "the rows; roofline.achieved then counts the bytes of THAT layout (profiling aid: tools/profile_gpu.sh ... --compact-step)")
     ap.add_argument('--compact', action='store_true',
-                    help="--gather obs: hand the observations over as the lossless compact record (dcomp_pack_fragment: U (B + 2) + 2B words per "
-                         "env-step instead of U (4B + 1), 3.2x fewer bytes at 32 x 10); the pack kernel runs inside the timed region")
+                    help="--gather obs: hand the observations over as the lossless compact record (U (B + 2) + 2B words per env-step instead of "
+                         "U (4B + 1), 3.2x fewer bytes at 32 x 10), written by the steps themselves (dcomp_out.obs_compact: no rows, no pack pass)")
+    ap.add_argument('--compact-via-pack', action='store_true',
+                    help="--gather obs --compact: the steps write rows and dcomp_pack_fragment packs them inside the timed region (the two-pass form)")
     ap.add_argument('--gather-every', type=int, default=0,
                     help="--gather summary: steps between two hand-offs (all-gather of the per-env reward + sum_utility since the last one). "
                          "0 = min(episode length, max(4, steps // 2)): at least one collective falls inside ANY timed region")
@@ -524,8 +526,9 @@ def main():
         gather_stats['bytes_sent'] += sum(v.numel() * v.element_size() for v in frag.values())
     if gather is not None and args.gather == 'obs':
         assert L % F == 0 and K % F == 0 and W % F == 0, "--fragment must divide the episode length, steps and warmup"
-        frag_bufs = [{'obs': torch.empty((F,) + tuple(env.obs.shape), device=dev), 'reward': torch.empty((F,) + tuple(env.reward.shape), device=dev)}
-                     for _ in range(2)]
+        direct_compact = args.compact and not args.compact_via_pack
+        frag_bufs = [{'obs': None if direct_compact else torch.empty((F,) + tuple(env.obs.shape), device=dev),
+                      'reward': torch.empty((F,) + tuple(env.reward.shape), device=dev)} for _ in range(2)]
     codec = None
     if args.compact or (use_dist and not args.no_gather and args.kind == 'multi'):
         from deepcomp_amd.fragment import FragmentCodec
@@ -562,11 +565,15 @@ def main():
         if f == 0 and frag_pending[k] is not None:      # about to overwrite a buffer: its gather must have read it
             timed_wait(frag_pending[k])
             frag_pending[k] = None
-        env.step_into(pool[t & 15], frag_bufs[k]['obs'][f], frag_bufs[k]['reward'][f])
+        if args.compact and not args.compact_via_pack:     # the step writes the compact record itself: no rows, no pack pass
+            env.step_compact(pool[t & 15], frag_bufs[k]['packed'][f], frag_bufs[k]['reward'][f])
+        else:
+            env.step_into(pool[t & 15], frag_bufs[k]['obs'][f], frag_bufs[k]['reward'][f])
         if f == F - 1:
             send = frag_bufs[k]
-            if args.compact:                          # the hand-off carries the compact record, packed here on the compute stream
-                codec.pack(send['obs'], out=send['packed'])
+            if args.compact:                          # the hand-off carries the compact record
+                if args.compact_via_pack:             # ... packed here, on the compute stream
+                    codec.pack(send['obs'], out=send['packed'])
                 send = {'obs_compact': send['packed'], 'reward': send['reward']}
             frag = send if args.backend == 'nccl' else {n: v.cpu() for n, v in send.items()}
             frag_pending[k] = gather.all_gather_async(frag)
@@ -717,7 +724,8 @@ def main():
                    'bytes_in_timed_region': {'sent_per_rank': gather_stats['bytes_sent'], 'received_per_rank': gather_stats['bytes_sent'] * world},
                    'compute_stream_stall_ms_total': stall_ms, 'host_blocked_ms_total': gather_stats['wait_s'] * 1e3}
         if args.gather == 'obs':
-            handoff.update(fragment_steps=F, fragments=gather_stats['fragments'], compact=bool(args.compact), bytes_sent_per_rank_per_fragment=per_frag,
+            handoff.update(fragment_steps=F, fragments=gather_stats['fragments'], compact=bool(args.compact),
+                           compact_written_by=(None if not args.compact else 'dcomp_pack_fragment after the steps' if args.compact_via_pack else 'the steps (dcomp_out.obs_compact)'), bytes_sent_per_rank_per_fragment=per_frag,
                            bytes_received_per_rank_per_fragment=per_frag * world,
                            compute_stream_stall_ms_per_fragment=stall_ms / max(1, gather_stats['fragments']))
         else:

@@ -141,13 +141,17 @@ def test_bench_self_spawn_single_rank_rccl():
     assert j['n_gpus'] == 1 and j['handoff']['rccl_ranks'] == 1 and j['handoff']['backend'] == 'rccl'
 
 
-def test_bench_compact_observation_handoff_single_rank_rccl():
-    """`--gather obs --compact`: the fragment crosses the collective as the lossless compact record (dcomp_pack_fragment inside the
-    timed region): U (B + 2) + 2B words per env-step instead of U (4B + 1)."""
-    rc, out, j = _run([sys.executable, 'bench.py', '--gpus', '1', '--force-dist', '--gather', 'obs', '--compact', '--fragment', '5'] + COMMON)
+@pytest.mark.parametrize('via_pack', [False, True])
+def test_bench_compact_observation_handoff_single_rank_rccl(via_pack):
+    """`--gather obs --compact`: the fragment crosses the collective as the lossless compact record, U (B + 2) + 2B words per env-step
+    instead of U (4B + 1) -- written by the steps themselves (dcomp_out.obs_compact) or, `--compact-via-pack`, by dcomp_pack_fragment
+    inside the timed region."""
+    rc, out, j = _run([sys.executable, 'bench.py', '--gpus', '1', '--force-dist', '--gather', 'obs', '--compact', '--fragment', '5'] +
+                      (['--compact-via-pack'] if via_pack else []) + COMMON)
     assert rc == 0 and j is not None, out[-3000:]
     h = j['handoff']
     assert h['mode'] == 'obs' and h['compact'] is True and h['fragments'] == 4
+    assert ('dcomp_pack_fragment' in h['compact_written_by']) == via_pack
     words = 32 * (10 + 2) + 2 * 10
     assert h['bytes_sent_per_rank_per_fragment'] == 5 * 2048 * (words + 32) * 4
     assert h['bytes_in_timed_region']['sent_per_rank'] == 4 * h['bytes_sent_per_rank_per_fragment']

@@ -1,3 +1,1 @@
-date
-timeout 1500 python tools/fuzz_parity.py --cases 1500 --seed 808080 2>&1 | tail -15 | cut -c1-900
-date
+timeout 1500 python -m pytest tests/test_handoff_gpu.py -x -q -m gpu 2>&1 | grep -E "passed|failed|FAILED|Error|assert" | tail -8
