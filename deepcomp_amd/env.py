@@ -624,7 +624,9 @@ class BatchedMobileEnv:
             raise RuntimeError("rollout_policy() needs set_policy() and a reset() / step() after it")
         L = int(horizon or 0)
         T, t0 = int(num_steps), 0
-        keys = ('obs', 'reward', 'sum_utility', 'ue_dr', 'ue_utility', 'reward_before')
+        keys = ('obs', 'obs_compact', 'reward', 'sum_utility', 'ue_dr', 'ue_utility', 'reward_before')
+        if out is not None and out.get('obs_compact') is not None:
+            self._require_compact(out['obs_compact'], T)
         host_resets = L and self.rng_mode == _lib.RNG_TAPE and (self.rand_episodes or self._live is not None)   # a fresh host-drawn tape per episode
         if self.fused_rollout and not self.dynamic and not host_resets:
             return self.rollout(self.next_action.view(1, self.E, self.U), out=out, horizon=L, _policy_steps=T)
@@ -637,12 +639,16 @@ class BatchedMobileEnv:
                 self.rollout(self.next_action.view(1, self.E, self.U), out=frag, _policy_steps=n)
             else:
                 for i in range(n):
-                    self.step(self.next_action)
+                    if frag is not None and 'obs_compact' in frag:       # the step writes this step's record straight into the fragment
+                        self.step_compact(self.next_action, frag['obs_compact'][i], frag['reward'][i])
+                    else:
+                        self.step(self.next_action)
                     if frag is not None:
                         for k in frag:
-                            frag[k][i].copy_(getattr(self, k))
+                            if k != 'obs_compact' and not (k == 'reward' and 'obs_compact' in frag):
+                                frag[k][i].copy_(getattr(self, k))
             t0 += n
-        return (self.obs, self.reward) if out is None else (out['obs'], out['reward'])
+        return (self.obs, self.reward) if out is None else (out.get('obs', out.get('obs_compact')), out['reward'])
 
     def heuristic_actions(self, policy, epsilon=0.0, cluster_mask=None, obs=None, out=None):
         """The reference's heuristic baselines (deepcomp/agent/heuristics.py) for every (env, UE) in one launch

@@ -186,6 +186,18 @@ def test_rollout_gather_hands_rows_over_as_the_compact_record(torch_cuda):
         assert got['obs_compact'].shape == (1, T, E, codec.words) and got['obs'].shape == (1, T, E, U, 4 * B + 1)
         assert torch.equal(got['obs'][0].view(torch.int32), frag['obs'].view(torch.int32))
         assert torch.equal(got['reward'][0], frag['reward'])
+        # a fragment the steps wrote as the compact record themselves (rollout(out={'obs_compact': ...})) goes through unchanged and
+        # comes back as rows too: the same rows a twin env produces
+        rows_env = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=E, seed=9, rng='philox')
+        comp_env = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=E, seed=9, rng='philox')
+        acts = torch.randint(0, B + 1, (T, E, U), generator=g, device='cuda', dtype=torch.uint8)
+        rows = {'obs': torch.empty((T,) + tuple(rows_env.obs.shape), device='cuda'), 'reward': torch.empty((T,) + tuple(rows_env.reward.shape), device='cuda')}
+        comp = {'obs_compact': torch.empty((T, E, codec.words), dtype=torch.int32, device='cuda'), 'reward': torch.empty_like(rows['reward'])}
+        rows_env.reset(); comp_env.reset()
+        rows_env.rollout(acts, out=rows); comp_env.rollout(acts, out=comp)
+        got2 = gather.all_gather_async(dict(comp)).wait()
+        assert torch.equal(got2['obs'][0].view(torch.int32), rows['obs'].view(torch.int32))
+        assert torch.equal(got2['reward'][0], rows['reward'])
     finally:
         if own:
             dist.destroy_process_group()
@@ -312,3 +324,41 @@ def test_compact_record_is_refused_where_it_is_not_defined(torch_cuda):
     out = _lib.DcompOut(central.obs.data_ptr(), central.reward.data_ptr(), None, None, None, None, central.obs.data_ptr())
     rc = _lib.load().dcomp_step(central._h, central._st_ref, ctypes.c_void_p(a.data_ptr()), ctypes.byref(out), central._stream())
     assert rc == _lib.EINVAL
+
+
+@pytest.mark.parametrize('E,U,B,policy', [(64, 32, 10, '3gpp'), (4096, 10, 5, 'dynamic'), (16, 128, 32, 'fullcomp'), (24, 70, 24, '3gpp'), (2000, 32, 10, 'cluster')])
+def test_closed_policy_loop_with_compact_records(torch_cuda, E, U, B, policy):
+    """dcomp_set_policy decides on the registers the observation is written from, so a heuristic-driven loop needs no rows: twin
+    envs, one stepping rows, one the compact record, take the same decisions and produce the same observations -- step by step and
+    through rollout_policy (fused closed loop where the shape has one, one launch per step elsewhere), resets at the horizon included."""
+    torch = torch_cuda
+    from deepcomp_amd.fragment import FragmentCodec
+    rows_env, comp_env = _twin_envs(E, U, B, episode_length=6)
+    codec = FragmentCodec(U, B)
+    kw = {}
+    if policy == 'dynamic':
+        kw['epsilon'] = 0.4
+    if policy == 'cluster':
+        kw['cluster_mask'] = torch.tensor([7 << (3 * (b // 3)) & ((1 << B) - 1) for b in range(B)], dtype=torch.int32, device='cuda')   # clusters of 3
+    for env in (rows_env, comp_env):
+        env.reset()
+        env.set_policy(policy, **kw)
+        env.reset()                                   # the first decision comes from the reset kernel
+    packed = torch.empty((E, codec.words), dtype=torch.int32, device='cuda')
+    rew = torch.empty_like(comp_env.reward)
+    for t in range(5):
+        assert torch.equal(rows_env.next_action, comp_env.next_action), t
+        rows_env.step(rows_env.next_action)
+        comp_env.step_compact(comp_env.next_action, packed, rew)
+        assert torch.equal(_bits(codec.unpack(packed)), _bits(rows_env.obs)), t
+    T = 9
+    rows = {'obs': torch.empty((T,) + tuple(rows_env.obs.shape), device='cuda'), 'reward': torch.empty((T,) + tuple(rows_env.reward.shape), device='cuda')}
+    comp = {'obs_compact': torch.empty((T, E, codec.words), dtype=torch.int32, device='cuda'), 'reward': torch.empty_like(rows['reward'])}
+    rows_env.rollout_policy(T, out=rows, horizon=6)
+    comp_env.rollout_policy(T, out=comp, horizon=6)
+    assert torch.equal(_bits(codec.unpack(comp['obs_compact'])), _bits(rows['obs']))
+    assert torch.equal(_bits(comp['reward']), _bits(rows['reward']))
+    assert torch.equal(rows_env.next_action, comp_env.next_action)
+    assert torch.equal(rows_env.pos, comp_env.pos) and torch.equal(rows_env.conn, comp_env.conn)
+    rows_env.check(); comp_env.check()
+
