@@ -368,7 +368,6 @@ static int fill_params(dcomp_env *env, const dcomp_state *st, const dcomp_out *o
     if (out->obs_compact) {
         if (out->obs) return fail(DCOMP_EINVAL, "out->obs and out->obs_compact are alternatives: set one, leave the other NULL");
         if (env->cfg.env_kind != DCOMP_MULTI) return fail(DCOMP_EINVAL, "out->obs_compact: the compact record is defined for multi-agent observations (central observations carry no per-env columns)");
-        if (env->dyn) return fail(DCOMP_EUNSUPPORTED, "out->obs_compact with UE arrival / departure: write rows and use dcomp_pack_fragment");
     }
     if (env->kp.any_maxcap && !st->conn_since) return fail(DCOMP_EINVAL, "a max-cap BS needs state.conn_since (see dcomp_state_sizes)");
     if (env->dyn && !st->uid) return fail(DCOMP_EINVAL, "UE arrival/departure needs state.uid");
@@ -491,7 +490,7 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
     const size_t obs_step = EU * (size_t)(multi ? 4 * env->cfg.num_bs + 1 : 2 * env->cfg.num_bs + 1);
     auto out_slice = [&](KParams &k, int t) {                  // where step t's outputs go
         if (!every) return;
-        k.obs = out->obs_compact ? reinterpret_cast<float *>(out->obs_compact) + E * (size_t)dcomp_frag::env_words(env->cfg.num_ue, env->cfg.num_bs) * t
+        k.obs = out->obs_compact ? reinterpret_cast<float *>(out->obs_compact) + E * (size_t)dcomp_frag::env_words(env->cap, env->cfg.num_bs) * t
                                  : out->obs + obs_step * t;
         if (out->reward) k.reward = out->reward + (multi ? EU : E) * t;
         if (out->sum_utility) k.sum_util = out->sum_utility + E * t;

@@ -1057,11 +1057,15 @@ __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, B
     // belongs to a live UE (alive == active), so the entries need no select.
     const bool live = DYN ? alive : true;
     const float util_n = live ? util * (1.0f / MAX_UTIL) : 0.f;
+    // DYN + compact record: the per-env columns are stored ONCE per env, by the lane of the last SLOT -- which may be unlisted, so
+    // that lane needs the env's values, not its own row's zeros (every lane of an env holds the same sums)
+    float env_cols[DYN ? 2 * B : 1];
 #pragma unroll
     for (int b = 0; b < B; b++) {
         l2[b] = live ? fast_exp2(l2[b] - l2max) : 0.f;                                          // variants.py:276-284
         // avg utility of the UEs at b, 0 for an idle BS (its sum is 0): variants.py:299, station.py:71-76
         const float avg = tsum[b] * fast_rcp(fmaxf(cnt[b], 1.f)) * (1.0f / MAX_UTIL);
+        if (DYN) { env_cols[b] = cnt[b] * inv_u; env_cols[B + b] = avg; }
         tsum[b] = live ? avg : 0.f;
         cnt[b] = live ? cnt[b] * inv_u : 0.f;                                                   // variants.py:296
     }
@@ -1135,8 +1139,8 @@ __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, B
                     if (tail) {
 #pragma unroll
                         for (int b = 0; b < B; b++) {
-                            if (one || (unsigned)(at + CW + b) < (unsigned)cw) rec[CW + b] = __float_as_uint(cnt[b]);
-                            if (one || (unsigned)(at + CW + B + b) < (unsigned)cw) rec[CW + B + b] = __float_as_uint(tsum[b]);
+                            if (one || (unsigned)(at + CW + b) < (unsigned)cw) rec[CW + b] = __float_as_uint(DYN ? env_cols[b] : cnt[b]);
+                            if (one || (unsigned)(at + CW + B + b) < (unsigned)cw) rec[CW + B + b] = __float_as_uint(DYN ? env_cols[B + b] : tsum[b]);
                         }
                     }
                 }

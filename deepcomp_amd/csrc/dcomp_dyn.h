@@ -224,7 +224,7 @@ __global__ __launch_bounds__(DCOMP_BLOCK) void step_kernel_dyn(const KParams p)
         p.uid[idx] = alive ? (uint16_t)uidw : (uint16_t)0;
     }
     // 8. observation, reward, info
-    const Outs o{p.obs, p.reward, p.sum_util, p.ue_dr, p.ue_util, p.rb_out, p.next_act, 0};
+    const Outs o{p.obs, p.reward, p.sum_util, p.ue_dr, p.ue_util, p.rb_out, p.next_act, p.obs_compact};
     write_outputs<B, UPAD, false, true>(p, o, sh, active, env, env_local, u, idx, wave, lane, gbase, alive ? conn : 0u, in_range, l2, cnt, util,
                                   curr, reward_before, alive, cur);
 }

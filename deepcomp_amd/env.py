@@ -495,9 +495,8 @@ class BatchedMobileEnv:
         return fragment_words(self.U, self.B)
 
     def _require_compact(self, packed, steps=1):
-        if self.kind != _lib.MULTI or self.dynamic:
-            raise NotImplementedError("compact observation records exist for multi-agent envs with a fixed UE list "
-                                      "(write rows and use deepcomp_amd.fragment.FragmentCodec.pack otherwise)")
+        if self.kind != _lib.MULTI:
+            raise NotImplementedError("compact observation records exist for multi-agent observations (central observations carry no per-env columns)")
         self._require(packed, torch.int32, steps * self.E * self.compact_words, 'packed')
 
     def step_compact(self, action, packed, reward):

@@ -212,8 +212,8 @@ int dcomp_set_policy(dcomp_env *env, const dcomp_policy *p, uint8_t *next_action
  *                          recomputed; rows of unlisted UE slots (all zeros, UE arrival / departure) are recognised by their
  *                          all-zero dr block (a listed UE's best station has dr == 1, variants.py:279-284).
  * Both only enqueue one streaming kernel on `stream`.
- * Multi-agent envs with a fixed UE list can skip the rows altogether: with dcomp_out.obs_compact set (and obs NULL) dcomp_reset /
- * dcomp_step / dcomp_rollout_ex write this record themselves, word for word what dcomp_pack_fragment makes of the rows the same call
+ * Multi-agent envs can skip the rows altogether: with dcomp_out.obs_compact set (and obs NULL) dcomp_reset / dcomp_step /
+ * dcomp_step_dyn / dcomp_rollout_ex write this record themselves, word for word what dcomp_pack_fragment makes of the rows the same call
  * would have written (a third of the step's store traffic and no pack pass; [T][E][words] with every_step). */
 int dcomp_fragment_words(int32_t num_ue, int32_t num_bs);       /* words per env-step; -1: bad arguments */
 int dcomp_pack_fragment(const float *obs, int64_t num_env_steps, int32_t num_ue, int32_t num_bs, uint32_t *packed, int32_t *flags,

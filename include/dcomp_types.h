@@ -88,7 +88,7 @@ typedef struct dcomp_out {
     float *ue_utility;
     float *reward_before;        /* optional [E][U]: clip(utility at the pre-move rates)/20 per UE (base.py:158-167, 446) --
                                   * the reward the single-agent env hands out (base.py:358-369); NULL to skip */
-    uint32_t *obs_compact;       /* optional, MULTI with a fixed UE list only: [E][U (B + 2) + 2B] -- the lossless compact record of the
+    uint32_t *obs_compact;       /* optional, MULTI only: [E][U (B + 2) + 2B] (U = max_ues slots when UEs arrive / depart) -- the lossless compact record of the
                                   * observation rows (dcomp_fragment_words / dcomp_unpack_fragment in dcomp.h: per UE dr[B] | utility |
                                   * connection mask, then ues_at_bs[B] | util_at_bs[B] once per env) written by the step itself INSTEAD of
                                   * the rows: set it and leave obs NULL.  dcomp_unpack_fragment() of it is bit-identical to the rows the

@@ -362,3 +362,48 @@ def test_closed_policy_loop_with_compact_records(torch_cuda, E, U, B, policy):
     assert torch.equal(rows_env.pos, comp_env.pos) and torch.equal(rows_env.conn, comp_env.conn)
     rows_env.check(); comp_env.check()
 
+
+
+@pytest.mark.parametrize('E,large,nslow,nfast,arrival', [(300, True, 4, 2, {3: 2, 9: -3, 15: 4, 22: -2, 31: 1}),
+                                                          (64, False, 60, 10, {2: 5, 4: -20, 11: 30, 20: -3, 28: 40}),
+                                                          (5000, True, 3, 0, {1: 1, 2: 1, 3: -2, 8: 3, 9: 3, 30: -5})])
+def test_compact_record_with_ue_arrival_and_departure(torch_cuda, E, large, nslow, nfast, arrival):
+    """A changing UE list: the record of an unlisted slot is all zeros, the per-env columns come from the env (the last slot's lane may
+    be unlisted); twin envs as above, step by step and through rollout()'s event feed with a reset at the horizon."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    from deepcomp_amd.fragment import FragmentCodec
+    scn = (scenarios.large_map('mixed') if large else scenarios.grid_map(12, 'mixed')).with_ues(num_slow=nslow, num_fast=nfast)
+    m, bs, ues = build_from_scenario(scn)
+    mk = lambda: BatchedMobileEnv(m, bs, ues, 'multi', num_envs=E, seed=11, episode_length=40, rng='philox', rand_episodes=True, ue_arrival=arrival)
+    rows_env, comp_env = mk(), mk()
+    U, B = rows_env.U, rows_env.B
+    codec = FragmentCodec(U, B)
+    g = torch.Generator(device='cuda').manual_seed(5)
+    packed = torch.full((E, codec.words), -1, dtype=torch.int32, device='cuda')
+    rew = torch.empty_like(comp_env.reward)
+    rows_env.reset(); comp_env.reset_compact(packed)
+    assert torch.equal(_bits(codec.unpack(packed)), _bits(rows_env.obs)) and torch.equal(codec.pack(rows_env.obs), packed)
+    seen_dead = False
+    for t in range(34):
+        a = torch.randint(0, B + 1, (E, U), generator=g, device='cuda', dtype=torch.uint8)
+        rows_env.step(a)
+        packed.fill_(-1)
+        comp_env.step_compact(a, packed, rew)
+        assert torch.equal(_bits(codec.unpack(packed)), _bits(rows_env.obs)), t
+        assert torch.equal(codec.pack(rows_env.obs), packed), t
+        assert torch.equal(_bits(rew), _bits(rows_env.reward)), t
+        assert rows_env.num_ue == comp_env.num_ue
+        seen_dead |= rows_env.num_ue < U
+    assert seen_dead
+    T = 12                                                   # crosses the horizon (40): events start over with the new episode
+    acts = torch.randint(0, B + 1, (T, E, U), generator=g, device='cuda', dtype=torch.uint8)
+    rows = {'obs': torch.empty((T,) + tuple(rows_env.obs.shape), device='cuda'), 'reward': torch.empty((T,) + tuple(rows_env.reward.shape), device='cuda')}
+    comp = {'obs_compact': torch.empty((T, E, codec.words), dtype=torch.int32, device='cuda'), 'reward': torch.empty_like(rows['reward'])}
+    rows_env.rollout(acts, out=rows, horizon=40); comp_env.rollout(acts, out=comp, horizon=40)
+    assert torch.equal(_bits(codec.unpack(comp['obs_compact'])), _bits(rows['obs']))
+    assert torch.equal(codec.pack(rows['obs']), comp['obs_compact'])
+    codec.check(); rows_env.check(); comp_env.check()
+    assert torch.equal(rows_env.uid, comp_env.uid) and torch.equal(rows_env.pos, comp_env.pos)

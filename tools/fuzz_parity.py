@@ -184,16 +184,16 @@ def run_case(c, torch):
             tol = (ATOL_UTIL if kind == 'multi' else ATOL_OBS) * (U if reward == 'sum' else 1)
             np.testing.assert_allclose(core.reward.cpu().numpy(), rew_o, atol=tol, rtol=0, err_msg=f'{tag}: reward')
 
-    # round 4: multi-agent envs with a fixed UE list also run a TWIN whose steps write the compact record themselves
+    # round 4: multi-agent envs also run a TWIN whose steps write the compact record themselves
     # (dcomp_out.obs_compact): unpack of it must be the core env's rows bit for bit, pack of the rows the record word for word
     twin = codec = packed = trew = None
-    if kind == 'multi' and not arrival:
+    if kind == 'multi':
         from deepcomp_amd.fragment import FragmentCodec
         os.environ['DCOMP_TIGHT'] = '1' if c.get('tight') else '0'
         try:
             twin = BatchedMobileEnv(c['m'], c['bs'], c['ues'], kind, num_envs=E, seed=c['seed'], reward=reward,
                                     rng='reference' if tape else 'philox', rand_episodes=c.get('rand_episodes', True) if tape else True,
-                                    env_id_base=c['base'], episode_length=L, tape_depth=depth if tape else None)
+                                    env_id_base=c['base'], episode_length=L, ue_arrival=arrival, tape_depth=depth if tape else None)
         finally:
             os.environ.pop('DCOMP_TIGHT', None)
         codec = FragmentCodec(U, B)
