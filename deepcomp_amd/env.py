@@ -57,6 +57,11 @@ SNR_THRESHOLD = 2e-8          # station.py:10
 MIN_UTILITY, MAX_UTILITY = -20, 20   # constants.py:40-41
 
 
+def _fragment_obs(out):
+    """The observation buffer of a rollout's `out` dict: the rows, or the compact record where the caller asked for that."""
+    return out['obs'] if out.get('obs') is not None else out.get('obs_compact')
+
+
 def _coord(v):
     return -1 if v == 'random' else int(v)
 
@@ -523,7 +528,8 @@ class BatchedMobileEnv:
 
         out: None -> the outputs of the last step land in self.obs / self.reward / info tensors; or a dict with 'obs'
         [T, *obs.shape] and 'reward' [T, *reward.shape] (optionally 'sum_utility' [T, E], 'ue_dr' / 'ue_utility' [T, E, U]):
-        the outputs of EVERY step (a rollout fragment).  horizon: reset the envs inside the rollout whenever env.time has
+        the outputs of EVERY step (a rollout fragment); multi-agent envs: 'obs_compact' (int32 [T, E, compact_words]) INSTEAD of
+        'obs' has every step write the lossless compact record itself (see step_compact).  horizon: reset the envs inside the rollout whenever env.time has
         reached it (RLlib's horizon = episode_length, env_setup.py:281); same sequence as `if time == L: reset()` before
         every step."""
         if actions.dim() != 3:
@@ -550,7 +556,7 @@ class BatchedMobileEnv:
                 n = min(T - t0, L - self.time)
                 self.rollout(actions[t0:t0 + n], out=None if out is None else {k: out[k][t0:t0 + n] for k in keys if out.get(k) is not None})
                 t0 += n
-            return (self.obs, self.reward) if out is None else (out.get('obs', out.get('obs_compact')), out['reward'])
+            return (self.obs, self.reward) if out is None else (_fragment_obs(out), out['reward'])
         o = self._out
         if out is not None:
             packed = out.get('obs_compact')          # the compact record of every step instead of the rows (see step_compact)
@@ -580,7 +586,7 @@ class BatchedMobileEnv:
                                                 ctypes.byref(opts), self._stream()))
         if self._policy_key is not None:
             self._policy_launched()
-        return (self.obs, self.reward) if out is None else (out.get('obs', out.get('obs_compact')), out['reward'])
+        return (self.obs, self.reward) if out is None else (_fragment_obs(out), out['reward'])
 
     def _rollout_events(self, T, L, opts):
         """UE departures / arrivals of the next T steps (base.py:433-443) for dcomp_rollout_ex's event feed: the schedule is
@@ -647,7 +653,7 @@ class BatchedMobileEnv:
                             if k != 'obs_compact' and not (k == 'reward' and 'obs_compact' in frag):
                                 frag[k][i].copy_(getattr(self, k))
             t0 += n
-        return (self.obs, self.reward) if out is None else (out.get('obs', out.get('obs_compact')), out['reward'])
+        return (self.obs, self.reward) if out is None else (_fragment_obs(out), out['reward'])
 
     def heuristic_actions(self, policy, epsilon=0.0, cluster_mask=None, obs=None, out=None):
         """The reference's heuristic baselines (deepcomp/agent/heuristics.py) for every (env, UE) in one launch
