@@ -1,1 +1,7 @@
-timeout 1750 python tools/fuzz_parity.py --cases 2500 --seed 111111 2>&1 | tail -14 | cut -c1-700 | tee gpurun_out/r04_fuzz_seed111111.txt
+date
+python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -2
+date
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|FAILED|Error|^E " | tail -8
+date
+s=$(date +%s); python bench.py > gpurun_out/bench_default.json 2>/dev/null; e=$(date +%s); echo "default bench.py: $((e-s)) s"; tail -c 150 gpurun_out/bench_default.json; echo
+s=$(date +%s); python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_driver.json 2>/dev/null; e=$(date +%s); echo "driver form: $((e-s)) s"
