@@ -517,7 +517,10 @@ def main():
     # --gather obs: the rollout hand-off north_star describes.  Steps write into a fragment buffer [F, E, U, 4B+1] (two of
     # them, alternating); a finished fragment is all-gathered on the side stream while the next one is being stepped.
     F = args.fragment
-    G = args.gather_every or min(L, max(4, K // 2))         # summary hand-off period: >= 1 collective inside any timed region of >= 4 steps
+    # summary hand-off period: once per episode (the cadence of a learner's per-episode logging), or once per timed region where that is
+    # shorter -- with the half-period phase shift below exactly one collective then falls inside a region of K < L steps (round 4 first
+    # used K // 2: two hand-offs in the driver's 20 steps, 10 % of a 1.6 ms region; one is what "self-proving" needs)
+    G = args.gather_every or min(L, max(4, K))
     frag_bufs, frag_pending, gather_stats = None, [None, None], {'wait_s': 0.0, 'fragments': 0, 'collectives': 0, 'bytes_sent': 0, 'since': 0}
 
     def count_collectives(frag):
@@ -760,6 +763,8 @@ def main():
                     env.step_into(pool[f & 15], bufs[k]['obs'][f], bufs[k]['reward'][f])
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         steps(0); steps(1)                                   # warm
+        for i in range(4):                                   # ... the hand-off too: the first calls allocate the gathered tensors (GBs: a hipMalloc
+            g2.all_gather_async(outgoing(i & 1)).wait()      # of 1.4 GB inside the timed loop read 30 ms per fragment on one box, 0.9 ms on others)
         fence()
         ev[0].record()
         for i in range(nfrag):

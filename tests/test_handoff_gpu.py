@@ -85,7 +85,7 @@ def test_bench_spawns_its_own_ranks_n2_gloo_same_device():
 
 def test_driver_form_n2_has_a_collective_inside_the_timed_region():
     """with the driver's exact `--steps 20 --warmup 5` and an episode of 100 steps NO collective fell inside the timed region,
-    while config.collective claimed one per episode.  The default hand-off now happens every min(L, max(4, K // 2)) = 10 steps, is
+    while config.collective claimed one per episode.  The default hand-off now happens every min(L, max(4, K)) = 20 steps (phase-shifted by half a period), is
     counted where it is issued, and every rank runs the same pre-warm at every N.  Two self-spawned ranks on one device (gloo: RCCL
     refuses two ranks on one GPU), default workload, secondary configurations on -- the driver's command line otherwise."""
     env_clean = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
@@ -96,10 +96,10 @@ def test_driver_form_n2_has_a_collective_inside_the_timed_region():
     j = json.loads(lines[-1])
     h = j['handoff']
     assert j['n_gpus'] == 2 and j['steps'] == 20 and j['warmup'] == 5 and h['mode'] == 'summary' and h['rccl_ranks'] == 2
-    assert h['period_steps'] == 10 and h['collectives_in_timed_region'] == 2              # one [E, U + 1] tensor after timed steps 5 and 15
-    assert h['bytes_in_timed_region']['sent_per_rank'] == 2 * 4 * 65536 * (32 + 1)
+    assert h['period_steps'] == 20 and h['collectives_in_timed_region'] == 1              # one [E, U + 1] tensor after timed step 10
+    assert h['bytes_in_timed_region']['sent_per_rank'] == 4 * 65536 * (32 + 1)
     assert h['bytes_in_timed_region']['received_per_rank'] == 2 * h['bytes_in_timed_region']['sent_per_rank']
-    assert '2 collective(s) inside the timed region' in j['config']['collective'] and 'every rank' in j['config']['prewarm']
+    assert '1 collective(s) inside the timed region' in j['config']['collective'] and 'every rank' in j['config']['prewarm']
     a = j['also']
     assert a['measured'].startswith('before the warm-up') and 'config2_4096x10x5_central_fused_rollout' in a     # the pre-warm ran at N = 2 too
     assert a['config4_strong_262144x32x10']['envs_per_gpu'] == 131072 and a['config5_strong_32768x128x32']['envs_per_gpu'] == 16384
@@ -116,7 +116,7 @@ def test_single_rank_rccl_driver_form_counts_its_collectives():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     j = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
     h = j['handoff']
-    assert h['backend'] == 'rccl' and h['rccl_ranks'] == 1 and h['collectives_in_timed_region'] == 2 and h['period_steps'] == 10
+    assert h['backend'] == 'rccl' and h['rccl_ranks'] == 1 and h['collectives_in_timed_region'] == 1 and h['period_steps'] == 20
 
 
 def test_bench_spawns_its_own_ranks_summary_mode_probe():
@@ -185,5 +185,5 @@ def test_bench_under_torch_distributed_run_two_gloo_ranks():
     rc, out, j = _run(cmd)
     assert rc == 0 and j is not None, out[-3000:]
     assert j['n_gpus'] == 2 and j['steps'] == 20 and j['config']['parallelism'] == 'env-shard x2' and j['config']['envs_per_gpu'] == 4096
-    assert j['handoff']['rccl_ranks'] == 2 and j['handoff']['collectives_in_timed_region'] == 2
+    assert j['handoff']['rccl_ranks'] == 2 and j['handoff']['collectives_in_timed_region'] == 1
     assert len([l for l in out.splitlines() if l.startswith('{"metric"')]) == 1
