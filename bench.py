@@ -434,6 +434,9 @@ def main():
     ap.add_argument('--gather-every', type=int, default=0,
                     help="--gather summary: steps between two hand-offs (all-gather of the per-env reward + sum_utility since the last one). "
                          "0 = min(episode length, max(4, steps // 2)): at least one collective falls inside ANY timed region")
+    ap.add_argument('--idle-before-timing-us', type=int, default=0,
+                    help="diagnostic: the host sleeps this long (GPU idle) right before the timed region -- how much of an N > 1 line's slower "
+                         "kernels is the idle time its barrier adds in front of a 1.6 ms region")
     ap.add_argument('--prewarm', type=int, default=300,
                     help='untimed launches of the headline kernel on every rank before the warm-up steps (clock / power management settles over '
                          'the first ~300 launches after idle; identical at every N so that the points of a scaling curve share one warm state)')
@@ -703,6 +706,8 @@ def main():
     for e in ev_pool[:2]:
         e.record()                              # first use of the event machinery outside the timed region
     torch.cuda.synchronize(dev)
+    if args.idle_before_timing_us:
+        time.sleep(args.idle_before_timing_us * 1e-6)
     t0 = time.perf_counter()
     t_env = run(K, t_env, spans)
     drain()
