@@ -1,5 +1,4 @@
-python bench.py --gpus 1 --spawn --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r04_bench_line_spawn.json; python - <<'PY'
-import json
-s=json.load(open('gpurun_out/r04_bench_line_spawn.json')); p=s['also']['obs_handoff_probe']
-print(s['value'], s['ms_per_step'], s['handoff']['collectives_in_timed_region'], p['ms_per_fragment_with_overlapped_all_gather'], p['compact_record']['ms_per_fragment_with_overlapped_all_gather'], p['compact_record_from_the_step']['ms_per_fragment_with_overlapped_all_gather'])
-PY
+# scratch: the command file `gpurun -- 'bash tools/_gpu_cmd.sh'` runs on the GPU box (rewritten per call during development)
+python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -2
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|FAILED|Error|^E " | tail -8
+python bench.py --gpus 1 --steps 20 --warmup 5 | tail -c 400
