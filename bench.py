@@ -688,6 +688,20 @@ def main():
     # at the clocks a running job has, instead of inside the 5-15 % slower transient of the first ~300 launches after idle
     # (tools/kprobe.py) that a 25-launch run would otherwise never leave.  `--also-after` restores the old order (A/B).
     default_workload = (E, U, B, args.kind, args.sharing) == (65536, 32, 10, 'multi', 'mixed')
+    # The hand-off machinery is brought up HERE, before the secondary configurations and the pre-warm launches: the first use of the side
+    # stream and of the communicator (stream + channel set-up, the three rotating sets of gather buffers) is followed by the same 5-15 %
+    # slower transient of ~200 launches as a cold start (tools/diag_stream.py: 92 / 84 us per step right after the first hand-off, 76 us
+    # with a hand-off in the middle of 100 steps in steady state).  Until the end of round 4 the first hand-off came right before the
+    # timed region and the transient fell INTO it: `--force-dist --steps 100` read 0.097 ms per step against 0.081 plain.
+    if gather is not None:
+        env.reset()
+        for _ in range(3):
+            if frag_bufs is None:
+                hand_off_summary()
+            else:
+                pending.append(gather.all_gather_async({'reward': env.reward} if args.backend == 'nccl' else {'reward': env.reward.cpu()}))
+        drain()
+        torch.cuda.synchronize(dev)
     also_first = None
     if not args.no_also and default_workload and not args.also_after:
         also_first = measure_also(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev)
