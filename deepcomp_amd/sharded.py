@@ -68,7 +68,10 @@ class RolloutGather:
 
     def __init__(self, group=None, use_side_stream=True, reuse_buffers=0, codec=None):
         """reuse_buffers = k > 0: the gathered tensors come from k alternating sets of buffers instead of fresh allocations (a
-        hand-off every few steps should not pay the allocator): the tensors of a handle are valid until k further calls."""
+        hand-off every few steps should not pay the allocator): the tensors of a handle are valid until k further calls.
+        The side stream, the communicator's channels and the buffer sets come into being with the first k hand-offs, and the first use
+        of a second stream is followed by a cold-start-like transient of the step kernels (~200 launches 10-20 % slow,
+        tools/diag_stream.py): a sampler that measures itself should hand over k fragments before it starts the clock."""
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
