@@ -312,10 +312,24 @@ def self_spawn(n):
     LAST.  A rank that dies takes the others down (no hung rendezvous)."""
     import socket
     import subprocess
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
+    # a port BELOW the kernel's ephemeral range (32768-60999): one found with bind(0) lies inside it, and in the seconds until rank 0 has
+    # imported torch and bound its store, any outgoing connection on the box can be handed the same number (seen once: EADDRINUSE)
+    import random
+    port = None
+    for _ in range(64):
+        cand = random.randrange(20000, 32000)
+        s = socket.socket()
+        try:
+            s.bind(('127.0.0.1', cand))
+            port = cand
+        except OSError:
+            pass
+        finally:
+            s.close()
+        if port is not None:
+            break
+    if port is None:
+        sys.exit("bench.py: no free rendezvous port between 20000 and 32000")
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',

@@ -16,11 +16,19 @@ COMMON = ['--envs', '2048', '--steps', '20', '--warmup', '10', '--no-cpu-baselin
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """Below the kernel's ephemeral range: a bind(0) port can be handed to any outgoing connection before the launcher binds it."""
+    import random
+    for _ in range(64):
+        p = random.randrange(20000, 32000)
+        s = socket.socket()
+        try:
+            s.bind(('127.0.0.1', p))
+            return p
+        except OSError:
+            continue
+        finally:
+            s.close()
+    raise RuntimeError('no free port')
 
 
 def _run(cmd):

@@ -12,11 +12,19 @@ import torch.multiprocessing as mp
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
+    """Below the kernel's ephemeral range: a bind(0) port can be handed to any outgoing connection before rank 0 binds it."""
+    import random
+    for _ in range(64):
+        port = random.randrange(20000, 32000)
+        s = socket.socket()
+        try:
+            s.bind(('127.0.0.1', port))
+            return port
+        except OSError:
+            continue
+        finally:
+            s.close()
+    raise RuntimeError('no free port')
 
 
 def _worker(rank, world, port, total_envs, ret):
