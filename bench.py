@@ -41,7 +41,11 @@ def survey_bytes_per_env_step(U, B, kind):
     return U * (55 + 16 * B + 24) + 4 if kind == 'multi' else U * (51 + 8 * B + 24) + 8
 
 
-def cpu_baseline(scn, kind, U, B, budget_s=15.0):
+# BASELINE.md section 2, mixed sharing, 1 core: env-steps/s of the reference's own step() by (env kind, U, B)
+REFERENCE_STEP_PER_CORE = {('central', 3, 3): 2122.0, ('central', 10, 5): 398.0, ('multi', 32, 10): 69.9, ('multi', 128, 32): 9.4}
+
+
+def cpu_baseline(scn, kind, U, B, budget_s=12.0):
     """The CPU oracle (oracle/dcomp_oracle.c, OpenMP over envs) on a bounded sample of the same workload."""
     from oracle import oracle as orc
     threads = orc.lib().orc_max_threads()
@@ -75,8 +79,32 @@ def cpu_baseline(scn, kind, U, B, budget_s=15.0):
     for t in range(steps):
         batch.step(acts[t])
     dt = time.perf_counter() - t0
-    return {'value': E * steps / dt, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{E} envs x {steps} steps ({U} UE x {B} BS, {kind}), oracle/dcomp_oracle.c with OpenMP over envs, {dt:.1f} s'}
+    out = {'value': E * steps / dt, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
+           'sample': f'{E} envs x {steps} steps ({U} UE x {B} BS, {kind}), oracle/dcomp_oracle.c with OpenMP over envs, {dt:.1f} s'}
+    # "single core and all cores".  The same port on ONE thread (~3 s), which is what links this box to the reference's
+    # own step(): REFERENCE_STEP_PER_CORE below was timed in the build container with the reference's unmodified deepcomp.env.* (BASELINE.md
+    # section 2; the Python reference cannot travel to this box), so port-on-one-core / that figure is how much faster the C restatement is
+    # than the reference per core -- and all-cores / single-core is this box's parallel speed-up, which normalises `value` across boxes.
+    del batch, probe
+    one = make(64)
+    one.num_threads = 1
+    one.reset()
+    a1 = rng.integers(0, B + 1, size=(8, 64, U)).astype(np.uint8)
+    one.step(a1[0])
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 2.5:
+        one.step(a1[n & 7])
+        n += 1
+    dt1 = time.perf_counter() - t0
+    ref = REFERENCE_STEP_PER_CORE.get((kind, U, B))
+    out['single_core'] = {'value': 64 * n / dt1, 'unit': 'env-steps/s', 'cores': 1,
+                          'sample': f'64 envs x {n} steps on one thread, {dt1:.1f} s', 'all_cores_over_single_core': out['value'] / (64 * n / dt1)}
+    if ref:
+        out['reference_step'] = {'value': ref, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'reference',
+                                 'where': "the reference's own MultiAgentMobileEnv / CentralRelNormEnv step() on one core of the BUILD container (8 x Xeon 2.1 GHz), "
+                                          'BASELINE.md section 2 -- not re-timed here: no reference source travels to the GPU box',
+                                 'port_single_core_over_reference_step': 64 * n / dt1 / ref}
+    return out
 
 
 def measure_rollout(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev, E, U, B, kind, T, L=100, steps=2000, launches_too=False):
@@ -372,6 +400,62 @@ def self_spawn(n):
     sys.exit(1)
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def _fmt_cpulist(cpus):
+    out, run = [], []
+    for c in sorted(cpus) + [None]:
+        if run and (c is None or c != run[-1] + 1):
+            out.append(str(run[0]) if len(run) == 1 else f'{run[0]}-{run[-1]}')
+            run = []
+        if c is not None:
+            run.append(c)
+    return ','.join(out)
+
+
+def pin_to_gpu_numa_node(torch, local_rank, enable=True, sysfs='/sys'):
+    """Bind THIS rank (and the threads it starts later: RCCL proxies, the gloo store) to the CPUs of the NUMA node its GPU hangs off.
+    Eight Python launch loops at 40-80 us per step on a two-socket host otherwise run wherever the scheduler puts them, half of them a
+    socket away from their GPU's PCIe root.  Works under any launcher -- torch.distributed.run sets no affinity --
+    because every rank does it for itself: PCI address of cuda:<local_rank> -> /sys/bus/pci/devices/<bdf>/numa_node ->
+    /sys/devices/system/node/node<n>/cpulist, intersected with the affinity the process was given (cgroup / taskset limits are kept).
+    Returns what was done, for config.rank_placement."""
+    info = {'local_rank': local_rank, 'pinned': False}
+    try:
+        before = os.sched_getaffinity(0)
+        info['cpus_before'] = len(before)
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = f'{getattr(pr, "pci_domain_id", 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0'
+        info['pci'] = bdf
+        node = int(open(f'{sysfs}/bus/pci/devices/{bdf}/numa_node').read())
+        info['numa_node'] = node
+        if node < 0:
+            info['why_not'] = 'the platform reports no NUMA node for this GPU (numa_node = -1)'
+            return info
+        cpus = _parse_cpulist(open(f'{sysfs}/devices/system/node/node{node}/cpulist').read()) & before
+        if not cpus:
+            info['why_not'] = f'no CPU of node {node} is in this process\'s affinity mask'
+            return info
+        info['cpus'] = _fmt_cpulist(cpus)
+        if not enable:
+            info['why_not'] = '--no-pin'
+            return info
+        if cpus != before:
+            os.sched_setaffinity(0, cpus)
+        info['pinned'] = True
+    except Exception as ex:      # noqa: BLE001 -- placement is an optimisation: never fail the run over it
+        info['why_not'] = f'{type(ex).__name__}: {ex}'[:200]
+    return info
+
+
 def traffic_from_profile(workload_key, kernel_name=None, want_entry=False):
     """roofline.traffic comes from a TRACKED rocprofv3 --pmc summary (profiles/traffic.json, registered by
     tools/register_traffic.py from a summary tools/summarize_prof.py wrote on the GPU box), never from a literal in this file:
@@ -399,6 +483,53 @@ def traffic_from_profile(workload_key, kernel_name=None, want_entry=False):
 
 
 SIMDS, CLOCK_GHZ, CYCLES_PER_VALU = 1024, 2.4, 4      # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies a 16-lane SIMD for 4 cycles
+
+
+class SmiSampler:
+    """amdsmi gpu_metrics polled from a thread while a block of launches runs: the gfx clock and socket power the part really holds under
+    this kernel (sustained stepping is power-limited: ~2.1 GHz at ~1.37 kW, not the 2.4 GHz peak; profiles/r05_c3_clock_trace.txt).
+    The firmware refreshes its (filtered) table every ~20 ms, so the block has to last a few tens of ms.  Never fails the run."""
+
+    def __init__(self, index=0, period=0.004):
+        import threading
+        self.rows, self._stop, self.err = [], threading.Event(), None
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            self._h = amdsmi.amdsmi_get_processor_handles()[index]
+            self._get = amdsmi.amdsmi_get_gpu_metrics_info
+            self._get(self._h)
+        except Exception as ex:      # noqa: BLE001
+            self.err = f'{type(ex).__name__}: {ex}'[:120]
+            return
+        self._period = period
+        self._th = threading.Thread(target=self._loop, daemon=True)
+        self._th.start()
+
+    def _loop(self):
+        while not self._stop.is_set():
+            try:
+                m = self._get(self._h)
+                clk = [c for c in (m.get('current_gfxclks') or []) if isinstance(c, (int, float)) and 0 < c < 60000]
+                if clk:
+                    self.rows.append((sum(clk) / len(clk), m.get('current_socket_power'), m.get('ppt_residency_acc')))
+            except Exception:        # noqa: BLE001
+                pass
+            self._stop.wait(self._period)
+
+    def stop(self):
+        if self.err:
+            return {'error': self.err}
+        self._stop.set()
+        self._th.join(timeout=1.0)
+        if not self.rows:
+            return {'error': 'no sample'}
+        last = self.rows[-3:]                     # the table is a filtered view: the last readings of the block are the closest to its steady state
+        pw = [r[1] for r in last if isinstance(r[1], (int, float))]
+        ppt = [r[2] for r in self.rows if isinstance(r[2], (int, float))]
+        return {'gfxclk_mhz': sum(r[0] for r in last) / len(last), 'socket_power_w': sum(pw) / len(pw) if pw else None,
+                'power_throttle_residency_advanced': bool(ppt and ppt[-1] > ppt[0]), 'samples': len(self.rows),
+                'how': 'amdsmi gpu_metrics (firmware-filtered, ~20 ms refresh) polled while the steady-state launches ran; mean of the last 3 readings'}
 
 
 def valu_bound(ent, kernel_ms):
@@ -459,6 +590,7 @@ def main():
     ap.add_argument('--no-check', action='store_true', help='skip the device error-flag check (ablation builds)')
     ap.add_argument('--traffic-bytes', type=float, default=None, help='HBM bytes per launch from a rocprofv3 --pmc pass')
     ap.add_argument('--also-after', action='store_true', help='measure the secondary configurations after the timed region (round-2 order; A/B)')
+    ap.add_argument('--no-pin', action='store_true', help="do not bind the rank to the CPUs of its GPU's NUMA node (A/B; config.rank_placement says what was done)")
     ap.add_argument('--spawn', action='store_true', help='start the ranks from this process even for --gpus 1 (what --gpus N > 1 does by itself '
                                                          'when no launcher set WORLD_SIZE)')
     args = ap.parse_args()
@@ -492,6 +624,8 @@ def main():
                  f"launcher (it spawns its ranks itself) or torch.distributed.run with --nproc-per-node {args.gpus}")
     if not args.same_device and torch.cuda.device_count() < world:
         sys.exit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible (--same-device --backend gloo: dry run on one)")
+    t_wall0 = time.time()
+    placement = pin_to_gpu_numa_node(torch, local_rank, enable=not args.no_pin)
     if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -750,10 +884,17 @@ def main():
     drain()
     fence(closing=True)
     elapsed = time.perf_counter() - t0
+    elapsed_ranks, placements = [elapsed], [placement]
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        # every rank's own clock over the same bracket: `value` uses the MAX (the contract), the line also shows min / max / all, so
+        # that a straggler rank is visible instead of hidden behind the MAX
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        elapsed_ranks = [float(t.item()) for t in every]
+        elapsed = max(elapsed_ranks)
+        placements = [None] * world
+        dist.all_gather_object(placements, placement)
     if not args.no_check:
         env.check()
     handoff = None
@@ -873,13 +1014,15 @@ def main():
     # The first few hundred launches after idle run 5-15 % slower (clock / power management settling: 91 -> 115 -> 82 us per
     # launch over 300 launches on a cold MI355X, tools/kprobe.py): with the driver's --steps 20 the timed region lies inside
     # that transient.  The steady state is reported NEXT to it, never instead of it: >= 300 further launches untimed, then 200 timed.
-    steady_ms = None
+    steady_ms, steady_clk = None, None
     if world == 1 and not T and frag_bufs is None and gather is None:
         t = run(max(0, 300 - K), t_env)
         sp2 = []
         ev_pool.extend(torch.cuda.Event(enable_timing=True) for _ in range(2 * (200 // L + 3)))
+        smi = SmiSampler(local_rank)              # gfx clock / socket power WHILE the steady-state launches run (profiles/r05_c3_clock_trace.txt)
         run(200, t, sp2)
         torch.cuda.synchronize(dev)
+        steady_clk = smi.stop()
         steady_ms = sum(a.elapsed_time(b) for a, b, _ in sp2) / sum(n for _, _, n in sp2)
     resets_timed = sum(1 for s in range(t_env - K, t_env) if s % L == 0)
     also_late = None
@@ -902,7 +1045,8 @@ def main():
                                    f'log utility, reward avg, episode {L} ({resets_timed} reset launch(es) inside the timed {K} steps), random actions' + (f', rollout chunks of {T}' if T else '') +
                                    (', observations written as the COMPACT record (dcomp_out.obs_compact; not the BASELINE output format -- roofline bytes are the compact layout\'s)' if packed_main is not None else ''),
                        'envs_per_gpu': E, 'num_ue': U, 'num_bs': B, 'pair_steps_per_s': world * E * K / elapsed * U * B,
-                       'parallelism': f'env-shard x{world}',
+                       'parallelism': f'env-shard x{world}' + ("; every rank bound to the CPUs of its GPU's NUMA node" if all(pl and pl.get('pinned') for pl in placements) else ''),
+                       'rank_placement': placements,
                        'collective': ('none on the data path' if gather is None else
                                       f'all-gather of {F}-step observation + reward fragments ({F * (env.obs.numel() + env.reward.numel()) * 4 * world / 1e6:.0f} MB received per rank), side stream, overlapped'
                                       if args.gather == 'obs' else
@@ -919,22 +1063,48 @@ def main():
                          'launch_bound': kern_ms < 0.02,
                          'algorithmic_bytes_per_env_step': sbpe, 'layout_bytes_per_env_step': bpe},
         }
+        out['elapsed_per_rank_ms'] = {'min': min(elapsed_ranks) * 1e3, 'max': max(elapsed_ranks) * 1e3, 'ranks': [e * 1e3 for e in elapsed_ranks],
+                                      'what': 'each rank\'s own host clock over the timed region (fence to fence); value and ms_per_step use the MAX'}
         if handoff is not None:
             out['handoff'] = handoff
         if obs_probe is not None:
             out.setdefault('also', {})['obs_handoff_probe'] = obs_probe
+            if handoff is not None and 'error' not in obs_probe:
+                # north_star's hand-off is the ROLLOUT batch (observations), `value` carries the per-env summary only (SURVEY 8e's link
+                # budget): the throughput with every observation delivered to every rank stands next to it, at top level, so that a
+                # 1 -> 8 curve of `value` is never read as "rollouts delivered"
+                def _wr(pr):
+                    return {'env_steps_per_s': pr['env_steps_per_s_with_obs_handoff'], 'exposed_handoff_ms_per_fragment': pr['exposed_handoff_ms_per_fragment'],
+                            'bytes_received_per_rank_per_fragment': pr['bytes_received_per_rank_per_fragment'],
+                            'all_gather_GBps_per_rank_ingress': pr['all_gather_GBps_per_rank_ingress']}
+                wr = {'what': (f'{F}-step fragments of observations + rewards of EVERY env all-gathered to EVERY rank on a side stream while the next fragment is '
+                               'stepped (measured after the timed region, never part of `value`; whole-job env-steps/s, detail in also.obs_handoff_probe)'),
+                      'fragment_steps': F, 'rows': _wr(obs_probe)}
+                if isinstance(obs_probe.get('compact_record'), dict):
+                    wr['compact_record_packed_after_the_steps'] = _wr(obs_probe['compact_record'])
+                if isinstance(obs_probe.get('compact_record_from_the_step'), dict):
+                    wr['compact_record_written_by_the_steps'] = _wr(obs_probe['compact_record_from_the_step'])
+                wr['value_carries'] = 'the summary hand-off (handoff.what), not these'
+                handoff['with_rollout_handoff'] = wr
         if sharded:
             out.setdefault('also', {}).update(sharded)
         if steady_ms is not None:
             out['roofline']['steady_state'] = {'kernel_ms': steady_ms, 'achieved': sbpe * E / (steady_ms * 1e-3) / 1e9,
                                                'frac': sbpe * E / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                               'how': f'200 launches timed after {max(300, K)} untimed ones (same HIP-event method)'}
+                                               'how': f'200 launches timed after {max(300, K)} untimed ones (same HIP-event method)',
+                                               'clock_and_power': steady_clk}
         if args.traffic_bytes is None:
             ent, src = traffic_from_profile(f'{E}x{U}x{B}_{args.kind}_{args.sharing}' + ('_compact' if packed_main is not None else ''), env.step_kernel_name, want_entry=True)
             out['roofline']['traffic'] = (2.0 * ent['fetch_kib'] + ent['write_kib']) * 1024.0 if ent else None
             out['roofline']['traffic_source'] = src
             if ent and valu_bound(ent, kern_ms):
                 out['roofline']['valu'] = valu_bound(ent, kern_ms)
+                if steady_ms is not None and steady_clk and steady_clk.get('gfxclk_mhz'):
+                    # the same floor at the clock the part HOLDS under this kernel (power-limited), against the steady-state launch time
+                    ghz = steady_clk['gfxclk_mhz'] / 1e3
+                    fl = ent['valu_insts_per_launch'] * CYCLES_PER_VALU / (SIMDS * ghz * 1e9) * 1e3
+                    out['roofline']['valu']['at_sustained_clock'] = {'gfxclk_ghz': ghz, 'issue_floor_ms': fl, 'frac': fl / steady_ms,
+                                                                     'of': 'roofline.steady_state.kernel_ms'}
         else:
             out['roofline']['traffic_source'] = '--traffic-bytes'
         if not args.no_stream:
@@ -954,6 +1124,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        out['wall_s'] = time.time() - t_wall0          # this rank's whole run after `import torch` (set-up, secondary figures, CPU baseline)
         # RCCL prints a version banner through C stdio; flush it first so that the JSON line is the LAST line of output
         import ctypes
         try:

@@ -6,7 +6,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DCOMP_LIB') or os.path.join(_HERE, 'csrc', 'libdcomp_hip.so')   # DCOMP_LIB: tools/ablate.py timing variants
 
-OK, EINVAL, EHIP, EACTION, ETAPE, EPOS, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+OK, EINVAL, EHIP, EACTION, ETAPE, EPOS, EUNSUPPORTED, EABI = 0, -1, -2, -3, -4, -5, -6, -7
+ABI_VERSION = 2                 # include/dcomp.h DCOMP_ABI_VERSION: what the struct declarations below describe
 CENTRAL, MULTI = 0, 1
 REWARD = {'avg': 0, 'sum': 1, 'min': 2}
 SHARING = {'resource-fair': 0, 'rate-fair': 1, 'max-cap': 2, 'proportional-fair': 3}
@@ -65,7 +66,7 @@ class DcompPolicy(ctypes.Structure):
 
 POLICY = {'3gpp': 0, 'fullcomp': 1, 'dynamic': 2, 'cluster': 3}
 
-EXPORTS = ['dcomp_create', 'dcomp_destroy', 'dcomp_state_sizes', 'dcomp_obs_dim', 'dcomp_reset', 'dcomp_step',
+EXPORTS = ['dcomp_abi_version', 'dcomp_create_v', 'dcomp_create', 'dcomp_destroy', 'dcomp_state_sizes', 'dcomp_obs_dim', 'dcomp_reset', 'dcomp_step',
            'dcomp_step_dyn', 'dcomp_num_ue',
            'dcomp_rollout', 'dcomp_rollout_ex', 'dcomp_rollout_is_fused', 'dcomp_rollout_fused_for', 'dcomp_lanes_per_env', 'dcomp_step_kernel_name', 'dcomp_check', 'dcomp_time', 'dcomp_episode', 'dcomp_set_episode', 'dcomp_set_seed', 'dcomp_set_tape', 'dcomp_get_counters', 'dcomp_set_counters', 'dcomp_mt_draw_tape',
            'dcomp_connect_threshold', 'dcomp_last_error', 'dcomp_version', 'dcomp_selftest', 'dcomp_heuristic_actions', 'dcomp_set_policy',
@@ -91,7 +92,9 @@ def load():
     import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
-    L.dcomp_create.argtypes = [ctypes.POINTER(DcompCfg), ctypes.POINTER(vp)]
+    L.dcomp_create.argtypes = [ctypes.POINTER(DcompCfg), ctypes.POINTER(vp)]        # the ABI-1 symbol: refuses (include/dcomp.h, ABI guard)
+    if hasattr(L, 'dcomp_create_v'):
+        L.dcomp_create_v.argtypes = [i32] + [ctypes.c_size_t] * 4 + [ctypes.POINTER(DcompCfg), ctypes.POINTER(vp)]
     L.dcomp_destroy.argtypes = [vp]
     L.dcomp_state_sizes.argtypes = [vp] + [ctypes.POINTER(ctypes.c_size_t)] * 6
     L.dcomp_obs_dim.argtypes = [vp, _ip, _ip]
@@ -147,6 +150,16 @@ def last_error():
     return load().dcomp_last_error().decode()
 
 
+def create(cfg, handle):
+    """dcomp_create_v with the sizes of THIS module's struct declarations: a library built from other headers refuses (DCOMP_EABI)
+    instead of reading past a struct."""
+    L = load()
+    if not hasattr(L, 'dcomp_create_v'):            # DCOMP_LIB timing variants built from ABI-1 sources
+        return L.dcomp_create(ctypes.byref(cfg), ctypes.byref(handle))
+    return L.dcomp_create_v(ABI_VERSION, ctypes.sizeof(DcompCfg), ctypes.sizeof(DcompState), ctypes.sizeof(DcompOut),
+                            ctypes.sizeof(DcompRolloutOpts), ctypes.byref(cfg), ctypes.byref(handle))
+
+
 def check(rc):
     """Map a negative return code to the exception the reference raises in the same situation."""
     if rc == OK:
@@ -158,4 +171,6 @@ def check(rc):
         raise NotImplementedError(msg)     # user.py:92, central.py:73
     if rc == EINVAL:
         raise ValueError(msg)
+    if rc == EABI:
+        raise ImportError(msg)             # binding and library were built from different headers
     raise DcompError(f"dcomp error {rc}: {msg}")

@@ -10,6 +10,7 @@
 #include <thread>
 #include <vector>
 
+#define DCOMP_BUILDING_LIBRARY 1     // (no dcomp_create -> dcomp_create_v macro in here)
 #include "../../include/dcomp.h"
 #include "dcomp_blist.h"
 #include "dcomp_device.h"
@@ -93,10 +94,29 @@ extern "C" double dcomp_connect_threshold(void)
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 extern "C" const char *dcomp_last_error(void) { return g_err; }
-extern "C" const char *dcomp_version(void) { return "deepcomp_amd 0.1 (gfx950)"; }
+#define DCOMP_STR2(x) #x
+#define DCOMP_STR(x) DCOMP_STR2(x)
+extern "C" const char *dcomp_version(void) { return "deepcomp_amd 0.2 (gfx950, ABI " DCOMP_STR(DCOMP_ABI_VERSION) ")"; }
+extern "C" int dcomp_abi_version(void) { return DCOMP_ABI_VERSION; }
 
-extern "C" int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out)
+// The version-1 entry point.  A binary that still calls it was compiled against structs this library no longer reads the same way
+// (dcomp_out had six pointers): refuse instead of reading past them.
+extern "C" int dcomp_create(const dcomp_cfg *, dcomp_env **out)
 {
+    if (out) *out = nullptr;
+    return fail(DCOMP_EABI, "dcomp_create is the ABI-1 entry point and this library is ABI %d: rebuild the caller against include/dcomp.h "
+                            "(its dcomp_create macro calls dcomp_create_v) or call dcomp_create_v with the caller's struct sizes", DCOMP_ABI_VERSION);
+}
+
+extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state_size, size_t out_size, size_t rollout_opts_size,
+                              const dcomp_cfg *cfg, dcomp_env **out)
+{
+    if (out) *out = nullptr;
+    if (abi_version != DCOMP_ABI_VERSION || cfg_size != sizeof(dcomp_cfg) || state_size != sizeof(dcomp_state) || out_size != sizeof(dcomp_out) ||
+        rollout_opts_size != sizeof(dcomp_rollout_opts))
+        return fail(DCOMP_EABI, "ABI mismatch: caller has version %d, sizeof dcomp_cfg / dcomp_state / dcomp_out / dcomp_rollout_opts = %zu / %zu / %zu / %zu; "
+                                "this library has version %d and %zu / %zu / %zu / %zu", (int)abi_version, cfg_size, state_size, out_size, rollout_opts_size,
+                    DCOMP_ABI_VERSION, sizeof(dcomp_cfg), sizeof(dcomp_state), sizeof(dcomp_out), sizeof(dcomp_rollout_opts));
     if (!cfg || !out) return fail(DCOMP_EINVAL, "null argument");
     *out = nullptr;
     const int E = cfg->num_envs, U = cfg->num_ue, B = cfg->num_bs;

@@ -198,7 +198,7 @@ class BatchedMobileEnv:
         self._cfg = c
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(L.dcomp_create(ctypes.byref(c), ctypes.byref(self._h)))
+            _lib.check(_lib.create(c, self._h))
 
         n, dev = self.E * U, self.device
         self.pos = torch.zeros((n, 2), dtype=torch.float64, device=dev)

@@ -41,7 +41,21 @@
 extern "C" {
 #endif
 
-int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out);                 /* MobileEnv.__init__  base.py:27-84 */
+/* ---- ABI guard.  The structs of dcomp_types.h grow at their END from version to version (version 2 added dcomp_out.obs_compact):
+ * a caller compiled against an older header would make the library read past its struct.  So the handle is created through
+ * dcomp_create_v, which takes the caller's idea of the ABI -- DCOMP_ABI_VERSION and the sizes of the four structs the library
+ * reads through caller pointers -- and refuses (DCOMP_EABI; dcomp_last_error() names both sides) unless all of them are the
+ * library's own.  C / C++ callers keep writing dcomp_create(cfg, &env): the macro below passes the values of THIS header.  FFI
+ * callers (ctypes, cgo, JNI) call dcomp_create_v with the sizes of THEIR struct declarations.  The plain
+ * `dcomp_create` symbol stays exported for one reason: a binary built against a version-1 header calls it, and gets DCOMP_EABI
+ * instead of undefined behaviour.  Every struct passed to the library must be zero-initialised before its fields are set (a field
+ * the caller does not know about is then NULL = "not requested"). */
+#define DCOMP_ABI_VERSION 2
+#define DCOMP_EABI (-7)        /* caller and library disagree about the ABI version or a struct size */
+int dcomp_abi_version(void);                                             /* the library's DCOMP_ABI_VERSION */
+int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state_size, size_t out_size, size_t rollout_opts_size,
+                   const dcomp_cfg *cfg, dcomp_env **out);               /* MobileEnv.__init__  base.py:27-84 */
+int dcomp_create(const dcomp_cfg *cfg, dcomp_env **out);                 /* version-1 entry point: always DCOMP_EABI (see above) */
 int dcomp_destroy(dcomp_env *env);
 int dcomp_state_sizes(const dcomp_env *env, size_t *pos_bytes, size_t *mv_bytes, size_t *conn_bytes,
                       size_t *ewma_bytes, size_t *flags_bytes, size_t *since_bytes);
@@ -221,6 +235,12 @@ int dcomp_pack_fragment(const float *obs, int64_t num_env_steps, int32_t num_ue,
 int dcomp_unpack_fragment(const uint32_t *packed, int64_t num_env_steps, int32_t num_ue, int32_t num_bs, float *obs, void *stream);
 
 int dcomp_selftest(int op, int width, const double *x, const double *y, double *out, int64_t n, void *stream);
+
+#ifndef DCOMP_BUILDING_LIBRARY
+/* callers compiled against this header create their handles through the guarded entry point (see "ABI guard" above) */
+#define dcomp_create(cfg, out) \
+    dcomp_create_v(DCOMP_ABI_VERSION, sizeof(dcomp_cfg), sizeof(dcomp_state), sizeof(dcomp_out), sizeof(dcomp_rollout_opts), (cfg), (out))
+#endif
 
 #ifdef __cplusplus
 }

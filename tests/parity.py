@@ -6,20 +6,40 @@ Round 2 compared the packed observation tensor with ``rtol=1e-5, atol=1e-5``: fo
 8 envs.  Here the packed row is split by meaning:
 
 * ``connected``                      exact
-* ``dr`` (= snr_b / max snr, variants.py:276-284)   rtol 1e-5 against the oracle's FP64 value, atol 1e-9 (float32 observations
-                                     below 1e-9 -- a UE standing ON a station pushes the others to 1e-50 -- are flushed / denormal)
+* ``dr`` (= snr_b / max snr, variants.py:276-284)   rtol 1e-5 against the oracle's FP64 value on EVERY entry a float32 observation can
+                                     hold as a normal number (>= 2^-126 = 1.18e-38: far stations of the 32-station map sit at 1e-13, a
+                                     UE a metre from a station pushes the others to 1e-10 ... 1e-30); entries below that -- a UE
+                                     standing ON a station pushes the others to 1e-50 -- must come out flushed or denormal
+                                     (round 4 used atol = 1e-9, which left everything below 1e-9 unchecked)
 * ``ues_at_bs`` (count / U)          atol 1e-6
-* ``util_at_bs``, ``utility``        atol 1e-5 on [-1, 1]: utility is 10 log10(rate), a 1e-5 RELATIVE rate error is 4.3e-5 / 20
+* ``util_at_bs``, ``utility``        atol 5e-6 on [-1, 1]: utility is 10 log10(rate), a 1e-5 RELATIVE rate error is 4.3e-5 / 20 = 2.2e-6
 * per-UE data rate ``ue_dr`` (station.py:129-220 summed, user.py:64-69) and ``ewma`` (user.py:148-157)
                                      rtol 1e-5, atol 1e-30 against the oracle's FP64 curr_dr / ewma
-* per-UE utility on [-20, 20]        atol 1e-4
+* per-UE utility on [-20, 20]        atol 5e-5 (= 4.3e-5, what the 1e-5 rate bar implies, + float32 rounding of a value near 20;
+                                     measured <= 2.1e-5; rounds 1-4: 1e-4)
 """
 import numpy as np
 
 RTOL_RATE = 1e-5
-ATOL_DR_OBS = 1e-9
-ATOL_OBS = 1e-5
-ATOL_UTIL = 1e-4
+F32_MIN_NORMAL = float(np.finfo(np.float32).tiny)          # 2^-126
+ATOL_OBS = 5e-6
+ATOL_UTIL = 5e-5
+
+
+def assert_dr_obs(got, want, msg=''):
+    """obs['dr'] -- relative SNR in (0, 1], variants.py:276-284.  RELATIVE on every entry float32 holds as a normal number; what lies
+    below must be flushed / denormal on the device too.  want: FP64 (oracle / fixture) or the oracle's float32 rows."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, f'{msg}: obs dr shape {got.shape} vs {want.shape}'
+    normal = want >= F32_MIN_NORMAL
+    if normal.any():
+        rel = np.abs(got[normal] - want[normal]) / want[normal]
+        k = int(np.argmax(rel))
+        assert rel[k] <= RTOL_RATE, (f'{msg}: obs dr (relative SNR) off by {rel[k]:.3e} relative at value {want[normal][k]:.3e} '
+                                     f'(got {got[normal][k]:.9e}); bar {RTOL_RATE}')
+    if (~normal).any():
+        assert np.all(np.abs(got[~normal]) <= 1.0000001 * F32_MIN_NORMAL), f'{msg}: obs dr entries below the float32 normal range are not flushed / denormal'
 
 
 def split_packed(obs, kind, U, B):
@@ -39,7 +59,7 @@ def assert_obs(got_packed, oracle_obs, kind, U, B, dr_rel=None, msg=''):
     g = split_packed(got_packed, kind, U, B)
     w_conn, w_dr = oracle_obs[:, :, :B], oracle_obs[:, :, B:2 * B]
     assert np.array_equal(g['connected'], w_conn), f'{msg}: connected flags differ'
-    np.testing.assert_allclose(g['dr'], w_dr if dr_rel is None else dr_rel, rtol=RTOL_RATE, atol=ATOL_DR_OBS, err_msg=f'{msg}: obs dr (relative SNR)')
+    assert_dr_obs(g['dr'], w_dr if dr_rel is None else dr_rel, msg)
     if kind == 'multi':
         np.testing.assert_allclose(g['ues_at_bs'], oracle_obs[:, :, 2 * B:3 * B], rtol=0, atol=1e-6, err_msg=f'{msg}: ues_at_bs')
         np.testing.assert_allclose(g['util_at_bs'], oracle_obs[:, :, 3 * B:4 * B], rtol=0, atol=ATOL_OBS, err_msg=f'{msg}: util_at_bs')

@@ -213,12 +213,41 @@ def test_create_rejects_bad_config_without_gpu(lib):
     from deepcomp_amd import _lib
     c, keep = _cfg(3, 10, 10, [1, 1, 1], [3, 3, 3])          # map too small for the 10 m waypoint border
     h = ctypes.c_void_p()
-    assert lib.dcomp_create(ctypes.byref(c), ctypes.byref(h)) == _lib.EINVAL
+    assert _lib.create(c, h) == _lib.EINVAL
     assert b'map' in lib.dcomp_last_error()
     with pytest.raises(ValueError):
         _lib.check(_lib.EINVAL)
     with pytest.raises(AssertionError):
         _lib.check(_lib.EACTION)
+
+
+def test_abi_guard_rejects_a_stale_caller_without_gpu(lib):
+    """dcomp_out grew a 7th pointer with nothing to stop a caller compiled against six.  Handles are now created through
+    dcomp_create_v(version, struct sizes, ...): anything but the library's own values -> DCOMP_EABI, before the config is even looked at;
+    the version-1 symbol `dcomp_create` refuses always."""
+    from deepcomp_amd import _lib
+    assert lib.dcomp_abi_version() == _lib.ABI_VERSION == 2 and b'ABI 2' in lib.dcomp_version()
+    c, keep = _cfg(3, 100, 100, [1, 1, 1], [3, 3, 3])
+    h = ctypes.c_void_p(1234)
+    sizes = [ctypes.sizeof(x) for x in (_lib.DcompCfg, _lib.DcompState, _lib.DcompOut, _lib.DcompRolloutOpts)]
+    assert lib.dcomp_create(ctypes.byref(c), ctypes.byref(h)) == _lib.EABI and h.value is None        # the ABI-1 entry point
+    assert b'ABI-1' in lib.dcomp_last_error()
+    stale_out = sizes[2] - ctypes.sizeof(ctypes.c_void_p)                                               # dcomp_out without obs_compact
+    assert lib.dcomp_create_v(2, sizes[0], sizes[1], stale_out, sizes[3], ctypes.byref(c), ctypes.byref(h)) == _lib.EABI
+    assert str(stale_out).encode() in lib.dcomp_last_error() and str(sizes[2]).encode() in lib.dcomp_last_error()
+    assert lib.dcomp_create_v(1, *sizes, ctypes.byref(c), ctypes.byref(h)) == _lib.EABI
+    with pytest.raises(ImportError):
+        _lib.check(_lib.EABI)
+    # the header's own macro passes exactly these sizes: compile a two-line C caller against include/ and compare
+    import subprocess
+    import tempfile
+    src = ('#include "dcomp.h"\n#include <stdio.h>\nint main(void){printf("%d %zu %zu %zu %zu\\n", DCOMP_ABI_VERSION, sizeof(dcomp_cfg), '
+           'sizeof(dcomp_state), sizeof(dcomp_out), sizeof(dcomp_rollout_opts));return 0;}\n')
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, 'a.c'), 'w').write(src)
+        subprocess.run(['gcc', '-I', os.path.join(REPO, 'include'), '-o', os.path.join(d, 'a'), os.path.join(d, 'a.c')], check=True)
+        got = subprocess.run([os.path.join(d, 'a')], stdout=subprocess.PIPE, text=True, check=True).stdout.split()
+    assert [int(x) for x in got] == [_lib.ABI_VERSION] + sizes, 'the ctypes mirrors and include/dcomp*.h disagree about a struct size'
 
 
 def test_scenario_tables_match_reference_geometry():

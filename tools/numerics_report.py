@@ -54,3 +54,50 @@ for t in range(T):
 print(f'{E} envs x {U} UE x {B} BS, {T} steps, {err["n_rates"]} non-zero per-UE rates compared; masks and FP64 positions bit-exact')
 print(f'max relative error  data rate {err["rate_rel"]:.2e} | EWMA rate (> 1e-30) {err["ewma_rel"]:.2e} | obs dr (relative SNR, vs f32-rounded oracle) {err["obs_dr_rel"]:.2e}')
 print(f'max absolute error  utility [-20,20] {err["util_abs"]:.2e} | multi-agent reward [-20,20] {err["reward_abs"]:.2e}')
+
+
+# obs['dr'] (relative SNR, variants.py:276-284) by MAGNITUDE, against the oracle's FP64 value: the parity bar (tests/parity.py) is
+# relative down to float32's smallest normal number, so the small entries are measured here too -- 32 stations (far stations at
+# 1e-13) and UEs parked on / next to stations (the others' entries fall to 1e-10 ... 1e-50).
+E2, U2, B2, T2 = 256, 32, 32, 40
+OFFS = (0.0, 1e-9, 1e-6, 1e-4, 1e-2, 0.3)
+scn = scenarios.grid_map(B2, 'mixed').with_ues(num_static=6, num_slow=20, num_fast=6)
+for i, off in enumerate(OFFS):                                   # static UE i stands `off` metres from station i
+    x, y = scn.bs_pos[i]
+    scn.ue_specs[i]['pos_x'], scn.ue_specs[i]['pos_y'] = int(x), int(y)
+    scn.bs_pos[i] = (x + off, y)
+m, bs, ues = build_from_scenario(scn)
+core = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=E2, seed=9, rng='philox')
+init_xy = [(s['pos_x'], s['pos_y']) if s['pos_x'] != 'random' else (-1, -1) for s in scn.ue_specs]
+oenvs = []
+for e in range(E2):
+    o = orc.OracleEnv(int(scn.width), int(scn.height), scn.bs_pos, scn.bs_sharing, [s['velocity'] for s in scn.ue_specs], kind=orc.MULTI, init_xy=init_xy)
+    o.set_philox(9, e)
+    oenvs.append(o)
+ob = orc.OracleBatch(oenvs)
+core.reset()
+ob.reset()
+tiny = float(np.finfo(np.float32).tiny)
+dec = {}
+below = [0, 0.0]
+for t in range(T2):
+    a = rng.integers(0, B2 + 1, size=(E2, U2)).astype(np.uint8)
+    core.step(torch.from_numpy(a).cuda())
+    o_obs, o_rew, o_conn, o_pos = ob.step(a)
+    assert np.array_equal(core.state_host()['conn'], o_conn) and np.array_equal(core.state_host()['pos'], o_pos)
+    want = ob.rates(want_dr_rel=True)['dr_rel']
+    got = core.obs_views()['dr'].cpu().numpy().astype(np.float64).reshape(want.shape)
+    nrm = want >= tiny
+    rel = np.abs(got[nrm] - want[nrm]) / want[nrm]
+    d = np.floor(np.log10(want[nrm])).astype(int)
+    for k in np.unique(d):
+        r = rel[d == k]
+        c = dec.setdefault(int(k), [0, 0.0])
+        c[0] += r.size
+        c[1] = max(c[1], float(r.max()))
+    below[0] += int((~nrm).sum())
+    below[1] = max(below[1], float(np.abs(got[~nrm]).max()) if (~nrm).any() else 0.0)
+print(f'\nobs dr by magnitude, {E2} envs x {U2} UE x {B2} BS, {T2} steps; static UEs {OFFS} m from a station; FP64 oracle values:')
+for k in sorted(dec, reverse=True):
+    print(f'   [1e{k:+03d}, 1e{k + 1:+03d}): n = {dec[k][0]:9d}   max relative error {dec[k][1]:.2e}')
+print(f'   below 2^-126: n = {below[0]}, largest device value {below[1]:.3e} (must be flushed / denormal)')
