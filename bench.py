@@ -45,34 +45,50 @@ def survey_bytes_per_env_step(U, B, kind):
 REFERENCE_STEP_PER_CORE = {('central', 3, 3): 2122.0, ('central', 10, 5): 398.0, ('multi', 32, 10): 69.9, ('multi', 128, 32): 9.4}
 
 
-def cpu_baseline(scn, kind, U, B, budget_s=12.0):
-    """The CPU oracle (oracle/dcomp_oracle.c, OpenMP over envs) on a bounded sample of the same workload."""
+def cpu_baseline(scn, kind, U, B, budget_s=12.0, restore_affinity=None):
+    """The CPU oracle (oracle/dcomp_oracle.c, OpenMP over envs) on a bounded sample of the same workload, on the box's HOST cores: the
+    rank's NUMA binding (pin_to_gpu_numa_node) is lifted for it (restore_affinity = the mask the process started with).  How many
+    threads: the GPU box is a slice of a shared host, and a team as large as the visible CPU count collapses there (256 threads: 4 x 10^3
+    env-steps/s, 128: 1.2 x 10^5, one: 3.1 x 10^4 -- profiles/r05_cpu_baseline_threads.txt), so a 0.4 s probe per candidate team size picks
+    the fastest and `cores` reports the team that was used."""
     from oracle import oracle as orc
-    threads = orc.lib().orc_max_threads()
+    if restore_affinity:
+        try:
+            os.sched_setaffinity(0, restore_affinity)
+        except OSError:
+            pass
+    avail = len(os.sched_getaffinity(0))
+    max_threads = max(1, min(orc.lib().orc_max_threads(), avail))
 
-    def make(E):
+    def make(E, nt):
         envs = []
         for e in range(E):
             o = orc.OracleEnv(int(scn.width), int(scn.height), scn.bs_pos, scn.bs_sharing,
                               [s['velocity'] for s in scn.ue_specs], kind=orc.MULTI if kind == 'multi' else orc.CENTRAL)
             o.set_philox(42, e)
             envs.append(o)
-        return orc.OracleBatch(envs, num_threads=threads)
+        return orc.OracleBatch(envs, num_threads=nt)
 
     rng = np.random.default_rng(7)
-    probe = make(threads * 8)
+    cands = sorted({n for n in (max_threads, avail // 2, avail // 4, avail // 8, 64, 32, 16, 8) if 1 <= n <= max_threads}, reverse=True)
+    probe = make(max(cands) * 4, max(cands))
     probe.reset()
     a = rng.integers(0, B + 1, size=(probe.E, U)).astype(np.uint8)
-    probe.step(a)                                    # thread-pool start-up outside the probe
-    t0, n = time.perf_counter(), 0
-    while time.perf_counter() - t0 < 1.0:
-        probe.step(a)
-        n += 1
-    rate = probe.E * n / (time.perf_counter() - t0)
+    tried = {}
+    for nt in cands:
+        probe.num_threads = nt
+        probe.step(a)                                # thread-pool start-up outside the probe
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 0.4:
+            probe.step(a)
+            n += 1
+        tried[nt] = probe.E * n / (time.perf_counter() - t0)
+    threads = max(tried, key=tried.get)
+    rate = tried[threads]
     steps = 100
     E = int(max(threads, min(32768, rate * budget_s / steps)))
     E = (E // threads) * threads
-    batch = make(E)
+    batch = make(E, threads)
     batch.reset()
     acts = rng.integers(0, B + 1, size=(steps, E, U)).astype(np.uint8)
     t0 = time.perf_counter()
@@ -80,14 +96,14 @@ def cpu_baseline(scn, kind, U, B, budget_s=12.0):
         batch.step(acts[t])
     dt = time.perf_counter() - t0
     out = {'value': E * steps / dt, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
-           'sample': f'{E} envs x {steps} steps ({U} UE x {B} BS, {kind}), oracle/dcomp_oracle.c with OpenMP over envs, {dt:.1f} s'}
+           'sample': f'{E} envs x {steps} steps ({U} UE x {B} BS, {kind}), oracle/dcomp_oracle.c with OpenMP over envs, {dt:.1f} s',
+           'cpus_visible': avail, 'team_sizes_probed_env_steps_per_s': {str(k): round(v) for k, v in tried.items()}}
     # "single core and all cores".  The same port on ONE thread (~3 s), which is what links this box to the reference's
     # own step(): REFERENCE_STEP_PER_CORE below was timed in the build container with the reference's unmodified deepcomp.env.* (BASELINE.md
     # section 2; the Python reference cannot travel to this box), so port-on-one-core / that figure is how much faster the C restatement is
     # than the reference per core -- and all-cores / single-core is this box's parallel speed-up, which normalises `value` across boxes.
     del batch, probe
-    one = make(64)
-    one.num_threads = 1
+    one = make(64, 1)
     one.reset()
     a1 = rng.integers(0, B + 1, size=(8, 64, U)).astype(np.uint8)
     one.step(a1[0])
@@ -529,7 +545,7 @@ class SmiSampler:
         ppt = [r[2] for r in self.rows if isinstance(r[2], (int, float))]
         return {'gfxclk_mhz': sum(r[0] for r in last) / len(last), 'socket_power_w': sum(pw) / len(pw) if pw else None,
                 'power_throttle_residency_advanced': bool(ppt and ppt[-1] > ppt[0]), 'samples': len(self.rows),
-                'how': 'amdsmi gpu_metrics (firmware-filtered, ~20 ms refresh) polled while the steady-state launches ran; mean of the last 3 readings'}
+                'how': 'amdsmi gpu_metrics (firmware-filtered, ~20 ms refresh) polled while the steady-state launches and ~0.25 s of further stepping ran; mean of the last 3 readings'}
 
 
 def valu_bound(ent, kernel_ms):
@@ -625,6 +641,7 @@ def main():
     if not args.same_device and torch.cuda.device_count() < world:
         sys.exit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible (--same-device --backend gloo: dry run on one)")
     t_wall0 = time.time()
+    affinity_at_start = os.sched_getaffinity(0)
     placement = pin_to_gpu_numa_node(torch, local_rank, enable=not args.no_pin)
     if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -1019,8 +1036,10 @@ def main():
         t = run(max(0, 300 - K), t_env)
         sp2 = []
         ev_pool.extend(torch.cuda.Event(enable_timing=True) for _ in range(2 * (200 // L + 3)))
-        smi = SmiSampler(local_rank)              # gfx clock / socket power WHILE the steady-state launches run (profiles/r05_c3_clock_trace.txt)
-        run(200, t, sp2)
+        smi = SmiSampler(local_rank)              # gfx clock / socket power WHILE the launches run (profiles/r05_c3_clock_trace.txt)
+        t = run(200, t, sp2)
+        if smi.err is None:                       # the firmware's table is a ~20 ms filtered view and the clock needs ~0.3 s of load to settle at its
+            run(3000, t)                          # power-limited value: keep stepping (untimed) until the reading means something
         torch.cuda.synchronize(dev)
         steady_clk = smi.stop()
         steady_ms = sum(a.elapsed_time(b) for a, b, _ in sp2) / sum(n for _, _, n in sp2)
@@ -1119,7 +1138,7 @@ def main():
             out.setdefault('also', {}).update(also_late)
             out['also']['measured'] = 'after the timed region (round-2 order)'
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(scn, args.kind, U, B)
+            out['cpu_baseline'] = cpu_baseline(scn, args.kind, U, B, restore_affinity=affinity_at_start)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

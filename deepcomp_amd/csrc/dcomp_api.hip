@@ -93,6 +93,15 @@ extern "C" double dcomp_connect_threshold(void)
 
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// Rows (num_steps * num_envs * num_ue) from which an every-step fragment no longer fits the fused rollout kernel's 32-bit row indices.
+// DCOMP_FUSED_ROW_LIMIT_LOG2 lowers it (tests: the one-launch-per-step fallback of dcomp_rollout_ex without a 2^31-row fragment).
+static uint64_t fused_row_limit()
+{
+    const char *e = getenv("DCOMP_FUSED_ROW_LIMIT_LOG2");
+    const int l2 = e ? atoi(e) : 31;
+    return (uint64_t)1 << (l2 >= 1 && l2 <= 31 ? l2 : 31);
+}
+
 extern "C" const char *dcomp_last_error(void) { return g_err; }
 #define DCOMP_STR2(x) #x
 #define DCOMP_STR(x) DCOMP_STR2(x)
@@ -546,7 +555,7 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
     }
     // the fused kernel addresses step t's outputs as (idx + t * E * U) on the caller's base pointers with 32-bit row indices: a
     // fragment beyond that takes the one-launch-per-step path below (same results), except the closed loop, which has no other path
-    const bool fits32 = !(every && (uint64_t)T * EU >= ((uint64_t)1 << 31));
+    const bool fits32 = !(every && (uint64_t)T * EU >= fused_row_limit());
     if (loop && !fits32) return fail(DCOMP_EINVAL, "policy_loop fragment too long: num_steps * num_envs * num_ue must stay below 2^31 (split the rollout)");
     if (fits32 && (env->fused || (env->fused_long && (T >= 4 || loop)))) {
         // with a registered policy: the variant that carries the rules; tape-driven central envs: the central-only instantiation
@@ -642,7 +651,7 @@ extern "C" int dcomp_rollout_fused_for(const dcomp_env *env, int32_t num_steps, 
 {
     if (!env || num_steps < 1) return -1;
     const uint64_t EU = (uint64_t)env->cfg.num_envs * env->cap;
-    if (every_step && (uint64_t)num_steps * EU >= ((uint64_t)1 << 31)) return 0;
+    if (every_step && (uint64_t)num_steps * EU >= fused_row_limit()) return 0;
     return (env->fused || (env->fused_long && (num_steps >= 4 || policy_loop))) ? 1 : 0;
 }
 extern "C" int dcomp_lanes_per_env(const dcomp_env *env) { return env ? (env->tight_g ? env->tight_g : env->upad) : -1; }

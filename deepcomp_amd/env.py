@@ -767,6 +767,10 @@ class BatchedMobileEnv:
         torch.cuda.current_stream(self.device).synchronize()
         sd = {'config': self._fingerprint(), 'counters': list(c), 'outbuf': self._outbuf.detach().cpu().clone(),
               'pending_seed': int(self.seed_value) if self._reseeded else None}      # seed() since the last reset(): in force from the next one
+        # the registered policy's decision for the NEXT step: saved as it is.  The last launch may have written its observation somewhere
+        # else than self.obs (step_into, step_compact, rollout(out=...)), so it cannot be re-derived from `outbuf` on the other side.
+        sd['next_action'] = (self.next_action.detach().cpu().clone()
+                             if self._policy_key is not None and self.next_action is not None and self._next_action_fresh else None)
         for k in ('pos', 'mv', 'conn', 'ewma', 'conn_since', 'uid', 'orig_consumed'):
             t = getattr(self, k)
             sd[k] = None if t is None else t.detach().cpu().clone()
@@ -775,8 +779,18 @@ class BatchedMobileEnv:
     def load_state_dict(self, sd):
         if self.rng_mode != _lib.RNG_PHILOX:
             raise NotImplementedError("load_state_dict() needs rng='philox' (counter-based draws)")
-        if sd['config'] != self._fingerprint():
-            raise ValueError("checkpoint belongs to a differently configured env batch")
+        want, have = self._fingerprint(), dict(sd['config'])
+        layout = have.get('state_layout')
+        if layout == 2:
+            # round-3 checkpoints: no 'velocity' key (fixed non-integer velocities did not exist), 'seed' = the seed of the running episode
+            # as well (seed() on a live env was not checkpointable: no pending_seed) -- same tensors, same counters
+            have['velocity'], have['state_layout'] = want['velocity'], want['state_layout']
+        elif layout != want['state_layout']:
+            raise ValueError(f"checkpoint format v{layout} is not supported: this build reads v2 and v{want['state_layout']} "
+                             f"(state_dict() writes v{want['state_layout']})")
+        if have != want:
+            diff = sorted(k for k in set(have) | set(want) if have.get(k) != want.get(k))
+            raise ValueError(f"checkpoint belongs to a differently configured env batch (differs in: {', '.join(diff)})")
         for k in ('pos', 'mv', 'conn', 'ewma', 'conn_since', 'uid', 'orig_consumed'):
             if sd[k] is not None:
                 getattr(self, k).copy_(sd[k])
@@ -791,11 +805,15 @@ class BatchedMobileEnv:
             self.env_seeds = self.seed_value + self._seed_stride * (self.env_id_base + np.arange(self.E, dtype=np.int64))
             self._reseeded = False
         if self._policy_key is not None:
-            # next_action still holds the decision for the observation of BEFORE the restore: redo it on the restored one (the
-            # stand-alone policy kernel gives what the in-step policy would have written -- tests/test_adapters_gpu.py holds the
-            # two equal), so that `step(env.next_action)` / rollout_policy() continue the checkpointed run bit-identically
-            policy, eps, _ = self._policy_key
-            self.heuristic_actions(policy, epsilon=eps, cluster_mask=self._policy_cm, obs=self.obs, out=self.next_action)
+            if sd.get('next_action') is not None:
+                # the checkpointed run's own decision for its next step (whatever buffer its last observation went to)
+                self.next_action.copy_(sd['next_action'])
+            else:
+                # a checkpoint written without a registered policy (or before next_action was saved): decide on the restored observation --
+                # the stand-alone policy kernel gives what the in-step policy would have written (tests/test_adapters_gpu.py holds the two
+                # equal).  Only right if the checkpointed run's last launch wrote self.obs (step / reset / rollout without out=).
+                policy, eps, _ = self._policy_key
+                self.heuristic_actions(policy, epsilon=eps, cluster_mask=self._policy_cm, obs=self.obs, out=self.next_action)
             self._next_action_fresh = True
 
     def info(self):
@@ -813,12 +831,27 @@ class BatchedMobileEnv:
         self._out = self._make_out(self.obs, self.reward)
         self._out_ref = ctypes.byref(self._out)
 
-    def outputs_host(self, synced=False):
+    def outputs_host(self, synced=False, persistent=False):
         """Everything the last reset()/step() produced as a dict of numpy views: ONE device->host copy, or (host_io) the
-        pinned buffer itself -- then the caller has synchronised (check()) and consumes the views before the next step."""
-        if self.host_io and not synced:
+        pinned buffer itself -- then the caller has synchronised (check()) and consumes the views before the next step.
+        persistent: the copy lands in ONE pinned host buffer that lives as long as the env, and the SAME dict of views over it is
+        returned every time (refilled in place, nothing allocated per call): for callers that build per-env views of it once and
+        consume a step's values before the next step (deepcomp_amd.rllib_adapter)."""
+        if self.host_io:
+            if not synced:
+                torch.cuda.current_stream(self.device).synchronize()
+            h = self._outbuf.numpy()
+        elif persistent:
+            m = self.__dict__.get('_host_mirror')
+            if m is None:
+                m = self._host_mirror = torch.empty(self._outbuf.shape, dtype=torch.float32).pin_memory()
+                hv = m.numpy()
+                self._host_views = {name: hv[o:o + cnt].reshape(shape) for name, (o, cnt, shape) in self._sections.items()}
+            m.copy_(self._outbuf, non_blocking=True)
             torch.cuda.current_stream(self.device).synchronize()
-        h = self._outbuf.numpy() if self.host_io else self._outbuf.cpu().numpy()
+            return self._host_views
+        else:
+            h = self._outbuf.cpu().numpy()
         return {name: h[o:o + cnt].reshape(shape) for name, (o, cnt, shape) in self._sections.items()}
 
     def obs_views_host(self, host):

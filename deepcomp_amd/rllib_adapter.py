@@ -14,8 +14,14 @@ Caller contract kept (deepcomp/util/env_setup.py:262-316, deepcomp/util/simulati
 ``action_space``, agent ids = ``ue.id`` strings, ``horizon`` = episode_length -> all envs of a batch reach it in the same step.
 
 Two ways to consume a batch:
-* the protocol methods (per-env Python dicts; what an unmodified RLlib sampler calls) -- E bounded by Python, fine for the
-  handful of envs per worker RLlib uses;
+* the protocol methods (per-env Python dicts; what an unmodified RLlib sampler calls).  Since round 5 the per-env observation
+  dicts are built ONCE, as numpy views over one persistent pinned host buffer that every step refills with one asynchronous
+  device->host copy (``BatchedMobileEnv.outputs_host(persistent=True)``): ``vector_step`` / ``poll`` allocate no per-env object
+  for observations, ``dones`` / multi-agent ``infos`` are shared constants resp. one dict per step.  The views alias the buffer:
+  a step's observations must be consumed (RLlib's preprocessor copies them while flattening) before the next step overwrites
+  them; ``env_config['persistent_views'] = False`` restores fresh arrays per step.  ``env_config['info_level']``: 'full' (default,
+  the reference's info dicts, base.py:383-411), 'scalar' (time + scalar_metrics) or 'none' (time only) for the central env,
+  whose per-UE metric dicts are the remaining per-env Python work.  Measured rates: INTEGRATION.md section 1, tools/adapter_rate.py;
 * ``poll_tensors() / send_action_tensor()`` -- the same data as device tensors ``[E, U, 4B+1]`` / ``[E, U(2B+1)]`` with no
   host copy and no per-env objects: what a learner on the same GPU (or a custom sampler) uses at E = 65 536.
 
@@ -100,11 +106,23 @@ class CentralVectorEnv(_VectorEnvBase, _LockStepResets):
         self._ue_keys = [f'UE {ue}' for ue in env_config['ue_list']]          # the keys of info()'s vector_metrics (base.py:407-408)
         self._all = None
         self._obs = None
+        self._persistent = bool(env_config.get('persistent_views', True))
+        self._info_level = env_config.get('info_level', 'full')
+        if self._info_level not in ('full', 'scalar', 'none'):
+            raise ValueError("info_level must be 'full', 'scalar' or 'none'")
+        self._dones = [False] * self.core.E
         self._init_resets()
 
     def _obs_list(self):
         U, B = self.core.U, self.core.B
         _warn_protocol_path(self)
+        if self._persistent:
+            first = self._all is None
+            self._all = self.core.outputs_host(persistent=True)        # ONE D2H copy into the env's pinned buffer; the SAME views every step
+            if first:                                                  # the per-env dicts of views: built once, refilled in place
+                host = self._all['obs']
+                self._obs = [{'connected': row[:U * B], 'dr': row[U * B:2 * U * B], 'utility': row[2 * U * B:]} for row in host]
+            return self._obs
         self._all = self.core.outputs_host()                           # ONE D2H copy of obs + reward + info; below are views
         host = self._all['obs']
         self._obs = [{'connected': row[:U * B], 'dr': row[U * B:2 * U * B], 'utility': row[2 * U * B:]} for row in host]
@@ -129,12 +147,18 @@ class CentralVectorEnv(_VectorEnvBase, _LockStepResets):
         self.core.check()
         self._stepped = True
         obs = self._obs_list()
-        rew, su = self._all['reward'].tolist(), self._all['sum_utility'].tolist()
-        dr, ut = self._all['ue_dr'].tolist(), self._all['ue_utility'].tolist()
+        rew = self._all['reward'].tolist()
         t, keys = self.core.time, self._ue_keys
-        infos = [{'time': t, 'scalar_metrics': {'sum_utility': su[e]},                                  # base.py:383-411
-                  'vector_metrics': {'dr': dict(zip(keys, dr[e])), 'utility': dict(zip(keys, ut[e]))}} for e in range(self.core.E)]
-        return obs, rew, [False] * self.core.E, infos
+        if self._info_level == 'full':                                                                  # base.py:383-411
+            su, dr, ut = self._all['sum_utility'].tolist(), self._all['ue_dr'].tolist(), self._all['ue_utility'].tolist()
+            infos = [{'time': t, 'scalar_metrics': {'sum_utility': s_}, 'vector_metrics': {'dr': dict(zip(keys, d_)), 'utility': dict(zip(keys, u_))}}
+                     for s_, d_, u_ in zip(su, dr, ut)]
+        elif self._info_level == 'scalar':
+            infos = [{'time': t, 'scalar_metrics': {'sum_utility': s_}} for s_ in self._all['sum_utility'].tolist()]
+        else:
+            ti = {'time': t}
+            infos = [ti] * self.core.E
+        return obs, rew, (self._dones if self._persistent else [False] * self.core.E), infos
 
     # ---- zero-copy path
     def poll_tensors(self):
@@ -166,17 +190,32 @@ class MultiAgentBaseEnv(_BaseEnvBase, _LockStepResets):
         self._all = None
         self._reset_obs = None
         self._fresh = True
+        self._persistent = bool(env_config.get('persistent_views', True))
+        self._view_dict = None
+        import operator
+        self._pick = operator.itemgetter(*self.agent_ids) if len(self.agent_ids) > 1 else (lambda d, k=self.agent_ids[0]: (d[k],))
+        self._dones = {e: {'__all__': False} for e in range(self.core.E)}
+        self._no_infos = {e: {} for e in range(self.core.E)}
+        self._zeros = {e: dict.fromkeys(self.agent_ids, 0.0) for e in range(self.core.E)}
+        self._act_host = np.zeros((self.core.E, self.core.U), dtype=np.uint8)
         self._init_resets()
         self._reset_for(None)
 
-    def _views(self):
+    def _build_views(self, host):
         B = self.core.B
-        _warn_protocol_path(self)
-        self._all = self.core.outputs_host()                            # ONE D2H copy of obs + reward + info
-        host = self._all['obs']                                         # [E, U, 4B+1]
         return {e: {aid: {'connected': host[e, i, 0:B], 'dr': host[e, i, B:2 * B], 'ues_at_bs': host[e, i, 2 * B:3 * B],
                           'util_at_bs': host[e, i, 3 * B:4 * B], 'utility': host[e, i, 4 * B:4 * B + 1]}
                     for i, aid in enumerate(self.agent_ids)} for e in range(self.core.E)}
+
+    def _views(self):
+        _warn_protocol_path(self)
+        if self._persistent:
+            self._all = self.core.outputs_host(persistent=True)         # ONE D2H copy into the env's pinned buffer
+            if self._view_dict is None:                                 # {env: {agent: {key: view}}} over that buffer: built once
+                self._view_dict = self._build_views(self._all['obs'])
+            return self._view_dict
+        self._all = self.core.outputs_host()                            # ONE D2H copy of obs + reward + info
+        return self._build_views(self._all['obs'])                      # [E, U, 4B+1]
 
     def _after_core_reset(self):
         self._reset_obs = self._views()
@@ -185,22 +224,33 @@ class MultiAgentBaseEnv(_BaseEnvBase, _LockStepResets):
         E = self.core.E
         if self._fresh:                                                 # right after a reset: observations only
             self._fresh = False
+            if self._persistent:
+                return self._reset_obs, self._zeros, self._dones, self._no_infos, {}
             zeros = {e: {a: 0.0 for a in self.agent_ids} for e in range(E)}
             dones = {e: {'__all__': False} for e in range(E)}
             return self._reset_obs, zeros, dones, {e: {} for e in range(E)}, {}
         obs = self._views()
-        rew = self._all['reward'].tolist()
-        rewards = {e: dict(zip(self.agent_ids, rew[e])) for e in range(E)}
+        ids = self.agent_ids
+        rewards = dict(enumerate(dict(zip(ids, row)) for row in self._all['reward'].tolist()))
+        if self._persistent:
+            # `dones` never changes (multi_agent.py:97-99: the horizon ends episodes, not the env); every agent of every env gets the SAME
+            # info dict of this step ({'time': t}, multi_agent.py:102-107) -- a new one per step, so nothing aliases across steps
+            per_env = dict.fromkeys(ids, {'time': self.core.time})
+            return obs, rewards, self._dones, dict.fromkeys(range(E), per_env), {}
         dones = {e: {'__all__': False} for e in range(E)}
-        infos = {e: {a: {'time': self.core.time} for a in self.agent_ids} for e in range(E)}
+        infos = {e: {a: {'time': self.core.time} for a in ids} for e in range(E)}
         return obs, rewards, dones, infos, {}
 
     def send_actions(self, action_dict):
-        a = np.zeros((self.core.E, self.core.U), dtype=np.uint8)
+        a = self._act_host
+        a.fill(0)
         for e, acts in action_dict.items():
-            for i, aid in enumerate(self.agent_ids):
-                if aid in acts:                                          # multi_agent.py:30: missing ids are no-ops
-                    a[e, i] = int(acts[aid])
+            try:
+                a[e] = self._pick(acts)                                  # every agent acted (RLlib's sampler): one C-level lookup per env
+            except KeyError:
+                for i, aid in enumerate(self.agent_ids):
+                    if aid in acts:                                      # multi_agent.py:30: missing ids are no-ops
+                        a[e, i] = int(acts[aid])
         self.core.step(torch.from_numpy(a).to(self.core.device))
         self.core.check()
         self._stepped = True

@@ -3,8 +3,8 @@
 These are *data* restated from the reference's scenario factory (numbers only):
 ``deepcomp/util/env_setup.py:40-49`` (mixed sharing rule), ``:52-62`` (small), ``:87-104`` (medium, 3 BS on
 an equilateral triangle), ``:107-142`` (large, <=7 BS hexagon), ``:164-176`` (custom, 4 BS) and ``:145-161``
-(UE mix: static, then slow, then fast, ids '1'..'U').  ``grid_map`` is the synthetic layout SURVEY.md §8d
-defines for BS counts the stock maps do not have (10, 32, ...).
+(UE mix: static, then slow, then fast, ids '1'..'U'), ``:205-226`` (the named UE-arrival schedules).  ``grid_map`` is the
+synthetic layout SURVEY.md §8d defines for BS counts the stock maps do not have (10, 32, ...).
 
 Everything returns plain Python/NumPy values; ``deepcomp_amd.entities`` turns them into the
 ``Map``/``Basestation``/``User`` config objects the env constructors take.
@@ -96,6 +96,25 @@ def grid_map(num_bs, sharing='mixed', pitch=100, border=50) -> Scenario:
     pos = [(border + pitch * (i % cols), border + pitch * (i // cols)) for i in range(num_bs)]
     return Scenario(2 * border + pitch * (cols - 1), 2 * border + pitch * (rows - 1), _ids(num_bs), pos,
                     [sharing_for_bs(sharing, i) for i in range(num_bs)], f'grid{num_bs}')
+
+
+# The CLI's named UE-arrival schedules (`--ue-arrival`, env_setup.py:205-226): {step: +n UEs arrive | -n UEs leave}, what
+# env_config['ue_arrival'] carries (base.py:52-56, 433-443).  Data; tests/golden/ue_arrival_schedules.json holds what the reference's own
+# get_ue_arrival returns.
+UE_ARRIVAL = {
+    'oneupdown': {10: 1, 30: -1},
+    'updownupdown': {10: 1, 20: -1, 30: 1, 40: -1},
+    '3up2down': {10: 3, 30: -2},
+    'updown': {10: 1, 15: 1, 20: 1, 40: 1, 50: -1, 60: -1},
+    'largeupdown': {20: 1, 30: -1, 40: 1, 45: 1, 50: 1, 55: 2, 60: 3, 65: 2, 70: 1, 75: -1, 80: -2, 85: -3, 90: -3, 95: -2},
+}
+
+
+def get_ue_arrival(name):
+    """Named schedule -> the dict env_config['ue_arrival'] / BatchedMobileEnv(ue_arrival=...) take; None -> None (fixed UE list).
+    A fresh dict every call (callers may edit theirs).  Unknown names: AssertionError, like the reference (env_setup.py:207)."""
+    assert name is None or name in UE_ARRIVAL, f"UE arrival {name!r} is not one of {sorted(UE_ARRIVAL)} / None"
+    return None if name is None else dict(UE_ARRIVAL[name])
 
 
 def get_scenario(map_size, sharing='mixed', bs_dist=100, num_bs=None) -> Scenario:

@@ -43,18 +43,29 @@ class GatherHandle:
     works: list
     stream: object = None
     codec: object = None            # FragmentCodec: out['obs'] arrived as the compact record and is unpacked by wait()
+    unpack_out: object = None       # where the unpacked rows go (a reused buffer of the RolloutGather; None: a fresh tensor)
+    check_lossless: bool = True
 
     def wait(self):
         """Block until the gathered fragment is usable; returns {name: tensor[world, ...fragment shape]}.  A fragment that
         crossed the links as the compact record (RolloutGather(codec=...)) comes back as the ROWS, bit-identical to what every
         rank's step kernel wrote (dcomp_unpack_fragment on the caller's current stream); the record itself stays available as
-        out['obs_compact']."""
+        out['obs_compact'].  "Bit-identical" is CHECKED, not assumed: every rank's pack kernel raises a flag word when its input was
+        not a multi-agent observation tensor (per-env columns that differ between the rows of an env, `connected` entries that are not
+        0 / 1), the words travel with the fragment (out['pack_flags'], one per rank) and a set word raises ValueError here -- one host
+        synchronisation per hand-off; RolloutGather(check_lossless=False) leaves the words to the caller."""
         for w in self.works:
             w.wait()
         if self.stream is not None:
             torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
         if self.codec is not None and 'obs' not in self.out:
-            self.out['obs'] = self.codec.unpack(self.out['obs_compact'])
+            self.out['obs'] = self.codec.unpack(self.out['obs_compact'], out=self.unpack_out)
+            if self.check_lossless and 'pack_flags' in self.out:
+                fl = self.out['pack_flags'].view(-1).tolist()
+                if any(fl):
+                    why = {1: 'per-env columns differ between the rows of an env', 2: '`connected` entry that is not 0 / 1'}
+                    raise ValueError('RolloutGather: the compact record is not lossless for this fragment -- ' + '; '.join(
+                        f"rank {r}: " + ', '.join(m for b, m in why.items() if f & b) for r, f in enumerate(fl) if f))
         return self.out
 
 
@@ -66,9 +77,10 @@ class RolloutGather:
     ``shard_bounds(...)[r][0] + e``.  One flat collective per tensor (large messages: on the fully connected
     xGMI mesh every GPU pushes its shard to its 7 peers concurrently)."""
 
-    def __init__(self, group=None, use_side_stream=True, reuse_buffers=0, codec=None):
-        """reuse_buffers = k > 0: the gathered tensors come from k alternating sets of buffers instead of fresh allocations (a
-        hand-off every few steps should not pay the allocator): the tensors of a handle are valid until k further calls.
+    def __init__(self, group=None, use_side_stream=True, reuse_buffers=0, codec=None, check_lossless=True):
+        """reuse_buffers = k > 0: the gathered tensors -- and, with a codec, the unpacked rows wait() returns, the largest tensor of a
+        hand-off -- come from k alternating sets of buffers instead of fresh allocations (a hand-off every few steps should not pay
+        the allocator: a GB-sized hipMalloc was seen to cost 30 ms): the tensors of a handle are valid until k further calls.
         The side stream, the communicator's channels and the buffer sets come into being with the first k hand-offs, and the first use
         of a second stream is followed by a cold-start-like transient of the step kernels (~200 launches 10-20 % slow,
         tools/diag_stream.py): a sampler that measures itself should hand over k fragments before it starts the clock."""
@@ -81,12 +93,16 @@ class RolloutGather:
         # codec (deepcomp_amd.fragment.FragmentCodec): fragment['obs'] (multi-agent rows [..., U, 4B+1]) crosses the links as the
         # lossless compact record -- 3.2-3.7x fewer bytes -- packed here, unpacked by GatherHandle.wait()
         self.codec = codec
+        self.check_lossless = bool(check_lossless)      # wait() reads the gathered pack flags (one host sync per hand-off) and raises if set
 
     def all_gather_async(self, fragment):
         out, works = {}, []
         if self.codec is not None and 'obs' in fragment:
             fragment = dict(fragment)
             fragment['obs_compact'] = self.codec.pack(fragment.pop('obs').contiguous())      # on the caller's stream, before the hand-over
+            # THIS fragment's flag word travels with it (the codec's word is sticky over all of its pack() calls: snapshot, then clear)
+            fragment['pack_flags'] = self.codec.flags.clone()
+            self.codec.flags.zero_()
         some = next(iter(fragment.values()))
         stream = None
         if some.is_cuda and self.use_side_stream:
@@ -107,8 +123,15 @@ class RolloutGather:
                     o = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
                 works.append(dist.all_gather_into_tensor(o.view(-1), t.view(-1), group=self.group, async_op=True))
                 out[name] = o
+        unpack_out = None
+        if self.codec is not None and 'obs_compact' in out and self._reuse:
+            oc = out['obs_compact']
+            key = ('obs/unpacked', tuple(oc.shape), oc.device, self._turn % self._reuse)
+            unpack_out = self._sets.get(key)
+            if unpack_out is None:
+                unpack_out = self._sets[key] = torch.empty(tuple(oc.shape[:-1]) + (self.codec.U, 4 * self.codec.B + 1), dtype=torch.float32, device=oc.device)
         self._turn += 1
-        return GatherHandle(out, works, stream, self.codec if 'obs_compact' in out else None)
+        return GatherHandle(out, works, stream, self.codec if 'obs_compact' in out else None, unpack_out, self.check_lossless)
 
     def all_gather(self, fragment):
         return self.all_gather_async(fragment).wait()

@@ -13,6 +13,7 @@ fixed action tape and records inputs + outputs as ``.npz`` data files:
   G5 traj_*.npz         full reset()+step() trajectories, central + multi    (base.py:169-189,413-466, ...)
   G6 estack_*.npz       the E-axis stack: env e seeded 42 + 20000*e
   G9 reseed_*.npz       MobileEnv.seed() on a live env, mid-episode and before a reset      (base.py:132-143,171-173)
+  G10 ue_arrival_schedules.json   the CLI's five named UE-arrival schedules, from the reference's own get_ue_arrival   (env_setup.py:205-226)
 
 Fixtures are data only: numbers in, numbers out.  Usage:  python tests/golden/gen_golden.py
 """
@@ -556,6 +557,27 @@ def gen_heuristics():
     print('heuristics: ok')
 
 
+def gen_ue_arrival():
+    """The five named UE-arrival schedules of the CLI (env_setup.py:205-226).  deepcomp.util.env_setup cannot be imported here (it needs a
+    real ray), so the reference's OWN get_ue_arrival is lifted out of its module with `ast` -- the function's source, compiled and run
+    unmodified against deepcomp.util.constants.SUPPORTED_UE_ARRIVAL -- and its return values are recorded: {name: [[step, count], ...]}."""
+    import ast
+    import json
+    from deepcomp.util import constants as ref_constants
+    path = '/root/reference/deepcomp/util/env_setup.py'
+    tree = ast.parse(open(path).read())
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'get_ue_arrival')
+    ns = {'SUPPORTED_UE_ARRIVAL': ref_constants.SUPPORTED_UE_ARRIVAL}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, 'exec'), ns)
+    out = {}
+    for name in sorted(n for n in ref_constants.SUPPORTED_UE_ARRIVAL if n is not None):
+        out[name] = [[int(t), int(c)] for t, c in ns['get_ue_arrival'](name).items()]        # insertion order = the reference's
+    assert ns['get_ue_arrival'](None) is None
+    with open(os.path.join(HERE, 'ue_arrival_schedules.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+    print('ue_arrival_schedules.json:', {k: len(v) for k, v in out.items()})
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1:                     # e.g. `gen_golden.py gen_movement_params`: only these generators
         for name in sys.argv[1:]:
@@ -574,3 +596,4 @@ if __name__ == '__main__':
     gen_heuristics()
     gen_dynamic()
     gen_single()
+    gen_ue_arrival()

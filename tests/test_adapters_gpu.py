@@ -76,6 +76,7 @@ def test_central_vector_env_against_reference_runs(torch_cuda):
     obs, rew, _, _ = vec.vector_step([g['actions'][0].tolist() for g in gs])
     for e in range(8):
         _check_central(obs[e], gs[e], 'step', 0, U, B)                    # fixed episodes (base.py:171-173): the same episode again
+    obs = [{k: v.copy() for k, v in o.items()} for o in obs]              # (the dicts are views of ONE host buffer the next step refills: keep a copy)
     # a request for the whole batch always resets (two in a row: two episodes), and so does a per-index request right after it
     ep = vec.core.episode
     vec.vector_reset(); vec.vector_reset()
@@ -143,6 +144,45 @@ def test_multi_agent_base_env_against_reference_runs(torch_cuda):
     for e in range(8):
         assert np.array_equal(oh[e, :, :B], gs[e]['step_obs_connected'][0])
         np.testing.assert_allclose(r[e].cpu().numpy(), gs[e]['step_reward'][0], atol=ATOL_UTIL, rtol=0)
+
+
+def test_protocol_adapters_build_their_views_once(torch_cuda):
+    """the protocol methods rebuilt E (x U) observation dicts every step.  Now the dicts are views over ONE pinned
+    host buffer that a step refills in place: the same objects come back every step (nothing allocated per env for observations), their
+    CONTENT is the new step's; env_config['persistent_views'] = False hands out fresh arrays; the fixtures hold both."""
+    from deepcomp_amd.rllib_adapter import CentralVectorEnv, MultiAgentBaseEnv
+    gs = _load('estack_grid10x5_central')
+    U, B = 10, 5
+    vec = CentralVectorEnv(_env_config(gs[0], 8))
+    fresh = CentralVectorEnv(dict(_env_config(gs[0], 8), persistent_views=False, info_level='scalar'))
+    o0, f0 = vec.vector_reset(), fresh.vector_reset()
+    keep = [o['dr'].copy() for o in f0]
+    for t in range(5):
+        acts = [g['actions'][t].tolist() for g in gs]
+        o1, rew, dones, infos = vec.vector_step(acts)
+        f1, frew, _, finfos = fresh.vector_step(acts)
+        assert o1 is o0 and all(a is b for a, b in zip(o1, o0)) and o1[3]['dr'].base is not None       # the same list of the same dicts of views
+        assert f1 is not f0 and rew == frew
+        assert 'vector_metrics' in infos[0] and 'vector_metrics' not in finfos[0] and finfos[2]['scalar_metrics'] == infos[2]['scalar_metrics']
+        for e in range(8):
+            _check_central(o1[e], gs[e], 'step', t, U, B)
+            _check_central(f1[e], gs[e], 'step', t, U, B)
+    assert all(np.array_equal(k, o['dr']) for k, o in zip(keep, f0))                 # fresh arrays: the reset observation is still intact
+    with pytest.raises(ValueError):
+        CentralVectorEnv(dict(_env_config(gs[0], 2), info_level='everything'))
+    gm = _load('estack_grid32x10_multi')
+    U, B = 32, 10
+    base = MultiAgentBaseEnv(_env_config(gm[0], 8))
+    obs0 = base.poll()[0]
+    for t in range(4):
+        base.send_actions({e: {str(u + 1): int(gm[e]['actions'][t][u]) for u in range(U)} for e in range(8)})
+        obs, rew, dones, infos, _ = base.poll()
+        assert obs is obs0 and obs[5]['7'] is obs0[5]['7']
+        assert infos[0]['1'] == {'time': t + 1} and infos[7]['32']['time'] == t + 1 and dones[4] == {'__all__': False}
+        for e in (0, 3, 7):
+            for u in (0, 9, 31):
+                _check_agent(obs[e][str(u + 1)], gm[e], 'step', t, u, B)
+                assert rew[e][str(u + 1)] == pytest.approx(float(gm[e]['step_reward'][t][u]), abs=ATOL_UTIL)
 
 
 # ------------------------------------------------------------------------------------ heuristic policy kernel (f4)

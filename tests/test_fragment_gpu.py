@@ -198,6 +198,23 @@ def test_rollout_gather_hands_rows_over_as_the_compact_record(torch_cuda):
         got2 = gather.all_gather_async(dict(comp)).wait()
         assert torch.equal(got2['obs'][0].view(torch.int32), rows['obs'].view(torch.int32))
         assert torch.equal(got2['reward'][0], rows['reward'])
+        # "bit-identical" is checked on this path, not assumed -- the pack kernel's flag word travels with the fragment and
+        # wait() raises when the record was not lossless (rows that are no observation rows); check_lossless=False leaves the word
+        assert got['pack_flags'].view(-1).tolist() == [0]
+        bad = frag['obs'].clone()
+        bad[1, 7, 3, 2 * B + 4] += 0.25                                    # a per-env column that differs between the rows of an env
+        with pytest.raises(ValueError, match='rank 0: per-env columns differ'):
+            gather.all_gather_async({'obs': bad, 'reward': frag['reward']}).wait()
+        h3 = gather.all_gather_async(sent)                                  # the flag word was the bad fragment's own: the next one is clean
+        assert h3.wait()['pack_flags'].view(-1).tolist() == [0]
+        loose = RolloutGather(use_side_stream=False, codec=codec, check_lossless=False)
+        assert loose.all_gather_async({'obs': bad, 'reward': frag['reward']}).wait()['pack_flags'].view(-1).tolist() == [1]
+        # reuse_buffers covers the unpacked rows too (the largest tensor of a hand-off): k alternating buffers, no allocation per hand-off
+        ring = RolloutGather(use_side_stream=False, codec=codec, reuse_buffers=2)
+        ptrs = [ring.all_gather_async(sent).wait()['obs'].data_ptr() for _ in range(5)]
+        assert ptrs[0] == ptrs[2] == ptrs[4] and ptrs[1] == ptrs[3] and ptrs[0] != ptrs[1]
+        last = ring.all_gather_async(sent).wait()
+        assert torch.equal(last['obs'][0].view(torch.int32), frag['obs'].view(torch.int32))
     finally:
         if own:
             dist.destroy_process_group()

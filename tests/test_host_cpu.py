@@ -250,6 +250,27 @@ def test_abi_guard_rejects_a_stale_caller_without_gpu(lib):
     assert [int(x) for x in got] == [_lib.ABI_VERSION] + sizes, 'the ctypes mirrors and include/dcomp*.h disagree about a struct size'
 
 
+def test_named_ue_arrival_schedules_are_the_references():
+    """env_setup.py:205-226: the five `--ue-arrival` schedules as data, against what the reference's own get_ue_arrival returned
+    (tests/golden/ue_arrival_schedules.json, recorded by gen_golden.py) -- and against the one a reference-run trajectory used."""
+    import json
+    from deepcomp_amd import scenarios as S
+    from deepcomp_amd import rng as _rng
+    want = json.load(open(os.path.join(REPO, 'tests', 'golden', 'ue_arrival_schedules.json')))
+    assert sorted(S.UE_ARRIVAL) == sorted(want) and len(want) == 5
+    for name, pairs in want.items():
+        got = S.get_ue_arrival(name)
+        assert list(got.items()) == [tuple(p) for p in pairs], name                 # same steps, same counts, same order
+        assert got is not S.UE_ARRIVAL[name]
+    assert S.get_ue_arrival(None) is None
+    with pytest.raises(AssertionError):
+        S.get_ue_arrival('sometimes')
+    g = np.load(os.path.join(REPO, 'tests', 'golden', 'dyn_medium_central_largeupdown_s42.npz'))
+    assert dict(zip(g['cfg_arrival_t'].tolist(), g['cfg_arrival_n'].tolist())) == S.UE_ARRIVAL['largeupdown']
+    # "large increase up to 12 (starting at 1)": the capacity the env derives (base.py:79-84) from the schedule
+    assert _rng.max_num_ue(1, 100, S.get_ue_arrival('largeupdown'), None) == int(g['cfg_max_ues']) == 12
+
+
 def test_scenario_tables_match_reference_geometry():
     """Numbers of env_setup.py:52-176 (also recorded in the golden fixtures by the reference run)."""
     from deepcomp_amd import scenarios as S

@@ -999,6 +999,53 @@ def test_checkpoint_resume_continues_a_heuristic_driven_run(torch_cuda):
     a.check(); b.check()
 
 
+def test_checkpoint_after_compact_stepping_restores_the_policys_own_decision(torch_cuda):
+    """step_compact / step_into / rollout(out=...) never update self.obs, so a decision re-derived from the saved output
+    buffer is stale.  state_dict() now carries next_action itself: a run that steps into compact records, checkpoints and resumes in
+    another env continues bit-identically; checkpoints of another format say so instead of 'differently configured'."""
+    torch = torch_cuda
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    scn = scenarios.grid_map(6, 'mixed').with_ues(num_slow=10, num_fast=2)
+    m, bs, ues = build_from_scenario(scn)
+
+    def make():
+        e = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=48, seed=21, rng='philox', rand_episodes=True, episode_length=50)
+        assert e.set_policy('3gpp')
+        return e
+    a = make()
+    a.reset()
+    rec = torch.empty((48, a.compact_words), dtype=torch.int32, device='cuda')
+    rew = torch.empty_like(a.reward)
+    for _ in range(6):
+        a.step_compact(a.next_action, rec, rew)          # self.obs still holds the reset observation
+    stale = a.heuristic_actions('3gpp', obs=a.obs)
+    assert not torch.equal(stale, a.next_action)         # what re-deriving from the saved output buffer would have restored
+    sd = a.state_dict()
+    assert sd['next_action'] is not None and torch.equal(sd['next_action'].cuda(), a.next_action)
+    b = make()
+    b.reset()
+    b.step(b.next_action)
+    b.load_state_dict(sd)
+    assert torch.equal(a.next_action, b.next_action)
+    ra, rb = torch.empty_like(rec), torch.empty_like(rec)
+    for _ in range(8):
+        a.step_compact(a.next_action, ra, rew); b.step_compact(b.next_action, rb, rew)
+        assert torch.equal(ra, rb)
+    assert torch.equal(a.pos, b.pos) and torch.equal(a.conn, b.conn) and torch.equal(a.ewma, b.ewma)
+    a.check(); b.check()
+    # formats: v2 (round 3: no 'velocity' key) is read; anything else is refused by NAME, not as "differently configured"
+    old = dict(sd, config={k: v for k, v in sd['config'].items() if k != 'velocity'})
+    old['config']['state_layout'] = 2
+    old['next_action'] = None
+    make().load_state_dict(old)
+    with pytest.raises(ValueError, match='checkpoint format v1 is not supported'):
+        make().load_state_dict(dict(sd, config=dict(sd['config'], state_layout=1)))
+    with pytest.raises(ValueError, match='differs in: E'):
+        BatchedMobileEnv(m, bs, ues, 'multi', num_envs=47, seed=21, rng='philox', rand_episodes=True, episode_length=50).load_state_dict(sd)
+
+
 def test_seed_on_a_live_env(torch_cuda):
     """MobileEnv.seed (base.py:132-143) on an existing env, counter-based and tape draws: after seed(s); reset() the env is
     indistinguishable from one constructed with seed s (round 1 raised NotImplementedError for Philox envs)."""

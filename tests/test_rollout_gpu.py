@@ -424,3 +424,36 @@ def test_rollout_is_fused_depends_on_the_number_of_steps(torch_cuda):
     assert not _make('multi', 128, 32, 64).rollout_is_fused(100)
     # an every-step fragment of >= 2^31 rows falls back to one launch per step instead of failing (64-bit offsets on the host)
     assert not big.rollout_is_fused(4096, every_step=True) and big.rollout_is_fused(4096, every_step=False)
+
+
+@pytest.mark.parametrize('kind,U,B,E', [('multi', 32, 10, 64), ('central', 10, 5, 256)])
+def test_fragments_beyond_the_fused_kernels_row_limit_fall_back_to_one_launch_per_step(torch_cuda, kind, U, B, E, monkeypatch):
+    """an every-step fragment of >= 2^31 rows (num_steps x num_envs x num_ue) leaves the fused rollout kernel (32-bit row
+    indices) for one launch per step with 64-bit offsets on the host -- a branch no test reached (it would take a 2^31-row
+    fragment).  DCOMP_FUSED_ROW_LIMIT_LOG2 lowers the limit: the same rollout, fragment and final state, bit for bit; the
+    closed loop, which has no other path, is refused."""
+    torch = torch_cuda
+    T = 16
+    g = torch.Generator(device='cuda').manual_seed(3)
+    acts = torch.randint(0, B + 1, (T, E, U), generator=g, device='cuda', dtype=torch.uint8)
+    fused = _make(kind, U, B, E)
+    assert fused.rollout_is_fused(T, every_step=True)
+    fused.reset()
+    keys = ('obs', 'reward', 'sum_utility', 'ue_dr', 'ue_utility')
+    want = {k: torch.empty((T,) + tuple(getattr(fused, k).shape), device='cuda') for k in keys}
+    fused.rollout(acts, out=want)
+    fused.check()
+    monkeypatch.setenv('DCOMP_FUSED_ROW_LIMIT_LOG2', '12')                 # T * E * U = 32 768 resp. 40 960 rows >= 2^12
+    env = _make(kind, U, B, E)
+    assert not env.rollout_is_fused(T, every_step=True) and env.rollout_is_fused(T, every_step=False)
+    env.reset()
+    got = {k: torch.full_like(v, float('nan')) for k, v in want.items()}
+    env.rollout(acts, out=got)
+    env.check()
+    for k in keys:
+        assert torch.equal(got[k], want[k]), k
+    assert _same_state(_state(env), _state(fused)) and env.time == T
+    assert env.set_policy('fullcomp')
+    env.reset()
+    with pytest.raises(ValueError, match='policy_loop fragment too long'):
+        env.rollout_policy(T, out={k: torch.empty_like(v) for k, v in want.items()})
