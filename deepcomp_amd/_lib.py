@@ -7,13 +7,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DCOMP_LIB') or os.path.join(_HERE, 'csrc', 'libdcomp_hip.so')   # DCOMP_LIB: tools/ablate.py timing variants
 
 OK, EINVAL, EHIP, EACTION, ETAPE, EPOS, EUNSUPPORTED, EABI = 0, -1, -2, -3, -4, -5, -6, -7
-ABI_VERSION = 2                 # include/dcomp.h DCOMP_ABI_VERSION: what the struct declarations below describe
+ABI_VERSION = 3                 # include/dcomp.h DCOMP_ABI_VERSION: what the struct declarations below describe
 CENTRAL, MULTI = 0, 1
 REWARD = {'avg': 0, 'sum': 1, 'min': 2}
 SHARING = {'resource-fair': 0, 'rate-fair': 1, 'max-cap': 2, 'proportional-fair': 3}
 UTILITY = {'log': 0, 'step': 1}
 RNG_TAPE, RNG_PHILOX = 0, 1
-MAX_BS, MAX_UE = 32, 256
+MAX_BS, MAX_UE = 64, 256
+MASK32_MAX_BS = 32              # up to here: one 32-bit connection mask per UE and the specialised kernels; beyond: state.conn_hi + the generic kernel
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int32)
@@ -34,7 +35,7 @@ class DcompCfg(ctypes.Structure):
 class DcompState(ctypes.Structure):
     _fields_ = [('pos', ctypes.c_void_p), ('mv', ctypes.c_void_p), ('conn', ctypes.c_void_p),
                 ('ewma', ctypes.c_void_p), ('flags', ctypes.c_void_p), ('conn_since', ctypes.c_void_p),
-                ('uid', ctypes.c_void_p), ('orig_consumed', ctypes.c_void_p)]
+                ('uid', ctypes.c_void_p), ('orig_consumed', ctypes.c_void_p), ('conn_hi', ctypes.c_void_p)]
 
 
 class DcompOut(ctypes.Structure):

@@ -34,7 +34,8 @@ def b_list():
 
 
 def _sources():
-    return [os.path.join(CSRC, f) for f in ('dcomp_device.h', 'dcomp_wide.h', 'dcomp_dyn.h', 'dcomp_blist.h', 'dcomp_inst.hip', 'dcomp_api.hip', 'dcomp_fragment.h')] + \
+    return [os.path.join(CSRC, f) for f in ('dcomp_device.h', 'dcomp_wide.h', 'dcomp_dyn.h', 'dcomp_blist.h', 'dcomp_inst.hip', 'dcomp_api.hip', 'dcomp_fragment.h',
+                                            'dcomp_big.h', 'dcomp_big.hip')] + \
         [os.path.join(os.path.dirname(HERE), 'include', f) for f in ('dcomp.h', 'dcomp_types.h')]
 
 
@@ -110,6 +111,8 @@ def build(force=False, jobs=None, extra_flags=()):
                                                                    '-o', o]))
     o_api = os.path.join(OBJ, 'dcomp_api.o')
     tasks.append((o_api, [hipcc] + CXXFLAGS + list(extra_flags) + ['-c', os.path.join(CSRC, 'dcomp_api.hip'), '-o', o_api]))
+    o_big = os.path.join(OBJ, 'dcomp_big.o')        # the generic kernel for 33 ... 64 stations: one object for every station count
+    tasks.append((o_big, [hipcc] + CXXFLAGS + list(extra_flags) + ['-c', os.path.join(CSRC, 'dcomp_big.hip'), '-o', o_big]))
 
     def obj_stamp(t):
         """An object is rebuilt when its command line or one of ITS inputs changed: the per-station-count objects do not
@@ -118,6 +121,8 @@ def build(force=False, jobs=None, extra_flags=()):
         h = hashlib.sha256(' '.join(t[1]).encode())
         for f in _sources():
             if f.endswith(('dcomp_api.hip', 'dcomp_fragment.h', os.sep + 'dcomp.h')) and not t[0].endswith('dcomp_api.o'):
+                continue
+            if f.endswith(('dcomp_big.h', 'dcomp_big.hip')) and not t[0].endswith(('dcomp_api.o', 'dcomp_big.o')):
                 continue
             h.update(os.path.basename(f).encode())
             h.update(open(f, 'rb').read())

@@ -15,6 +15,7 @@
 #include "dcomp_blist.h"
 #include "dcomp_device.h"
 #include "dcomp_fragment.h"
+#include "dcomp_big.h"
 
 namespace dcomp {
 #define DCOMP_DECL(n) KernelPair kernels_b##n(int upad, int mp);
@@ -68,6 +69,13 @@ struct dcomp_env {
     uint32_t n_removed, n_arrived;   // this episode (Philox draw words)
     int time;
     int64_t episode;            // index of the current episode (-1 before the first reset)
+    // 33 ... 64 stations (or DCOMP_FORCE_BIG=1): the generic kernel of dcomp_big.h instead of `kern`
+    bool big = false;
+    dcomp::BigKernels bigk{nullptr, nullptr, 0};
+    dcomp::BigParams bigp{};
+    double2 *d_bs = nullptr;
+    int32_t *d_mode = nullptr;
+    size_t big_lds = 0;
 };
 
 // ---- channel constants from the reference's own formula (station.py:26-30,110-127), FP64 on the host ----
@@ -166,10 +174,19 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
         static const int cyc[3] = {DCOMP_RES_FAIR, DCOMP_RATE_FAIR, DCOMP_PROP_FAIR};   // env_setup.py:40-49
         for (int b = 0; b < B; b++) if (cfg->bs_sharing[b] != cyc[b % 3]) mp = dcomp::MP_GENERIC;
     }
-    env->kern = dcomp::lookup_kernels(B, env->upad, mp);
+    // More than 32 stations: the generic kernel (dcomp_big.h; one instantiation per lane width, B a run-time value, connection set in two
+    // state words).  DCOMP_FORCE_BIG=1 sends smaller station counts there too (tests: generic against specialised kernels).
+    env->big = B > DCOMP_MASK32_MAX_BS || (getenv("DCOMP_FORCE_BIG") && atoi(getenv("DCOMP_FORCE_BIG")) != 0);
     env->mp_pattern = mp;
-    if (!env->kern.step) { delete env; return fail(DCOMP_EUNSUPPORTED, "no kernel built for num_bs=%d (built: " DCOMP_B_LIST_STR ")", B); }
-    {
+    if (env->big) {
+        if (DYN) { delete env; return fail(DCOMP_EUNSUPPORTED, "UE arrival / departure (max_ues) is not available with more than %d stations (generic kernel)", DCOMP_MASK32_MAX_BS); }
+        env->bigk = dcomp::big_kernels_for_upad(env->upad);
+        if (!env->bigk.step) { delete env; return fail(DCOMP_EUNSUPPORTED, "no generic kernel for %d lanes per env", env->upad); }
+        env->kern = dcomp::KernelPair{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        env->grid = (E + env->bigk.gpb - 1) / env->bigk.gpb;
+    } else {
+        env->kern = dcomp::lookup_kernels(B, env->upad, mp);
+        if (!env->kern.step) { delete env; return fail(DCOMP_EUNSUPPORTED, "no kernel built for num_bs=%d (built: " DCOMP_B_LIST_STR ")", B); }
         // the wide kernel (UPAD >= 64) always uses 256-thread workgroups; the others DCOMP_BLOCK
         const int gpb = DCOMP_BLOCK >= env->upad ? DCOMP_BLOCK / env->upad : 1;
         env->grid = (E + gpb - 1) / gpb;
@@ -212,11 +229,10 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
     }
     kp.any_maxcap = 0;
     for (int b = 0; b < B; b++) {
-        kp.bs_x[b] = cfg->bs_x[b]; kp.bs_y[b] = cfg->bs_y[b];
         int m = cfg->bs_sharing[b];
         if (m < 0 || m > 3) { delete env; return fail(DCOMP_EINVAL, "bs_sharing[%d]=%d not supported", b, m); }   // station.py:22
-        kp.bs_mode[b] = m;
-        if (m == DCOMP_MAX_CAP) { kp.any_maxcap = 1; kp.maxcap_mask |= 1u << b; }
+        if (b < DCOMP_MASK32_MAX_BS) { kp.bs_x[b] = cfg->bs_x[b]; kp.bs_y[b] = cfg->bs_y[b]; kp.bs_mode[b] = m; }
+        if (m == DCOMP_MAX_CAP) { kp.any_maxcap = 1; if (b < 32) kp.maxcap_mask |= 1u << b; env->bigp.maxcap_mask |= 1ull << b; }
         if (m == DCOMP_RATE_FAIR || m == DCOMP_PROP_FAIR) kp.any_sum_mode = 1;
     }
     std::vector<UeCfg> uc(U);
@@ -242,6 +258,20 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
     if (e == hipSuccess) e = hipMemcpy(env->d_ue_cfg, uc.data(), sizeof(UeCfg) * U, hipMemcpyHostToDevice);
     if (e != hipSuccess) { delete env; return fail(DCOMP_EHIP, "device setup failed: %s", hipGetErrorString(e)); }
     kp.ue_cfg = env->d_ue_cfg;
+    if (env->big) {
+        std::vector<double> xy(2 * (size_t)B);
+        std::vector<int32_t> md(B);
+        for (int b = 0; b < B; b++) { xy[2 * b] = cfg->bs_x[b]; xy[2 * b + 1] = cfg->bs_y[b]; md[b] = cfg->bs_sharing[b]; }
+        e = hipMalloc((void **)&env->d_bs, sizeof(double) * 2 * B);
+        if (e == hipSuccess) e = hipMalloc((void **)&env->d_mode, sizeof(int32_t) * B);
+        if (e == hipSuccess) e = hipMemcpy(env->d_bs, xy.data(), sizeof(double) * 2 * B, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(env->d_mode, md.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice);
+        env->big_lds = dcomp::big_lds_bytes(B, env->bigk.gpb);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(env->bigk.step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->big_lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(env->bigk.reset), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->big_lds);
+        if (e != hipSuccess) { dcomp_destroy(env); return fail(DCOMP_EHIP, "device setup failed (generic kernel, %zu bytes of LDS per workgroup): %s", env->big_lds, hipGetErrorString(e)); }
+        env->bigp.bs = env->d_bs; env->bigp.mode = env->d_mode; env->bigp.B = B;
+    }
     if (cfg->ue_velocity) {
         // movement.py:116-117 / 142-156 with a velocity that is no integer in 0..255: the device takes {v, qmax(v)} from a table,
         // qmax(v) = largest double q with sqrt_rn(q) <= v -- `distance <= velocity` without a square root, as for the integers
@@ -265,7 +295,7 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
             kp.ue_velq = env->d_ue_velq;
         }
     }
-    if (env->kern.step_wide && !kp.any_maxcap && !getenv("DCOMP_NO_WIDE")) {
+    if (!env->big && env->kern.step_wide && !kp.any_maxcap && !getenv("DCOMP_NO_WIDE")) {
         env->kern.step = env->kern.step_wide;
         // persistent launch: as many workgroups as are resident at once (LDS-bound: 4 per CU at B = 32), never more than there are slots
         int per_cu = 0, cus = 0;
@@ -296,7 +326,7 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
                                                                      // (a fourth wave per SIMD would wait for a second round)
         if (const char *e = getenv("DCOMP_FUSE_MAX_WAVES")) max_waves = atol(e);
         const long waves = (long)env->grid * (DCOMP_BLOCK / 64);
-        env->fused = !DYN && env->kern.step != env->kern.step_wide && env->kern.rollout != nullptr && waves <= max_waves;
+        env->fused = !DYN && !env->big && env->kern.step != env->kern.step_wide && env->kern.rollout != nullptr && waves <= max_waves;
         // Central envs with short rows (2B + 1 <= 17 floats per UE) are faster through the fused kernel at EVERY batch size once a
         // rollout is a few steps long: no kernel boundary (5.4 us per launch, a quarter of a 65 536 x 10 x 5 step), no state round
         // trip, pairs carried from step to step -- 65 536 x 10 x 5: 16.3 vs 19-20 us per step, 16 384: 4.2 vs 11.2, 262 144: 58 vs
@@ -304,7 +334,7 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
         // badly for that: 65 536 x 32 x 10: 129 vs 77 us.
         // Multi-agent rows (4B + 1 floats per lane) are short enough up to three stations -- the reference's stock small and medium
         // maps: 65 536 x 5 x 3 multi 8.1 vs 12.1 us per step (T = 50); at 10 x 5 it is a draw (23.4 vs 23.3), at 16 x 8 a loss (51.8 vs 38.2).
-        env->fused_long = !DYN && env->kern.step != env->kern.step_wide && env->kern.rollout != nullptr &&
+        env->fused_long = !DYN && !env->big && env->kern.step != env->kern.step_wide && env->kern.rollout != nullptr &&
                           ((cfg->env_kind == DCOMP_CENTRAL && B <= 8) || (cfg->env_kind == DCOMP_MULTI && B <= 3)) && !getenv("DCOMP_NO_FUSED_LONG");
         // Tight packing of UE lists whose length is not a power of two (dcomp_device.h, struct Seg): G = U lanes per env,
         // 64 / G envs per wavefront, segmented ds_bpermute reductions (~13 instead of 4 instructions each).  It pays where the
@@ -339,6 +369,8 @@ extern "C" int dcomp_destroy(dcomp_env *env)
     if (!env) return DCOMP_OK;
     if (env->d_ue_cfg) (void)hipFree(env->d_ue_cfg);
     if (env->d_ue_velq) (void)hipFree(env->d_ue_velq);
+    if (env->d_bs) (void)hipFree(env->d_bs);
+    if (env->d_mode) (void)hipFree(env->d_mode);
     delete env;
     return DCOMP_OK;
 }
@@ -369,6 +401,10 @@ extern "C" int dcomp_obs_dim(const dcomp_env *env, int32_t *floats_per_env, int3
 // One launch of the step kernel (plain step; also the per-step launches of a rollout that is not fused).
 static void launch_step(dcomp_env *env, KParams &kp, void *stream)
 {
+    if (env->big) {
+        hipLaunchKernelGGL(env->bigk.step, dim3(env->grid), dim3(256), env->big_lds, (hipStream_t)stream, kp, env->bigp);
+        return;
+    }
     if (env->tight_g) {
         kp.tight_g = env->tight_g; kp.tight_gpw = env->tight_gpw; kp.tight_magic = env->tight_magic;
         const dcomp::KernelFn k = (env->cfg.env_kind == DCOMP_CENTRAL && env->kern.tight_central) ? env->kern.tight_central : env->kern.step_tight;
@@ -399,6 +435,12 @@ static int fill_params(dcomp_env *env, const dcomp_state *st, const dcomp_out *o
         if (env->cfg.env_kind != DCOMP_MULTI) return fail(DCOMP_EINVAL, "out->obs_compact: the compact record is defined for multi-agent observations (central observations carry no per-env columns)");
     }
     if (env->kp.any_maxcap && !st->conn_since) return fail(DCOMP_EINVAL, "a max-cap BS needs state.conn_since (see dcomp_state_sizes)");
+    if (env->big) {
+        if (!st->conn_hi) return fail(DCOMP_EINVAL, "more than %d stations: state.conn_hi (stations 32-63 of the connection set, sized like conn) is required", DCOMP_MASK32_MAX_BS);
+        if (out->obs_compact) return fail(DCOMP_EUNSUPPORTED, "out->obs_compact: the compact record holds one 32-bit connection mask per UE (num_bs <= %d)", DCOMP_MASK32_MAX_BS);
+        if (env->kp.next_act) return fail(DCOMP_EUNSUPPORTED, "dcomp_set_policy is not available on the generic kernel (num_bs > %d)", DCOMP_MASK32_MAX_BS);
+        env->bigp.conn_hi = st->conn_hi;
+    }
     if (env->dyn && !st->uid) return fail(DCOMP_EINVAL, "UE arrival/departure needs state.uid");
     kp = env->kp;
     kp.uid = st->uid;
@@ -432,7 +474,8 @@ extern "C" int dcomp_reset(dcomp_env *env, const dcomp_state *st, const dcomp_ta
     env->cur_ue = env->cfg.num_ue; env->n_removed = env->n_arrived = 0;      // base.py:177-182
     kp.cur_ue = env->cur_ue;
     kp.episode = (uint32_t)env->episode;
-    hipLaunchKernelGGL(env->kern.reset, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
+    if (env->big) hipLaunchKernelGGL(env->bigk.reset, dim3(env->grid), dim3(256), env->big_lds, (hipStream_t)stream, kp, env->bigp);
+    else hipLaunchKernelGGL(env->kern.reset, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
     HIP_TRY(hipGetLastError());
     return DCOMP_OK;
 }
@@ -534,7 +577,8 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
         k.cur_ue = env->cur_ue;
         k.episode = (uint32_t)env->episode;
         k.time = 0u;
-        hipLaunchKernelGGL(env->kern.reset, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, k);
+        if (env->big) hipLaunchKernelGGL(env->bigk.reset, dim3(env->grid), dim3(256), env->big_lds, (hipStream_t)stream, k, env->bigp);
+        else hipLaunchKernelGGL(env->kern.reset, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, k);
     };
     if (env->dyn) {
         // The whole arrival / departure schedule of the T steps is validated BEFORE the first launch (it used to be checked step by
@@ -662,7 +706,8 @@ extern "C" int dcomp_step_kernel_name(const dcomp_env *env, char *buf, int32_t l
 {
     if (!env || !buf || len < 1) return fail(DCOMP_EINVAL, "null argument");
     const int B = env->cfg.num_bs, W = env->upad, MP = env->mp_pattern;
-    if (env->tight_g) {
+    if (env->big) std::snprintf(buf, (size_t)len, "big_kernel<%d, false>", W < 4 ? 4 : W);
+    else if (env->tight_g) {
         const bool cen = env->cfg.env_kind == DCOMP_CENTRAL && env->kern.tight_central;
         std::snprintf(buf, (size_t)len, "step_kernel_tight<%d, %d, %d, %d>", B, W, MP, cen ? 0 : -1);
     } else if (env->dyn) std::snprintf(buf, (size_t)len, "step_kernel_dyn<%d, %d, %d>", B, W, MP);
@@ -943,6 +988,7 @@ extern "C" int dcomp_set_policy(dcomp_env *env, const dcomp_policy *p, uint8_t *
 {
     if (!env) return fail(DCOMP_EINVAL, "null argument");
     if (!p || !next_action) { env->kp.next_act = nullptr; return DCOMP_OK; }
+    if (env->big) return fail(DCOMP_EUNSUPPORTED, "the in-step policy is not available on the generic kernel (num_bs > %d); use dcomp_heuristic_actions on the observation tensor", DCOMP_MASK32_MAX_BS);
     if (p->policy < DCOMP_POLICY_3GPP || p->policy > DCOMP_POLICY_CLUSTER) return fail(DCOMP_EINVAL, "unknown policy %d", p->policy);
     if ((p->num_envs && p->num_envs != env->cfg.num_envs) || (p->num_ue && p->num_ue != env->kp.U) || (p->num_bs && p->num_bs != env->cfg.num_bs))
         return fail(DCOMP_EINVAL, "policy shape (%d, %d, %d) is not the env's (%d, %d, %d)", p->num_envs, p->num_ue, p->num_bs,
@@ -1036,14 +1082,14 @@ extern "C" int dcomp_selftest(int op, int width, const double *x, const double *
 // ---- compact rollout fragments for the learner hand-off (dcomp_fragment.h) ----
 extern "C" int dcomp_fragment_words(int32_t num_ue, int32_t num_bs)
 {
-    if (num_ue < 1 || num_ue > DCOMP_MAX_UE || num_bs < 1 || num_bs > DCOMP_MAX_BS) return -1;
+    if (num_ue < 1 || num_ue > DCOMP_MAX_UE || num_bs < 1 || num_bs > DCOMP_MASK32_MAX_BS) return -1;    // one 32-bit connection mask per UE
     return dcomp_frag::env_words(num_ue, num_bs);
 }
 
 static int fragment_params(dcomp_frag::FragParams &p, int64_t n, int U, int B, int &grid, size_t &lds_pack, size_t &lds_unpack)
 {
-    if (n < 1 || U < 1 || U > DCOMP_MAX_UE || B < 1 || B > DCOMP_MAX_BS)
-        return fail(DCOMP_EINVAL, "fragment: need num_env_steps >= 1, 1 <= num_ue <= %d, 1 <= num_bs <= %d", DCOMP_MAX_UE, DCOMP_MAX_BS);
+    if (n < 1 || U < 1 || U > DCOMP_MAX_UE || B < 1 || B > DCOMP_MASK32_MAX_BS)
+        return fail(DCOMP_EINVAL, "fragment: need num_env_steps >= 1, 1 <= num_ue <= %d, 1 <= num_bs <= %d", DCOMP_MAX_UE, DCOMP_MASK32_MAX_BS);
     if (dcomp_frag::fill(p, n, U, B, grid, lds_pack, lds_unpack)) return fail(DCOMP_EINVAL, "fragment too long for one launch: split it (num_env_steps * chunks >= 2^31)");
     return DCOMP_OK;
 }

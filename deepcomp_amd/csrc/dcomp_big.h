@@ -1,0 +1,351 @@
+// dcomp_big.h -- the env step for 33 ... 64 base stations (round 5; the reference has no limit: station.py:16-30, base.py:79-84).
+//
+// The kernels of dcomp_device.h / dcomp_wide.h unroll the station loop (one object file per B = 1 ... 32, per-station register arrays,
+// a 32-bit connection mask): the right shape for the BASELINE configurations, not for arbitrary B.  This file is the GENERIC path:
+// ONE instantiation per lane-group width serves every B up to 64 -- B is a run-time value, the per-station values of a UE live in
+// its row of LDS (stride B + 1), the connection set is two 32-bit state words per UE (`conn` = stations 0-31 as before, `conn_hi` =
+// stations 32-63: dcomp_state.conn_hi), the BS table is a device array staged in LDS per workgroup.  Same semantics, same
+// numerics (FP64 positions / decisions in the reference's operation order, FP32 log2-domain rates via the same device functions),
+// same outputs as the narrow kernels -- tests/test_bigb_gpu.py holds it to the oracle at B = 33 ... 64 and to the narrow kernels
+// at B <= 32 (DCOMP_FORCE_BIG=1).  It is NOT tuned: ~3 workgroup barriers and three owner-thread reduction passes per step.
+//
+// Mapping: one lane = one (env, UE); an env takes UPAD = next pow2 >= U lanes; a 256-lane workgroup 256 / UPAD envs.
+// Per-station sums over an env's UEs (station.py:152-202, 63-83): thread t of the workgroup OWNS the (env, station) pairs
+// t, t + 256, ... and adds up the rows of that env in UE order -- deterministic, no atomics, conflict-free (consecutive threads own
+// consecutive stations).  Not supported here (dcomp_create_v says so): UE arrival / departure, the fused rollout (dcomp_rollout_ex
+// launches one step per launch), the in-step policy, the compact record.
+#pragma once
+#include "dcomp_device.h"
+
+namespace dcomp {
+
+struct BigParams {
+    uint32_t *conn_hi;                 // [E*U] stations 32 ... 63 of the connection set
+    const double2 *bs;                 // [B] station positions
+    const int32_t *mode;               // [B] DCOMP_*_FAIR / MAX_CAP
+    int32_t B;
+    unsigned long long maxcap_mask;    // bit b: station b is max-cap
+};
+
+// LDS bytes one workgroup needs (host and device use the same carve)
+__host__ __device__ inline size_t big_lds_bytes(int B, int gpb)
+{
+    return 64 * sizeof(double2) + 256 * sizeof(double2) + 256 * sizeof(unsigned long long) + (size_t)256 * (B + 1) * 4 + 4 * 256 * 4 +
+           (size_t)5 * gpb * B * 4 + 64 * 4;
+}
+
+__device__ __forceinline__ void big_pair(double px, double py, const double2 bp, const KParams &p, bool &in_range, float &l2)
+{
+    bool near;
+    pair_eval(px, py, bp.x, bp.y, p, in_range, l2, near);
+    if (near) {                                                    // rare, per lane: within 1.26 m of the station
+        const double dx = bp.x - px, dy = bp.y - py;
+        if ((float)__builtin_fma(dy, dy, dx * dx) < 1e-20f) l2 = pair_eval_tiny(px, py, bp.x, bp.y, p);
+    }
+}
+__device__ __forceinline__ float big_rate(float l2)                // bw * log2(1 + snr), station.py:129-138
+{
+    bool big;
+    float r = rate_unshared_small(l2, big);
+    if (big) r = rate_unshared_any(l2);
+    return r;
+}
+
+template <int UPAD, bool RESET>
+__global__ __launch_bounds__(256) void big_kernel(const KParams p, const BigParams x)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+    constexpr int GPB = 256 / UPAD;
+    const int B = x.B, BR = B + 1, U = p.U;
+    double2 *const bs_s = reinterpret_cast<double2 *>(big_smem);
+    double2 *const pos_s = bs_s + 64;
+    unsigned long long *const mask_s = reinterpret_cast<unsigned long long *>(pos_s + 256);
+    float *const row = reinterpret_cast<float *>(mask_s + 256);
+    float *const ewma_s = row + 256 * BR, *const util_s = ewma_s + 256, *const rb_s = util_s + 256, *const l2max_s = rb_s + 256;
+    float *const agg_n = l2max_s + 256, *const agg_s = agg_n + GPB * B, *const agg_u = agg_s + GPB * B, *const agg_m = agg_u + GPB * B;
+    uint32_t *const mc_win = reinterpret_cast<uint32_t *>(agg_m + GPB * B);
+    int *const mode_s = reinterpret_cast<int *>(mc_win + GPB * B);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int env_local = tid / UPAD, u = tid % UPAD;
+    const int env0 = blockIdx.x * GPB, env = env0 + env_local;
+    const bool active = env < p.E && u < U;
+    const bool alive = active && (!RESET || u < p.U0);
+    const int idx = env * U + u;
+    float *const myrow = row + tid * BR;
+    for (int i = tid; i < B; i += 256) { bs_s[i] = x.bs[i]; mode_s[i] = x.mode[i]; }
+
+    double px = 0.0, py = 0.0;
+    unsigned long long mv = 0, conn = 0;
+    uint32_t act = 0;
+    float ewma = 0.f, dr_req = 1.f;
+    bool step_util = false;
+    int vrange = MV_CFG_ARRIVED;
+    if (alive) {
+        const UeCfg c = p.ue_cfg[u];
+        step_util = c.util == DCOMP_UTIL_STEP; dr_req = c.dr_req;
+        vrange = mv_cfg_pack(c.vel_lo, c.vel_hi, c.pause, c.border);
+    }
+    if (RESET) {                                                   // MobileEnv.reset (base.py:169-189): user.py:98-116 + movement.py:110-122
+        if (alive) reset_ue(p, env, u, p.episode, px, py, mv);
+        if (active) {
+            p.pos[idx] = make_double2(px, py);
+            p.mv[idx] = mv;
+            p.conn[idx] = 0u;
+            x.conn_hi[idx] = 0u;
+            p.ewma[idx] = 0.f;
+        }
+    } else if (active) {
+        const double2 q = p.pos[idx];
+        px = q.x; py = q.y;
+        mv = p.mv[idx];
+        conn = (unsigned long long)p.conn[idx] | ((unsigned long long)x.conn_hi[idx] << 32);
+        ewma = p.ewma[idx];
+        act = p.action[idx];
+        if (act > (uint32_t)B) { atomicOr(p.flags, DCOMP_FLAG_BAD_ACTION); act = 0; }
+    }
+    __syncthreads();                                               // the BS table
+
+    // (env, station) sums over the UEs of an env.  WHAT: 0 = sharing terms from the l2snr values parked in the rows (count, sum of
+    // 1 / rate resp. rate / (ewma + eps), the max-cap winner), 1 = utility sums (count, sum, min over the connected UEs).
+    auto aggregate = [&](int what) {
+        const int P = GPB * B;
+        for (int q = tid; q < P; q += 256) {
+            const int el = q / B, b = q - el * B, base = el * UPAD;
+            float n = 0.f, s = 0.f, mn = MAX_UTIL;
+            uint32_t win = 0xFFFFFFFFu;
+            if (env0 + el < p.E) {
+                const int mode = mode_s[b];
+                for (int v = 0; v < U; v++) {
+                    if (!((mask_s[base + v] >> b) & 1ull)) continue;
+                    n += 1.f;
+                    if (what == 1) { const float uv = util_s[base + v]; s += uv; mn = fminf(mn, uv); }
+                    else if (mode == DCOMP_RATE_FAIR) s += fast_rcp(big_rate(row[(base + v) * BR + b]));                           // station.py:177-180
+                    else if (mode == DCOMP_PROP_FAIR) s += big_rate(row[(base + v) * BR + b]) * fast_rcp(ewma_s[base + v] + EPS);   // station.py:150, 192-195
+                }
+                if (what == 0 && mode == DCOMP_MAX_CAP && n > 0.f) {
+                    // station.py:183-187: the UE with the highest FP64 rate is served; equal rates -> the oldest connection, then the lowest UE
+                    // index (dcomp_device.h shared_rates has the derivation: nearest UE, contenders within 1e-7, the collapsing FP64 key)
+                    const double2 bp = bs_s[b];
+                    double dmin = 1e300;
+                    for (int v = 0; v < U; v++) if ((mask_s[base + v] >> b) & 1ull) {
+                        const double dx = bp.x - pos_s[base + v].x, dy = bp.y - pos_s[base + v].y;
+                        dmin = fmin(dmin, __builtin_fma(dy, dy, dx * dx));
+                    }
+                    int ncand = 0, only = 0;
+                    for (int v = 0; v < U; v++) if ((mask_s[base + v] >> b) & 1ull) {
+                        const double dx = bp.x - pos_s[base + v].x, dy = bp.y - pos_s[base + v].y;
+                        if (__builtin_fma(dy, dy, dx * dx) <= dmin * (1.0 + 1e-7)) { ncand++; only = v; }
+                    }
+                    if (ncand == 1) win = (uint32_t)only;
+                    else {
+                        unsigned long long best = 0ull;
+                        uint32_t bestw = 0xFFFFFFFFu;
+                        for (int v = 0; v < U; v++) if ((mask_s[base + v] >> b) & 1ull) {
+                            const double dx = bp.x - pos_s[base + v].x, dy = bp.y - pos_s[base + v].y;
+                            if (__builtin_fma(dy, dy, dx * dx) > dmin * (1.0 + 1e-7)) continue;
+                            const unsigned long long key = maxcap_rate_key(p.pl_c1, p.pl_c2, pos_s[base + v].x, pos_s[base + v].y, bp.x, bp.y);
+                            const uint32_t w = ((uint32_t)p.conn_since[((size_t)(env0 + el) * U + v) * B + b] << 8) | (uint32_t)v;
+                            if (key > best || (key == best && w < bestw)) { best = key; bestw = w; }
+                        }
+                        win = bestw & 0xFFu;
+                    }
+                }
+            }
+            if (what == 1) { agg_n[q] = n; agg_u[q] = s; agg_m[q] = mn; }
+            else { agg_n[q] = n; agg_s[q] = s; mc_win[q] = win; }
+        }
+    };
+    // this UE's share of every station it is connected to (station.py:152-202); keep = park it in the row (the stale rates of user.py:148-157)
+    auto shared = [&](bool keep) -> float {
+        const float inv_ewma = fast_rcp(ewma + EPS);
+        float curr = 0.f;
+        for (unsigned long long m = conn; m; m &= m - 1ull) {
+            const int b = __ffsll((long long)m) - 1, q = env_local * B + b, mode = mode_s[b];
+            const float dru = big_rate(myrow[b]);
+            float out;
+            if (mode == DCOMP_RES_FAIR) out = dru * fast_rcp(fmaxf(agg_n[q], 1.f));                         // station.py:171-173
+            else if (mode == DCOMP_RATE_FAIR) out = fast_rcp(agg_s[q]);                                     // station.py:180
+            else if (mode == DCOMP_PROP_FAIR) out = (dru * inv_ewma) * fast_rcp(agg_s[q] + EPS) * dru;      // station.py:194-195
+            else out = mc_win[q] == (uint32_t)u ? dru : 0.f;                                                // station.py:183-187
+            curr += out;
+            if (keep) myrow[b] = out;
+        }
+        return curr;
+    };
+
+    float reward_before = 0.f;
+    if (!RESET) {
+        // 1. the pre-move position matters where the UE is connected and at the station it acts on (base.py:247-263 -> user.py:190-222)
+        const unsigned long long act_bit = act ? 1ull << (act - 1u) : 0ull;
+        unsigned long long inr_old = 0ull;
+        for (unsigned long long need = active ? (conn | act_bit) : 0ull; need; need &= need - 1ull) {
+            const int b = __ffsll((long long)need) - 1;
+            bool ir;
+            float l;
+            big_pair(px, py, bs_s[b], p, ir, l);
+            inr_old |= (unsigned long long)ir << b;
+            myrow[b] = l;
+        }
+        if (act_bit) {
+            if (conn & act_bit) conn &= ~act_bit;
+            else if (inr_old & act_bit) {
+                conn |= act_bit;
+                if (x.maxcap_mask & act_bit) p.conn_since[(size_t)idx * B + (act - 1u)] = (uint16_t)p.time;
+            }
+        }
+        mask_s[tid] = active ? conn : 0ull;
+        ewma_s[tid] = ewma;
+        pos_s[tid] = make_double2(px, py);
+        __threadfence_block();
+        __syncthreads();
+        // 2. rates before the move (base.py:446) -> reward_before (base.py:158-167)
+        aggregate(0);
+        __syncthreads();
+        const float curr_pre = shared(true);
+        reward_before = clamp_med3(ue_utility(curr_pre, step_util, dr_req), MIN_UTIL, MAX_UTIL) * (1.0f / MAX_UTIL);
+        // 3. move (base.py:447 -> user.py:159-173)
+        if (active) {
+            move_ue<false>(p, env, (uint32_t)u + 1u, p.episode, px, py, mv, vrange);
+            if (px < 0.0 || py < 0.0 || px > (double)p.map_w || py > (double)p.map_h) atomicOr(p.flags, DCOMP_FLAG_OUTSIDE_MAP);
+        }
+        // 4. drop what is out of range at the new position (user.py:175-188); EWMA from the STALE rates of what stays (user.py:148-157)
+        float stale = 0.f;
+        for (unsigned long long m = conn; m; m &= m - 1ull) {
+            const int b = __ffsll((long long)m) - 1;
+            const double dx = bs_s[b].x - px, dy = bs_s[b].y - py;
+            if (__builtin_fma(dy, dy, dx * dx) < p.dt2) stale += myrow[b];
+            else conn &= ~(1ull << b);
+        }
+        ewma = __builtin_fmaf(0.9f, stale, 0.1f * ewma);
+        __syncthreads();                                           // every owner thread is done with the pre-move rows / masks
+    }
+    // 5. every station at the (new) position: log2 snr into the row, the in-range mask, the row maximum
+    unsigned long long in_range = 0ull;
+    float l2max = -3.0e38f;
+    for (int b = 0; b < B; b++) {
+        bool ir;
+        float l;
+        big_pair(px, py, bs_s[b], p, ir, l);
+        in_range |= (unsigned long long)ir << b;
+        myrow[b] = l;
+        l2max = fmaxf(l2max, l);
+    }
+    mask_s[tid] = alive ? conn : 0ull;
+    ewma_s[tid] = ewma;
+    pos_s[tid] = make_double2(px, py);
+    l2max_s[tid] = l2max;
+    __syncthreads();
+    // 6. rates after the move (base.py:451)
+    float curr = 0.f;
+    if (!RESET) {
+        aggregate(0);
+        __syncthreads();
+        curr = shared(false);
+    }
+    const float util = ue_utility(curr, step_util, dr_req);
+    if (!RESET && active) {
+        p.pos[idx] = make_double2(px, py);
+        p.mv[idx] = mv;
+        p.conn[idx] = (uint32_t)conn;
+        x.conn_hi[idx] = (uint32_t)(conn >> 32);
+        p.ewma[idx] = ewma;
+    }
+    util_s[tid] = alive ? util : 0.f;
+    rb_s[tid] = alive ? reward_before : 0.f;
+    __syncthreads();
+    // 7. per-station utility aggregates (station.py:63-83), reward, info, observation
+    aggregate(1);
+    __syncthreads();
+    const int kind = p.kind, n_eff = RESET ? p.U0 : U;
+    if (kind == DCOMP_CENTRAL) {                                   // central.py:65-73: over the UEs' rewards_before
+        if (active && u == 0) {
+            const int base = env_local * UPAD;
+            float r = p.reward_agg == DCOMP_REWARD_MIN ? 1.f : 0.f, su = 0.f;
+            for (int v = 0; v < n_eff; v++) {
+                r = p.reward_agg == DCOMP_REWARD_MIN ? fminf(r, rb_s[base + v]) : r + rb_s[base + v];
+                su += util_s[base + v];
+            }
+            if (p.reward_agg == DCOMP_REWARD_AVG) r = r / (float)n_eff;
+            if (p.reward) p.reward[env] = RESET ? 0.f : r;
+            if (p.sum_util) p.sum_util[env] = su;
+        }
+    } else {
+        float reward = 0.f;
+        if (!RESET) {
+            reward = util;                                         // multi_agent.py:52 (own utility, NOT normalised)
+            if (p.reward_agg == DCOMP_REWARD_SUM) {                // multi_agent.py:73-79
+                if (in_range != 0ull) {
+                    const int base = env_local * UPAD;
+                    float s = 0.f;
+                    for (int v = 0; v < U; v++) if (mask_s[base + v] & conn) s += rb_s[base + v];
+                    reward = s;
+                }
+            } else if (p.reward_agg == DCOMP_REWARD_AVG) {         // multi_agent.py:60-71
+                float n = 0.f, t = 0.f;
+                for (unsigned long long m = in_range; m; m &= m - 1ull) { const int q = env_local * B + __ffsll((long long)m) - 1; n += agg_n[q]; t += agg_u[q]; }
+                if (n > 0.f) reward = conn == 0ull ? (t + util) / (n + 1.f) : t / n;
+            } else {                                               // multi_agent.py:81-85, station.py:78-83
+                float m_ = util;
+                for (unsigned long long m = in_range; m; m &= m - 1ull) { const int q = env_local * B + __ffsll((long long)m) - 1; m_ = fminf(m_, agg_n[q] > 0.f ? agg_m[q] : MAX_UTIL); }
+                reward = in_range != 0ull ? m_ : util;
+            }
+        }
+        if (active && p.reward) stream_store(&p.reward[idx], alive ? reward : 0.f);
+        if (active && u == 0 && p.sum_util) {
+            const int base = env_local * UPAD;
+            float su = 0.f;
+            for (int v = 0; v < n_eff; v++) su += util_s[base + v];
+            p.sum_util[env] = su;
+        }
+    }
+    if (active) {                                                  // base.py:383-411
+        if (p.ue_dr) stream_store(&p.ue_dr[idx], alive ? curr : 0.f);
+        if (p.ue_util) stream_store(&p.ue_util[idx], alive ? util : 0.f);
+        if (p.rb_out) stream_store(&p.rb_out[idx], alive ? reward_before : 0.f);
+    }
+    if (!p.obs) return;
+    const float inv_u = 1.0f / (float)n_eff;
+    if (kind == DCOMP_MULTI) {
+        // rows [E][U][4B+1] = connected | dr | ues_at_bs | util_at_bs | utility (variants.py:271-305): a wavefront per row, lanes along it
+        const int ROW = 4 * B + 1;
+        for (int r = wave; r < 256; r += 4) {
+            const int el = r / UPAD, uu = r - el * UPAD;
+            if (uu >= U || env0 + el >= p.E) continue;             // (wave-uniform)
+            const bool live = !RESET || uu < p.U0;
+            float *const dst = p.obs + ((size_t)(env0 + el) * U + uu) * ROW;
+            const unsigned long long mk = mask_s[r];
+            const float lm = l2max_s[r];
+            for (int c = lane; c < ROW; c += 64) {
+                float v = 0.f;
+                if (live) {
+                    if (c < B) v = (float)((mk >> c) & 1ull);
+                    else if (c < 2 * B) v = fast_exp2(row[r * BR + (c - B)] - lm);                                     // variants.py:276-284
+                    else if (c < 3 * B) v = agg_n[el * B + (c - 2 * B)] * inv_u;                                       // variants.py:296
+                    else if (c < 4 * B) { const int q = el * B + (c - 3 * B); v = agg_u[q] * fast_rcp(fmaxf(agg_n[q], 1.f)) * (1.0f / MAX_UTIL); }   // variants.py:299
+                    else v = util_s[r] * (1.0f / MAX_UTIL);
+                }
+                stream_store(dst + c, v);
+            }
+        }
+    } else {
+        // central.py:31-57: [E][U (2B+1)] = connected[U][B] | dr[U][B] | utility[U]; the lanes of an env walk its block
+        if (env < p.E) {
+            float *const dst = p.obs + (size_t)env * U * (2 * B + 1);
+            const int base = env_local * UPAD, UB = U * B;
+            for (int c = u; c < UB; c += UPAD) {
+                const int uu = c / B, b = c - uu * B;
+                const bool live = !RESET || uu < p.U0;
+                stream_store(dst + c, live ? (float)((mask_s[base + uu] >> b) & 1ull) : 0.f);
+                stream_store(dst + UB + c, live ? fast_exp2(row[(base + uu) * BR + b] - l2max_s[base + uu]) : 0.f);
+            }
+            for (int c = u; c < U; c += UPAD) stream_store(dst + 2 * UB + c, util_s[base + c] * (1.0f / MAX_UTIL));
+        }
+    }
+}
+
+using BigKernelFn = void (*)(const KParams, const BigParams);
+struct BigKernels { BigKernelFn step, reset; int gpb; };
+BigKernels big_kernels_for_upad(int upad);
+
+}  // namespace dcomp

@@ -1,0 +1,22 @@
+// dcomp_big.hip -- instantiates the generic kernel of dcomp_big.h (33 ... 64 stations) for every lane-group width: one object,
+// 14 kernels, whatever the station count.
+#include "dcomp_big.h"
+
+namespace dcomp {
+template <int UPAD>
+static BigKernels big_make() { return BigKernels{big_kernel<UPAD, false>, big_kernel<UPAD, true>, 256 / UPAD}; }
+
+BigKernels big_kernels_for_upad(int upad)
+{
+    switch (upad) {
+    case 1: case 2: case 4: return big_make<4>();
+    case 8: return big_make<8>();
+    case 16: return big_make<16>();
+    case 32: return big_make<32>();
+    case 64: return big_make<64>();
+    case 128: return big_make<128>();
+    case 256: return big_make<256>();
+    default: return BigKernels{nullptr, nullptr, 0};
+    }
+}
+}  // namespace dcomp

@@ -170,8 +170,8 @@ struct KParams {
     float log2k;               // log2(K) + L2_OFF
     float log2k_s;             // log2(K) + L2_OFF - 12 * half_gamma  (pair_eval scales d^2 by 2^-12)
     double dt2;                // squared connect-threshold distance
-    double bs_x[DCOMP_MAX_BS], bs_y[DCOMP_MAX_BS];
-    int32_t bs_mode[DCOMP_MAX_BS];
+    double bs_x[DCOMP_MASK32_MAX_BS], bs_y[DCOMP_MASK32_MAX_BS];   // (stations of the specialised kernels; 33 ... 64 stations: dcomp_big.h reads a device table)
+    int32_t bs_mode[DCOMP_MASK32_MAX_BS];
 };
 
 // ---------------------------------------------------------------------------------------------- cross-lane
@@ -377,9 +377,9 @@ __device__ __forceinline__ float pair_eval_tiny(double px, double py, double bx,
 }
 // All B pairs of one UE; returns the in-range mask.
 #if DCOMP_BS_IN_LDS
-__shared__ double g_bs_lds[2 * DCOMP_MAX_BS];
+__shared__ double g_bs_lds[2 * DCOMP_MASK32_MAX_BS];
 #define DCOMP_BSX(b) (*(volatile double *)&g_bs_lds[b])
-#define DCOMP_BSY(b) (*(volatile double *)&g_bs_lds[DCOMP_MAX_BS + (b)])
+#define DCOMP_BSY(b) (*(volatile double *)&g_bs_lds[DCOMP_MASK32_MAX_BS + (b)])
 #else
 #if DCOMP_BS_VOLATILE
 #define DCOMP_BSX(b) (*(const volatile double *)&p.bs_x[b])
@@ -1484,7 +1484,7 @@ __device__ __forceinline__ void step_kernel_body(const KParams &p, BlockSharedT<
 
 #if DCOMP_BS_IN_LDS
 #pragma unroll
-    for (int b = 0; b < B; b++) if (tid == b) { g_bs_lds[b] = p.bs_x[b]; g_bs_lds[DCOMP_MAX_BS + b] = p.bs_y[b]; }
+    for (int b = 0; b < B; b++) if (tid == b) { g_bs_lds[b] = p.bs_x[b]; g_bs_lds[DCOMP_MASK32_MAX_BS + b] = p.bs_y[b]; }
     __syncthreads();
 #endif
     double px = 0.0, py = 0.0;

@@ -13,6 +13,7 @@ observations living in device tensors (``pos[E*U,2] f64``, ``mv[E*U] i64``, ``co
   device tensors (zero-copy for a learner on the same GPU).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -204,6 +205,8 @@ class BatchedMobileEnv:
         self.pos = torch.zeros((n, 2), dtype=torch.float64, device=dev)
         self.mv = torch.zeros(n, dtype=torch.int64, device=dev)
         self.conn = torch.zeros(n, dtype=torch.int32, device=dev)
+        # more than 32 stations: stations 32-63 of the connection sets in a second word per UE (dcomp_state.conn_hi; generic kernel)
+        self.conn_hi = torch.zeros(n, dtype=torch.int32, device=dev) if (B > _lib.MASK32_MAX_BS or os.environ.get('DCOMP_FORCE_BIG', '0') not in ('', '0')) else None
         self.ewma = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flags = torch.zeros(4, dtype=torch.int32, device=dev)
         # all outputs of one step live in ONE flat buffer (sections 16-byte aligned): the single-env compatibility mode
@@ -230,7 +233,8 @@ class BatchedMobileEnv:
         self._st = _lib.DcompState(self.pos.data_ptr(), self.mv.data_ptr(), self.conn.data_ptr(), self.ewma.data_ptr(),
                                    self.flags.data_ptr(), self.conn_since.data_ptr() if self.conn_since is not None else None,
                                    self.uid.data_ptr() if self.dynamic else None,
-                                   self.orig_consumed.data_ptr() if self.dynamic else None)
+                                   self.orig_consumed.data_ptr() if self.dynamic else None,
+                                   self.conn_hi.data_ptr() if self.conn_hi is not None else None)
         self._dyn_streams = None
         self._ev_keep = None
         self._out = self._make_out(self.obs, self.reward)
@@ -771,7 +775,7 @@ class BatchedMobileEnv:
         # else than self.obs (step_into, step_compact, rollout(out=...)), so it cannot be re-derived from `outbuf` on the other side.
         sd['next_action'] = (self.next_action.detach().cpu().clone()
                              if self._policy_key is not None and self.next_action is not None and self._next_action_fresh else None)
-        for k in ('pos', 'mv', 'conn', 'ewma', 'conn_since', 'uid', 'orig_consumed'):
+        for k in ('pos', 'mv', 'conn', 'conn_hi', 'ewma', 'conn_since', 'uid', 'orig_consumed'):
             t = getattr(self, k)
             sd[k] = None if t is None else t.detach().cpu().clone()
         return sd
@@ -791,8 +795,8 @@ class BatchedMobileEnv:
         if have != want:
             diff = sorted(k for k in set(have) | set(want) if have.get(k) != want.get(k))
             raise ValueError(f"checkpoint belongs to a differently configured env batch (differs in: {', '.join(diff)})")
-        for k in ('pos', 'mv', 'conn', 'ewma', 'conn_since', 'uid', 'orig_consumed'):
-            if sd[k] is not None:
+        for k in ('pos', 'mv', 'conn', 'conn_hi', 'ewma', 'conn_since', 'uid', 'orig_consumed'):
+            if sd.get(k) is not None:
                 getattr(self, k).copy_(sd[k])
         self._outbuf.copy_(sd['outbuf'])
         self.flags.zero_()
@@ -902,7 +906,10 @@ class BatchedMobileEnv:
             'pausing': ((mv >> 47) & 1).astype(np.int32).reshape(E, U),
             'curr_pause': ((mv >> 40) & 0x7F).astype(np.int32).reshape(E, U),
             'cursor': ((mv >> 48) & 0xFFFF).astype(np.int32).reshape(E, U),
-            'conn': self.conn.cpu().numpy().astype(np.uint32).reshape(E, U),
+            # one mask per UE: uint32, or uint64 with more than 32 stations (conn | conn_hi << 32)
+            'conn': (self.conn.cpu().numpy().astype(np.uint32).reshape(E, U) if self.B <= _lib.MASK32_MAX_BS else
+                     (self.conn.cpu().numpy().astype(np.uint32).astype(np.uint64) |
+                      (self.conn_hi.cpu().numpy().astype(np.uint32).astype(np.uint64) << np.uint64(32))).reshape(E, U)),
             'ewma': self.ewma.cpu().numpy().reshape(E, U),
             'uid': (self.uid.cpu().numpy().astype(np.uint16).reshape(E, U) & 0x7FFF) if self.dynamic else
                    np.tile(np.arange(1, U + 1, dtype=np.uint16), (E, 1)),
@@ -987,11 +994,13 @@ class _RefSurfaceEnv(_GymEnv):
     def _host_view(self):
         if self._view_cache is None:
             c = self.core
-            conn = c.conn[:c.U].cpu().numpy().astype(np.uint32)
+            conn = c.conn[:c.U].cpu().numpy().astype(np.uint32).astype(np.uint64)
+            if c.conn_hi is not None:
+                conn = conn | (c.conn_hi[:c.U].cpu().numpy().astype(np.uint32).astype(np.uint64) << np.uint64(32))
             self._view_cache = {
                 'pos': c.pos[:c.U].cpu().numpy(), 'ewma': c.ewma[:c.U].cpu().numpy().tolist(),
                 'curr_dr': self._host['ue_dr'][0].tolist(), 'utility': self._host['ue_utility'][0].tolist(),
-                'num_conn': [int(((conn >> b) & 1).sum()) for b in range(c.B)],
+                'num_conn': [int(((conn >> np.uint64(b)) & np.uint64(1)).sum()) for b in range(c.B)],
             }
         return self._view_cache
 

@@ -21,6 +21,8 @@
  *   pos   double[E*U][2]   UE position x,y (FP64: connect/drop decisions are bit-exact vs the reference)
  *   mv    uint64[E*U]      waypoint x:16 | y:16 | velocity:8 | pausing:1 (bit 47) + curr_pause:7 (bits 40-46) | draw cursor:16
  *   conn  uint32[E*U]      bit b set <=> UE connected to BS b                  (user.py:34 bs_dr keys)
+ *   conn_hi uint32[E*U]    the same for stations 32 ... 63; only with more than 32 stations (generic kernel, csrc/dcomp_big.h:
+ *                          no UE arrival / departure, no fused rollout, no in-step policy, no compact record there)
  *   ewma  float [E*U]      exponentially weighted average rate                 (user.py:148-157)
  *   flags uint32[4]        sticky device-side error bits, read by dcomp_check()
  *   With UE arrival / departure (cfg.max_ues >= cfg.num_ue; 0 = fixed list) every per-UE array has max_ues slots per env; slot =
@@ -41,7 +43,7 @@
 extern "C" {
 #endif
 
-/* ---- ABI guard.  The structs of dcomp_types.h grow at their END from version to version (version 2 added dcomp_out.obs_compact):
+/* ---- ABI guard.  The structs of dcomp_types.h grow at their END from version to version (version 2 added dcomp_out.obs_compact, version 3 dcomp_state.conn_hi):
  * a caller compiled against an older header would make the library read past its struct.  So the handle is created through
  * dcomp_create_v, which takes the caller's idea of the ABI -- DCOMP_ABI_VERSION and the sizes of the four structs the library
  * reads through caller pointers -- and refuses (DCOMP_EABI; dcomp_last_error() names both sides) unless all of them are the
@@ -50,7 +52,7 @@ extern "C" {
  * `dcomp_create` symbol stays exported for one reason: a binary built against a version-1 header calls it, and gets DCOMP_EABI
  * instead of undefined behaviour.  Every struct passed to the library must be zero-initialised before its fields are set (a field
  * the caller does not know about is then NULL = "not requested"). */
-#define DCOMP_ABI_VERSION 2
+#define DCOMP_ABI_VERSION 3
 #define DCOMP_EABI (-7)        /* caller and library disagree about the ABI version or a struct size */
 int dcomp_abi_version(void);                                             /* the library's DCOMP_ABI_VERSION */
 int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state_size, size_t out_size, size_t rollout_opts_size,

@@ -654,8 +654,21 @@ void orc_batch_step(orc_env **envs, int E, const uint8_t *action, float *obs, fl
         int stride = e->kind == ORC_MULTI ? 4 * B + 1 : 2 * B + 1;
         if (obs) pack_obs(e, obs + (size_t)i * U * stride);
         if (reward) { if (e->kind == ORC_MULTI) for (int u = 0; u < U; u++) reward[(size_t)i * U + u] = u < e->nU ? (float)e->reward[u] : 0.f; else reward[i] = (float)e->reward[0]; }
-        if (conn_bits) for (int u = 0; u < U; u++) { uint32_t m = 0; if (u < e->nU) for (int k = 0; k < e->ue_nbs[u]; k++) m |= 1u << e->ue_bs[u * B + k]; conn_bits[(size_t)i * U + u] = m; }
+        if (conn_bits) for (int u = 0; u < U; u++) { uint32_t m = 0; if (u < e->nU) for (int k = 0; k < e->ue_nbs[u]; k++) if (e->ue_bs[u * B + k] < 32) m |= 1u << e->ue_bs[u * B + k]; conn_bits[(size_t)i * U + u] = m; }   /* stations 0-31; 32-63: orc_batch_conn_hi */
         if (pos) for (int u = 0; u < U; u++) { pos[((size_t)i * U + u) * 2] = u < e->nU ? e->px[u] : 0.0; pos[((size_t)i * U + u) * 2 + 1] = u < e->nU ? e->py[u] : 0.0; }
+    }
+}
+/* Stations 32 ... 63 of every UE's connection set (user.py:34 bs_dr keys), as the device keeps them in state.conn_hi. */
+void orc_batch_conn_hi(orc_env **envs, int E, uint32_t *conn_hi)
+{
+    for (int i = 0; i < E; i++) {
+        const orc_env *e = envs[i];
+        const int U = e->U, B = e->B;
+        for (int u = 0; u < U; u++) {
+            uint32_t m = 0;
+            if (u < e->nU) for (int k = 0; k < e->ue_nbs[u]; k++) if (e->ue_bs[u * B + k] >= 32) m |= 1u << (e->ue_bs[u * B + k] - 32);
+            conn_hi[(size_t)i * U + u] = m;
+        }
     }
 }
 /* FP64 per-UE rates of every env of a batch, for the at-scale parity tests (north_star: 1e-5 RELATIVE on data-rate floats):

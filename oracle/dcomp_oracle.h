@@ -89,6 +89,7 @@ void   orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t 
 void orc_batch_reset(orc_env **envs, int num_envs, float *obs, int num_threads);
 void orc_batch_step(orc_env **envs, int num_envs, const uint8_t *action, float *obs, float *reward,
                     uint32_t *conn_bits /*[E][U]*/, double *pos /*[E][U][2]*/, int num_threads);
+void orc_batch_conn_hi(orc_env **envs, int num_envs, uint32_t *conn_hi /*[E][U]: stations 32-63 of the connection sets*/);
 void orc_batch_rates(orc_env **envs, int num_envs, double *curr_dr, double *ewma, double *utility, double *dr_rel, int num_threads);
 int  orc_max_threads(void);
 

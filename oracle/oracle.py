@@ -90,6 +90,7 @@ def lib():
         L.orc_batch_step.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _c_u8p, _c_fp, _c_fp, _c_u32p,
                                      _c_dp, ctypes.c_int]
         L.orc_batch_rates.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _c_dp, _c_dp, _c_dp, _c_dp, ctypes.c_int]
+        L.orc_batch_conn_hi.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _c_u32p]
         L.orc_max_threads.restype = ctypes.c_int
         _lib = L
     return _lib
@@ -484,6 +485,10 @@ class OracleBatch:
         pos = np.zeros((self.E, self.U, 2), dtype=np.float64)
         lib().orc_batch_step(self._handles, self.E, _p(a, _c_u8p), _p(obs, _c_fp), _p(rew, _c_fp), _p(conn, _c_u32p),
                              _p(pos, _c_dp), self.num_threads)
+        if self.B > 32:                          # stations 32-63: a second word per UE, as the device's state.conn_hi; returned as ONE uint64 mask
+            hi = np.zeros((self.E, self.U), dtype=np.uint32)
+            lib().orc_batch_conn_hi(self._handles, self.E, _p(hi, _c_u32p))
+            conn = conn.astype(np.uint64) | (hi.astype(np.uint64) << np.uint64(32))
         return obs, rew, conn, pos
 
 

@@ -557,6 +557,39 @@ def gen_heuristics():
     print('heuristics: ok')
 
 
+def gen_many_stations():
+    """More than 32 base stations (round 5: the native env's 32-station limit went; the reference has none, station.py:16-30): dense grids
+    (45 / 40 m pitch: ~7 stations in range of a UE).  Static UEs parked next to stations of index >= 32 and a scripted opening make sure
+    the connection sets use the high stations: several UEs per high station (sharing sums), two UEs on ONE spot at a max-cap station
+    (rate tie -> the older connection wins, station.py:184-186), connect / disconnect / reconnect."""
+    S = scenarios
+
+    def park(scn, where):                       # static UE i at station `b` + (dx, dy)
+        for i, (b, dx, dy) in enumerate(where):
+            x, y = scn.bs_pos[b]
+            scn.ue_specs[i]['pos_x'], scn.ue_specs[i]['pos_y'] = int(x + dx), int(y + dy)
+
+    def opening(U, B, moves, steps=12):         # moves: {step: {ue: station}} -> action rows (station + 1), 0 elsewhere
+        rows = [[0] * U for _ in range(steps)]
+        for t, m in moves.items():
+            for ue, b in m.items():
+                rows[t][ue] = b + 1
+        return rows
+    scn = S.grid_map(40, 'mixed', pitch=45, border=25).with_ues(num_static=4, num_slow=5, num_fast=3)
+    park(scn, [(37, 3, 4), (37, -10, 0), (38, 20, 5), (33, 0, 0)])
+    run_trajectory('traj_dense12x40_multi_s42', scn, 'multi', 42, 40, tape_mode='sticky',
+                   scripted=opening(12, 40, {0: {0: 37, 1: 37, 2: 38, 3: 33}, 1: {0: 38, 1: 36, 2: 37, 3: 32}, 3: {0: 37}, 4: {0: 37, 2: 39}, 6: {1: 30, 3: 34}}))
+    scn = S.grid_map(64, 'mixed', pitch=40, border=20).with_ues(num_static=3, num_slow=2, num_fast=1)
+    park(scn, [(63, -5, -5), (62, 10, 0), (40, 0, 1)])
+    run_trajectory('traj_dense6x64_central_min_s43', scn, 'central', 43, 40, reward='min', tape_mode='sticky',
+                   scripted=opening(6, 64, {0: {0: 63, 1: 62, 2: 40}, 1: {0: 62, 1: 63, 2: 48}, 2: {0: 55, 2: 32}, 5: {0: 63}}))
+    scn = S.grid_map(36, 'max-cap', pitch=45, border=25).with_ues(num_static=5, num_slow=3, num_fast=1)
+    scn.bs_sharing[33] = 'rate-fair'; scn.bs_sharing[34] = 'proportional-fair'; scn.bs_sharing[3] = 'resource-fair'
+    park(scn, [(35, 6, 8), (35, 6, 8), (35, -6, 8), (33, 10, 0), (34, 0, 12)])     # UEs 0 and 1 on ONE spot: equal rates at max-cap station 35
+    run_trajectory('traj_dense9x36_maxcap_multi_sum_s42', scn, 'multi', 42, 40, reward='sum', tape_mode='sticky',
+                   scripted=opening(9, 36, {0: {1: 35, 3: 33, 4: 34}, 1: {0: 35, 2: 35, 3: 34, 4: 33}, 2: {1: 35}, 3: {1: 35, 0: 34}, 5: {2: 35, 0: 35}, 6: {0: 35}}))
+
+
 def gen_ue_arrival():
     """The five named UE-arrival schedules of the CLI (env_setup.py:205-226).  deepcomp.util.env_setup cannot be imported here (it needs a
     real ray), so the reference's OWN get_ue_arrival is lifted out of its module with `ast` -- the function's source, compiled and run
@@ -597,3 +630,4 @@ if __name__ == '__main__':
     gen_dynamic()
     gen_single()
     gen_ue_arrival()
+    gen_many_stations()

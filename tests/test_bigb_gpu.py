@@ -1,0 +1,199 @@
+"""More than 32 base stations (round 5).  The reference has no station limit (station.py:16-30, base.py:79-84); the native env had 32 (one
+32-bit connection mask per UE, one kernel instantiation per station count).  33 ... 64 stations now take the GENERIC kernel of
+deepcomp_amd/csrc/dcomp_big.h (run-time B, per-UE rows in LDS, the connection set in state.conn + state.conn_hi).  Held to:
+
+* the reference itself -- three reference-run trajectories with 36 / 40 / 64 stations (tests/golden/traj_dense*: static UEs parked at
+  stations >= 32, scripted connects / disconnects, a max-cap rate tie) go through test_parity_gpu.py::test_golden_trajectory like every
+  other traj_* fixture, and through tests/test_oracle_golden.py on the CPU;
+* the oracle, on Philox batches at B = 33 ... 64 across lane widths, env kinds, reward aggregations and sharing models (here);
+* the specialised kernels, with DCOMP_FORCE_BIG=1 at B <= 32: masks / positions identical, floats to the last bits (here).
+"""
+import numpy as np
+import pytest
+
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def _scenario(U, B, sharing, pitch=45):
+    from deepcomp_amd import scenarios
+    n_static = max(1, U // 8)
+    scn = scenarios.grid_map(B, 'mixed' if sharing == 'mixed' else sharing, pitch=pitch, border=25).with_ues(
+        num_static=n_static, num_slow=U - n_static - U // 4, num_fast=U // 4)
+    if sharing == 'max-cap':                                  # a few other models among the max-cap stations, one of them beyond 31
+        for b, m in ((1, 'resource-fair'), (B - 1, 'rate-fair'), (B - 2, 'proportional-fair')):
+            scn.bs_sharing[b] = m
+    return scn
+
+
+def _oracle_batch(scn, kind, reward, E, seed):
+    from oracle import oracle as orc
+    envs = []
+    for e in range(E):
+        o = orc.OracleEnv(int(scn.width), int(scn.height), scn.bs_pos, scn.bs_sharing, [s['velocity'] for s in scn.ue_specs],
+                          kind=orc.MULTI if kind == 'multi' else orc.CENTRAL, reward_agg={'avg': 0, 'sum': 1, 'min': 2}[reward])
+        o.set_philox(seed, e)
+        envs.append(o)
+    return orc.OracleBatch(envs)
+
+
+def _near_actions(rng, core, B, frac=0.6):
+    """Actions biased towards stations that are in range (so that UEs hold several connections, high stations included)."""
+    E, U = core.E, core.U
+    pos = core.state_host()['pos']                                             # [E, U, 2]
+    bs = np.stack([core._bs_x, core._bs_y], axis=1)                            # [B, 2]
+    d = np.linalg.norm(pos[:, :, None, :] - bs[None, None, :, :], axis=-1)     # [E, U, B]
+    near = d < 68.0
+    a = rng.integers(0, B + 1, size=(E, U))
+    pick = np.where(near.any(-1), (near * rng.random((E, U, B))).argmax(-1) + 1, a)
+    a = np.where(rng.random((E, U)) < frac, pick, a)
+    a[rng.random((E, U)) < 0.15] = 0
+    return a.astype(np.uint8)
+
+
+SHAPES = [('multi', 32, 64, 96, 'avg', 'mixed'), ('central', 10, 40, 128, 'avg', 'mixed'), ('multi', 3, 33, 200, 'min', 'mixed'),
+          ('multi', 12, 48, 64, 'sum', 'mixed'), ('multi', 70, 36, 12, 'avg', 'mixed'), ('central', 130, 40, 6, 'min', 'mixed'),
+          ('multi', 128, 64, 8, 'avg', 'mixed'), ('multi', 200, 56, 3, 'sum', 'mixed'), ('central', 256, 33, 2, 'sum', 'mixed'),
+          ('multi', 20, 40, 48, 'avg', 'max-cap'), ('central', 9, 64, 64, 'sum', 'max-cap'), ('multi', 64, 64, 10, 'min', 'rate-fair'),
+          ('multi', 16, 50, 64, 'avg', 'proportional-fair'), ('multi', 1, 64, 128, 'avg', 'mixed'), ('central', 5, 37, 300, 'avg', 'resource-fair')]
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+def test_generic_kernel_against_the_oracle(torch_cuda, shape):
+    """reset + 14 steps against the FP64 oracle: connection sets (64-bit), FSM state and FP64 positions bit-exact; rates / EWMA / obs.dr
+    within 1e-5 relative, the utility-scaled entries and rewards at the bars of tests/parity.py -- the same assertions as for <= 32 stations."""
+    torch = torch_cuda
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    kind, U, B, E, reward, sharing = shape
+    scn = _scenario(U, B, sharing)
+    m, bs, ues = build_from_scenario(scn)
+    core = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=77, reward=reward, rng='philox')
+    assert core.step_kernel_name.startswith('big_kernel<') and core.conn_hi is not None
+    ob = _oracle_batch(scn, kind, reward, E, 77)
+    rng = np.random.default_rng(B * 1000 + U)
+    core.reset()
+    parity.assert_step(core, ob, ob.reset(), None, None, None, kind, reward, msg='reset')
+    high = 0
+    for t in range(14):
+        a = _near_actions(rng, core, B)
+        core.step(torch.from_numpy(a).cuda())
+        o_obs, o_rew, o_conn, o_pos = ob.step(a)
+        parity.assert_step(core, ob, o_obs, o_rew, o_conn, o_pos, kind, reward, msg=f'step {t}')
+        high += int((o_conn >> np.uint64(32) != 0).sum())
+    core.check()
+    assert high > 0, 'no connection to a station beyond 31 was ever made: the scenario does not test the second mask word'
+    assert np.array_equal(core.conn_hi.cpu().numpy().astype(np.uint32).reshape(E, U), (o_conn >> np.uint64(32)).astype(np.uint32))
+
+
+@pytest.mark.parametrize('kind,U,B,E,reward,sharing', [('multi', 32, 10, 64, 'avg', 'mixed'), ('central', 10, 5, 100, 'avg', 'mixed'),
+                                                       ('multi', 128, 32, 4, 'min', 'mixed'), ('multi', 20, 7, 40, 'sum', 'max-cap'),
+                                                       ('central', 70, 12, 9, 'min', 'rate-fair')])
+def test_generic_kernel_equals_the_specialised_kernels(torch_cuda, kind, U, B, E, reward, sharing, monkeypatch):
+    """DCOMP_FORCE_BIG=1 sends station counts the specialised kernels serve through the generic one: positions, movement words and
+    connection sets identical after 25 steps, every float within float32 rounding of the other path (the sums run in another order)."""
+    torch = torch_cuda
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    scn = _scenario(U, B, sharing, pitch=60)
+    m, bs, ues = build_from_scenario(scn)
+    mk = lambda: BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=5, reward=reward, rng='philox')       # noqa: E731
+    ref = mk()
+    monkeypatch.setenv('DCOMP_FORCE_BIG', '1')
+    big = mk()
+    monkeypatch.delenv('DCOMP_FORCE_BIG')
+    assert big.step_kernel_name.startswith('big_kernel<') and not ref.step_kernel_name.startswith('big_kernel<')
+    rng = np.random.default_rng(3)
+    ref.reset(); big.reset()
+    assert torch.equal(ref.pos, big.pos) and torch.equal(ref.mv, big.mv)
+    torch.testing.assert_close(big.obs, ref.obs, rtol=2e-6, atol=2e-6)
+    for t in range(25):
+        a = torch.from_numpy(_near_actions(rng, ref, B)).cuda()
+        ref.step(a); big.step(a)
+        assert torch.equal(ref.pos, big.pos) and torch.equal(ref.mv, big.mv) and torch.equal(ref.conn, big.conn), f'step {t}'
+        torch.testing.assert_close(big.obs, ref.obs, rtol=3e-6, atol=3e-6, msg=lambda s_: f'step {t} obs: {s_}')
+        torch.testing.assert_close(big.reward, ref.reward, rtol=0, atol=2e-5 * (U if reward == 'sum' else 1))
+        torch.testing.assert_close(big.ewma, ref.ewma, rtol=3e-6, atol=1e-30)
+        torch.testing.assert_close(big.ue_dr, ref.ue_dr, rtol=3e-6, atol=1e-30)
+        torch.testing.assert_close(big.sum_utility, ref.sum_utility, rtol=0, atol=2e-5 * U)
+    assert int(big.conn_hi.abs().sum()) == 0
+    ref.check(); big.check()
+
+
+def test_many_stations_what_works_and_what_says_no(torch_cuda):
+    """48 stations: rollout() (one launch per step) == step(), checkpoints carry conn_hi, bad actions are flagged; the features that
+    live in the specialised kernels only say so (UE arrival / departure, in-step policy, compact record, the fragment codec)."""
+    torch = torch_cuda
+    from deepcomp_amd import fragment
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    U, B, E = 12, 48, 40
+    scn = _scenario(U, B, 'mixed')
+    m, bs, ues = build_from_scenario(scn)
+    kw = dict(num_envs=E, seed=9, rng='philox', rand_episodes=True, episode_length=20)
+    a, b = BatchedMobileEnv(m, bs, ues, 'multi', **kw), BatchedMobileEnv(m, bs, ues, 'multi', **kw)
+    rng = np.random.default_rng(1)
+    a.reset(); b.reset()
+    T = 30                                                        # across the horizon of 20
+    acts = torch.from_numpy(np.stack([_near_actions(rng, a, B) for _ in range(T)])).cuda()
+    assert not a.rollout_is_fused(T)
+    want = {'obs': torch.empty((T,) + tuple(a.obs.shape), device='cuda'), 'reward': torch.empty((T,) + tuple(a.reward.shape), device='cuda')}
+    got = {k: torch.empty_like(v) for k, v in want.items()}
+    for t in range(T):
+        if a.time == 20:
+            a.reset()
+        a.step_into(acts[t], want['obs'][t], want['reward'][t])
+    b.rollout(acts, out=got, horizon=20)
+    assert torch.equal(got['obs'], want['obs']) and torch.equal(got['reward'], want['reward'])
+    assert torch.equal(a.pos, b.pos) and torch.equal(a.conn, b.conn) and torch.equal(a.conn_hi, b.conn_hi) and int(a.conn_hi.abs().sum()) > 0
+    # checkpoint / resume with the second mask word
+    sd = a.state_dict()
+    c = BatchedMobileEnv(m, bs, ues, 'multi', **kw)
+    c.reset()
+    c.load_state_dict(sd)
+    for t in range(5):
+        a.step(acts[t]); c.step(acts[t])
+    assert torch.equal(a.conn_hi, c.conn_hi) and torch.equal(a.obs, c.obs) and torch.equal(a.pos, c.pos)
+    # action B + 1 is outside the space (base.py:238)
+    bad = acts[0].clone(); bad[3, 2] = B + 1
+    a.step(bad)
+    with pytest.raises(AssertionError):
+        a.check()
+    # what the generic kernel does not have
+    assert a.set_policy('3gpp') is False
+    with pytest.raises((ValueError, NotImplementedError)):
+        fragment.fragment_words(U, B)
+    with pytest.raises((ValueError, NotImplementedError)):
+        a.step_compact(acts[0], torch.empty((E, 4), dtype=torch.int32, device='cuda'), a.reward)
+    with pytest.raises(NotImplementedError):
+        BatchedMobileEnv(m, bs, ues, 'multi', ue_arrival={3: 1}, **kw)
+    with pytest.raises(ValueError):
+        BatchedMobileEnv(*build_from_scenario(_scenario(4, 65, 'mixed')), 'multi', num_envs=2, rng='philox')
+
+
+def test_many_stations_at_scale_against_the_oracle(torch_cuda):
+    """4 096 x 32 UE x 64 stations (8.4 M pairs per step), 5 steps, every UE against the oracle."""
+    torch = torch_cuda
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    E, U, B = 4096, 32, 64
+    scn = _scenario(U, B, 'mixed')
+    m, bs, ues = build_from_scenario(scn)
+    core = BatchedMobileEnv(m, bs, ues, 'multi', num_envs=E, seed=42, rng='philox')
+    ob = _oracle_batch(scn, 'multi', 'avg', E, 42)
+    rng = np.random.default_rng(8)
+    core.reset()
+    parity.assert_step(core, ob, ob.reset(), None, None, None, 'multi', msg='reset')
+    for t in range(5):
+        a = _near_actions(rng, core, B)
+        core.step(torch.from_numpy(a).cuda())
+        parity.assert_step(core, ob, *ob.step(a), 'multi', msg=f'step {t}')
+    core.check()

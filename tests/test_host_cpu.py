@@ -226,16 +226,21 @@ def test_abi_guard_rejects_a_stale_caller_without_gpu(lib):
     dcomp_create_v(version, struct sizes, ...): anything but the library's own values -> DCOMP_EABI, before the config is even looked at;
     the version-1 symbol `dcomp_create` refuses always."""
     from deepcomp_amd import _lib
-    assert lib.dcomp_abi_version() == _lib.ABI_VERSION == 2 and b'ABI 2' in lib.dcomp_version()
+    assert lib.dcomp_abi_version() == _lib.ABI_VERSION == 3 and b'ABI 3' in lib.dcomp_version()
     c, keep = _cfg(3, 100, 100, [1, 1, 1], [3, 3, 3])
     h = ctypes.c_void_p(1234)
     sizes = [ctypes.sizeof(x) for x in (_lib.DcompCfg, _lib.DcompState, _lib.DcompOut, _lib.DcompRolloutOpts)]
     assert lib.dcomp_create(ctypes.byref(c), ctypes.byref(h)) == _lib.EABI and h.value is None        # the ABI-1 entry point
     assert b'ABI-1' in lib.dcomp_last_error()
     stale_out = sizes[2] - ctypes.sizeof(ctypes.c_void_p)                                               # dcomp_out without obs_compact
-    assert lib.dcomp_create_v(2, sizes[0], sizes[1], stale_out, sizes[3], ctypes.byref(c), ctypes.byref(h)) == _lib.EABI
+    assert lib.dcomp_create_v(3, sizes[0], sizes[1], stale_out, sizes[3], ctypes.byref(c), ctypes.byref(h)) == _lib.EABI
     assert str(stale_out).encode() in lib.dcomp_last_error() and str(sizes[2]).encode() in lib.dcomp_last_error()
-    assert lib.dcomp_create_v(1, *sizes, ctypes.byref(c), ctypes.byref(h)) == _lib.EABI
+    stale_state = sizes[1] - ctypes.sizeof(ctypes.c_void_p)                                             # dcomp_state without conn_hi (ABI 2)
+    assert lib.dcomp_create_v(3, sizes[0], stale_state, sizes[2], sizes[3], ctypes.byref(c), ctypes.byref(h)) == _lib.EABI
+    assert lib.dcomp_create_v(2, *sizes, ctypes.byref(c), ctypes.byref(h)) == _lib.EABI
+    c65, keep65 = _cfg(3, 100, 100, [1, 1, 1], [3, 3, 3])
+    c65.num_bs = 65                                    # one station more than the two mask words hold
+    assert _lib.create(c65, h) == _lib.EINVAL and b'num_bs<=64' in lib.dcomp_last_error()
     with pytest.raises(ImportError):
         _lib.check(_lib.EABI)
     # the header's own macro passes exactly these sizes: compile a two-line C caller against include/ and compare

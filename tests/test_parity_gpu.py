@@ -65,7 +65,7 @@ def _compare(core, g, prefix, i, e=0, with_reward=False):
         assert np.array_equal(st[k][e], g[f'{prefix}_{k}'][i]), f'{prefix}[{i}] {k} not bit-exact'
     assert np.array_equal(st['pausing'][e], g[f'{prefix}_pausing'][i]), f'{prefix}[{i}] pausing'
     assert np.array_equal(st['curr_pause'][e], g[f'{prefix}_curr_pause'][i]), f'{prefix}[{i}] curr_pause'
-    conn = ((st['conn'][e][:, None] >> np.arange(B)[None, :]) & 1).astype(np.uint8)
+    conn = ((st['conn'][e][:, None] >> np.arange(B, dtype=st['conn'].dtype)[None, :]) & 1).astype(np.uint8)     # (uint64 masks with > 32 stations)
     assert np.array_equal(conn, g[f'{prefix}_conn'][i]), f'{prefix}[{i}] connection mask'
     np.testing.assert_allclose(st['ewma'][e], g[f'{prefix}_ewma'][i], rtol=RTOL_RATE, atol=1e-30, err_msg=f"{prefix}[{i}] ewma")
     v = {k: t.cpu().numpy()[e] for k, t in core.obs_views().items()}
@@ -463,7 +463,7 @@ def test_golden_dynamic_ue_trajectory(torch_cuda, name, via_rollout):
         for k in ('pos', 'wp', 'vel'):
             assert np.array_equal(st[k][0], g[f'{prefix}_{k}'][i]), f'{prefix}[{i}] {k} not bit-exact'
         assert np.array_equal(st['pausing'][0], g[f'{prefix}_pausing'][i]) and np.array_equal(st['curr_pause'][0], g[f'{prefix}_curr_pause'][i])
-        conn = ((st['conn'][0][:, None] >> np.arange(B)[None, :]) & 1).astype(np.uint8)
+        conn = ((st['conn'][0][:, None] >> np.arange(B, dtype=st['conn'].dtype)[None, :]) & 1).astype(np.uint8)
         assert np.array_equal(conn, g[f'{prefix}_conn'][i]), f'{prefix}[{i}] connection mask'
         np.testing.assert_allclose(st['ewma'][0], g[f'{prefix}_ewma'][i], rtol=RTOL_RATE, atol=1e-30)
         v = {k: t.cpu().numpy()[0] for k, t in core.obs_views().items()}

@@ -2,5 +2,5 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -2
-for m in nopin pin pin_restore torch_nopin torch_pin; do python tools/_cpu_diag.py $m 2>&1 | tail -1; done
-timeout 2400 python -m pytest tests -x -q -m gpu --durations=8 2>&1 | tail -40 > $O/r05_pytest2.txt; tail -14 $O/r05_pytest2.txt
+timeout 1200 python -m pytest tests/test_bigb_gpu.py -q -x 2>&1 | tail -40 > $O/r05_bigb.txt; tail -40 $O/r05_bigb.txt | cut -c1-300
+timeout 600 python -m pytest tests/test_parity_gpu.py -q -x -k "dense" 2>&1 | tail -15 | cut -c1-300
