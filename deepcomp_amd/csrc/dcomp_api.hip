@@ -71,7 +71,7 @@ struct dcomp_env {
     int64_t episode;            // index of the current episode (-1 before the first reset)
     // 33 ... 64 stations (or DCOMP_FORCE_BIG=1): the generic kernel of dcomp_big.h instead of `kern`
     bool big = false;
-    dcomp::BigKernels bigk{nullptr, nullptr, 0};
+    dcomp::BigKernels bigk{nullptr, nullptr, 0, 0};
     dcomp::BigParams bigp{};
     double2 *d_bs = nullptr;
     int32_t *d_mode = nullptr;
@@ -266,7 +266,7 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
         if (e == hipSuccess) e = hipMalloc((void **)&env->d_mode, sizeof(int32_t) * B);
         if (e == hipSuccess) e = hipMemcpy(env->d_bs, xy.data(), sizeof(double) * 2 * B, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(env->d_mode, md.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice);
-        env->big_lds = dcomp::big_lds_bytes(B, env->bigk.gpb);
+        env->big_lds = dcomp::big_lds_bytes(B, env->bigk.gpb, env->bigk.block);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(env->bigk.step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->big_lds);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(env->bigk.reset), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->big_lds);
         if (e != hipSuccess) { dcomp_destroy(env); return fail(DCOMP_EHIP, "device setup failed (generic kernel, %zu bytes of LDS per workgroup): %s", env->big_lds, hipGetErrorString(e)); }
@@ -402,7 +402,7 @@ extern "C" int dcomp_obs_dim(const dcomp_env *env, int32_t *floats_per_env, int3
 static void launch_step(dcomp_env *env, KParams &kp, void *stream)
 {
     if (env->big) {
-        hipLaunchKernelGGL(env->bigk.step, dim3(env->grid), dim3(256), env->big_lds, (hipStream_t)stream, kp, env->bigp);
+        hipLaunchKernelGGL(env->bigk.step, dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, kp, env->bigp);
         return;
     }
     if (env->tight_g) {
@@ -474,7 +474,7 @@ extern "C" int dcomp_reset(dcomp_env *env, const dcomp_state *st, const dcomp_ta
     env->cur_ue = env->cfg.num_ue; env->n_removed = env->n_arrived = 0;      // base.py:177-182
     kp.cur_ue = env->cur_ue;
     kp.episode = (uint32_t)env->episode;
-    if (env->big) hipLaunchKernelGGL(env->bigk.reset, dim3(env->grid), dim3(256), env->big_lds, (hipStream_t)stream, kp, env->bigp);
+    if (env->big) hipLaunchKernelGGL(env->bigk.reset, dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, kp, env->bigp);
     else hipLaunchKernelGGL(env->kern.reset, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
     HIP_TRY(hipGetLastError());
     return DCOMP_OK;
@@ -577,7 +577,7 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
         k.cur_ue = env->cur_ue;
         k.episode = (uint32_t)env->episode;
         k.time = 0u;
-        if (env->big) hipLaunchKernelGGL(env->bigk.reset, dim3(env->grid), dim3(256), env->big_lds, (hipStream_t)stream, k, env->bigp);
+        if (env->big) hipLaunchKernelGGL(env->bigk.reset, dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, k, env->bigp);
         else hipLaunchKernelGGL(env->kern.reset, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, k);
     };
     if (env->dyn) {

@@ -9,9 +9,10 @@
 // same outputs as the narrow kernels -- tests/test_bigb_gpu.py holds it to the oracle at B = 33 ... 64 and to the narrow kernels
 // at B <= 32 (DCOMP_FORCE_BIG=1).  It is NOT tuned: ~3 workgroup barriers and three owner-thread reduction passes per step.
 //
-// Mapping: one lane = one (env, UE); an env takes UPAD = next pow2 >= U lanes; a 256-lane workgroup 256 / UPAD envs.
+// Mapping: one lane = one (env, UE); an env takes UPAD = next pow2 >= U lanes; a workgroup is ONE wavefront (64 / UPAD envs) or, for
+// envs of more than 64 lanes, the env's own UPAD lanes.
 // Per-station sums over an env's UEs (station.py:152-202, 63-83): thread t of the workgroup OWNS the (env, station) pairs
-// t, t + 256, ... and adds up the rows of that env in UE order -- deterministic, no atomics, conflict-free (consecutive threads own
+// t, t + BLK, ... and adds up the rows of that env in UE order -- deterministic, no atomics, conflict-free (consecutive threads own
 // consecutive stations).  Not supported here (dcomp_create_v says so): UE arrival / departure, the fused rollout (dcomp_rollout_ex
 // launches one step per launch), the in-step policy, the compact record.
 #pragma once
@@ -27,10 +28,14 @@ struct BigParams {
     unsigned long long maxcap_mask;    // bit b: station b is max-cap
 };
 
+// Workgroup size: ONE wavefront, or as many as an env needs.  The rows cost (B + 1) * 4 bytes of LDS per lane (260 at B = 64), so a CU holds
+// ~7 wavefronts of this kernel at most; 256-lane workgroups (the first version) fit ONCE per CU at B = 64 -- 4 wavefronts, one per SIMD,
+// nothing to hide a barrier or an LDS round trip behind (8 192 x 32 x 64: 181 us, SQ_WAIT_ANY 44 % of the wave cycles).
+__host__ __device__ constexpr int big_block(int upad) { return upad < 64 ? 64 : upad; }
 // LDS bytes one workgroup needs (host and device use the same carve)
-__host__ __device__ inline size_t big_lds_bytes(int B, int gpb)
+__host__ __device__ inline size_t big_lds_bytes(int B, int gpb, int blk)
 {
-    return 64 * sizeof(double2) + 256 * sizeof(double2) + 256 * sizeof(unsigned long long) + (size_t)256 * (B + 1) * 4 + 4 * 256 * 4 +
+    return 64 * sizeof(double2) + (size_t)blk * sizeof(double2) + (size_t)blk * sizeof(unsigned long long) + (size_t)blk * (B + 1) * 4 + (size_t)4 * blk * 4 +
            (size_t)5 * gpb * B * 4 + 64 * 4;
 }
 
@@ -52,17 +57,17 @@ __device__ __forceinline__ float big_rate(float l2)                // bw * log2(
 }
 
 template <int UPAD, bool RESET>
-__global__ __launch_bounds__(256) void big_kernel(const KParams p, const BigParams x)
+__global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, const BigParams x)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
-    constexpr int GPB = 256 / UPAD;
+    constexpr int BLK = big_block(UPAD), NWAVE = BLK / 64, GPB = BLK / UPAD;
     const int B = x.B, BR = B + 1, U = p.U;
     double2 *const bs_s = reinterpret_cast<double2 *>(big_smem);
     double2 *const pos_s = bs_s + 64;
-    unsigned long long *const mask_s = reinterpret_cast<unsigned long long *>(pos_s + 256);
-    float *const row = reinterpret_cast<float *>(mask_s + 256);
-    float *const ewma_s = row + 256 * BR, *const util_s = ewma_s + 256, *const rb_s = util_s + 256, *const l2max_s = rb_s + 256;
-    float *const agg_n = l2max_s + 256, *const agg_s = agg_n + GPB * B, *const agg_u = agg_s + GPB * B, *const agg_m = agg_u + GPB * B;
+    unsigned long long *const mask_s = reinterpret_cast<unsigned long long *>(pos_s + BLK);
+    float *const row = reinterpret_cast<float *>(mask_s + BLK);
+    float *const ewma_s = row + BLK * BR, *const util_s = ewma_s + BLK, *const rb_s = util_s + BLK, *const l2max_s = rb_s + BLK;
+    float *const agg_n = l2max_s + BLK, *const agg_s = agg_n + GPB * B, *const agg_u = agg_s + GPB * B, *const agg_m = agg_u + GPB * B;
     uint32_t *const mc_win = reinterpret_cast<uint32_t *>(agg_m + GPB * B);
     int *const mode_s = reinterpret_cast<int *>(mc_win + GPB * B);
 
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(256) void big_kernel(const KParams p, const BigPara
     const bool alive = active && (!RESET || u < p.U0);
     const int idx = env * U + u;
     float *const myrow = row + tid * BR;
-    for (int i = tid; i < B; i += 256) { bs_s[i] = x.bs[i]; mode_s[i] = x.mode[i]; }
+    for (int i = tid; i < B; i += BLK) { bs_s[i] = x.bs[i]; mode_s[i] = x.mode[i]; }
 
     double px = 0.0, py = 0.0;
     unsigned long long mv = 0, conn = 0;
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(256) void big_kernel(const KParams p, const BigPara
     // 1 / rate resp. rate / (ewma + eps), the max-cap winner), 1 = utility sums (count, sum, min over the connected UEs).
     auto aggregate = [&](int what) {
         const int P = GPB * B;
-        for (int q = tid; q < P; q += 256) {
+        for (int q = tid; q < P; q += BLK) {
             const int el = q / B, b = q - el * B, base = el * UPAD;
             float n = 0.f, s = 0.f, mn = MAX_UTIL;
             uint32_t win = 0xFFFFFFFFu;
@@ -306,46 +311,48 @@ __global__ __launch_bounds__(256) void big_kernel(const KParams p, const BigPara
     }
     if (!p.obs) return;
     const float inv_u = 1.0f / (float)n_eff;
-    if (kind == DCOMP_MULTI) {
-        // rows [E][U][4B+1] = connected | dr | ues_at_bs | util_at_bs | utility (variants.py:271-305): a wavefront per row, lanes along it
-        const int ROW = 4 * B + 1;
-        for (int r = wave; r < 256; r += 4) {
-            const int el = r / UPAD, uu = r - el * UPAD;
-            if (uu >= U || env0 + el >= p.E) continue;             // (wave-uniform)
-            const bool live = !RESET || uu < p.U0;
+    // Multi-agent rows (variants.py:271-305): a wavefront per UE row, lanes along the stations (B <= 64: one trip), uniform control flow --
+    // four stores of B contiguous floats (connected | dr | ues_at_bs | util_at_bs) + the row's utility.  (First version: one loop over the
+    // 4B + 1 columns with a branch per block, 125 instead of ~35 instructions per row: 8 192 x 32 x 64 334 -> 181 us.)
+    const int w0 = __builtin_amdgcn_readfirstlane(wave);
+    const int ROW = 4 * B + 1, UB = U * B;
+    for (int r = w0; r < BLK && kind == DCOMP_MULTI; r += NWAVE) {
+        const int el = r / UPAD, uu = r - el * UPAD;
+        if (uu >= U || env0 + el >= p.E) continue;                 // (wave-uniform)
+        const bool live = !RESET || uu < p.U0;
+        const float un = live ? util_s[r] * (1.0f / MAX_UTIL) : 0.f;
+        {
             float *const dst = p.obs + ((size_t)(env0 + el) * U + uu) * ROW;
-            const unsigned long long mk = mask_s[r];
-            const float lm = l2max_s[r];
-            for (int c = lane; c < ROW; c += 64) {
-                float v = 0.f;
-                if (live) {
-                    if (c < B) v = (float)((mk >> c) & 1ull);
-                    else if (c < 2 * B) v = fast_exp2(row[r * BR + (c - B)] - lm);                                     // variants.py:276-284
-                    else if (c < 3 * B) v = agg_n[el * B + (c - 2 * B)] * inv_u;                                       // variants.py:296
-                    else if (c < 4 * B) { const int q = el * B + (c - 3 * B); v = agg_u[q] * fast_rcp(fmaxf(agg_n[q], 1.f)) * (1.0f / MAX_UTIL); }   // variants.py:299
-                    else v = util_s[r] * (1.0f / MAX_UTIL);
-                }
-                stream_store(dst + c, v);
+            if (lane < B) {
+                const int q = el * B + lane;
+                const float n = agg_n[q];
+                stream_store(dst + lane, live ? (float)((mask_s[r] >> lane) & 1ull) : 0.f);
+                stream_store(dst + B + lane, live ? fast_exp2(row[r * BR + lane] - l2max_s[r]) : 0.f);                                   // variants.py:276-284
+                stream_store(dst + 2 * B + lane, live ? n * inv_u : 0.f);                                                                  // variants.py:296
+                stream_store(dst + 3 * B + lane, live ? agg_u[q] * fast_rcp(fmaxf(n, 1.f)) * (1.0f / MAX_UTIL) : 0.f);                     // variants.py:299
             }
+            if (lane == 0) stream_store(dst + 4 * B, un);
         }
-    } else {
-        // central.py:31-57: [E][U (2B+1)] = connected[U][B] | dr[U][B] | utility[U]; the lanes of an env walk its block
-        if (env < p.E) {
-            float *const dst = p.obs + (size_t)env * U * (2 * B + 1);
-            const int base = env_local * UPAD, UB = U * B;
-            for (int c = u; c < UB; c += UPAD) {
-                const int uu = c / B, b = c - uu * B;
-                const bool live = !RESET || uu < p.U0;
-                stream_store(dst + c, live ? (float)((mask_s[base + uu] >> b) & 1ull) : 0.f);
-                stream_store(dst + UB + c, live ? fast_exp2(row[(base + uu) * BR + b] - l2max_s[base + uu]) : 0.f);
-            }
-            for (int c = u; c < U; c += UPAD) stream_store(dst + 2 * UB + c, util_s[base + c] * (1.0f / MAX_UTIL));
+    }
+    if (kind == DCOMP_CENTRAL && env < p.E) {
+        // central rows are short (U (2B+1) floats per ENV): the lanes of an env walk its connected / dr blocks, (UE, station) advanced
+        // incrementally (no division per element), then the utilities
+        float *const dst = p.obs + (size_t)env * U * (2 * B + 1);
+        const int base = env_local * UPAD;
+        int uu = u / B, b = u - uu * B;
+        for (int c = u; c < UB; c += UPAD) {
+            const bool live = !RESET || uu < p.U0;
+            stream_store(dst + c, live ? (float)((mask_s[base + uu] >> b) & 1ull) : 0.f);
+            stream_store(dst + UB + c, live ? fast_exp2(row[(base + uu) * BR + b] - l2max_s[base + uu]) : 0.f);
+            b += UPAD;
+            while (b >= B) { b -= B; uu++; }
         }
+        for (int c = u; c < U; c += UPAD) stream_store(dst + 2 * UB + c, util_s[base + c] * (1.0f / MAX_UTIL));
     }
 }
 
 using BigKernelFn = void (*)(const KParams, const BigParams);
-struct BigKernels { BigKernelFn step, reset; int gpb; };
+struct BigKernels { BigKernelFn step, reset; int gpb, block; };
 BigKernels big_kernels_for_upad(int upad);
 
 }  // namespace dcomp

@@ -4,7 +4,7 @@
 
 namespace dcomp {
 template <int UPAD>
-static BigKernels big_make() { return BigKernels{big_kernel<UPAD, false>, big_kernel<UPAD, true>, 256 / UPAD}; }
+static BigKernels big_make() { return BigKernels{big_kernel<UPAD, false>, big_kernel<UPAD, true>, big_block(UPAD) / UPAD, big_block(UPAD)}; }
 
 BigKernels big_kernels_for_upad(int upad)
 {
@@ -16,7 +16,7 @@ BigKernels big_kernels_for_upad(int upad)
     case 64: return big_make<64>();
     case 128: return big_make<128>();
     case 256: return big_make<256>();
-    default: return BigKernels{nullptr, nullptr, 0};
+    default: return BigKernels{nullptr, nullptr, 0, 0};
     }
 }
 }  // namespace dcomp

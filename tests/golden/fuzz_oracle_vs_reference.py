@@ -126,6 +126,7 @@ def main():
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--dump', default=None, help='--near-ties: write the configurations the reference confirmed to this JSON file (inputs only)')
     ap.add_argument('--max-pairs', type=int, default=240, help='U*B cap (the reference needs ~30 us per pair and step)')
+    ap.add_argument('--many-stations', type=float, default=0.0, help='fraction of the cases with 33 ... 64 stations (fuzz_parity.many_stations; round 5)')
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     bad = done = 0
@@ -153,9 +154,15 @@ def main():
         print(f'{done - bad} / {done} max-cap near-tie configurations (found among {tried} max-cap configurations): oracle == reference')
         sys.exit(1 if bad else 0)
     while done < a.cases:
-        spec = fuzz_parity.random_spec(rng)
+        spec = fuzz_parity.many_stations(fuzz_parity.random_spec(rng), a.many_stations)
         if spec['U'] * spec['B'] > a.max_pairs:
-            continue
+            if not spec.get('many_stations'):
+                continue
+            n = max(1, a.max_pairs // spec['B'])           # keep the many-station cases: fewer UEs instead
+            spec['U'] = n
+            for k in ('vel', 'util', 'req', 'init', 'pause', 'border'):
+                if spec.get(k) is not None:
+                    spec[k] = spec[k][:n]
         done += 1
         try:
             (run_one_dynamic if spec['arrival'] else run_one)(spec)

@@ -15,7 +15,7 @@ sys.path.insert(0, REPO)
 
 from tests import parity  # noqa: E402
 
-RTOL_RATE, ATOL_UTIL, ATOL_OBS = 1e-5, 1e-4, 1e-5
+RTOL_RATE, ATOL_UTIL, ATOL_OBS = parity.RTOL_RATE, parity.ATOL_UTIL, parity.ATOL_OBS        # one place for the bars (tests/parity.py)
 SHARING = ['resource-fair', 'rate-fair', 'max-cap', 'proportional-fair']
 
 
@@ -92,6 +92,28 @@ def random_spec(rng):
 
 def _spec_rest(**kw):
     return kw
+
+
+def many_stations(spec, frac):
+    """Round 5 (a stream of its own, keyed by the case's seed: every older spec stays what it was): with probability `frac` the case gets
+    33 ... 64 stations -- the generic kernel of csrc/dcomp_big.h.  The extra stations are drawn like the first ones; features the generic
+    kernel does not have are dropped from the case (UE arrival / departure; the compact-record twin is skipped by run_case)."""
+    r5 = np.random.default_rng(spec['seed'] ^ 0x51ED270B)
+    if r5.random() >= frac:
+        return spec
+    c = dict(spec)
+    B0, B = c['B'], int(r5.choice([33, 34, 36, 40, 47, 48, 56, 63, 64]))
+    if c['U'] * B > 5000:
+        c['U'] = max(1, 5000 // B)
+        for k in ('vel', 'util', 'req', 'init', 'pause', 'border'):
+            if c.get(k) is not None:
+                c[k] = c[k][:c['U']]
+    integer_bs = all(float(x).is_integer() and float(y).is_integer() for x, y in c['bs_xy'])
+    c['bs_xy'] = list(c['bs_xy']) + [[float(r5.integers(0, c['w'] + 1)), float(r5.integers(0, c['h'] + 1))] if integer_bs else
+                                      [float(r5.uniform(0, c['w'])), float(r5.uniform(0, c['h']))] for _ in range(B - B0)]
+    c['sh'] = list(c['sh']) + [c['sh'][b % B0] if len(set(c['sh'])) > 1 or r5.random() < 0.5 else SHARING[int(r5.integers(0, 4))] for b in range(B0, B)]
+    c['B'], c['arrival'], c['many_stations'] = B, None, True
+    return c
 
 
 def build_case(spec):
@@ -187,7 +209,7 @@ def run_case(c, torch):
     # round 4: multi-agent envs also run a TWIN whose steps write the compact record themselves
     # (dcomp_out.obs_compact): unpack of it must be the core env's rows bit for bit, pack of the rows the record word for word
     twin = codec = packed = trew = None
-    if kind == 'multi':
+    if kind == 'multi' and B <= 32:                     # (the compact record holds one 32-bit connection mask per UE)
         from deepcomp_amd.fragment import FragmentCodec
         os.environ['DCOMP_TIGHT'] = '1' if c.get('tight') else '0'
         try:
@@ -270,7 +292,7 @@ def run_case(c, torch):
 
 
 def describe(c):
-    return (f"{'TIGHT ' if c.get('tight') else ''}{'ROLLOUT x' + str(c['rollout']) + ' ' if c.get('rollout') else ''}{'PAUSE/BORDER ' if c.get('pause') else ''}{'TAPE rand_episodes=' + str(c.get('rand_episodes')) + ' ' if c.get('tape') else ''}{'DYN ' + str(c['arrival']) + ' ' if c.get('arrival') else ''}{c['kind']} U={c['U']} B={c['B']} E={c['E']} map={c['w']}x{c['h']} reward={c['reward']} sharing={sorted(set(c['sh']))} "
+    return (f"{'MANY-STATIONS ' if c.get('many_stations') else ''}{'TIGHT ' if c.get('tight') else ''}{'ROLLOUT x' + str(c['rollout']) + ' ' if c.get('rollout') else ''}{'PAUSE/BORDER ' if c.get('pause') else ''}{'TAPE rand_episodes=' + str(c.get('rand_episodes')) + ' ' if c.get('tape') else ''}{'DYN ' + str(c['arrival']) + ' ' if c.get('arrival') else ''}{c['kind']} U={c['U']} B={c['B']} E={c['E']} map={c['w']}x{c['h']} reward={c['reward']} sharing={sorted(set(c['sh']))} "
             f"seed={c['seed']} base={c['base']} steps={c['steps']} p_noop={c['p_noop']}")
 
 
@@ -278,12 +300,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=200)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--many-stations', type=float, default=0.0, help='fraction of the cases that get 33 ... 64 stations (generic kernel, csrc/dcomp_big.h)')
     a = ap.parse_args()
     import torch
     rng = np.random.default_rng(a.seed)
     bad = 0
     for i in range(a.cases):
-        c = random_case(rng)
+        c = build_case(many_stations(random_spec(rng), a.many_stations))
         try:
             run_case(c, torch)
         except (AssertionError, Exception) as ex:      # noqa: BLE001

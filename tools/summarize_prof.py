@@ -36,6 +36,6 @@ for f in find('pmc_*/**/*counter_collection.csv'):
             agg[row['Kernel_Name'][:60]][row['Counter_Name']].append(float(row['Counter_Value']))
     print(os.path.relpath(f, out))
     for k, cs in agg.items():
-        if 'step_kernel' not in k and 'reset_kernel' not in k and 'rollout_kernel' not in k:
+        if 'step_kernel' not in k and 'reset_kernel' not in k and 'rollout_kernel' not in k and 'big_kernel' not in k:
             continue
         print('  ', k, {c: (sum(v) / len(v)) for c, v in cs.items()}, 'dispatches', len(next(iter(cs.values()))))
