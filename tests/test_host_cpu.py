@@ -255,6 +255,20 @@ def test_abi_guard_rejects_a_stale_caller_without_gpu(lib):
     assert [int(x) for x in got] == [_lib.ABI_VERSION] + sizes, 'the ctypes mirrors and include/dcomp*.h disagree about a struct size'
 
 
+def test_header_is_c99_and_the_c_host_example_builds_without_gpu(lib, tmp_path):
+    """include/dcomp.h is a C header (the FFI of a Go / Java / C host binds it): it must pass a pedantic C99 compiler, and
+    examples/c_host_step.cpp -- the non-Python host tests/test_c_host_gpu.py runs on the GPU -- must compile and link against the library."""
+    import subprocess
+    src = tmp_path / 'a.c'
+    src.write_text('#include "dcomp.h"\nint main(void) { dcomp_cfg c = {0}; dcomp_out o = {0}; dcomp_env *e = 0; (void)o; return dcomp_create(&c, &e) == DCOMP_EABI; }\n')
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-Werror', '-pedantic', '-fsyntax-only', '-I', os.path.join(REPO, 'include'), str(src)], check=True)
+    csrc = os.path.join(REPO, 'deepcomp_amd', 'csrc')
+    r = subprocess.run(['hipcc', '--offload-arch=gfx950', '-O2', '-I', os.path.join(REPO, 'include'), '-o', str(tmp_path / 'c_host_step'),
+                        os.path.join(REPO, 'examples', 'c_host_step.cpp'), '-L', csrc, '-ldcomp_hip', f'-Wl,-rpath,{csrc}'],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+
+
 def test_named_ue_arrival_schedules_are_the_references():
     """env_setup.py:205-226: the five `--ue-arrival` schedules as data, against what the reference's own get_ue_arrival returned
     (tests/golden/ue_arrival_schedules.json, recorded by gen_golden.py) -- and against the one a reference-run trajectory used."""

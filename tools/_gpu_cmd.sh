@@ -2,12 +2,8 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -1
-timeout 600 python -m pytest tests/test_bigb_gpu.py -q -x 2>&1 | tail -3
-timeout 600 python -m pytest tests/test_parity_gpu.py -q -x -k "dense" 2>&1 | tail -2
-B="python bench.py --no-also --no-cpu-baseline --no-stream --steps 200 --warmup 20"
-for cfg in "--envs 8192 --ues 32 --bs 64" "--envs 8192 --ues 32 --bs 33" "--envs 65536 --ues 32 --bs 40" "--envs 2048 --ues 128 --bs 64" "--envs 65536 --ues 10 --bs 40 --kind central"; do
-  echo "== $cfg"; $B $cfg 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']; print(r['kernel'], 'kernel_ms', round(r['kernel_ms'],4), 'frac', round(r['frac'],3), 'env-steps/s', round(j['value']))"
-done
-echo "== generic at 8192x32x32 and 65536x32x10"
-DCOMP_FORCE_BIG=1 $B --envs 8192 --ues 32 --bs 32 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']; print(r['kernel'], 'kernel_ms', round(r['kernel_ms'],4), 'frac', round(r['frac'],3))"
-DCOMP_FORCE_BIG=1 $B 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']; print(r['kernel'], 'kernel_ms', round(r['kernel_ms'],4), 'frac', round(r['frac'],3))"
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -12 > $O/r05_gpu_pytest_tail.txt; tail -4 $O/r05_gpu_pytest_tail.txt
+bash tools/profile_all.sh r05 2>&1 | tail -16 | cut -c1-260
+timeout 900 python tools/fuzz_parity.py --cases 1500 --seed 737373 --many-stations 0.5 > $O/r05_fuzz_seed737373.txt 2>&1; tail -2 $O/r05_fuzz_seed737373.txt | cut -c1-300
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r05_bench_line.json 2> $O/r05_bench_line.err; tail -c 700 $O/r05_bench_line.json
+python bench.py --gpus 1 --spawn --steps 20 --warmup 5 --no-cpu-baseline > $O/r05_bench_line_spawn.json 2> $O/r05_bench_line_spawn.err; tail -c 300 $O/r05_bench_line_spawn.json

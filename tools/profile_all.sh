@@ -20,6 +20,7 @@ bash tools/profile_gpu.sh ${P}_c5big --envs 32768 --ues 128 --bs 32 > /dev/null 
 bash tools/profile_gpu.sh ${P}_c3compact --compact-step > /dev/null 2>&1; keep ${P}_c3compact
 bash tools/profile_gpu.sh ${P}_c5bigcompact --envs 32768 --ues 128 --bs 32 --compact-step > /dev/null 2>&1; keep ${P}_c5bigcompact
 bash tools/profile_gpu.sh ${P}_central --envs 65536 --ues 10 --bs 5 --kind central > /dev/null 2>&1; keep ${P}_central
+bash tools/profile_gpu.sh ${P}_big64 --envs 8192 --ues 32 --bs 64 > /dev/null 2>&1; keep ${P}_big64        # the generic kernel (33 ... 64 stations)
 bash tools/profile_rollout.sh ${P}_c2roll 4096 10 5 central 100 > /dev/null 2>&1; keep ${P}_c2roll
 bash tools/profile_rollout.sh ${P}_centralroll 65536 10 5 central 50 > /dev/null 2>&1; keep ${P}_centralroll
 ls -la $DST
