@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('DCOMP_LIB') or os.path.join(_HERE, 'csrc', 'libdcomp_hip.so')   # DCOMP_LIB: tools/ablate.py timing variants
+LIB_PATH = os.environ.get('DCOMP_LIB') or os.path.join(_HERE, 'csrc', 'libdcomp_hip.so')   # DCOMP_LIB: tools/ab/ablate.py timing variants
 
 OK, EINVAL, EHIP, EACTION, ETAPE, EPOS, EUNSUPPORTED, EABI = 0, -1, -2, -3, -4, -5, -6, -7
 ABI_VERSION = 3                 # include/dcomp.h DCOMP_ABI_VERSION: what the struct declarations below describe

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """A/B of library builds on ONE GPU box (boxes differ by +-3 %, so only same-box comparisons count).
 
-  python tools/ab_lib.py build <tag> [--ref GITREF] [--b 5,10,32] [--flags "-DX=1 ..."]     (build container)
+  python tools/ab/ab_lib.py build <tag> [--ref GITREF] [--b 5,10,32] [--flags "-DX=1 ..."]     (build container)
         -> deepcomp_amd/csrc/variants/libdcomp_hip_<tag>.so from the working tree, or from the sources at GITREF
            (csrc/ + include/ exported to a scratch directory); only the listed base-station counts (seconds, not minutes)
-  python tools/ab_lib.py run <tag> <tag> ... [--rounds 2] [--only c3,c2roll,...]              (GPU box, via gpurun)
+  python tools/ab/ab_lib.py run <tag> <tag> ... [--rounds 2] [--only c3,c2roll,...]              (GPU box, via gpurun)
         -> every workload timed with every library, interleaved `rounds` times, one child process per (library, round);
            prints kernel ms per step (HIP events, steady state) and the ratio to the first tag
-  python tools/ab_lib.py measure [--only ...]     (child: the library is whatever DCOMP_LIB names)
+  python tools/ab/ab_lib.py measure [--only ...]     (child: the library is whatever DCOMP_LIB names)
 
 Workloads: BASELINE config 3 (65 536 x 32 x 10 multi, one launch per step), config 2 through the fused rollout (4 096 x 10 x 5
 central, 100 steps per launch, every step's outputs), one GPU's share of config 5 (4 096 x 128 x 32) and of config 4
@@ -20,7 +20,7 @@ import subprocess
 import sys
 import tempfile
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))     # tools/ab/ -> the repo
 CSRC = os.path.join(REPO, 'deepcomp_amd', 'csrc')
 VAR = os.path.join(CSRC, 'variants')
 BASE = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast-honor-pragmas']

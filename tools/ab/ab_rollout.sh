@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: A/B of timing variants on the fused rollout.  usage: tools/ab_rollout.sh "<tag> ..." E U B kind T
+# GPU box: A/B of timing variants on the fused rollout.  usage: tools/ab/ab_rollout.sh "<tag> ..." E U B kind T
 cd $GRAFT_REPO_ROOT
 TAGS=$1; shift
 for t in $TAGS; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: A/B of timing variants built by tools/ablate.py.  usage: tools/ab_variants.sh "<tag> ..." [bench args]
+# GPU box: A/B of timing variants built by tools/ab/ablate.py.  usage: tools/ab/ab_variants.sh "<tag> ..." [bench args]
 cd $GRAFT_REPO_ROOT
 TAGS=$1; shift
 for t in $TAGS; do

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Timing-only ablation variants of the step kernel (results are WRONG by construction; never shipped).
 
-  python tools/ablate.py build            # here: builds deepcomp_amd/csrc/variants/libdcomp_hip_abl<N>.so for B=10
-  python tools/ablate.py run              # on the GPU box: bench each variant, print kernel_ms table
+  python tools/ab/ablate.py build            # here: builds deepcomp_amd/csrc/variants/libdcomp_hip_abl<N>.so for B=10
+  python tools/ab/ablate.py run              # on the GPU box: bench each variant, print kernel_ms table
 bits: 1 pre-move rates, 2 move, 4 post-move rates, 8 obs stores, 16 per-BS utility sums, 32 pre-move pairs,
       64 post-move pairs, 128 philox
 """
@@ -11,7 +11,7 @@ import os
 import subprocess
 import sys
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))     # tools/ab/ -> the repo
 CSRC = os.path.join(REPO, 'deepcomp_amd', 'csrc')
 VAR = os.path.join(CSRC, 'variants')
 MASKS = [0, 1, 2, 4, 8, 16, 32, 64, 128, 1 | 4, 32 | 64, 8 | 16, 255]
