@@ -124,8 +124,15 @@ class StaticClustering:
 
     def act(self, env, out=None):
         if self._bits is None or self._bits.device != env.device:      # bit o of word b = cell o in b's cluster
-            w = (self.member.to(torch.int64) << torch.arange(self.member.shape[1], device=self.member.device)).sum(dim=1)
-            self._bits = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).to(env.device).contiguous()
+            B = self.member.shape[1]
+
+            def word(cols):                                             # the int32 bit pattern of 32 membership columns
+                w = (cols.to(torch.int64) << torch.arange(cols.shape[1], device=cols.device)).sum(dim=1)
+                return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
+            if B <= 32:
+                self._bits = word(self.member).to(env.device).contiguous()
+            else:                                                       # [B, 2]: stations 0-31 | 32-63 (include/dcomp.h, dcomp_policy.cluster_mask)
+                self._bits = torch.stack([word(self.member[:, :32]), word(self.member[:, 32:])], dim=1).to(env.device).contiguous()
         return _act(env, 'cluster', cluster_mask=self._bits, out=out)
 
     def _build(self):

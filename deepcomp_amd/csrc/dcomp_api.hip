@@ -945,38 +945,39 @@ __global__ void __launch_bounds__(256) heuristic_kernel(PolicyParams p, const fl
     const float *row = buf + lane * S;
     const int64_t r = r0 + lane;
     const int u = (int)(r % p.U);
-    uint32_t conn = 0;
+    unsigned long long conn = 0;                                       // (64-bit sets: up to 64 stations, round 5)
     float mx = -__builtin_huge_valf();
     int best = 0;
 #pragma unroll 8
     for (int b = 0; b < B; b++) {
-        conn |= (row[b] > 0.5f ? 1u : 0u) << b;
+        conn |= (row[b] > 0.5f ? 1ull : 0ull) << b;
         const float d = row[B + b];
         if (d > mx) { mx = d; best = b; }                              // strict: the first maximum (np.argmax, heuristics.py:27)
     }
     int a = 0;
     if (u >= p.active) a = 0;
     else if (p.policy == DCOMP_POLICY_3GPP) {
-        if ((conn >> best) & 1u) a = 0;                                // heuristics.py:30-31: already at the best cell
-        else if (conn) a = __builtin_ffs((int)conn);                   // :33-36: drop the (first) other connection
+        if ((conn >> best) & 1ull) a = 0;                              // heuristics.py:30-31: already at the best cell
+        else if (conn) a = __builtin_ffsll((long long)conn);           // :33-36: drop the (first) other connection
         else a = best + 1;                                             // :38
     } else {
-        uint32_t sel = B == 32 ? ~0u : (1u << B) - 1u;                 // FullCoMP: every cell
+        unsigned long long sel = B == 64 ? ~0ull : (1ull << B) - 1ull; // FullCoMP: every cell
         if (p.policy == DCOMP_POLICY_DYNAMIC) {
             const float thr = mx * p.eps;                              // heuristics.py:87-90
             sel = 0;
 #pragma unroll 8
-            for (int b = 0; b < B; b++) sel |= (row[B + b] >= thr ? 1u : 0u) << b;
-        } else if (p.policy == DCOMP_POLICY_CLUSTER) sel = p.cluster[best];   // :172-176
-        const uint32_t drop = conn & ~sel;
-        if (drop) a = __builtin_ffs((int)drop);                        // :96-99 / :178-181: index order
+            for (int b = 0; b < B; b++) sel |= (row[B + b] >= thr ? 1ull : 0ull) << b;
+        } else if (p.policy == DCOMP_POLICY_CLUSTER)                   // :172-176; one word per station up to 32 stations, two (lo, hi) beyond
+            sel = B <= 32 ? (unsigned long long)p.cluster[best] : ((unsigned long long)p.cluster[2 * best] | ((unsigned long long)p.cluster[2 * best + 1] << 32));
+        const unsigned long long drop = conn & ~sel;
+        if (drop) a = __builtin_ffsll((long long)drop);                // :96-99 / :178-181: index order
         else {
-            uint32_t cand = sel & ~conn;
+            const unsigned long long cand = sel & ~conn;
             float m2 = -__builtin_huge_valf();
 #pragma unroll 8
             for (int b = 0; b < B; b++) {
                 const float d = row[B + b];
-                if (((cand >> b) & 1u) && d > m2) { m2 = d; a = b + 1; }   // strongest first, first of equals (:57-63, :101-106)
+                if (((cand >> b) & 1ull) && d > m2) { m2 = d; a = b + 1; }   // strongest first, first of equals (:57-63, :101-106)
             }
         }
     }
@@ -1003,8 +1004,8 @@ extern "C" int dcomp_set_policy(dcomp_env *env, const dcomp_policy *p, uint8_t *
 extern "C" int dcomp_heuristic_actions(const dcomp_policy *p, const float *obs, uint8_t *action, void *stream)
 {
     if (!p || !obs || !action) return fail(DCOMP_EINVAL, "null argument");
-    if (p->num_envs < 1 || p->num_ue < 1 || p->num_ue > DCOMP_MAX_UE || p->num_bs < 1 || p->num_bs > DCOMP_MAX_BS || p->num_bs > 32)
-        return fail(DCOMP_EINVAL, "need num_envs>=1, 1<=num_ue<=%d, 1<=num_bs<=32 (got %d, %d, %d)", DCOMP_MAX_UE, p->num_envs, p->num_ue, p->num_bs);
+    if (p->num_envs < 1 || p->num_ue < 1 || p->num_ue > DCOMP_MAX_UE || p->num_bs < 1 || p->num_bs > DCOMP_MAX_BS)
+        return fail(DCOMP_EINVAL, "need num_envs>=1, 1<=num_ue<=%d, 1<=num_bs<=%d (got %d, %d, %d)", DCOMP_MAX_UE, DCOMP_MAX_BS, p->num_envs, p->num_ue, p->num_bs);
     if (p->policy < DCOMP_POLICY_3GPP || p->policy > DCOMP_POLICY_CLUSTER) return fail(DCOMP_EINVAL, "unknown policy %d", p->policy);
     if (p->obs_kind != DCOMP_CENTRAL && p->obs_kind != DCOMP_MULTI) return fail(DCOMP_EINVAL, "obs_kind must be DCOMP_CENTRAL or DCOMP_MULTI");
     if (p->num_active < 0 || p->num_active > p->num_ue) return fail(DCOMP_EINVAL, "num_active (%d) outside [0, num_ue]", p->num_active);
@@ -1017,6 +1018,13 @@ extern "C" int dcomp_heuristic_actions(const dcomp_policy *p, const float *obs, 
     const size_t per_wave = (size_t)64 * ((k.multi ? 4 : 2) * p->num_bs + 1) * sizeof(float);
     int wpb = (int)(60 * 1024 / per_wave);
     wpb = wpb > 4 ? 4 : wpb < 1 ? 1 : wpb;
+    if (per_wave * wpb > 64 * 1024) {           // 64 rows of more than 60 stations: one wave per workgroup, above the default 64 KiB of dynamic LDS
+        static bool raised = false;
+        if (!raised) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(heuristic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+            raised = true;
+        }
+    }
     const int64_t waves = (k.rows + 63) / 64;
     dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
     hipLaunchKernelGGL(heuristic_kernel, grid, block, per_wave * wpb, (hipStream_t)stream, k, obs, action);

@@ -675,7 +675,7 @@ class BatchedMobileEnv:
         if policy == 'cluster':
             if cluster_mask is None:
                 raise ValueError("policy 'cluster' needs cluster_mask")
-            self._require(cluster_mask, torch.int32, self.B, 'cluster_mask')
+            self._require(cluster_mask, torch.int32, self.B * (1 if self.B <= _lib.MASK32_MAX_BS else 2), 'cluster_mask')   # > 32 stations: [B, 2] words (lo, hi)
             cm = cluster_mask.data_ptr()
         p = _lib.DcompPolicy(_lib.POLICY[policy], self.kind, self.E, self.U, self.B, self.num_ue, float(epsilon), cm)
         with torch.cuda.device(self.device):
@@ -699,7 +699,7 @@ class BatchedMobileEnv:
         if policy == 'cluster':
             if cluster_mask is None:
                 raise ValueError("policy 'cluster' needs cluster_mask")
-            self._require(cluster_mask, torch.int32, self.B, 'cluster_mask')
+            self._require(cluster_mask, torch.int32, self.B * (1 if self.B <= _lib.MASK32_MAX_BS else 2), 'cluster_mask')   # > 32 stations: [B, 2] words (lo, hi)
             cm = cluster_mask.data_ptr()
         # two buffers, written alternately: the tensor handed to step() stays what the caller read until the step after
         # (and with UE arrival / departure slots shift, so a step must not write the tensor it reads its actions from)

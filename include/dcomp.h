@@ -198,7 +198,8 @@ typedef struct dcomp_policy {
     int32_t num_envs, num_ue, num_bs;
     int32_t num_active;          /* UEs listed (<= num_ue) */
     float epsilon;               /* DCOMP_POLICY_DYNAMIC (heuristics.py:75) */
-    const uint32_t *cluster_mask;/* DCOMP_POLICY_CLUSTER, device [num_bs] */
+    const uint32_t *cluster_mask;/* DCOMP_POLICY_CLUSTER, device [num_bs]: bit o of word b = station o is in b's cluster; with more than 32
+                                  * stations [num_bs][2] = {stations 0-31, stations 32-63} per station */
 } dcomp_policy;
 int dcomp_heuristic_actions(const dcomp_policy *p, const float *obs, uint8_t *action, void *stream);
 

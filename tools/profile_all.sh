@@ -18,6 +18,7 @@ bash tools/profile_gpu.sh ${P}_c4share --envs 32768 > /dev/null 2>&1; keep ${P}_
 bash tools/profile_gpu.sh ${P}_c5 --envs 4096 --ues 128 --bs 32 > /dev/null 2>&1; keep ${P}_c5
 bash tools/profile_gpu.sh ${P}_c5big --envs 32768 --ues 128 --bs 32 > /dev/null 2>&1; keep ${P}_c5big
 bash tools/profile_gpu.sh ${P}_c3compact --compact-step > /dev/null 2>&1; keep ${P}_c3compact
+bash tools/profile_gpu.sh ${P}_c5compact --envs 4096 --ues 128 --bs 32 --compact-step > /dev/null 2>&1; keep ${P}_c5compact
 bash tools/profile_gpu.sh ${P}_c5bigcompact --envs 32768 --ues 128 --bs 32 --compact-step > /dev/null 2>&1; keep ${P}_c5bigcompact
 bash tools/profile_gpu.sh ${P}_central --envs 65536 --ues 10 --bs 5 --kind central > /dev/null 2>&1; keep ${P}_central
 bash tools/profile_gpu.sh ${P}_big64 --envs 8192 --ues 32 --bs 64 > /dev/null 2>&1; keep ${P}_big64        # the generic kernel (33 ... 64 stations)
