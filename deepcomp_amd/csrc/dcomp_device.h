@@ -239,8 +239,11 @@ __device__ __forceinline__ void group_reduce_vec(float (&v)[N])
 #pragma unroll
     for (int i = 0; i < N; i++) v[i] = group_reduce<W, Op>(v[i]);
 #else
+    // The empty asm after every combine keeps the SLP vectoriser from pairing the N independent adds of a stage into v_pk_add_f32: a packed
+    // add cannot take a DPP operand, so every pair then cost v_mov_b32_dpp x 2 + v_pk_add_f32 instead of v_add_f32_dpp x 2 (round 5: the
+    // launch is VALU-issue-bound at the clock the part holds under it, profiles/r05_c3_clock_trace.txt)
 #define DCOMP_STAGE(EXPR)                          \
-    _Pragma("unroll") for (int i = 0; i < N; i++) v[i] = Op::f(v[i], EXPR);
+    _Pragma("unroll") for (int i = 0; i < N; i++) { v[i] = Op::f(v[i], EXPR); asm volatile("" : "+v"(v[i])); }
     if (W >= 2) { DCOMP_STAGE(dpp_f32<DCOMP_DPP_QUAD_X1>(v[i])) }
     if (W >= 4) { DCOMP_STAGE(dpp_f32<DCOMP_DPP_QUAD_X2>(v[i])) }
     if (W >= 8) { DCOMP_STAGE(dpp_f32<DCOMP_DPP_HALF_MIRROR>(v[i])) }
@@ -345,14 +348,22 @@ __device__ __forceinline__ float clamp_med3(float x, float lo, float hi) { retur
 //   snr = K * (d + 1e-16)^(-gamma)  ->  log2 snr = log2 K - (gamma/2) * log2(d^2)   for d >> 1e-16.
 // `tiny` flags d^2 < 1e-20 (UE sitting on a BS: waypoints and BS positions share the integer grid), where the
 // +1e-16 of station.py:116 matters; those pairs are redone by pair_eval_tiny under a wave-uniform rare branch.
+// (pair_eval_q: the same with the float d^2 handed back instead of the `near` test -- eval_pairs keeps the MINIMUM over the stations and
+// tests once: one v_med3 per station instead of a compare and an OR)
+__device__ __forceinline__ void pair_eval_q(double px, double py, double bx, double by, const KParams &p, bool &in_range, float &l2snr, float &q);
 __device__ __forceinline__ void pair_eval(double px, double py, double bx, double by, const KParams &p, bool &in_range,
                                           float &l2snr, bool &tiny)
+{
+    float q;
+    pair_eval_q(px, py, bx, by, p, in_range, l2snr, q);
+    tiny = q < NEAR_D2;                          // "near": superset of the d^2 < 1e-20 pairs the fix-up replaces
+}
+__device__ __forceinline__ void pair_eval_q(double px, double py, double bx, double by, const KParams &p, bool &in_range, float &l2snr, float &q)
 {
     double dx = bx - px, dy = by - py;
     double dsq = __builtin_fma(dy, dy, dx * dx);
     in_range = dsq < p.dt2;                      // snr > 2e-8  <=>  d < d_T, decided in FP64
-    float q = (float)dsq;
-    tiny = q < NEAR_D2;                          // "near": superset of the d^2 < 1e-20 pairs the fix-up replaces
+    q = (float)dsq;
     // v_log_f32's absolute error scales with |result| (log2 d^2 ~ 12 near the connect range -> ~1e-6, i.e. ~1.1e-6
     // relative in snr = 2^l2snr).  Scaling d^2 by 2^-12 first puts every in-range pair at |log2| < 4 for the price
     // of one multiply (the exact alternative, frexp + two FMAs, costs 3 % of the step; tools/numerics_report.py has
@@ -399,15 +410,16 @@ __device__ __forceinline__ uint32_t eval_pairs(double px, double py, const KPara
                                                const double *bsx = nullptr, const double *bsy = nullptr)
 {
     uint32_t in_range = 0;
-    bool anynear = false;
+    float qmin = 3.0e38f;
 #pragma unroll
     for (int b = 0; b < B; b++) {
-        bool ir, near;
-        pair_eval(px, py, bsx ? bsx[b] : DCOMP_BSX(b), bsy ? bsy[b] : DCOMP_BSY(b), p, ir, l2[b], near);
+        bool ir;
+        float q;
+        pair_eval_q(px, py, bsx ? bsx[b] : DCOMP_BSX(b), bsy ? bsy[b] : DCOMP_BSY(b), p, ir, l2[b], q);
         in_range |= (uint32_t)ir << b;
-        anynear |= near;
+        qmin = min_med3(qmin, q);
     }
-    const bool nw = __ballot(anynear) != 0ull;
+    const bool nw = __ballot(qmin < NEAR_D2) != 0ull;
     if (near_wave) *near_wave = nw;
     if (nw) {                                    // rare (~3 % of the wavefronts): a lane within 1.26 m of a BS
 #pragma unroll
@@ -890,6 +902,9 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
     }
 #pragma unroll
     for (int b = 0; b < B; b++) {
+        // No contraction in here: without the select below the caller's `curr += dr[b]` would see a bare product and the compiler could fuse it
+        // into an FMA in one kernel instantiation and not in another (step vs fused rollout: one ulp apart, tests/test_rollout_gpu.py)
+#pragma clang fp contract(off)
         const bool c = (conn >> b) & 1u;
         const int mode = bs_mode_of<MP>(p, b);
         float dru = dr[b], out = 0.f;
@@ -897,7 +912,9 @@ __device__ __forceinline__ void shared_rates(const KParams &p, BlockSharedT<B, U
         else if (mode == DCOMP_RATE_FAIR) out = fast_rcp(agg[b]);                                    // station.py:180
         else if (mode == DCOMP_PROP_FAIR) out = (dru * inv_ewma) * fast_rcp(agg[b] + EPS) * dru;     // station.py:194-195
         else out = ((mc_winner >> b) & 1u) ? dru : 0.f;
-        dr[b] = c ? out : 0.f;
+        // dru is 0 where the UE is not connected, so the resource-fair and proportional-fair shares are 0 there by themselves (finite
+        // factors: rcp(max(cnt, 1)), rcp(agg + eps)); only 1 / sum of a rate-fair station is the same for every lane and needs the select
+        dr[b] = (mode == DCOMP_RES_FAIR || mode == DCOMP_PROP_FAIR) ? out : (c ? out : 0.f);
     }
 }
 
@@ -1001,7 +1018,7 @@ __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, B
         } else {
             r[0] = seg_reduce<G::WG, OpSum>(alive ? reward_before : 0.f, sg, lane);
             xwave_reduce_<1, G::NW, OpSum>(r, sh, wave, lane);
-            if (p.reward_agg == DCOMP_REWARD_AVG) r[0] = r[0] / (float)n_eff;
+            if (p.reward_agg == DCOMP_REWARD_AVG) r[0] = r[0] * fast_rcp((float)n_eff);      // (v_rcp_f32, 1 ulp: the IEEE division sequence is 11 instructions)
         }
         reward = r[0];
     } else if (!RESET) {
@@ -1022,8 +1039,15 @@ __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, B
             if (p.reward_agg == DCOMP_REWARD_AVG) {                 // multi_agent.py:60-71
                 float n = 0.f, t = 0.f;
 #pragma unroll
-                for (int b = 0; b < B; b++) if ((in_range >> b) & 1u) { n += cnt[b]; t += tsum[b]; }
-                if (n > 0.f) reward = (conn == 0u) ? (t + util) / (n + 1.f) : t / n;
+                for (int b = 0; b < B; b++) {                        // (bit -> 0.f / 1.f, two FMAs: exactly the conditional adds, four instructions per station)
+                    const float ind = (float)((in_range >> b) & 1u);
+                    n = __builtin_fmaf(ind, cnt[b], n);
+                    t = __builtin_fmaf(ind, tsum[b], t);
+                }
+                if (n > 0.f) {                                       // ONE reciprocal (1 ulp) instead of two IEEE divisions (2 x 12 instructions)
+                    const bool lone = conn == 0u;
+                    reward = (lone ? t + util : t) * fast_rcp(lone ? n + 1.f : n);
+                }
             } else {                                                // multi_agent.py:81-85, station.py:78-83
                 float tmin[B];
 #pragma unroll
@@ -1052,7 +1076,7 @@ __device__ __forceinline__ void write_outputs(const KParams &p, const Outs &o, B
     }
 
     // ---- observation entries (in place): l2 -> snr_b / max snr, tsum -> avg utility at BS, cnt -> UEs at BS / U
-    const float inv_u = 1.0f / (float)n_eff;
+    const float inv_u = fast_rcp((float)n_eff);
     // DYN (UE lists that change, and reset of such envs): dead slots produce zero rows.  Otherwise every row that is stored
     // belongs to a live UE (alive == active), so the entries need no select.
     const bool live = DYN ? alive : true;
@@ -1394,7 +1418,11 @@ __device__ __forceinline__ void step_once(const KParams &p, BlockSharedT<B, UPAD
     // 4. move (base.py:447 -> user.py:159-173)
     if (active && !(DCOMP_ABLATE & 2)) {
         move_ue<!STORE>(p, env, (uint32_t)u + 1u, episode, px, py, mv, vrange);       // !STORE = the fused rollout
-        if (px < 0.0 || py < 0.0 || px > (double)p.map_w || py > (double)p.map_h) atomicOr(p.flags, DCOMP_FLAG_OUTSIDE_MAP);
+        // movement.py:165-166: inside [0, W] x [0, H].  Non-negative doubles order like their bit patterns, and a negative one (or a NaN) has
+        // the top bit set: two unsigned 64-bit compares instead of four FP64 compares (px / py cannot be -0.0: a UE lands on integer waypoints
+        // as (double)int, and x + (-0.0) = x otherwise)
+        if ((unsigned long long)__double_as_longlong(px) > (unsigned long long)__double_as_longlong((double)p.map_w) ||
+            (unsigned long long)__double_as_longlong(py) > (unsigned long long)__double_as_longlong((double)p.map_h)) atomicOr(p.flags, DCOMP_FLAG_OUTSIDE_MAP);
     }
     // 5. pairs at the new position; drop lost connections (user.py:175-188); EWMA from the stale rates (user.py:148-157)
     if (!(DCOMP_ABLATE & 64)) in_range = eval_pairs<B>(px, py, p, l2, &near_post, bsx, bsy);
@@ -1406,7 +1434,8 @@ __device__ __forceinline__ void step_once(const KParams &p, BlockSharedT<B, UPAD
     conn &= in_range;
     float stale = 0.f;
 #pragma unroll
-    for (int b = 0; b < B; b++) stale += ((conn >> b) & 1u) ? dr[b] : 0.f;
+    for (int b = 0; b < B; b++)                        // (bit -> 0 / -1 with one v_bfe_i32, AND, add: the select form costs two instructions more per station)
+        stale += __int_as_float(__float_as_int(dr[b]) & __builtin_amdgcn_sbfe((int)conn, b, 1));
     ewma = __builtin_fmaf(0.9f, stale, 0.1f * ewma);   // one explicit contraction: every kernel variant rounds alike
     // 6. rates after the move (base.py:451)
     if (CARRY) shared_rates<B, UPAD, MP, S, false, 1>(p, sh, conn, l2, ewma, px, py, u, idx, env_local, wave, lane, gbase, dr, cnt, (int)near_post, sg, nullptr, carry->dru);

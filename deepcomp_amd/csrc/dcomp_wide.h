@@ -448,7 +448,7 @@ __device__ __forceinline__ void wide_step_one(const KParams &p, WideShared<B, UP
         return a;
     };
     float rn = 0.f, rt = 0.f, rmin = util;
-    const float inv_u = 1.0f / (float)p.U;
+    const float inv_u = fast_rcp((float)p.U);                      // (v_rcp_f32: the IEEE division sequence is 11 instructions)
     if (multi && p.reward_agg != DCOMP_REWARD_SUM) {                              // multi_agent.py:60-71, 81-85
         // over the stations in range of this UE (1-2 of the B on the grid layouts): sparse again, per-lane station index
         uint32_t todo = active ? inr_new : 0u;
@@ -474,7 +474,7 @@ __device__ __forceinline__ void wide_step_one(const KParams &p, WideShared<B, UP
 #pragma unroll
             for (int k = 1; k < NW; k++) r = is_min ? OpMin::f(r, sh.xw[0][w0 + k]) : r + sh.xw[0][w0 + k];
         }
-        if (p.reward_agg == DCOMP_REWARD_AVG) r = r / (float)p.U;
+        if (p.reward_agg == DCOMP_REWARD_AVG) r = r * fast_rcp((float)p.U);
         reward = r;
     } else {                                                                      // multi_agent.py:39-95
         reward = util;
@@ -488,7 +488,7 @@ __device__ __forceinline__ void wide_step_one(const KParams &p, WideShared<B, UP
                 reward = s;
             }
         } else if (p.reward_agg == DCOMP_REWARD_AVG) {
-            if (rn > 0.f) reward = (conn == 0u) ? (rt + util) / (rn + 1.f) : rt / rn;
+            if (rn > 0.f) { const bool lone = conn == 0u; reward = (lone ? rt + util : rt) * fast_rcp(lone ? rn + 1.f : rn); }   // one reciprocal, not two IEEE divisions
         } else {
             reward = rmin;
         }

@@ -49,7 +49,7 @@ def test_policy_entry_point_refuses_bad_arguments_on_the_host(lib):
     good = dict(policy=1, obs_kind=_lib.MULTI, num_envs=4, num_ue=3, num_bs=5, num_active=3, epsilon=0.5, cluster_mask=None)
     fake = ctypes.c_void_p(4096)                       # never dereferenced: every case below fails validation first
     assert lib.dcomp_heuristic_actions(None, fake, fake, None) == EINVAL
-    for bad in (dict(policy=7), dict(obs_kind=5), dict(num_bs=33), dict(num_ue=0), dict(num_active=4), dict(policy=2, epsilon=1.5),
+    for bad in (dict(policy=7), dict(obs_kind=5), dict(num_bs=65), dict(num_ue=0), dict(num_active=4), dict(policy=2, epsilon=1.5),      # (64 stations since round 5)
                 dict(policy=3)):
         p = _lib.DcompPolicy(**{**good, **bad})
         assert lib.dcomp_heuristic_actions(ctypes.byref(p), fake, fake, None) == EINVAL, bad

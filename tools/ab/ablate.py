@@ -30,7 +30,7 @@ def build():
     for m in MASKS:
         so = os.path.join(VAR, f'libdcomp_hip_abl{m}{TAG}.so')
         cmd = ['hipcc'] + FLAGS + EXTRA + [f'-DDCOMP_ABLATE={m}', f'-DDCOMP_B={ABL_B}', '-shared', os.path.join(CSRC, 'dcomp_inst.hip'),
-                                   os.path.join(CSRC, 'dcomp_api.hip'), '-o', so, '-lpthread']
+                                   os.path.join(CSRC, 'dcomp_api.hip'), os.path.join(CSRC, 'dcomp_big.hip'), '-o', so, '-lpthread']
         procs.append((m, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         if len(procs) % 6 == 0:
             for _, p in procs[-6:]:
