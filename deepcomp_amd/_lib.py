@@ -13,7 +13,8 @@ REWARD = {'avg': 0, 'sum': 1, 'min': 2}
 SHARING = {'resource-fair': 0, 'rate-fair': 1, 'max-cap': 2, 'proportional-fair': 3}
 UTILITY = {'log': 0, 'step': 1}
 RNG_TAPE, RNG_PHILOX = 0, 1
-MAX_BS, MAX_UE = 64, 256
+MAX_BS, MAX_UE = 64, 1024
+SPECIAL_MAX_UE = 256             # up to here the specialised kernels; 257 ... 1 024 UEs per env: the generic kernel (csrc/dcomp_big.h)
 MASK32_MAX_BS = 32              # up to here: one 32-bit connection mask per UE and the specialised kernels; beyond: state.conn_hi + the generic kernel
 
 _dp = ctypes.POINTER(ctypes.c_double)

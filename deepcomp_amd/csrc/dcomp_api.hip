@@ -176,10 +176,14 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
     }
     // More than 32 stations: the generic kernel (dcomp_big.h; one instantiation per lane width, B a run-time value, connection set in two
     // state words).  DCOMP_FORCE_BIG=1 sends smaller station counts there too (tests: generic against specialised kernels).
-    env->big = B > DCOMP_MASK32_MAX_BS || (getenv("DCOMP_FORCE_BIG") && atoi(getenv("DCOMP_FORCE_BIG")) != 0);
+    env->big = B > DCOMP_MASK32_MAX_BS || CAP > DCOMP_SPECIAL_MAX_UE || (getenv("DCOMP_FORCE_BIG") && atoi(getenv("DCOMP_FORCE_BIG")) != 0);
     env->mp_pattern = mp;
     if (env->big) {
-        if (DYN) { delete env; return fail(DCOMP_EUNSUPPORTED, "UE arrival / departure (max_ues) is not available with more than %d stations (generic kernel)", DCOMP_MASK32_MAX_BS); }
+        if (DYN) { delete env; return fail(DCOMP_EUNSUPPORTED, "UE arrival / departure (max_ues) is not available with more than %d stations or %d UE slots per env (generic kernel)", DCOMP_MASK32_MAX_BS, DCOMP_SPECIAL_MAX_UE); }
+        if (dcomp::big_lds_bytes(B, 1, env->upad < 64 ? 64 : env->upad) > 160 * 1024) {
+            delete env;
+            return fail(DCOMP_EINVAL, "%d UEs x %d stations do not fit one workgroup's LDS (generic kernel: (num_bs + 1) * %d lanes * 4 bytes of rows + tables > 160 KB)", U, B, env->upad);
+        }
         env->bigk = dcomp::big_kernels_for_upad(env->upad);
         if (!env->bigk.step) { delete env; return fail(DCOMP_EUNSUPPORTED, "no generic kernel for %d lanes per env", env->upad); }
         env->kern = dcomp::KernelPair{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1090,14 +1094,14 @@ extern "C" int dcomp_selftest(int op, int width, const double *x, const double *
 // ---- compact rollout fragments for the learner hand-off (dcomp_fragment.h) ----
 extern "C" int dcomp_fragment_words(int32_t num_ue, int32_t num_bs)
 {
-    if (num_ue < 1 || num_ue > DCOMP_MAX_UE || num_bs < 1 || num_bs > DCOMP_MASK32_MAX_BS) return -1;    // one 32-bit connection mask per UE
+    if (num_ue < 1 || num_ue > DCOMP_SPECIAL_MAX_UE || num_bs < 1 || num_bs > DCOMP_MASK32_MAX_BS) return -1;    // one 32-bit connection mask per UE; envs of the specialised kernels
     return dcomp_frag::env_words(num_ue, num_bs);
 }
 
 static int fragment_params(dcomp_frag::FragParams &p, int64_t n, int U, int B, int &grid, size_t &lds_pack, size_t &lds_unpack)
 {
-    if (n < 1 || U < 1 || U > DCOMP_MAX_UE || B < 1 || B > DCOMP_MASK32_MAX_BS)
-        return fail(DCOMP_EINVAL, "fragment: need num_env_steps >= 1, 1 <= num_ue <= %d, 1 <= num_bs <= %d", DCOMP_MAX_UE, DCOMP_MASK32_MAX_BS);
+    if (n < 1 || U < 1 || U > DCOMP_SPECIAL_MAX_UE || B < 1 || B > DCOMP_MASK32_MAX_BS)
+        return fail(DCOMP_EINVAL, "fragment: need num_env_steps >= 1, 1 <= num_ue <= %d, 1 <= num_bs <= %d", DCOMP_SPECIAL_MAX_UE, DCOMP_MASK32_MAX_BS);
     if (dcomp_frag::fill(p, n, U, B, grid, lds_pack, lds_unpack)) return fail(DCOMP_EINVAL, "fragment too long for one launch: split it (num_env_steps * chunks >= 2^31)");
     return DCOMP_OK;
 }

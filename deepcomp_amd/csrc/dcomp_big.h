@@ -36,7 +36,7 @@ __host__ __device__ constexpr int big_block(int upad) { return upad < 64 ? 64 : 
 __host__ __device__ inline size_t big_lds_bytes(int B, int gpb, int blk)
 {
     return 64 * sizeof(double2) + (size_t)blk * sizeof(double2) + (size_t)blk * sizeof(unsigned long long) + (size_t)blk * (B + 1) * 4 + (size_t)4 * blk * 4 +
-           (size_t)5 * gpb * B * 4 + 64 * 4;
+           (size_t)5 * gpb * B * 4 + 64 * 4 + (size_t)blk * 16;
 }
 
 __device__ __forceinline__ void big_pair(double px, double py, const double2 bp, const KParams &p, bool &in_range, float &l2)
@@ -67,7 +67,8 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
     unsigned long long *const mask_s = reinterpret_cast<unsigned long long *>(pos_s + BLK);
     float *const row = reinterpret_cast<float *>(mask_s + BLK);
     float *const ewma_s = row + BLK * BR, *const util_s = ewma_s + BLK, *const rb_s = util_s + BLK, *const l2max_s = rb_s + BLK;
-    float *const agg_n = l2max_s + BLK, *const agg_s = agg_n + GPB * B, *const agg_u = agg_s + GPB * B, *const agg_m = agg_u + GPB * B;
+    float4 *const part_s = reinterpret_cast<float4 *>(l2max_s + BLK);     // partial sums of split pairs (aggregate); 16-byte aligned here
+    float *const agg_n = reinterpret_cast<float *>(part_s + BLK), *const agg_s = agg_n + GPB * B, *const agg_u = agg_s + GPB * B, *const agg_m = agg_u + GPB * B;
     uint32_t *const mc_win = reinterpret_cast<uint32_t *>(agg_m + GPB * B);
     int *const mode_s = reinterpret_cast<int *>(mc_win + GPB * B);
 
@@ -113,21 +114,41 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
 
     // (env, station) sums over the UEs of an env.  WHAT: 0 = sharing terms from the l2snr values parked in the rows (count, sum of
     // 1 / rate resp. rate / (ewma + eps), the max-cap winner), 1 = utility sums (count, sum, min over the connected UEs).
+    // Envs of many lanes have few pairs per workgroup (512 lanes, 10 stations: 10 owners walking 512 rows each while 502 lanes wait: 4 096 x 512 x 10
+    // took 1.39 ms): there the rows of a pair are split over NSPLIT threads -- thread q * NSPLIT + k sums rows k, k + NSPLIT, ... -- and the owner
+    // adds the partial sums in the order k = 0 ... NSPLIT - 1 (still deterministic).
     auto aggregate = [&](int what) {
         const int P = GPB * B;
+        int nsplit = P >= BLK ? 1 : BLK / P;
+        nsplit = nsplit > 32 ? 32 : nsplit;
+        auto rows_of = [&](int el, int b, int first, int stride, float &n, float &s, float &mn) {
+            const int base = el * UPAD, mode = mode_s[b];
+            for (int v = first; v < U; v += stride) {
+                if (!((mask_s[base + v] >> b) & 1ull)) continue;
+                n += 1.f;
+                if (what == 1) { const float uv = util_s[base + v]; s += uv; mn = fminf(mn, uv); }
+                else if (mode == DCOMP_RATE_FAIR) s += fast_rcp(big_rate(row[(base + v) * BR + b]));                           // station.py:177-180
+                else if (mode == DCOMP_PROP_FAIR) s += big_rate(row[(base + v) * BR + b]) * fast_rcp(ewma_s[base + v] + EPS);   // station.py:150, 192-195
+            }
+        };
+        if (nsplit > 1) {
+            float n = 0.f, s = 0.f, mn = MAX_UTIL;
+            if (tid < P * nsplit) {
+                const int q = tid / nsplit, k = tid - q * nsplit, el = q / B, b = q - el * B;
+                if (env0 + el < p.E) rows_of(el, b, k, nsplit, n, s, mn);
+            }
+            part_s[tid] = make_float4(n, s, mn, 0.f);
+            __syncthreads();
+        }
         for (int q = tid; q < P; q += BLK) {
             const int el = q / B, b = q - el * B, base = el * UPAD;
             float n = 0.f, s = 0.f, mn = MAX_UTIL;
             uint32_t win = 0xFFFFFFFFu;
             if (env0 + el < p.E) {
                 const int mode = mode_s[b];
-                for (int v = 0; v < U; v++) {
-                    if (!((mask_s[base + v] >> b) & 1ull)) continue;
-                    n += 1.f;
-                    if (what == 1) { const float uv = util_s[base + v]; s += uv; mn = fminf(mn, uv); }
-                    else if (mode == DCOMP_RATE_FAIR) s += fast_rcp(big_rate(row[(base + v) * BR + b]));                           // station.py:177-180
-                    else if (mode == DCOMP_PROP_FAIR) s += big_rate(row[(base + v) * BR + b]) * fast_rcp(ewma_s[base + v] + EPS);   // station.py:150, 192-195
-                }
+                if (nsplit > 1) {
+                    for (int k = 0; k < nsplit; k++) { const float4 t = part_s[q * nsplit + k]; n += t.x; s += t.y; mn = fminf(mn, t.z); }
+                } else rows_of(el, b, 0, 1, n, s, mn);
                 if (what == 0 && mode == DCOMP_MAX_CAP && n > 0.f) {
                     // station.py:183-187: the UE with the highest FP64 rate is served; equal rates -> the oldest connection, then the lowest UE
                     // index (dcomp_device.h shared_rates has the derivation: nearest UE, contenders within 1e-7, the collapsing FP64 key)
@@ -150,10 +171,10 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                             const double dx = bp.x - pos_s[base + v].x, dy = bp.y - pos_s[base + v].y;
                             if (__builtin_fma(dy, dy, dx * dx) > dmin * (1.0 + 1e-7)) continue;
                             const unsigned long long key = maxcap_rate_key(p.pl_c1, p.pl_c2, pos_s[base + v].x, pos_s[base + v].y, bp.x, bp.y);
-                            const uint32_t w = ((uint32_t)p.conn_since[((size_t)(env0 + el) * U + v) * B + b] << 8) | (uint32_t)v;
+                            const uint32_t w = ((uint32_t)p.conn_since[((size_t)(env0 + el) * U + v) * B + b] << 10) | (uint32_t)v;     // (16-bit step, UE index < 1 024)
                             if (key > best || (key == best && w < bestw)) { best = key; bestw = w; }
                         }
-                        win = bestw & 0xFFu;
+                        win = bestw & 0x3FFu;
                     }
                 }
             }

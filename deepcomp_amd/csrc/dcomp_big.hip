@@ -16,6 +16,8 @@ BigKernels big_kernels_for_upad(int upad)
     case 64: return big_make<64>();
     case 128: return big_make<128>();
     case 256: return big_make<256>();
+    case 512: return big_make<512>();
+    case 1024: return big_make<1024>();
     default: return BigKernels{nullptr, nullptr, 0, 0};
     }
 }

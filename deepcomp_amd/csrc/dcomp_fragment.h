@@ -248,7 +248,7 @@ static int rows_per_chunk(int U, int B)
 
 static int fill(FragParams &p, int64_t n, int U, int B, int &grid, size_t &lds_pack, size_t &lds_unpack)
 {
-    if (n < 1 || U < 1 || U > DCOMP_MAX_UE || B < 1 || B > DCOMP_MASK32_MAX_BS) return DCOMP_EINVAL;
+    if (n < 1 || U < 1 || U > DCOMP_SPECIAL_MAX_UE || B < 1 || B > DCOMP_MASK32_MAX_BS) return DCOMP_EINVAL;
     p.U = U; p.B = B;
     p.R = rows_per_chunk(U, B);
     p.chunks = (U + p.R - 1) / p.R;

@@ -205,8 +205,8 @@ class BatchedMobileEnv:
         self.pos = torch.zeros((n, 2), dtype=torch.float64, device=dev)
         self.mv = torch.zeros(n, dtype=torch.int64, device=dev)
         self.conn = torch.zeros(n, dtype=torch.int32, device=dev)
-        # more than 32 stations: stations 32-63 of the connection sets in a second word per UE (dcomp_state.conn_hi; generic kernel)
-        self.conn_hi = torch.zeros(n, dtype=torch.int32, device=dev) if (B > _lib.MASK32_MAX_BS or os.environ.get('DCOMP_FORCE_BIG', '0') not in ('', '0')) else None
+        # more than 32 stations (or more than 256 UE slots per env): the generic kernel; stations 32-63 of the connection sets in a second word per UE (dcomp_state.conn_hi)
+        self.conn_hi = torch.zeros(n, dtype=torch.int32, device=dev) if (B > _lib.MASK32_MAX_BS or U > _lib.SPECIAL_MAX_UE or os.environ.get('DCOMP_FORCE_BIG', '0') not in ('', '0')) else None      # (every env of the generic kernel has the word)
         self.ewma = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flags = torch.zeros(4, dtype=torch.int32, device=dev)
         # all outputs of one step live in ONE flat buffer (sections 16-byte aligned): the single-env compatibility mode

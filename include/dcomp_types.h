@@ -16,7 +16,9 @@ extern "C" {
 #define DCOMP_MAX_BS 64          /* the connection set of a UE is two 32-bit words: state.conn (stations 0-31), state.conn_hi (32-63) */
 #define DCOMP_MASK32_MAX_BS 32   /* up to here `conn` alone holds it and the specialised kernels run (one instantiation per station count);
                                   * 33 ... 64 stations take the generic kernel of csrc/dcomp_big.h and need state.conn_hi */
-#define DCOMP_MAX_UE 256         /* one env never spans more than one 256-lane workgroup */
+#define DCOMP_MAX_UE 1024        /* an env is ONE workgroup (its per-station sums meet in one LDS): 1 024 lanes at most */
+#define DCOMP_SPECIAL_MAX_UE 256 /* up to here the specialised kernels (256-lane workgroups); 257 ... 1 024 UEs per env take the generic kernel of
+                                  * csrc/dcomp_big.h, as long as its rows fit the LDS: (num_bs + 1) * next_pow2(num_ue) * 4 bytes + ~30 KB <= 160 KB */
 
 enum { DCOMP_OK = 0, DCOMP_EINVAL = -1, DCOMP_EHIP = -2, DCOMP_EACTION = -3, DCOMP_ETAPE = -4, DCOMP_EPOS = -5,
        DCOMP_EUNSUPPORTED = -6 };
@@ -39,7 +41,7 @@ typedef struct dcomp_env dcomp_env;
  * bs_sharing; ue_list -> ue_*; 'reward' -> reward_agg; 'seed' -> seed; 'episode_length'. */
 typedef struct dcomp_cfg {
     int32_t num_envs;            /* E: envs owned by this handle (one GPU's shard) */
-    int32_t num_ue;              /* U <= DCOMP_MAX_UE: UEs in the configured ue_list (= after every reset) */
+    int32_t num_ue;              /* U <= DCOMP_MAX_UE: UEs in the configured ue_list (= after every reset); the reference has no limit (base.py:79-84) */
     int32_t num_bs;              /* B <= DCOMP_MAX_BS (the reference has no limit: station.py:16-30) */
     int32_t map_w, map_h;
     int32_t env_kind;            /* DCOMP_CENTRAL | DCOMP_MULTI */
@@ -74,8 +76,8 @@ typedef struct dcomp_state {     /* device, caller-allocated; sizes via dcomp_st
     uint16_t *uid;               /* [E*max_ues] UE id per slot, bit 15 = arrived during the episode; only with max_ues > 0 */
     uint16_t *orig_consumed;     /* [E*num_ue] optional: movement triples an initial UE had consumed when it left the
                                   * list (0xFFFF = never left) -- lets a tape-mode host continue that UE's stream */
-    uint32_t *conn_hi;           /* [E*U] like conn: bit b set <=> connected to station 32 + b.  Required when num_bs > DCOMP_MASK32_MAX_BS,
-                                  * ignored (may be NULL) otherwise.  ABI version 3. */
+    uint32_t *conn_hi;           /* [E*U] like conn: bit b set <=> connected to station 32 + b.  Required when num_bs > DCOMP_MASK32_MAX_BS or
+                                  * num_ue > DCOMP_SPECIAL_MAX_UE (generic kernel), ignored (may be NULL) otherwise.  ABI version 3. */
 } dcomp_state;
 
 /* Outputs of reset()/step().  obs layout = RLlib's flatten order of the reference's Dict spaces

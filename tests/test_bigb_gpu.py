@@ -94,6 +94,35 @@ def test_generic_kernel_against_the_oracle(torch_cuda, shape):
     assert np.array_equal(core.conn_hi.cpu().numpy().astype(np.uint32).reshape(E, U), (o_conn >> np.uint64(32)).astype(np.uint32))
 
 
+@pytest.mark.parametrize('shape', [('multi', 300, 10, 6, 'avg', 'mixed'), ('central', 512, 8, 3, 'min', 'mixed'), ('multi', 1000, 5, 2, 'sum', 'mixed'),
+                                   ('multi', 400, 40, 2, 'avg', 'max-cap'), ('central', 257, 32, 4, 'sum', 'rate-fair'), ('multi', 1024, 12, 1, 'min', 'mixed')])
+def test_more_than_256_ues_per_env_against_the_oracle(torch_cuda, shape):
+    """The other size limit the reference does not have (base.py:79-84): 257 ... 1 024 UEs in ONE env -- a workgroup of up to 1 024 lanes of the
+    generic kernel, as long as its LDS rows fit.  Same assertions as everywhere: masks / positions bit-exact, floats at the bars of tests/parity.py."""
+    torch = torch_cuda
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    kind, U, B, E, reward, sharing = shape
+    scn = _scenario(U, B, sharing)
+    m, bs, ues = build_from_scenario(scn)
+    core = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=31, reward=reward, rng='philox')
+    assert core.step_kernel_name.startswith('big_kernel<') and core.lanes_per_env in (512, 1024) and core.conn_hi is not None
+    ob = _oracle_batch(scn, kind, reward, E, 31)
+    rng = np.random.default_rng(U)
+    core.reset()
+    parity.assert_step(core, ob, ob.reset(), None, None, None, kind, reward, msg='reset')
+    for t in range(8):
+        a = _near_actions(rng, core, B)
+        core.step(torch.from_numpy(a).cuda())
+        parity.assert_step(core, ob, *ob.step(a), kind, reward, msg=f'step {t}')
+    core.check()
+    if shape is not None and U == 1024:
+        with pytest.raises(ValueError, match="LDS"):                      # 1 024 lanes x 65 floats of rows do not fit 160 KB
+            BatchedMobileEnv(*build_from_scenario(_scenario(1024, 64, 'mixed')), 'multi', num_envs=1, rng='philox')
+        with pytest.raises(ValueError):
+            BatchedMobileEnv(*build_from_scenario(_scenario(1025, 4, 'mixed')), 'multi', num_envs=1, rng='philox')
+
+
 @pytest.mark.parametrize('kind,U,B,E,reward,sharing', [('multi', 32, 10, 64, 'avg', 'mixed'), ('central', 10, 5, 100, 'avg', 'mixed'),
                                                        ('multi', 128, 32, 4, 'min', 'mixed'), ('multi', 20, 7, 40, 'sum', 'max-cap'),
                                                        ('central', 70, 12, 9, 'min', 'rate-fair')])

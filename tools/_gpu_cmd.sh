@@ -1,9 +1,7 @@
-# scratch: the command file `gpurun -- 'bash tools/_gpu_cmd.sh'` runs on the GPU box (rewritten per call during development)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -1
-rm -rf $O/profiles_r05
-bash tools/profile_all.sh r05 2>&1 | tail -14 | cut -c1-260
-python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r05_bench_line.json 2> $O/r05_bench_line.err; tail -c 200 $O/r05_bench_line.json
-python bench.py --gpus 1 --spawn --steps 20 --warmup 5 --no-cpu-baseline > $O/r05_bench_line_spawn.json 2> $O/r05_bench_line_spawn.err; tail -c 200 $O/r05_bench_line_spawn.json
-bash tools/measure_configs.sh > $O/r05_measure_configs.txt 2>&1; tail -20 $O/r05_measure_configs.txt | cut -c1-200
+timeout 900 python -m pytest tests/test_bigb_gpu.py -x -q 2>&1 | tail -6 | cut -c1-250
+timeout 300 python -m pytest tests/test_parity_gpu.py -x -q -k dense 2>&1 | tail -2
+B="python bench.py --no-also --no-cpu-baseline --no-stream --steps 100 --warmup 10"
+for cfg in "--envs 4096 --ues 512 --bs 10" "--envs 1024 --ues 1000 --bs 10" "--envs 8192 --ues 32 --bs 64" "--envs 2048 --ues 128 --bs 64" "--envs 65536 --ues 32 --bs 40"; do echo "== $cfg"; $B $cfg 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']; print(r['kernel'], 'kernel_ms', round(r['kernel_ms'],4), 'frac', round(r['frac'],3), 'env-steps/s', round(j['value']))"; done
