@@ -116,6 +116,28 @@ def many_stations(spec, frac):
     return c
 
 
+def many_ues(spec, frac):
+    """Round 5, like many_stations: with probability `frac` the case gets 257 ... 1 024 UEs in ONE env (512- / 1 024-lane workgroups of the generic
+    kernel).  The extra UEs repeat the case's own UE specs cyclically; the station count shrinks until the rows fit the LDS; few envs, few steps
+    (the oracle walks every UE x station pair on the host)."""
+    r6 = np.random.default_rng(spec['seed'] ^ 0x6A09E667)
+    if r6.random() >= frac:
+        return spec
+    c = dict(spec)
+    U0, U = c['U'], int(r6.choice([257, 300, 400, 512, 600, 1000, 1024]))
+    lanes = 512 if U <= 512 else 1024
+    Bmax = min(64, (160 * 1024 - 2048 - 60 * lanes) // (lanes * 4) - 1)          # big_lds_bytes(): (4 (B + 1) + 56) bytes per lane + tables <= 160 KB
+    if c['B'] > Bmax:
+        c['B'] = int(Bmax)
+        c['bs_xy'], c['sh'] = c['bs_xy'][:c['B']], c['sh'][:c['B']]
+    for k in ('vel', 'util', 'req', 'init', 'pause', 'border'):
+        if c.get(k) is not None:
+            c[k] = [c[k][i % U0] for i in range(U)]
+    c['U'], c['arrival'], c['many_ues'] = U, None, True
+    c['E'], c['steps'] = min(c['E'], 3), min(c['steps'], 16)
+    return c
+
+
 def build_case(spec):
     from deepcomp_amd.entities import Basestation, Map, Point, RandomWaypoint, User
     c = dict(spec)
@@ -209,7 +231,7 @@ def run_case(c, torch):
     # round 4: multi-agent envs also run a TWIN whose steps write the compact record themselves
     # (dcomp_out.obs_compact): unpack of it must be the core env's rows bit for bit, pack of the rows the record word for word
     twin = codec = packed = trew = None
-    if kind == 'multi' and B <= 32:                     # (the compact record holds one 32-bit connection mask per UE)
+    if kind == 'multi' and B <= 32 and c['U'] <= 256:   # (the compact record: one 32-bit connection mask per UE, envs of the specialised kernels)
         from deepcomp_amd.fragment import FragmentCodec
         os.environ['DCOMP_TIGHT'] = '1' if c.get('tight') else '0'
         try:
@@ -292,7 +314,7 @@ def run_case(c, torch):
 
 
 def describe(c):
-    return (f"{'MANY-STATIONS ' if c.get('many_stations') else ''}{'TIGHT ' if c.get('tight') else ''}{'ROLLOUT x' + str(c['rollout']) + ' ' if c.get('rollout') else ''}{'PAUSE/BORDER ' if c.get('pause') else ''}{'TAPE rand_episodes=' + str(c.get('rand_episodes')) + ' ' if c.get('tape') else ''}{'DYN ' + str(c['arrival']) + ' ' if c.get('arrival') else ''}{c['kind']} U={c['U']} B={c['B']} E={c['E']} map={c['w']}x{c['h']} reward={c['reward']} sharing={sorted(set(c['sh']))} "
+    return (f"{'MANY-UES ' if c.get('many_ues') else ''}{'MANY-STATIONS ' if c.get('many_stations') else ''}{'TIGHT ' if c.get('tight') else ''}{'ROLLOUT x' + str(c['rollout']) + ' ' if c.get('rollout') else ''}{'PAUSE/BORDER ' if c.get('pause') else ''}{'TAPE rand_episodes=' + str(c.get('rand_episodes')) + ' ' if c.get('tape') else ''}{'DYN ' + str(c['arrival']) + ' ' if c.get('arrival') else ''}{c['kind']} U={c['U']} B={c['B']} E={c['E']} map={c['w']}x{c['h']} reward={c['reward']} sharing={sorted(set(c['sh']))} "
             f"seed={c['seed']} base={c['base']} steps={c['steps']} p_noop={c['p_noop']}")
 
 
@@ -301,12 +323,13 @@ def main():
     ap.add_argument('--cases', type=int, default=200)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--many-stations', type=float, default=0.0, help='fraction of the cases that get 33 ... 64 stations (generic kernel, csrc/dcomp_big.h)')
+    ap.add_argument('--many-ues', type=float, default=0.0, help='fraction of the cases that get 257 ... 1 024 UEs per env (generic kernel)')
     a = ap.parse_args()
     import torch
     rng = np.random.default_rng(a.seed)
     bad = 0
     for i in range(a.cases):
-        c = build_case(many_stations(random_spec(rng), a.many_stations))
+        c = build_case(many_ues(many_stations(random_spec(rng), a.many_stations), a.many_ues))
         try:
             run_case(c, torch)
         except (AssertionError, Exception) as ex:      # noqa: BLE001
