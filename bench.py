@@ -491,6 +491,9 @@ def traffic_from_profile(workload_key, kernel_name=None, want_entry=False):
     src = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/{ent['tag']}_summary.txt, kernel {ent['kernel']}, commit {ent.get('commit', '?')}"
     if ent.get('kernel_fingerprint') != hip_build.kernel_fingerprint() and ent.get('source_fingerprint') != hip_build.source_fingerprint():
         return None, 'STALE (kernel sources changed since): ' + src
+    if ent['kernel'].startswith('big_kernel') and ent.get('source_fingerprint') != hip_build.source_fingerprint() \
+            and ent.get('generic_fingerprint') != hip_build.generic_fingerprint():
+        return None, 'STALE (csrc/dcomp_big.h changed since): ' + src
     if kernel_name is not None and kernel_name != ent['kernel']:
         return None, f'STALE (this library dispatches to {kernel_name}): ' + src
     if want_entry:

@@ -76,6 +76,16 @@ def kernel_fingerprint(read=None):
     return h.hexdigest()
 
 
+def generic_fingerprint(read=None):
+    """The generic kernel (csrc/dcomp_big.h, 33 ... 64 stations / 257 ... 1 024 UEs) on top of kernel_fingerprint(): a `big_kernel` entry of
+    profiles/traffic.json is valid only while this matches too (the specialised kernels' entries do not depend on dcomp_big.h)."""
+    h = hashlib.sha256(kernel_fingerprint(read).encode())
+    for f in ('dcomp_big.h', 'dcomp_big.hip'):
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), 'rb').read() if read is None else read(f))
+    return h.hexdigest()
+
+
 def source_fingerprint():
     """Hash of the kernel sources + flags of the product build: profiles record it (tools/summarize_prof.py), bench.py compares
     it with the library it runs -- a PMC figure taken from other sources is reported as stale.  Needs no git."""

@@ -180,7 +180,7 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
     env->mp_pattern = mp;
     if (env->big) {
         if (DYN) { delete env; return fail(DCOMP_EUNSUPPORTED, "UE arrival / departure (max_ues) is not available with more than %d stations or %d UE slots per env (generic kernel)", DCOMP_MASK32_MAX_BS, DCOMP_SPECIAL_MAX_UE); }
-        if (dcomp::big_lds_bytes(B, 1, env->upad < 64 ? 64 : env->upad) > 160 * 1024) {
+        if (dcomp::big_lds_bound(B, env->upad < 64 ? 64 : env->upad) > 160 * 1024) {
             delete env;
             return fail(DCOMP_EINVAL, "%d UEs x %d stations do not fit one workgroup's LDS (generic kernel: (num_bs + 1) * %d lanes * 4 bytes of rows + tables > 160 KB)", U, B, env->upad);
         }
@@ -270,7 +270,7 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
         if (e == hipSuccess) e = hipMalloc((void **)&env->d_mode, sizeof(int32_t) * B);
         if (e == hipSuccess) e = hipMemcpy(env->d_bs, xy.data(), sizeof(double) * 2 * B, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(env->d_mode, md.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice);
-        env->big_lds = dcomp::big_lds_bytes(B, env->bigk.gpb, env->bigk.block);
+        env->big_lds = (size_t)dcomp::big_carve(B, env->bigk.gpb, env->bigk.block, env->bigp.maxcap_mask != 0ull).total;
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(env->bigk.step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->big_lds);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(env->bigk.reset), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->big_lds);
         if (e != hipSuccess) { dcomp_destroy(env); return fail(DCOMP_EHIP, "device setup failed (generic kernel, %zu bytes of LDS per workgroup): %s", env->big_lds, hipGetErrorString(e)); }

@@ -7,7 +7,9 @@
 // stations 32-63: dcomp_state.conn_hi), the BS table is a device array staged in LDS per workgroup.  Same semantics, same
 // numerics (FP64 positions / decisions in the reference's operation order, FP32 log2-domain rates via the same device functions),
 // same outputs as the narrow kernels -- tests/test_bigb_gpu.py holds it to the oracle at B = 33 ... 64 and to the narrow kernels
-// at B <= 32 (DCOMP_FORCE_BIG=1).  It is NOT tuned: ~3 workgroup barriers and three owner-thread reduction passes per step.
+// at B <= 32 (DCOMP_FORCE_BIG=1).  Three workgroup-wide reduction passes per step (sharing terms before and after the move, utility
+// sums); 0.2-0.45 of the HBM peak where the specialised kernels reach 0.7-0.85.  What round 5 found it bound by (DESIGN_LOG R5.7): partial-line
+// non-temporal stores (now plain), the LDS rows' cap on resident wavefronts (the carve below), per-mode loops in the reduction passes (now one).
 //
 // Mapping: one lane = one (env, UE); an env takes UPAD = next pow2 >= U lanes; a workgroup is ONE wavefront (64 / UPAD envs) or, for
 // envs of more than 64 lanes, the env's own UPAD lanes.
@@ -17,6 +19,23 @@
 // launches one step per launch), the in-step policy, the compact record.
 #pragma once
 #include "dcomp_device.h"
+
+// A/B switches (tools/ab/ablate_big.sh, DESIGN_LOG R5.7); the defaults are the measured best
+#ifndef DCOMP_BIG_WUNROLL
+#define DCOMP_BIG_WUNROLL 4   // rows of the observation writer in flight per wavefront (1: -4 %)
+#endif
+#ifndef DCOMP_BIG_PUNROLL
+#define DCOMP_BIG_PUNROLL 2   // stations of the post-move pair loop in flight per lane
+#endif
+#ifndef DCOMP_BIG_NT
+#define DCOMP_BIG_NT 0        // 1: non-temporal stores like the narrow kernels (whose stores are whole 16-byte-per-lane lines); see big_store
+#endif
+#ifndef DCOMP_BIG_EARLY
+#define DCOMP_BIG_EARLY 1     // the connected | dr blocks of the observation leave right after the post-move pairs, under the rest of the step (0: +1-3 %)
+#endif
+#ifndef DCOMP_BIG_ABL
+#define DCOMP_BIG_ABL 0       // timing-only ablation (results WRONG): 1 max-cap winner, 2 utility aggregates, 4 rows, 8 pairs, 16 sharing aggregates, 32 move
+#endif
 
 namespace dcomp {
 
@@ -29,14 +48,36 @@ struct BigParams {
 };
 
 // Workgroup size: ONE wavefront, or as many as an env needs.  The rows cost (B + 1) * 4 bytes of LDS per lane (260 at B = 64), so a CU holds
-// ~7 wavefronts of this kernel at most; 256-lane workgroups (the first version) fit ONCE per CU at B = 64 -- 4 wavefronts, one per SIMD,
+// 7-8 wavefronts of this kernel at most; 256-lane workgroups (the first version) fit ONCE per CU at B = 64 -- 4 wavefronts, one per SIMD,
 // nothing to hide a barrier or an LDS round trip behind (8 192 x 32 x 64: 181 us, SQ_WAIT_ANY 44 % of the wave cycles).
 __host__ __device__ constexpr int big_block(int upad) { return upad < 64 ? 64 : upad; }
-// LDS bytes one workgroup needs (host and device use the same carve)
-__host__ __device__ inline size_t big_lds_bytes(int B, int gpb, int blk)
+// LDS one workgroup carves (host and device use the same function).  Per lane: its row (B stations + one pad column that also holds the row
+// maximum), its connection set, ewma / utility (one slot: the utility is written after the last reader of the ewma) and reward_before; per
+// (env, station): three aggregate slots (count | sum of the sharing terms, later of the utilities | max-cap winner, later the minimum
+// utility).  Only where they are used: the partial sums of split pairs, the FP64 positions (max-cap stations only).
+// 64 stations, 32 UEs, no max-cap: 20 480 bytes = EIGHT wavefronts per CU (the first carve, 24 064 bytes, held six).
+struct BigCarve { int mask, row, ewma, rb, agg, mode, part, pos, total; };
+__host__ __device__ inline BigCarve big_carve(int B, int gpb, int blk, bool maxcap)
+{
+    BigCarve c;
+    int o = B * (int)sizeof(double2);
+    c.mask = o; o += blk * 8;
+    c.row = o; o += blk * (B + 1) * 4;
+    c.ewma = o; o += blk * 4;
+    c.rb = o; o += blk * 4;
+    c.agg = o; o += 3 * gpb * B * 4;
+    c.mode = o; o += B * 4;
+    o = (o + 15) & ~15;
+    c.part = o; if (2 * gpb * B <= blk) o += blk * 16;          // aggregate() splits a pair's rows over >= 2 threads
+    c.pos = o; if (maxcap) o += blk * 16;
+    c.total = o;
+    return c;
+}
+// what dcomp_create_v checks against the 160 KB of a CU (before it knows the sharing modes; the documented bound of include/dcomp_types.h)
+__host__ __device__ inline size_t big_lds_bound(int B, int blk)
 {
     return 64 * sizeof(double2) + (size_t)blk * sizeof(double2) + (size_t)blk * sizeof(unsigned long long) + (size_t)blk * (B + 1) * 4 + (size_t)4 * blk * 4 +
-           (size_t)5 * gpb * B * 4 + 64 * 4 + (size_t)blk * 16;
+           (size_t)5 * B * 4 + 64 * 4 + (size_t)blk * 16;
 }
 
 __device__ __forceinline__ void big_pair(double px, double py, const double2 bp, const KParams &p, bool &in_range, float &l2)
@@ -47,6 +88,17 @@ __device__ __forceinline__ void big_pair(double px, double py, const double2 bp,
         const double dx = bp.x - px, dy = bp.y - py;
         if ((float)__builtin_fma(dy, dy, dx * dx) < 1e-20f) l2 = pair_eval_tiny(px, py, bp.x, bp.y, p);
     }
+}
+// Every output store of this kernel.  PLAIN stores: the rows leave as 4-byte-per-lane pieces of B floats at a stride of 4B + 1 floats, i.e. as
+// partial cache lines, and a non-temporal partial line does not wait in the L2 for its other half (8 192 x 32 x 64, resource-fair, same box:
+// 134 us with non-temporal, 81 us with plain stores; staging 4 rows in LDS for 16-byte-per-lane whole lines was SLOWER than either, R5.7).
+__device__ __forceinline__ void big_store(float *ptr, float v)
+{
+#if DCOMP_BIG_NT
+    stream_store(ptr, v);
+#else
+    *ptr = v;
+#endif
 }
 __device__ __forceinline__ float big_rate(float l2)                // bw * log2(1 + snr), station.py:129-138
 {
@@ -62,15 +114,18 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
     extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
     constexpr int BLK = big_block(UPAD), NWAVE = BLK / 64, GPB = BLK / UPAD;
     const int B = x.B, BR = B + 1, U = p.U;
+    const bool any_maxcap = x.maxcap_mask != 0ull;
+    const BigCarve cv = big_carve(B, GPB, BLK, any_maxcap);
     double2 *const bs_s = reinterpret_cast<double2 *>(big_smem);
-    double2 *const pos_s = bs_s + 64;
-    unsigned long long *const mask_s = reinterpret_cast<unsigned long long *>(pos_s + BLK);
-    float *const row = reinterpret_cast<float *>(mask_s + BLK);
-    float *const ewma_s = row + BLK * BR, *const util_s = ewma_s + BLK, *const rb_s = util_s + BLK, *const l2max_s = rb_s + BLK;
-    float4 *const part_s = reinterpret_cast<float4 *>(l2max_s + BLK);     // partial sums of split pairs (aggregate); 16-byte aligned here
-    float *const agg_n = reinterpret_cast<float *>(part_s + BLK), *const agg_s = agg_n + GPB * B, *const agg_u = agg_s + GPB * B, *const agg_m = agg_u + GPB * B;
-    uint32_t *const mc_win = reinterpret_cast<uint32_t *>(agg_m + GPB * B);
-    int *const mode_s = reinterpret_cast<int *>(mc_win + GPB * B);
+    unsigned long long *const mask_s = reinterpret_cast<unsigned long long *>(big_smem + cv.mask);
+    float *const row = reinterpret_cast<float *>(big_smem + cv.row);
+    float *const ewma_s = reinterpret_cast<float *>(big_smem + cv.ewma), *const util_s = ewma_s, *const rb_s = reinterpret_cast<float *>(big_smem + cv.rb);
+    float *const agg_n = reinterpret_cast<float *>(big_smem + cv.agg), *const agg_s = agg_n + GPB * B, *const agg_u = agg_s;
+    uint32_t *const mc_win = reinterpret_cast<uint32_t *>(agg_s + GPB * B);
+    float *const agg_m = reinterpret_cast<float *>(mc_win);
+    int *const mode_s = reinterpret_cast<int *>(big_smem + cv.mode);
+    float4 *const part_s = reinterpret_cast<float4 *>(big_smem + cv.part);     // partial sums of split pairs (aggregate)
+    double2 *const pos_s = reinterpret_cast<double2 *>(big_smem + cv.pos);     // max-cap stations only
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int env_local = tid / UPAD, u = tid % UPAD;
@@ -117,18 +172,38 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
     // Envs of many lanes have few pairs per workgroup (512 lanes, 10 stations: 10 owners walking 512 rows each while 502 lanes wait: 4 096 x 512 x 10
     // took 1.39 ms): there the rows of a pair are split over NSPLIT threads -- thread q * NSPLIT + k sums rows k, k + NSPLIT, ... -- and the owner
     // adds the partial sums in the order k = 0 ... NSPLIT - 1 (still deterministic).
-    auto aggregate = [&](int what) {
+    auto aggregate = [&](int what, bool parked) {
+        if ((DCOMP_BIG_ABL & 2) && what == 1) return;
+        if ((DCOMP_BIG_ABL & 16) && what == 0) return;
         const int P = GPB * B;
         int nsplit = P >= BLK ? 1 : BLK / P;
         nsplit = nsplit > 32 ? 32 : nsplit;
+        // Branch-free and unrolled (a branch per row saved little -- SOME lane of the 64 is connected in most trips -- and put an LDS round trip + a
+        // rate evaluation on one dependent chain per row), and ONE loop for rate-fair and proportional-fair owners (the threads of a wavefront own
+        // stations of every mode: a loop per mode ran with a quarter of the lanes each).  Same sums: a row that is not connected adds +0.
+        // parked: the rows hold the RATES of the connected stations (pre-move pass), not log2 snr.
         auto rows_of = [&](int el, int b, int first, int stride, float &n, float &s, float &mn) {
             const int base = el * UPAD, mode = mode_s[b];
-            for (int v = first; v < U; v += stride) {
-                if (!((mask_s[base + v] >> b) & 1ull)) continue;
-                n += 1.f;
-                if (what == 1) { const float uv = util_s[base + v]; s += uv; mn = fminf(mn, uv); }
-                else if (mode == DCOMP_RATE_FAIR) s += fast_rcp(big_rate(row[(base + v) * BR + b]));                           // station.py:177-180
-                else if (mode == DCOMP_PROP_FAIR) s += big_rate(row[(base + v) * BR + b]) * fast_rcp(ewma_s[base + v] + EPS);   // station.py:150, 192-195
+            const bool sums = what == 0 && (mode == DCOMP_RATE_FAIR || mode == DCOMP_PROP_FAIR), rate_fair = mode == DCOMP_RATE_FAIR;
+            if (what == 1) {
+#pragma unroll 4
+                for (int v = first; v < U; v += stride) {
+                    const bool c = (mask_s[base + v] >> b) & 1ull;
+                    const float uv = util_s[base + v];
+                    n += c ? 1.f : 0.f; s += c ? uv : 0.f; mn = c ? fminf(mn, uv) : mn;
+                }
+            } else if (__builtin_amdgcn_ballot_w64(sums) != 0ull) {            // station.py:177-180 | station.py:150, 192-195
+#pragma unroll 4
+                for (int v = first; v < U; v += stride) {
+                    const bool c = ((mask_s[base + v] >> b) & 1ull) != 0ull, cs = c && sums;
+                    const float l = cs ? row[(base + v) * BR + b] : 0.f;          // (a row without this station holds leftovers)
+                    const float r = parked ? l : big_rate(l);
+                    const float y = fast_rcp(rate_fair ? r : ewma_s[base + v] + EPS);
+                    n += c ? 1.f : 0.f; s += cs ? (rate_fair ? y : r * y) : 0.f;
+                }
+            } else {
+#pragma unroll 4
+                for (int v = first; v < U; v += stride) n += ((mask_s[base + v] >> b) & 1ull) ? 1.f : 0.f;
             }
         };
         if (nsplit > 1) {
@@ -149,7 +224,7 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                 if (nsplit > 1) {
                     for (int k = 0; k < nsplit; k++) { const float4 t = part_s[q * nsplit + k]; n += t.x; s += t.y; mn = fminf(mn, t.z); }
                 } else rows_of(el, b, 0, 1, n, s, mn);
-                if (what == 0 && mode == DCOMP_MAX_CAP && n > 0.f) {
+                if (!(DCOMP_BIG_ABL & 1) && what == 0 && mode == DCOMP_MAX_CAP && n > 0.f) {
                     // station.py:183-187: the UE with the highest FP64 rate is served; equal rates -> the oldest connection, then the lowest UE
                     // index (dcomp_device.h shared_rates has the derivation: nearest UE, contenders within 1e-7, the collapsing FP64 key)
                     const double2 bp = bs_s[b];
@@ -183,12 +258,12 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
         }
     };
     // this UE's share of every station it is connected to (station.py:152-202); keep = park it in the row (the stale rates of user.py:148-157)
-    auto shared = [&](bool keep) -> float {
+    auto shared = [&](bool keep, bool parked) -> float {
         const float inv_ewma = fast_rcp(ewma + EPS);
         float curr = 0.f;
         for (unsigned long long m = conn; m; m &= m - 1ull) {
             const int b = __ffsll((long long)m) - 1, q = env_local * B + b, mode = mode_s[b];
-            const float dru = big_rate(myrow[b]);
+            const float dru = parked ? myrow[b] : big_rate(myrow[b]);
             float out;
             if (mode == DCOMP_RES_FAIR) out = dru * fast_rcp(fmaxf(agg_n[q], 1.f));                         // station.py:171-173
             else if (mode == DCOMP_RATE_FAIR) out = fast_rcp(agg_s[q]);                                     // station.py:180
@@ -211,7 +286,7 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
             float l;
             big_pair(px, py, bs_s[b], p, ir, l);
             inr_old |= (unsigned long long)ir << b;
-            myrow[b] = l;
+            myrow[b] = big_rate(l);                                // parked: rates, not log2 snr (nothing after this pass needs the latter)
         }
         if (act_bit) {
             if (conn & act_bit) conn &= ~act_bit;
@@ -222,16 +297,16 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
         }
         mask_s[tid] = active ? conn : 0ull;
         ewma_s[tid] = ewma;
-        pos_s[tid] = make_double2(px, py);
+        if (any_maxcap) pos_s[tid] = make_double2(px, py);
         __threadfence_block();
         __syncthreads();
         // 2. rates before the move (base.py:446) -> reward_before (base.py:158-167)
-        aggregate(0);
+        aggregate(0, true);
         __syncthreads();
-        const float curr_pre = shared(true);
+        const float curr_pre = shared(true, true);
         reward_before = clamp_med3(ue_utility(curr_pre, step_util, dr_req), MIN_UTIL, MAX_UTIL) * (1.0f / MAX_UTIL);
         // 3. move (base.py:447 -> user.py:159-173)
-        if (active) {
+        if (active && !(DCOMP_BIG_ABL & 32)) {
             move_ue<false>(p, env, (uint32_t)u + 1u, p.episode, px, py, mv, vrange);
             if (px < 0.0 || py < 0.0 || px > (double)p.map_w || py > (double)p.map_h) atomicOr(p.flags, DCOMP_FLAG_OUTSIDE_MAP);
         }
@@ -249,25 +324,62 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
     // 5. every station at the (new) position: log2 snr into the row, the in-range mask, the row maximum
     unsigned long long in_range = 0ull;
     float l2max = -3.0e38f;
+#pragma unroll DCOMP_BIG_PUNROLL
     for (int b = 0; b < B; b++) {
-        bool ir;
-        float l;
-        big_pair(px, py, bs_s[b], p, ir, l);
+        bool ir = true;
+        float l = 0.f;
+        if (!(DCOMP_BIG_ABL & 8)) big_pair(px, py, bs_s[b], p, ir, l);
         in_range |= (unsigned long long)ir << b;
         myrow[b] = l;
         l2max = fmaxf(l2max, l);
     }
     mask_s[tid] = alive ? conn : 0ull;
     ewma_s[tid] = ewma;
-    pos_s[tid] = make_double2(px, py);
-    l2max_s[tid] = l2max;
+    if (any_maxcap) pos_s[tid] = make_double2(px, py);
+    myrow[B] = l2max;                                              // the pad column
     __syncthreads();
+    // Observation, first half (variants.py:271-284): `connected` and the relative snr are final here -- their stores drain under the rest of the
+    // step instead of queueing behind it (a wavefront waiting on its stores holds its rows of LDS and keeps the next one out).
+    // Multi-agent rows: a wavefront per UE row, lanes along the stations (B <= 64: one trip), uniform control flow.
+    const int w0 = __builtin_amdgcn_readfirstlane(wave);
+    const int ROW = 4 * B + 1, UB = U * B, kind = p.kind;
+    auto rows_early = [&]() {
+        for (int el = 0; el < GPB && kind == DCOMP_MULTI; el++) {
+            if (env0 + el >= p.E) break;                           // (uniform)
+            float *const dst0 = p.obs + (size_t)(env0 + el) * U * ROW;
+#pragma unroll DCOMP_BIG_WUNROLL
+            for (int uu = w0; uu < U; uu += NWAVE) {
+                const int r = el * UPAD + uu;
+                const bool live = !RESET || uu < p.U0;
+                float *const dst = dst0 + (size_t)uu * ROW;
+                if (lane < B) {
+                    big_store(dst + lane, live ? (float)((mask_s[r] >> lane) & 1ull) : 0.f);
+                    big_store(dst + B + lane, live ? fast_exp2(row[r * BR + lane] - row[r * BR + B]) : 0.f);                               // variants.py:276-284
+                }
+            }
+        }
+        if (kind == DCOMP_CENTRAL && env < p.E) {
+            // central rows are short (U (2B+1) floats per ENV): the lanes of an env walk its connected / dr blocks, (UE, station) advanced
+            // incrementally (no division per element)
+            float *const dst = p.obs + (size_t)env * U * (2 * B + 1);
+            const int base = env_local * UPAD;
+            int uu = u / B, b = u - uu * B;
+            for (int c = u; c < UB; c += UPAD) {
+                const bool live = !RESET || uu < p.U0;
+                big_store(dst + c, live ? (float)((mask_s[base + uu] >> b) & 1ull) : 0.f);
+                big_store(dst + UB + c, live ? fast_exp2(row[(base + uu) * BR + b] - row[(base + uu) * BR + B]) : 0.f);
+                b += UPAD;
+                while (b >= B) { b -= B; uu++; }
+            }
+        }
+    };
+    if (DCOMP_BIG_EARLY && p.obs && !(DCOMP_BIG_ABL & 4)) rows_early();
     // 6. rates after the move (base.py:451)
     float curr = 0.f;
     if (!RESET) {
-        aggregate(0);
+        aggregate(0, false);
         __syncthreads();
-        curr = shared(false);
+        curr = shared(false, false);
     }
     const float util = ue_utility(curr, step_util, dr_req);
     if (!RESET && active) {
@@ -281,9 +393,9 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
     rb_s[tid] = alive ? reward_before : 0.f;
     __syncthreads();
     // 7. per-station utility aggregates (station.py:63-83), reward, info, observation
-    aggregate(1);
+    aggregate(1, false);
     __syncthreads();
-    const int kind = p.kind, n_eff = RESET ? p.U0 : U;
+    const int n_eff = RESET ? p.U0 : U;
     if (kind == DCOMP_CENTRAL) {                                   // central.py:65-73: over the UEs' rewards_before
         if (active && u == 0) {
             const int base = env_local * UPAD;
@@ -317,7 +429,7 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                 reward = in_range != 0ull ? m_ : util;
             }
         }
-        if (active && p.reward) stream_store(&p.reward[idx], alive ? reward : 0.f);
+        if (active && p.reward) big_store(&p.reward[idx], alive ? reward : 0.f);
         if (active && u == 0 && p.sum_util) {
             const int base = env_local * UPAD;
             float su = 0.f;
@@ -326,49 +438,40 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
         }
     }
     if (active) {                                                  // base.py:383-411
-        if (p.ue_dr) stream_store(&p.ue_dr[idx], alive ? curr : 0.f);
-        if (p.ue_util) stream_store(&p.ue_util[idx], alive ? util : 0.f);
-        if (p.rb_out) stream_store(&p.rb_out[idx], alive ? reward_before : 0.f);
+        if (p.ue_dr) big_store(&p.ue_dr[idx], alive ? curr : 0.f);
+        if (p.ue_util) big_store(&p.ue_util[idx], alive ? util : 0.f);
+        if (p.rb_out) big_store(&p.rb_out[idx], alive ? reward_before : 0.f);
     }
-    if (!p.obs) return;
+    if (!p.obs || (DCOMP_BIG_ABL & 4)) return;
+    if (!DCOMP_BIG_EARLY) rows_early();
     const float inv_u = 1.0f / (float)n_eff;
-    // Multi-agent rows (variants.py:271-305): a wavefront per UE row, lanes along the stations (B <= 64: one trip), uniform control flow --
-    // four stores of B contiguous floats (connected | dr | ues_at_bs | util_at_bs) + the row's utility.  (First version: one loop over the
-    // 4B + 1 columns with a branch per block, 125 instead of ~35 instructions per row: 8 192 x 32 x 64 334 -> 181 us.)
-    const int w0 = __builtin_amdgcn_readfirstlane(wave);
-    const int ROW = 4 * B + 1, UB = U * B;
-    for (int r = w0; r < BLK && kind == DCOMP_MULTI; r += NWAVE) {
-        const int el = r / UPAD, uu = r - el * UPAD;
-        if (uu >= U || env0 + el >= p.E) continue;                 // (wave-uniform)
-        const bool live = !RESET || uu < p.U0;
-        const float un = live ? util_s[r] * (1.0f / MAX_UTIL) : 0.f;
-        {
-            float *const dst = p.obs + ((size_t)(env0 + el) * U + uu) * ROW;
+    // second half (variants.py:286-305): ues_at_bs | util_at_bs (the same in every row of an env: variants.py:296, 299) + the row's utility
+    for (int el = 0; el < GPB && kind == DCOMP_MULTI; el++) {
+        if (env0 + el >= p.E) break;                               // (uniform)
+        float n_col = 0.f, u_col = 0.f;
+        if (lane < B) {
+            const int q = el * B + lane;
+            const float n = agg_n[q];
+            n_col = n * inv_u;
+            u_col = agg_u[q] * fast_rcp(fmaxf(n, 1.f)) * (1.0f / MAX_UTIL);
+        }
+        float *const dst0 = p.obs + (size_t)(env0 + el) * U * ROW;
+#pragma unroll DCOMP_BIG_WUNROLL
+        for (int uu = w0; uu < U; uu += NWAVE) {
+            const int r = el * UPAD + uu;
+            const bool live = !RESET || uu < p.U0;
+            float *const dst = dst0 + (size_t)uu * ROW;
             if (lane < B) {
-                const int q = el * B + lane;
-                const float n = agg_n[q];
-                stream_store(dst + lane, live ? (float)((mask_s[r] >> lane) & 1ull) : 0.f);
-                stream_store(dst + B + lane, live ? fast_exp2(row[r * BR + lane] - l2max_s[r]) : 0.f);                                   // variants.py:276-284
-                stream_store(dst + 2 * B + lane, live ? n * inv_u : 0.f);                                                                  // variants.py:296
-                stream_store(dst + 3 * B + lane, live ? agg_u[q] * fast_rcp(fmaxf(n, 1.f)) * (1.0f / MAX_UTIL) : 0.f);                     // variants.py:299
+                big_store(dst + 2 * B + lane, live ? n_col : 0.f);
+                big_store(dst + 3 * B + lane, live ? u_col : 0.f);
             }
-            if (lane == 0) stream_store(dst + 4 * B, un);
+            if (lane == 0) big_store(dst + 4 * B, live ? util_s[r] * (1.0f / MAX_UTIL) : 0.f);
         }
     }
     if (kind == DCOMP_CENTRAL && env < p.E) {
-        // central rows are short (U (2B+1) floats per ENV): the lanes of an env walk its connected / dr blocks, (UE, station) advanced
-        // incrementally (no division per element), then the utilities
         float *const dst = p.obs + (size_t)env * U * (2 * B + 1);
         const int base = env_local * UPAD;
-        int uu = u / B, b = u - uu * B;
-        for (int c = u; c < UB; c += UPAD) {
-            const bool live = !RESET || uu < p.U0;
-            stream_store(dst + c, live ? (float)((mask_s[base + uu] >> b) & 1ull) : 0.f);
-            stream_store(dst + UB + c, live ? fast_exp2(row[(base + uu) * BR + b] - l2max_s[base + uu]) : 0.f);
-            b += UPAD;
-            while (b >= B) { b -= B; uu++; }
-        }
-        for (int c = u; c < U; c += UPAD) stream_store(dst + 2 * UB + c, util_s[base + c] * (1.0f / MAX_UTIL));
+        for (int c = u; c < U; c += UPAD) big_store(dst + 2 * UB + c, util_s[base + c] * (1.0f / MAX_UTIL));
     }
 }
 

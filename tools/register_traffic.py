@@ -53,6 +53,7 @@ def main():
     txt = open(os.path.join(REPO, 'profiles', f'{tag}_summary.txt')).read()
     fp = re.search(r'^source_fingerprint: (\S+)', txt, re.M)
     kfp = re.search(r'^kernel_fingerprint: (\S+)', txt, re.M)
+    gfp = re.search(r'^generic_fingerprint: (\S+)', txt, re.M)
     vals = {}
     for line in txt.splitlines():
         line = line.strip()
@@ -75,6 +76,12 @@ def main():
                'bytes_per_launch': (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0,
                'valu_insts_per_launch': vals.get('SQ_INSTS_VALU'), 'waves_per_launch': vals.get('SQ_WAVES'),
                'note': 'bytes = (2 x FETCH_SIZE [gfx950 wide-read correction] + WRITE_SIZE) KiB per launch'}
+    if kern.startswith('big_kernel'):
+        # the generic kernel's own sources (build.generic_fingerprint); a summary from before that line existed belongs to the tree whose FULL
+        # fingerprint it names -- if that is this tree, this tree's generic fingerprint is the profile's
+        sys.path.insert(0, REPO)
+        from deepcomp_amd import build as b
+        db[key]['generic_fingerprint'] = gfp.group(1) if gfp else (b.generic_fingerprint() if fp and fp.group(1) == b.source_fingerprint() else None)
     if old.get('tag') == tag and not db[key]['kernel_fingerprint']:
         db[key]['kernel_fingerprint'] = old.get('kernel_fingerprint')
     with open(path, 'w') as f:

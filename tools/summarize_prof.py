@@ -12,6 +12,7 @@ try:                                    # which kernel sources these numbers bel
     from deepcomp_amd import build as _b
     print('source_fingerprint:', _b.source_fingerprint())
     print('kernel_fingerprint:', _b.kernel_fingerprint())
+    print('generic_fingerprint:', _b.generic_fingerprint())
 except Exception as ex:                 # noqa: BLE001
     print('source_fingerprint: unknown', ex)
 
