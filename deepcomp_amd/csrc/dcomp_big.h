@@ -33,6 +33,9 @@
 #ifndef DCOMP_BIG_EARLY
 #define DCOMP_BIG_EARLY 1     // the connected | dr blocks of the observation leave right after the post-move pairs, under the rest of the step (0: +1-3 %)
 #endif
+#ifndef DCOMP_BIG_PARK
+#define DCOMP_BIG_PARK 1      // post-move pass: rates parked in the rows by the UEs' own lanes (needs DCOMP_BIG_EARLY or no observation; 0: +3-5 % in mixed sharing)
+#endif
 #ifndef DCOMP_BIG_ABL
 #define DCOMP_BIG_ABL 0       // timing-only ablation (results WRONG): 1 max-cap winner, 2 utility aggregates, 4 rows, 8 pairs, 16 sharing aggregates, 32 move
 #endif
@@ -377,9 +380,17 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
     // 6. rates after the move (base.py:451)
     float curr = 0.f;
     if (!RESET) {
-        aggregate(0, false);
+        // With the first half of the rows gone (or no observation asked for) nothing needs log2 snr any more: every lane parks the RATES of its
+        // connected stations, like the pre-move pass, and the owner threads evaluate none (mixed sharing: they walked 64 rows x 2 pairs each).
+        const bool park = DCOMP_BIG_PARK && NWAVE <= 4 && (DCOMP_BIG_EARLY || !p.obs);     // (two more barriers: 16-wave workgroups lose 3 %)
+        if (park) {
+            __syncthreads();                                       // the readers of the log2 snr rows (rows_early) are done
+            for (unsigned long long m = conn; m; m &= m - 1ull) { const int b = __ffsll((long long)m) - 1; myrow[b] = big_rate(myrow[b]); }
+            __syncthreads();
+        }
+        aggregate(0, park);
         __syncthreads();
-        curr = shared(false, false);
+        curr = shared(false, park);
     }
     const float util = ue_utility(curr, step_util, dr_req);
     if (!RESET && active) {
