@@ -127,6 +127,7 @@ def main():
     ap.add_argument('--dump', default=None, help='--near-ties: write the configurations the reference confirmed to this JSON file (inputs only)')
     ap.add_argument('--max-pairs', type=int, default=240, help='U*B cap (the reference needs ~30 us per pair and step)')
     ap.add_argument('--many-stations', type=float, default=0.0, help='fraction of the cases with 33 ... 64 stations (fuzz_parity.many_stations; round 5)')
+    ap.add_argument('--many-ues', type=float, default=0.0, help='fraction of the cases with 257 ... 1 024 UEs in one env (fuzz_parity.many_ues; round 5), at <= 6 stations and 10 steps: the reference is slow')
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     bad = done = 0
@@ -154,8 +155,11 @@ def main():
         print(f'{done - bad} / {done} max-cap near-tie configurations (found among {tried} max-cap configurations): oracle == reference')
         sys.exit(1 if bad else 0)
     while done < a.cases:
-        spec = fuzz_parity.many_stations(fuzz_parity.random_spec(rng), a.many_stations)
-        if spec['U'] * spec['B'] > a.max_pairs:
+        spec = fuzz_parity.many_ues(fuzz_parity.many_stations(fuzz_parity.random_spec(rng), a.many_stations), a.many_ues)
+        if spec.get('many_ues'):                            # exempt from --max-pairs: few stations and steps instead
+            nb = min(spec['B'], 6)
+            spec.update(B=nb, bs_xy=spec['bs_xy'][:nb], sh=spec['sh'][:nb], steps=min(spec['steps'], 10))
+        elif spec['U'] * spec['B'] > a.max_pairs:
             if not spec.get('many_stations'):
                 continue
             n = max(1, a.max_pairs // spec['B'])           # keep the many-station cases: fewer UEs instead

@@ -126,7 +126,7 @@ def many_ues(spec, frac):
     c = dict(spec)
     U0, U = c['U'], int(r6.choice([257, 300, 400, 512, 600, 1000, 1024]))
     lanes = 512 if U <= 512 else 1024
-    Bmax = min(64, (160 * 1024 - 2048 - 60 * lanes) // (lanes * 4) - 1)          # big_lds_bytes(): (4 (B + 1) + 56) bytes per lane + tables <= 160 KB
+    Bmax = min(64, (160 * 1024 - 2048 - 60 * lanes) // (lanes * 4) - 1)          # big_lds_bound(): (4 (B + 1) + 56) bytes per lane + tables <= 160 KB
     if c['B'] > Bmax:
         c['B'] = int(Bmax)
         c['bs_xy'], c['sh'] = c['bs_xy'][:c['B']], c['sh'][:c['B']]
