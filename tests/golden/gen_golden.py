@@ -590,6 +590,15 @@ def gen_many_stations():
                    scripted=opening(9, 36, {0: {1: 35, 3: 33, 4: 34}, 1: {0: 35, 2: 35, 3: 34, 4: 33}, 2: {1: 35}, 3: {1: 35, 0: 34}, 5: {2: 35, 0: 35}, 6: {0: 35}}))
 
 
+def gen_many_ues():
+    """More than 256 UEs in ONE env (round 5: the native env's 256-UE limit went -- generic kernel, one 512- / 1 024-lane workgroup per env; the
+    reference has none, base.py:79-84).  Crowded cells: every sharing sum runs over ~100 UEs, the max-cap arg-max over as many contenders."""
+    scn = scenarios.medium_map('mixed').with_ues(num_static=20, num_slow=170, num_fast=80)       # 270 UEs x 3 stations
+    run_trajectory('traj_crowd270x3_multi_s42', scn, 'multi', 42, 12, tape_mode='sticky')
+    scn = scenarios.grid_map(4, 'mixed', pitch=90, border=40).with_ues(num_slow=200, num_fast=100)      # 300 UEs x 4 stations, central, min reward
+    run_trajectory('traj_crowd300x4_central_min_s43', scn, 'central', 43, 10, reward='min', tape_mode='uniform')
+
+
 def gen_ue_arrival():
     """The five named UE-arrival schedules of the CLI (env_setup.py:205-226).  deepcomp.util.env_setup cannot be imported here (it needs a
     real ray), so the reference's OWN get_ue_arrival is lifted out of its module with `ast` -- the function's source, compiled and run
@@ -631,3 +640,4 @@ if __name__ == '__main__':
     gen_single()
     gen_ue_arrival()
     gen_many_stations()
+    gen_many_ues()
