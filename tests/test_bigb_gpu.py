@@ -2,7 +2,7 @@
 32-bit connection mask per UE, one kernel instantiation per station count).  33 ... 64 stations now take the GENERIC kernel of
 deepcomp_amd/csrc/dcomp_big.h (run-time B, per-UE rows in LDS, the connection set in state.conn + state.conn_hi).  Held to:
 
-* the reference itself -- three reference-run trajectories with 36 / 40 / 64 stations (tests/golden/traj_dense*: static UEs parked at
+* the reference itself -- two reference-run trajectories with 270 / 300 UEs in one env (tests/golden/traj_crowd*) and three with 36 / 40 / 64 stations (tests/golden/traj_dense*: static UEs parked at
   stations >= 32, scripted connects / disconnects, a max-cap rate tie) go through test_parity_gpu.py::test_golden_trajectory like every
   other traj_* fixture, and through tests/test_oracle_golden.py on the CPU;
 * the oracle, on Philox batches at B = 33 ... 64 across lane widths, env kinds, reward aggregations and sharing models (here);
