@@ -328,6 +328,84 @@ def measure_also(torch, BatchedMobileEnv, scenarios, build_from_scenario, dev):
     return out
 
 
+# ------------------------------------------------------------------------------------------------- the predicted 1 -> 8 curve
+# Measured inputs (one MI355X, profiles/ of rounds 4-5) and stated assumptions; `python bench.py --predict` prints
+# the table without a GPU, DESIGN.md section 7 holds a copy, tests/test_bench_cpu.py pins the two together.
+PREDICT = {
+    'kernel_ms_config3': 0.0765,            # step_kernel<10,32,2>, 65 536 envs, HIP events (BENCH_r05: 0.0765; steady state 0.0757)
+    'n1_ms_per_step_steps20': 0.0778,       # BENCH_r05 ms_per_step (plain process, no process group): kernel + the closing synchronize
+    'dist_ms_per_step_steps20_one_rank': 0.0835,   # `--gpus 1 --spawn` (process group with ONE rank, the N > 1 code path): 0.082-0.085
+    'rank_spread': 0.03,                    # box-to-box / GPU-to-GPU spread of the same kernel seen over five rounds: +-3 %; value uses the MAX over ranks
+    'closing_allreduce_us_per_log2N': 8.0,  # ASSUMPTION: RCCL 4-byte all-reduce over xGMI ~ 20-45 us at 2-8 ranks = +8 us per doubling on top of the one-rank figure
+    'config4_share_ms': {1: 0.305, 2: 0.146, 4: 0.076, 8: 0.041},     # 262 144 / N envs x 32 x 10, kernel time (HIP events)
+    'config5_share_ms': {1: 0.486, 2: 0.248, 4: 0.124, 8: 0.054},     # 32 768 / N envs x 128 x 32
+    'sharded_host_overhead': 0.02,          # measure_sharded times 200 steps by the host clock incl. two reset launches and the closing barrier: +2 %
+    'link_GBps_per_direction': 76.5,        # ASSUMPTION: one xGMI link = 153 GB/s both directions together (the task statement's "7 links x ~153 GB/s per GPU") -> 76.5 GB/s one way
+    'link_efficiency': 0.8,                 # ASSUMPTION: fraction of a link's peak a large RCCL transfer sustains
+}
+
+
+def predict(steps=20, fragment=4):
+    """The curve the first 8-GPU run should be read against.  Weak scaling (the headline: 65 536 envs per GPU): every rank launches the same
+    kernel, nothing is exchanged on the data path, so ms_per_step(N) = the one-rank figure of the N > 1 code path + the closing collective's
+    growth with N, stretched by the slowest of N ranks (MAX over ranks).  Strong scaling (configs 4 and 5): the measured per-GPU shares.
+    With the rollout hand-off north_star names (every observation to every rank): a DIRECT all-gather on the fully connected mesh moves each
+    rank's fragment over N - 1 links at once, so a fragment takes bytes_per_rank / (link rate) whatever N is -- and that, not stepping,
+    bounds the job.  A ring would take (N - 1) x as long."""
+    P = PREDICT
+    E, U, B = 65536, 32, 10
+    link = P['link_GBps_per_direction'] * P['link_efficiency'] * 1e9
+    rows = []
+    for n in (1, 2, 4, 8):
+        import math
+        if n == 1:
+            ms = P['n1_ms_per_step_steps20'] if steps <= 50 else P['kernel_ms_config3'] + (P['n1_ms_per_step_steps20'] - P['kernel_ms_config3']) * 20 / steps
+        else:
+            fence = (P['dist_ms_per_step_steps20_one_rank'] - P['kernel_ms_config3']) * 20 / steps       # fixed costs of the bracket, spread over the steps
+            fence += P['closing_allreduce_us_per_log2N'] * 1e-3 * math.log2(n) / steps
+            # MAX over n ranks of a +-spread population: expected maximum of n uniform samples = mean + spread (n - 1) / (n + 1)
+            ms = (P['kernel_ms_config3'] + fence) * (1 + P['rank_spread'] * (n - 1) / (n + 1))
+        value = n * E / (ms * 1e-3)
+        frag_rows = fragment * (E * U * (4 * B + 1) + E * U) * 4              # bytes one rank sends per fragment (rows + rewards)
+        frag_cmp = fragment * (E * (U * (B + 2) + 2 * B) + E * U) * 4          # ... as the compact record
+        step_ms = fragment * P['kernel_ms_config3']
+
+        def with_handoff(bytes_per_rank):
+            if n == 1:
+                return E * fragment / (step_ms * 1e-3), 0.0
+            t = bytes_per_rank / link * 1e3                                   # all N - 1 peers at once, one link each
+            per = max(step_ms, t)                                             # overlapped on the side stream: the longer of the two
+            return n * E * fragment / (per * 1e-3), t
+        r_rate, r_ms = with_handoff(frag_rows)
+        c_rate, c_ms = with_handoff(frag_cmp)
+        rows.append({'n_gpus': n, 'weak_ms_per_step': ms, 'weak_value_env_steps_per_s': value,
+                     'config4_strong_ms_per_step': P['config4_share_ms'][n] * (1 + P['sharded_host_overhead']),
+                     'config5_strong_ms_per_step': P['config5_share_ms'][n] * (1 + P['sharded_host_overhead']),
+                     'with_rollout_handoff_rows_env_steps_per_s': r_rate, 'rows_fragment_transfer_ms': r_ms,
+                     'with_rollout_handoff_compact_env_steps_per_s': c_rate, 'compact_fragment_transfer_ms': c_ms})
+    base = rows[0]
+    for r in rows:
+        r['weak_speedup'] = r['weak_value_env_steps_per_s'] / base['weak_value_env_steps_per_s']
+        r['config4_strong_speedup'] = base['config4_strong_ms_per_step'] / r['config4_strong_ms_per_step']
+        r['config5_strong_speedup'] = base['config5_strong_ms_per_step'] / r['config5_strong_ms_per_step']
+    return {'steps': steps, 'fragment_steps': fragment, 'inputs': P, 'rows': rows,
+            'reading': ('weak: value(N) / value(1) -- north_star asks for >= 6 at N = 8; config 5 is super-linear because its 4 096-env share fits the '
+                        '256 MB Infinity Cache while the whole job does not; the hand-off columns are LINK-bound at every N > 1 (a fragment of '
+                        f'{fragment} steps is {fragment * P["kernel_ms_config3"]:.2f} ms of stepping against tens of ms on a link), which is why `value` '
+                        'carries the per-env summary and the full-observation hand-off is reported next to it')}
+
+
+def predict_table(pr):
+    L = [f"| N | weak ms/step (--steps {pr['steps']}) | weak env-steps/s | speed-up | config 4 strong ms/step (speed-up) | config 5 strong ms/step (speed-up) | "
+         f"+ rows hand-off env-steps/s (ms per {pr['fragment_steps']}-step fragment on a link) | + compact-record hand-off |", '|---|---|---|---|---|---|---|---|']
+    for r in pr['rows']:
+        L.append(f"| {r['n_gpus']} | {r['weak_ms_per_step']:.4f} | {r['weak_value_env_steps_per_s']:.3e} | {r['weak_speedup']:.2f} | "
+                 f"{r['config4_strong_ms_per_step']:.3f} ({r['config4_strong_speedup']:.2f}) | {r['config5_strong_ms_per_step']:.3f} ({r['config5_strong_speedup']:.2f}) | "
+                 f"{r['with_rollout_handoff_rows_env_steps_per_s']:.2e} ({r['rows_fragment_transfer_ms']:.1f}) | "
+                 f"{r['with_rollout_handoff_compact_env_steps_per_s']:.2e} ({r['compact_fragment_transfer_ms']:.1f}) |")
+    return '\n'.join(L)
+
+
 def stream_ceiling(torch, dev, write_bytes, rw_bytes, iters=100):
     """"also report against a measured device-copy bandwidth on the box".  torch's own elementwise kernels
     (fill = write-only, out-of-place add = read + write) on buffers of the step kernel's traffic, HIP-event timed."""
@@ -612,7 +690,26 @@ def main():
     ap.add_argument('--no-pin', action='store_true', help="do not bind the rank to the CPUs of its GPU's NUMA node (A/B; config.rank_placement says what was done)")
     ap.add_argument('--spawn', action='store_true', help='start the ranks from this process even for --gpus 1 (what --gpus N > 1 does by itself '
                                                          'when no launcher set WORLD_SIZE)')
+    ap.add_argument('--predict', action='store_true',
+                    help='no GPU needed: print the PREDICTED 1 / 2 / 4 / 8-GPU curve (weak scaling of the headline at --steps, strong scaling of configs 4 / 5, '
+                         'throughput with the rollout hand-off) from the measured single-GPU figures and the stated link assumptions, then exit')
+    ap.add_argument('--rccl-direct', action='store_true',
+                    help="N > 1: before the communicator is created, set RCCL's hints for the DIRECT all-gather (each rank writes its shard to every peer over "
+                         "that pair's own xGMI link) instead of the ring for the observation hand-off (deepcomp_amd.sharded.rccl_direct_hints); compare with the default")
+    ap.add_argument('--gather-algo', default='collective', choices=['collective', 'p2p'],
+                    help="how RolloutGather moves a fragment: 'collective' = all_gather_into_tensor (RCCL chooses), 'p2p' = one send to / one receive from every "
+                         "peer in one batch (the direct all-gather spelled out)")
+    ap.add_argument('--sustained-launches', type=int, default=40000,
+                    help='N = 1, default workload: back-to-back headline launches of the sustained leg (also.sustained; blocks of 1 000, HIP events); 0 = skip')
     args = ap.parse_args()
+    if args.predict:
+        pr = predict(steps=args.steps if args.steps != 1000 else 20, fragment=args.fragment)
+        print(predict_table(pr))
+        print(json.dumps({'predicted': pr}), flush=True)
+        return
+    if args.rccl_direct:
+        from deepcomp_amd.sharded import rccl_direct_hints
+        os.environ.update(rccl_direct_hints())          # inherited by self-spawned ranks; read by RCCL when the communicator comes up
     if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.spawn):
         self_spawn(args.gpus)                  # does not return
 
@@ -681,7 +778,7 @@ def main():
     pending = []
     if use_dist and not args.no_gather:
         from deepcomp_amd.sharded import RolloutGather
-        gather = RolloutGather(use_side_stream=(args.backend == 'nccl'), reuse_buffers=3)
+        gather = RolloutGather(use_side_stream=(args.backend == 'nccl'), reuse_buffers=3, algo=args.gather_algo)
         # the summary of one hand-off is ONE tensor [E, reward columns + 1] (per-env rewards | sum_utility): one staging kernel, one collective
         summary_stage = [torch.empty((E, env.reward.numel() // E + 1), device=dev) for _ in range(3)]
 
@@ -923,7 +1020,8 @@ def main():
         stall_ms = sum(a.elapsed_time(b) for a, b in gather_stats.get('stall_events', []))
         per_frag = F * ((E * codec.words if args.compact else env.obs.numel()) + env.reward.numel()) * 4
         handoff = {'mode': args.gather, 'backend': 'rccl' if args.backend == 'nccl' else args.backend, 'rccl_ranks': dist.get_world_size(),
-                   'overlapped_on_side_stream': args.backend == 'nccl',
+                   'overlapped_on_side_stream': args.backend == 'nccl', 'algo': args.gather_algo,
+                   'rccl_hints': {k: os.environ[k] for k in ('RCCL_DIRECT_ALLGATHER_THRESHOLD', 'NCCL_PROTO', 'NCCL_ALGO') if k in os.environ} or None,
                    # counted where the collectives are ISSUED (count_collectives), reset after the warm-up: what really ran between t0
                    # and the closing fence of the timed region (drain() waits for all of them before the fence)
                    'collectives_in_timed_region': gather_stats['collectives'],
@@ -942,7 +1040,7 @@ def main():
         """The rollout hand-off north_star names, measured next to the headline (never part of `value`): fragments of F steps
         of observations + rewards all-gathered over RCCL on a side stream while the next fragment is stepped."""
         from deepcomp_amd.sharded import RolloutGather
-        g2 = gather if gather is not None else RolloutGather(use_side_stream=(args.backend == 'nccl'))
+        g2 = gather if gather is not None else RolloutGather(use_side_stream=(args.backend == 'nccl'), algo=args.gather_algo)
         bufs = [{'obs': None if direct else torch.empty((F,) + tuple(env.obs.shape), device=dev),
                  'reward': torch.empty((F,) + tuple(env.reward.shape), device=dev)} for _ in range(2)]
         if compact:
@@ -1034,7 +1132,7 @@ def main():
     # The first few hundred launches after idle run 5-15 % slower (clock / power management settling: 91 -> 115 -> 82 us per
     # launch over 300 launches on a cold MI355X, tools/kprobe.py): with the driver's --steps 20 the timed region lies inside
     # that transient.  The steady state is reported NEXT to it, never instead of it: >= 300 further launches untimed, then 200 timed.
-    steady_ms, steady_clk = None, None
+    steady_ms, steady_clk, sustained = None, None, None
     if world == 1 and not T and frag_bufs is None and gather is None:
         t = run(max(0, 300 - K), t_env)
         sp2 = []
@@ -1042,10 +1140,40 @@ def main():
         smi = SmiSampler(local_rank)              # gfx clock / socket power WHILE the launches run (profiles/r05_c3_clock_trace.txt)
         t = run(200, t, sp2)
         if smi.err is None:                       # the firmware's table is a ~20 ms filtered view and the clock needs ~0.3 s of load to settle at its
-            run(3000, t)                          # power-limited value: keep stepping (untimed) until the reading means something
+            t = run(3000, t)                      # power-limited value: keep stepping (untimed) until the reading means something
         torch.cuda.synchronize(dev)
         steady_clk = smi.stop()
         steady_ms = sum(a.elapsed_time(b) for a, b, _ in sp2) / sum(n for _, _, n in sp2)
+        # SUSTAINED behaviour inside the driver-run line (">= 1 000 steps after 100 warm-up"): >= 3 s of
+        # back-to-back headline launches, timed with HIP events per run of launches between two resets (100 launches), reported in
+        # blocks of 1 000 launches; the gfx clock and socket power are read while it runs.
+        if default_workload and args.sustained_launches >= 2000 and packed_main is None:
+            n_s = args.sustained_launches // 1000 * 1000
+            sp3 = []
+            ev_pool.extend(torch.cuda.Event(enable_timing=True) for _ in range(2 * (n_s // L + 3)))
+            smi3 = SmiSampler(local_rank, period=0.02)
+            t_s0 = time.perf_counter()
+            t = run(n_s, t, sp3)
+            torch.cuda.synchronize(dev)
+            sus_wall = time.perf_counter() - t_s0
+            sus_clk = smi3.stop()
+            blocks, acc_ms, acc_n = [], 0.0, 0
+            for a_, b_, n_ in sp3:
+                acc_ms += a_.elapsed_time(b_)
+                acc_n += n_
+                if acc_n >= 1000:
+                    blocks.append(acc_ms / acc_n)
+                    acc_ms, acc_n = 0.0, 0
+            bs_ = sorted(blocks)
+            pick = lambda q: bs_[min(len(bs_) - 1, int(q * len(bs_)))]      # noqa: E731
+            sustained = {'launches': n_s, 'blocks_of': 1000, 'blocks': len(blocks), 'wall_s': sus_wall,
+                         'kernel_ms_p10': pick(0.10), 'kernel_ms_median': pick(0.50), 'kernel_ms_p90': pick(0.90),
+                         'kernel_ms_first_block': blocks[0], 'kernel_ms_last_block': blocks[-1], 'last_over_first': blocks[-1] / blocks[0],
+                         'kernel_ms_mean': sum(blocks) / len(blocks), 'clock_and_power_at_end': sus_clk,
+                         'how': f'{n_s} back-to-back launches of the headline kernel after the timed region and the steady-state leg (resets every {L} steps '
+                                'in between, outside the event pairs), HIP events per 100-launch run, grouped into blocks of 1 000 launches'}
+        else:
+            sustained = None
     resets_timed = sum(1 for s in range(t_env - K, t_env) if s % L == 0)
     also_late = None
     if not args.no_also and default_workload and args.also_after:
@@ -1115,10 +1243,19 @@ def main():
                                                'frac': sbpe * E / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                'how': f'200 launches timed after {max(300, K)} untimed ones (same HIP-event method)',
                                                'clock_and_power': steady_clk}
+        if sustained is not None:
+            sustained['achieved_at_median'] = sbpe * E / (sustained['kernel_ms_median'] * 1e-3) / 1e9
+            sustained['frac_at_median'] = sustained['achieved_at_median'] / HBM_PEAK_GBS
+            out.setdefault('also', {})['sustained'] = sustained
         if args.traffic_bytes is None:
             ent, src = traffic_from_profile(f'{E}x{U}x{B}_{args.kind}_{args.sharing}' + ('_compact' if packed_main is not None else ''), env.step_kernel_name, want_entry=True)
             out['roofline']['traffic'] = (2.0 * ent['fetch_kib'] + ent['write_kib']) * 1024.0 if ent else None
             out['roofline']['traffic_source'] = src
+            if ent and ent.get('avg_ns'):
+                # the same 7 652 B x 65 536 over the TRACKED rocprofv3 --kernel-trace mean of this kernel (profiles/<tag>_summary.txt): what a
+                # reader of profiles/ recomputes, next to the HIP-event figure of this run
+                out['roofline']['frac_profile'] = sbpe * E / (ent['avg_ns'] * 1e-9) / 1e9 / HBM_PEAK_GBS
+                out['roofline']['frac_profile_how'] = f"algorithmic bytes / the rocprofv3 --kernel-trace --stats mean ({ent['avg_ns'] / 1e3:.2f} us over {ent.get('calls', '?')} launches) in profiles/{ent['tag']}_summary.txt"
             if ent and valu_bound(ent, kern_ms):
                 out['roofline']['valu'] = valu_bound(ent, kern_ms)
                 if steady_ms is not None and steady_clk and steady_clk.get('gfxclk_mhz'):

@@ -70,8 +70,8 @@ POLICY = {'3gpp': 0, 'fullcomp': 1, 'dynamic': 2, 'cluster': 3}
 
 EXPORTS = ['dcomp_abi_version', 'dcomp_create_v', 'dcomp_create', 'dcomp_destroy', 'dcomp_state_sizes', 'dcomp_obs_dim', 'dcomp_reset', 'dcomp_step',
            'dcomp_step_dyn', 'dcomp_num_ue',
-           'dcomp_rollout', 'dcomp_rollout_ex', 'dcomp_rollout_is_fused', 'dcomp_rollout_fused_for', 'dcomp_lanes_per_env', 'dcomp_step_kernel_name', 'dcomp_check', 'dcomp_time', 'dcomp_episode', 'dcomp_set_episode', 'dcomp_set_seed', 'dcomp_set_tape', 'dcomp_get_counters', 'dcomp_set_counters', 'dcomp_mt_draw_tape',
-           'dcomp_connect_threshold', 'dcomp_last_error', 'dcomp_version', 'dcomp_selftest', 'dcomp_heuristic_actions', 'dcomp_set_policy',
+           'dcomp_rollout', 'dcomp_rollout_ex', 'dcomp_rollout_is_fused', 'dcomp_rollout_fused_for', 'dcomp_lanes_per_env', 'dcomp_needs_conn_hi', 'dcomp_step_kernel_name', 'dcomp_check', 'dcomp_time', 'dcomp_episode', 'dcomp_set_episode', 'dcomp_set_seed', 'dcomp_set_tape', 'dcomp_get_counters', 'dcomp_set_counters', 'dcomp_mt_draw_tape',
+           'dcomp_connect_threshold', 'dcomp_connect_boundary_sq', 'dcomp_last_error', 'dcomp_version', 'dcomp_selftest', 'dcomp_heuristic_actions', 'dcomp_set_policy',
            'dcomp_fragment_words', 'dcomp_pack_fragment', 'dcomp_unpack_fragment']
 
 _lib = None
@@ -115,6 +115,8 @@ def load():
             L.dcomp_rollout_fused_for.argtypes = [vp, i32, i32, i32]
         if hasattr(L, 'dcomp_lanes_per_env'):
             L.dcomp_lanes_per_env.argtypes = [vp]
+        if hasattr(L, 'dcomp_needs_conn_hi'):
+            L.dcomp_needs_conn_hi.argtypes = [vp]
         if hasattr(L, 'dcomp_step_kernel_name'):
             L.dcomp_step_kernel_name.argtypes = [vp, ctypes.c_char_p, i32]
     L.dcomp_check.argtypes = [vp, ctypes.POINTER(DcompState), vp]
@@ -129,6 +131,8 @@ def load():
     L.dcomp_set_counters.argtypes = [vp, ctypes.POINTER(i64)]
     L.dcomp_mt_draw_tape.argtypes = [ctypes.POINTER(DcompCfg), ctypes.POINTER(i64), i32, i32, vp, vp]
     L.dcomp_connect_threshold.restype = ctypes.c_double
+    if hasattr(L, 'dcomp_connect_boundary_sq'):
+        L.dcomp_connect_boundary_sq.restype = ctypes.c_double
     L.dcomp_last_error.restype = ctypes.c_char_p
     L.dcomp_version.restype = ctypes.c_char_p
     L.dcomp_selftest.argtypes = [i32, i32, vp, vp, vp, i64, vp]

@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #define DCOMP_BUILDING_LIBRARY 1     // (no dcomp_create -> dcomp_create_v macro in here)
@@ -88,15 +90,58 @@ static double ref_snr(double d)
     double pl = c1 + c2 * std::log10(d + 1e-16);
     return std::pow(10.0, (tx - pl) / 10.0) / noise;
 }
-extern "C" double dcomp_connect_threshold(void)
+// d_T = the smallest double d whose snr, computed the reference's way, is NOT above the threshold; -1 when that computed snr is not
+// monotone within 4 096 doubles either side of d_T (then `d < d_T` would not be the reference's decision; dcomp_create refuses).
+static double connect_threshold_checked()
 {
-    double lo = 60.0, hi = 80.0;    // snr(lo) > 2e-8 >= snr(hi)
-    for (int i = 0; i < 200; i++) {
-        double mid = 0.5 * (lo + hi);
-        if (mid == lo || mid == hi) break;
-        if (ref_snr(mid) > 2e-8) lo = mid; else hi = mid;
-    }
-    return hi;
+    static const double cached = [] {
+        double lo = 60.0, hi = 80.0;    // snr(lo) > 2e-8 >= snr(hi)
+        for (int i = 0; i < 200; i++) {
+            double mid = 0.5 * (lo + hi);
+            if (mid == lo || mid == hi) break;
+            if (ref_snr(mid) > 2e-8) lo = mid; else hi = mid;
+        }
+        double below = hi, above = hi;
+        for (int k = 0; k < 4096; k++) {
+            below = std::nextafter(below, 0.0);
+            if (!(ref_snr(below) > 2e-8) || ref_snr(above) > 2e-8) return -1.0;
+            above = std::nextafter(above, INFINITY);
+        }
+        return hi;
+    }();
+    return cached;
+}
+extern "C" double dcomp_connect_threshold(void) { return connect_threshold_checked(); }
+// The reference decides `snr(sqrt(dx*dx + dy*dy)) > 2e-8` (station.py:122-127, 222-226): with q = fl(fl(dx*dx) + fl(dy*dy)) -- two rounded
+// squares, one rounded sum, contraction off -- that is sqrt_rn(q) < d_T, and since the correctly rounded root is monotone,
+//     in range  <=>  q < X,   X = the smallest double q with sqrt_rn(q) >= d_T.
+// X is NOT fl(d_T * d_T) (one ulp above X for the reference's constants): the kernels compare against X (KParams::dt2), found here by
+// walking the doubles around d_T * d_T with the host's IEEE sqrt (checked against brute force in dcomp_create, qmax(v)).
+extern "C" double dcomp_connect_boundary_sq(void)
+{
+    const double dt = connect_threshold_checked();
+    if (!(dt > 0.0)) return -1.0;
+    double q = dt * dt;
+    while (std::sqrt(q) >= dt) q = std::nextafter(q, 0.0);
+    while (std::sqrt(q) < dt) q = std::nextafter(q, INFINITY);
+    return q;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the FUNCTION on a DEVICE, shared by every env that launches it: it is raised
+// ONCE per (function, device) to the most the kernel can ever ask for (the CU's 160 KB for the generic kernel, 72 KB for the heuristic
+// kernel), never to the current caller's own figure -- a later env with a smaller footprint must not lower the limit under an earlier one.
+static hipError_t raise_lds_limit(const void *fn, int bytes)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<const void *, int>> done;            // (function, device) pairs already raised
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto &d : done) if (d.first == fn && d.second == dev) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.emplace_back(fn, dev);
+    return e;
 }
 
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -217,8 +262,16 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
         kp.half_gamma = (float)(c2 / 20.0);
         kp.log2k = (float)(std::log2(ref_snr(1.0)) + (double)dcomp::L2_OFF);
         kp.log2k_s = (float)(std::log2(ref_snr(1.0)) + (double)dcomp::L2_OFF - 12.0 * (c2 / 20.0));
-        double dt = dcomp_connect_threshold();
-        kp.dt2 = dt * dt;
+        kp.dt2 = dcomp_connect_boundary_sq();       // X: q < X  <=>  snr(sqrt(q)) > 2e-8 in the reference's own arithmetic
+        {   // the kernels decide on a FUSED d^2 and redo a pair in the reference's form when (float)fused == (float)X (dcomp_device.h, dist_sq_ref):
+            // sound iff every double within 4 ulp of X has the float image of X -- else every pair takes the reference form
+            kp.dt2f = (float)kp.dt2;
+            double lo = kp.dt2, hi = kp.dt2;
+            for (int k = 0; k < 4; k++) { lo = std::nextafter(lo, 0.0); hi = std::nextafter(hi, INFINITY); }
+            kp.dsq_exact = ((float)lo == kp.dt2f && (float)hi == kp.dt2f) ? 0u : 1u;
+            if (getenv("DCOMP_DSQ_EXACT") && atoi(getenv("DCOMP_DSQ_EXACT")) != 0) kp.dsq_exact = 1u;      // tests: the always-exact path
+        }
+        if (!(kp.dt2 > 0.0)) { delete env; return fail(DCOMP_EUNSUPPORTED, "the host's log10 / pow make snr(d) non-monotone around the connect threshold: d < d_T would not be the reference's decision"); }
     }
     for (unsigned v = 0; v < 256; v++) {
         // the kernel's closed form of qmax(v) = max{q : sqrt_rn(q) <= v} (move_ue) against brute force
@@ -271,8 +324,8 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
         if (e == hipSuccess) e = hipMemcpy(env->d_bs, xy.data(), sizeof(double) * 2 * B, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(env->d_mode, md.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice);
         env->big_lds = (size_t)dcomp::big_carve(B, env->bigk.gpb, env->bigk.block, env->bigp.maxcap_mask != 0ull).total;
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(env->bigk.step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->big_lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(env->bigk.reset), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->big_lds);
+        if (e == hipSuccess) e = raise_lds_limit(reinterpret_cast<const void *>(env->bigk.step), 160 * 1024);
+        if (e == hipSuccess) e = raise_lds_limit(reinterpret_cast<const void *>(env->bigk.reset), 160 * 1024);
         if (e != hipSuccess) { dcomp_destroy(env); return fail(DCOMP_EHIP, "device setup failed (generic kernel, %zu bytes of LDS per workgroup): %s", env->big_lds, hipGetErrorString(e)); }
         env->bigp.bs = env->d_bs; env->bigp.mode = env->d_mode; env->bigp.B = B;
     }
@@ -702,6 +755,9 @@ extern "C" int dcomp_rollout_fused_for(const dcomp_env *env, int32_t num_steps, 
     if (every_step && (uint64_t)num_steps * EU >= fused_row_limit()) return 0;
     return (env->fused || (env->fused_long && (num_steps >= 4 || policy_loop))) ? 1 : 0;
 }
+// 1: this env runs on the generic kernel, whose connection sets take two words per UE -- dcomp_state.conn_hi is REQUIRED (dcomp_reset / dcomp_step
+// fail with DCOMP_EINVAL without it); 0: the specialised kernels, conn_hi is ignored.  The caller asks instead of re-deriving the rule.
+extern "C" int dcomp_needs_conn_hi(const dcomp_env *env) { return env ? (env->big ? 1 : 0) : -1; }
 extern "C" int dcomp_lanes_per_env(const dcomp_env *env) { return env ? (env->tight_g ? env->tight_g : env->upad) : -1; }
 
 // The instantiation dcomp_step launches for this env, spelled as rocprofv3 prints it ("step_kernel<10, 32, 2>"): bench.py ties a
@@ -1023,11 +1079,7 @@ extern "C" int dcomp_heuristic_actions(const dcomp_policy *p, const float *obs, 
     int wpb = (int)(60 * 1024 / per_wave);
     wpb = wpb > 4 ? 4 : wpb < 1 ? 1 : wpb;
     if (per_wave * wpb > 64 * 1024) {           // 64 rows of more than 60 stations: one wave per workgroup, above the default 64 KiB of dynamic LDS
-        static bool raised = false;
-        if (!raised) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(heuristic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
-            raised = true;
-        }
+        HIP_TRY(raise_lds_limit(reinterpret_cast<const void *>(heuristic_kernel), 72 * 1024));
     }
     const int64_t waves = (k.rows + 63) / 64;
     dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
         for (unsigned long long m = conn; m; m &= m - 1ull) {
             const int b = __ffsll((long long)m) - 1;
             const double dx = bs_s[b].x - px, dy = bs_s[b].y - py;
-            if (__builtin_fma(dy, dy, dx * dx) < p.dt2) stale += myrow[b];
+            if (dist_sq_ref(dx, dy) < p.dt2) stale += myrow[b];
             else conn &= ~(1ull << b);
         }
         ewma = __builtin_fmaf(0.9f, stale, 0.1f * ewma);

@@ -169,7 +169,10 @@ struct KParams {
     float half_gamma;          // path-loss exponent c2/10, halved (applied to log2 d^2)
     float log2k;               // log2(K) + L2_OFF
     float log2k_s;             // log2(K) + L2_OFF - 12 * half_gamma  (pair_eval scales d^2 by 2^-12)
-    double dt2;                // squared connect-threshold distance
+    double dt2;                // X = smallest double q with sqrt_rn(q) >= d_T: in range <=> dist_sq_ref < X (dcomp_connect_boundary_sq)
+    float dt2f;                // (float)X: a FUSED d^2 whose float image differs from this cannot sit within 4 doubles of X (host-checked),
+                               //   so there the fused compare IS the reference decision; on equality the pair is redone in the reference form
+    uint32_t dsq_exact;        // 1: that host check failed (X too close to a float rounding boundary): every pair takes the reference form
     double bs_x[DCOMP_MASK32_MAX_BS], bs_y[DCOMP_MASK32_MAX_BS];   // (stations of the specialised kernels; 33 ... 64 stations: dcomp_big.h reads a device table)
     int32_t bs_mode[DCOMP_MASK32_MAX_BS];
 };
@@ -350,6 +353,28 @@ __device__ __forceinline__ float clamp_med3(float x, float lo, float hi) { retur
 // +1e-16 of station.py:116 matters; those pairs are redone by pair_eval_tiny under a wave-uniform rare branch.
 // (pair_eval_q: the same with the float d^2 handed back instead of the `near` test -- eval_pairs keeps the MINIMUM over the stations and
 // tests once: one v_med3 per station instead of a compare and an OR)
+// The reference's squared distance: two rounded squares and a rounded sum (shapely Point.distance -> GEOS sqrt(dx*dx + dy*dy),
+// station.py:124), and its range decision: dist_sq_ref < X (X = KParams::dt2, dcomp_connect_boundary_sq).  fma(dy, dy, dx*dx) differs from the
+// two-rounding sum in the last bit for ~18 % of pairs -- by at most 2 ulp -- so a decision taken on the FUSED value can differ only where the
+// fused value lies within 2 ulp of X.  Round 6: the kernels keep the fused value for the common case (one FP64 instruction fewer per pair, and
+// the unfused form in every pair cost the headline kernel 35 VGPRs = two of its six waves per SIMD: 74.1 -> 79.0 us, profiles/r06_ab_dsq.txt)
+// and redo the decision in the reference's literal form exactly where the two CAN differ: when (float)fused == (float)X.  The host checks
+// that every double within 4 ulp of X has that float image (dsq_exact = 1 otherwise: always the reference form).  Hit rate ~1e-7 per pair;
+// tests/test_threshold_gpu.py puts 1 000+ placements per kernel family there.
+#ifndef DCOMP_DSQ_FUSED
+#define DCOMP_DSQ_FUSED 0          // 1: the round-5 predicate, fused value only (A/B; fails the threshold tests)
+#endif
+__device__ __forceinline__ double dist_sq_ref(double dx, double dy)
+{
+#pragma clang fp contract(off)
+    const double xx = dx * dx, yy = dy * dy;
+    return xx + yy;
+}
+// the rare side of the decision, kept out of line: (float)fused d^2 == (float)X
+__device__ __noinline__ bool in_range_exact(double px, double py, double bx, double by, double dt2)
+{
+    return dist_sq_ref(bx - px, by - py) < dt2;
+}
 __device__ __forceinline__ void pair_eval_q(double px, double py, double bx, double by, const KParams &p, bool &in_range, float &l2snr, float &q);
 __device__ __forceinline__ void pair_eval(double px, double py, double bx, double by, const KParams &p, bool &in_range,
                                           float &l2snr, bool &tiny)
@@ -357,12 +382,15 @@ __device__ __forceinline__ void pair_eval(double px, double py, double bx, doubl
     float q;
     pair_eval_q(px, py, bx, by, p, in_range, l2snr, q);
     tiny = q < NEAR_D2;                          // "near": superset of the d^2 < 1e-20 pairs the fix-up replaces
+#if !DCOMP_DSQ_FUSED
+    if (q == p.dt2f || p.dsq_exact) in_range = in_range_exact(px, py, bx, by, p.dt2);       // rare, per lane: the reference's literal form
+#endif
 }
 __device__ __forceinline__ void pair_eval_q(double px, double py, double bx, double by, const KParams &p, bool &in_range, float &l2snr, float &q)
 {
     double dx = bx - px, dy = by - py;
     double dsq = __builtin_fma(dy, dy, dx * dx);
-    in_range = dsq < p.dt2;                      // snr > 2e-8  <=>  d < d_T, decided in FP64
+    in_range = dsq < p.dt2;                      // PROVISIONAL where (float)dsq == p.dt2f: the caller redoes those pairs with in_range_exact
     q = (float)dsq;
     // v_log_f32's absolute error scales with |result| (log2 d^2 ~ 12 near the connect range -> ~1e-6, i.e. ~1.1e-6
     // relative in snr = 2^l2snr).  Scaling d^2 by 2^-12 first puts every in-range pair at |log2| < 4 for the price
@@ -411,6 +439,7 @@ __device__ __forceinline__ uint32_t eval_pairs(double px, double py, const KPara
 {
     uint32_t in_range = 0;
     float qmin = 3.0e38f;
+    bool edge = false;                           // some station of this lane sits where the fused d^2 cannot decide (pair_eval_q)
 #pragma unroll
     for (int b = 0; b < B; b++) {
         bool ir;
@@ -418,7 +447,16 @@ __device__ __forceinline__ uint32_t eval_pairs(double px, double py, const KPara
         pair_eval_q(px, py, bsx ? bsx[b] : DCOMP_BSX(b), bsy ? bsy[b] : DCOMP_BSY(b), p, ir, l2[b], q);
         in_range |= (uint32_t)ir << b;
         qmin = min_med3(qmin, q);
+        edge |= q == p.dt2f;
     }
+#if !DCOMP_DSQ_FUSED
+    if (__ballot(edge) != 0ull || p.dsq_exact) {  // rare (~1e-7 per pair), wave-uniform: every station of the wave again, in the reference's form
+        in_range = 0;
+#pragma unroll
+        for (int b = 0; b < B; b++)
+            in_range |= (uint32_t)in_range_exact(px, py, bsx ? bsx[b] : p.bs_x[b], bsy ? bsy[b] : p.bs_y[b], p.dt2) << b;
+    }
+#endif
     const bool nw = __ballot(qmin < NEAR_D2) != 0ull;
     if (near_wave) *near_wave = nw;
     if (nw) {                                    // rare (~3 % of the wavefronts): a lane within 1.26 m of a BS

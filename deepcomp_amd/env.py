@@ -206,7 +206,9 @@ class BatchedMobileEnv:
         self.mv = torch.zeros(n, dtype=torch.int64, device=dev)
         self.conn = torch.zeros(n, dtype=torch.int32, device=dev)
         # more than 32 stations (or more than 256 UE slots per env): the generic kernel; stations 32-63 of the connection sets in a second word per UE (dcomp_state.conn_hi)
-        self.conn_hi = torch.zeros(n, dtype=torch.int32, device=dev) if (B > _lib.MASK32_MAX_BS or U > _lib.SPECIAL_MAX_UE or os.environ.get('DCOMP_FORCE_BIG', '0') not in ('', '0')) else None      # (every env of the generic kernel has the word)
+        # (every env of the generic kernel has the word; the LIBRARY says whether this env is one -- it knows every reason to take that kernel)
+        needs_hi = (L.dcomp_needs_conn_hi(self._h) == 1) if hasattr(L, 'dcomp_needs_conn_hi') else (B > _lib.MASK32_MAX_BS or U > _lib.SPECIAL_MAX_UE)
+        self.conn_hi = torch.zeros(n, dtype=torch.int32, device=dev) if needs_hi else None
         self.ewma = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flags = torch.zeros(4, dtype=torch.int32, device=dev)
         # all outputs of one step live in ONE flat buffer (sections 16-byte aligned): the single-env compatibility mode
@@ -796,7 +798,7 @@ class BatchedMobileEnv:
             diff = sorted(k for k in set(have) | set(want) if have.get(k) != want.get(k))
             raise ValueError(f"checkpoint belongs to a differently configured env batch (differs in: {', '.join(diff)})")
         for k in ('pos', 'mv', 'conn', 'conn_hi', 'ewma', 'conn_since', 'uid', 'orig_consumed'):
-            if sd.get(k) is not None:
+            if sd.get(k) is not None and getattr(self, k) is not None:      # (e.g. conn_hi of a checkpoint written under DCOMP_FORCE_BIG, read without it: stations 32-63 do not exist)
                 getattr(self, k).copy_(sd[k])
         self._outbuf.copy_(sd['outbuf'])
         self.flags.zero_()
@@ -835,25 +837,28 @@ class BatchedMobileEnv:
         self._out = self._make_out(self.obs, self.reward)
         self._out_ref = ctypes.byref(self._out)
 
-    def outputs_host(self, synced=False, persistent=False):
+    def outputs_host(self, synced=False, persistent=False, slot=0):
         """Everything the last reset()/step() produced as a dict of numpy views: ONE device->host copy, or (host_io) the
         pinned buffer itself -- then the caller has synchronised (check()) and consumes the views before the next step.
         persistent: the copy lands in ONE pinned host buffer that lives as long as the env, and the SAME dict of views over it is
         returned every time (refilled in place, nothing allocated per call): for callers that build per-env views of it once and
-        consume a step's values before the next step (deepcomp_amd.rllib_adapter)."""
+        consume a step's values before the next step (deepcomp_amd.rllib_adapter).  slot: WHICH persistent buffer (each slot is its own
+        pinned buffer + view dict): the adapters keep a step's outputs (slot 0) apart from a reset's (slots 1 / 2), so that the views of the
+        last step survive a reset that RLlib requests env by env."""
         if self.host_io:
             if not synced:
                 torch.cuda.current_stream(self.device).synchronize()
             h = self._outbuf.numpy()
         elif persistent:
-            m = self.__dict__.get('_host_mirror')
-            if m is None:
-                m = self._host_mirror = torch.empty(self._outbuf.shape, dtype=torch.float32).pin_memory()
+            mirrors = self.__dict__.setdefault('_host_mirrors', {})
+            if slot not in mirrors:
+                m = torch.empty(self._outbuf.shape, dtype=torch.float32).pin_memory()
                 hv = m.numpy()
-                self._host_views = {name: hv[o:o + cnt].reshape(shape) for name, (o, cnt, shape) in self._sections.items()}
+                mirrors[slot] = (m, {name: hv[o:o + cnt].reshape(shape) for name, (o, cnt, shape) in self._sections.items()})
+            m, views = mirrors[slot]
             m.copy_(self._outbuf, non_blocking=True)
             torch.cuda.current_stream(self.device).synchronize()
-            return self._host_views
+            return views
         else:
             h = self._outbuf.cpu().numpy()
         return {name: h[o:o + cnt].reshape(shape) for name, (o, cnt, shape) in self._sections.items()}

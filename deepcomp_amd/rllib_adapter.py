@@ -19,9 +19,18 @@ Two ways to consume a batch:
   device->host copy (``BatchedMobileEnv.outputs_host(persistent=True)``): ``vector_step`` / ``poll`` allocate no per-env object
   for observations, ``dones`` / multi-agent ``infos`` are shared constants resp. one dict per step.  The views alias the buffer:
   a step's observations must be consumed (RLlib's preprocessor copies them while flattening) before the next step overwrites
-  them; ``env_config['persistent_views'] = False`` restores fresh arrays per step.  ``env_config['info_level']``: 'full' (default,
+  them.  A RESET never touches them: reset observations live in buffers of their own (two, used alternately), so when RLlib's
+  sampler resets env 0 at the horizon (``try_reset(0)`` / ``reset_at(0)``: the whole batch resets) the last step's observations of
+  envs 1 .. E-1, which it has not preprocessed yet, are still what the step wrote (round 6).
+  ``env_config['persistent_views'] = False`` restores fresh arrays per step.  ``env_config['info_level']``: 'full' (default,
   the reference's info dicts, base.py:383-411), 'scalar' (time + scalar_metrics) or 'none' (time only) for the central env,
   whose per-UE metric dicts are the remaining per-env Python work.  Measured rates: INTEGRATION.md section 1, tools/adapter_rate.py;
+* ``env_config['flat_obs'] = True`` (round 6): ``observation_space`` IS the flattened ``Box`` -- per agent ``4B + 1`` floats, central
+  ``U (2B + 1)``, in exactly the order RLlib's Dict-flattening preprocessor would produce (sorted keys: connected, dr, [ues_at_bs,
+  util_at_bs,] utility) -- and ``vector_step`` / ``poll`` hand out ROWS of the one pinned array (``host[e]`` / ``host[e, i]``), no
+  dicts.  RLlib then picks its no-op preprocessor for the Box, and the untouched fully connected policy of env_setup.py:273-283 sees the
+  same input vector as with the Dict space (the tests hold the flat rows to ``flatten_obs`` of the reference-run dicts).  The Dict
+  spaces stay the default: they are the reference's (central.py:147-151, variants.py:255-269);
 * ``poll_tensors() / send_action_tensor()`` -- the same data as device tensors ``[E, U, 4B+1]`` / ``[E, U(2B+1)]`` with no
   host copy and no per-env objects: what a learner on the same GPU (or a custom sampler) uses at E = 65 536.
 
@@ -83,6 +92,11 @@ class _LockStepResets:
     def _init_resets(self):
         self._served = set()
         self._stepped = True             # nothing has been reset yet
+        self._reset_slot = 2             # persistent views: reset outputs alternate between host buffers 1 and 2 (0 = step outputs)
+
+    def _next_reset_slot(self):
+        self._reset_slot = 3 - self._reset_slot
+        return self._reset_slot
 
     def _reset_for(self, index):
         if index is None or self._stepped or index in self._served:
@@ -100,12 +114,17 @@ class CentralVectorEnv(_VectorEnvBase, _LockStepResets):
     def __init__(self, env_config):
         self.core = _core_from_config(env_config, 'central')
         U, B = self.core.U, self.core.B
-        obs_space = spaces.Dict({'connected': spaces.MultiBinary(U * B), 'dr': spaces.Box(low=0, high=1, shape=(U * B,)),
-                                 'utility': spaces.Box(low=-1, high=1, shape=(U,))})
+        self._flat = bool(env_config.get('flat_obs', False))
+        if self._flat:       # the flattening of the Dict below, as the space itself: connected U*B | dr U*B | utility U, all inside [-1, 1]
+            obs_space = spaces.Box(low=-1, high=1, shape=(U * (2 * B + 1),))
+        else:
+            obs_space = spaces.Dict({'connected': spaces.MultiBinary(U * B), 'dr': spaces.Box(low=0, high=1, shape=(U * B,)),
+                                     'utility': spaces.Box(low=-1, high=1, shape=(U,))})
         _VectorEnvBase.__init__(self, obs_space, spaces.MultiDiscrete([B + 1] * U), self.core.E)
         self._ue_keys = [f'UE {ue}' for ue in env_config['ue_list']]          # the keys of info()'s vector_metrics (base.py:407-408)
         self._all = None
-        self._obs = None
+        self._obs = None                 # the observations handed out last (a step's or a reset's)
+        self._obs_p = {}                 # persistent views: {host buffer slot: [per-env dict of views]}
         self._persistent = bool(env_config.get('persistent_views', True))
         self._info_level = env_config.get('info_level', 'full')
         if self._info_level not in ('full', 'scalar', 'none'):
@@ -113,23 +132,24 @@ class CentralVectorEnv(_VectorEnvBase, _LockStepResets):
         self._dones = [False] * self.core.E
         self._init_resets()
 
-    def _obs_list(self):
+    def _obs_list(self, slot=0):
+        """slot 0: a step's outputs; 1 / 2: a reset's (buffers of their own: the last step's views stay valid across a reset)."""
         U, B = self.core.U, self.core.B
         _warn_protocol_path(self)
         if self._persistent:
-            first = self._all is None
-            self._all = self.core.outputs_host(persistent=True)        # ONE D2H copy into the env's pinned buffer; the SAME views every step
-            if first:                                                  # the per-env dicts of views: built once, refilled in place
-                host = self._all['obs']
-                self._obs = [{'connected': row[:U * B], 'dr': row[U * B:2 * U * B], 'utility': row[2 * U * B:]} for row in host]
+            self._all = self.core.outputs_host(persistent=True, slot=slot)   # ONE D2H copy into a pinned buffer of the env; the SAME views every time
+            if slot not in self._obs_p:                                       # the per-env dicts of views (flat_obs: the rows): built once per buffer, refilled in place
+                self._obs_p[slot] = (list(self._all['obs']) if self._flat else
+                                     [{'connected': row[:U * B], 'dr': row[U * B:2 * U * B], 'utility': row[2 * U * B:]} for row in self._all['obs']])
+            self._obs = self._obs_p[slot]
             return self._obs
         self._all = self.core.outputs_host()                           # ONE D2H copy of obs + reward + info; below are views
         host = self._all['obs']
-        self._obs = [{'connected': row[:U * B], 'dr': row[U * B:2 * U * B], 'utility': row[2 * U * B:]} for row in host]
+        self._obs = list(host) if self._flat else [{'connected': row[:U * B], 'dr': row[U * B:2 * U * B], 'utility': row[2 * U * B:]} for row in host]
         return self._obs
 
     def _after_core_reset(self):
-        self._obs_list()
+        self._obs_list(self._next_reset_slot())
 
     def vector_reset(self):
         self._reset_for(None)                    # always a fresh reset; the per-index requests that follow get a new one too
@@ -183,10 +203,14 @@ class MultiAgentBaseEnv(_BaseEnvBase, _LockStepResets):
         B = self.core.B
         self.agent_ids = [str(ue.id) for ue in env_config['ue_list']]
         self.action_space = spaces.Discrete(B + 1)
-        self.observation_space = spaces.Dict({'connected': spaces.MultiBinary(B), 'dr': spaces.Box(low=0, high=1, shape=(B,)),
-                                              'utility': spaces.Box(low=-1, high=1, shape=(1,)),
-                                              'ues_at_bs': spaces.Box(low=0, high=1, shape=(B,)),
-                                              'util_at_bs': spaces.Box(low=-1, high=1, shape=(B,))})
+        self._flat = bool(env_config.get('flat_obs', False))
+        if self._flat:       # the flattening of the Dict below, as the space itself: connected | dr | ues_at_bs | util_at_bs | utility
+            self.observation_space = spaces.Box(low=-1, high=1, shape=(4 * B + 1,))
+        else:
+            self.observation_space = spaces.Dict({'connected': spaces.MultiBinary(B), 'dr': spaces.Box(low=0, high=1, shape=(B,)),
+                                                  'utility': spaces.Box(low=-1, high=1, shape=(1,)),
+                                                  'ues_at_bs': spaces.Box(low=0, high=1, shape=(B,)),
+                                                  'util_at_bs': spaces.Box(low=-1, high=1, shape=(B,))})
         self._all = None
         self._reset_obs = None
         self._fresh = True
@@ -203,22 +227,27 @@ class MultiAgentBaseEnv(_BaseEnvBase, _LockStepResets):
 
     def _build_views(self, host):
         B = self.core.B
+        if self._flat:                            # {env: {agent: row of the pinned array}}
+            return {e: dict(zip(self.agent_ids, host[e])) for e in range(self.core.E)}
         return {e: {aid: {'connected': host[e, i, 0:B], 'dr': host[e, i, B:2 * B], 'ues_at_bs': host[e, i, 2 * B:3 * B],
                           'util_at_bs': host[e, i, 3 * B:4 * B], 'utility': host[e, i, 4 * B:4 * B + 1]}
                     for i, aid in enumerate(self.agent_ids)} for e in range(self.core.E)}
 
-    def _views(self):
+    def _views(self, slot=0):
+        """slot 0: a step's outputs; 1 / 2: a reset's (buffers of their own: the last step's views stay valid across a reset)."""
         _warn_protocol_path(self)
         if self._persistent:
-            self._all = self.core.outputs_host(persistent=True)         # ONE D2H copy into the env's pinned buffer
-            if self._view_dict is None:                                 # {env: {agent: {key: view}}} over that buffer: built once
-                self._view_dict = self._build_views(self._all['obs'])
-            return self._view_dict
+            self._all = self.core.outputs_host(persistent=True, slot=slot)   # ONE D2H copy into a pinned buffer of the env
+            if self._view_dict is None:
+                self._view_dict = {}
+            if slot not in self._view_dict:                             # {env: {agent: {key: view}}} over that buffer: built once
+                self._view_dict[slot] = self._build_views(self._all['obs'])
+            return self._view_dict[slot]
         self._all = self.core.outputs_host()                            # ONE D2H copy of obs + reward + info
         return self._build_views(self._all['obs'])                      # [E, U, 4B+1]
 
     def _after_core_reset(self):
-        self._reset_obs = self._views()
+        self._reset_obs = self._views(self._next_reset_slot())
 
     def poll(self):
         E = self.core.E

@@ -45,6 +45,7 @@ class GatherHandle:
     codec: object = None            # FragmentCodec: out['obs'] arrived as the compact record and is unpacked by wait()
     unpack_out: object = None       # where the unpacked rows go (a reused buffer of the RolloutGather; None: a fresh tensor)
     check_lossless: bool = True
+    error: object = None            # the message of a failed lossless check (every later wait() raises it again)
 
     def wait(self):
         """Block until the gathered fragment is usable; returns {name: tensor[world, ...fragment shape]}.  A fragment that
@@ -54,18 +55,23 @@ class GatherHandle:
         not a multi-agent observation tensor (per-env columns that differ between the rows of an env, `connected` entries that are not
         0 / 1), the words travel with the fragment (out['pack_flags'], one per rank) and a set word raises ValueError here -- one host
         synchronisation per hand-off; RolloutGather(check_lossless=False) leaves the words to the caller."""
+        if self.error is not None:                # a failed check stays failed: a second wait() must not hand out the lossy rows
+            raise ValueError(self.error)
         for w in self.works:
             w.wait()
+        self.works = []
         if self.stream is not None:
             torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
+            self.stream = None
         if self.codec is not None and 'obs' not in self.out:
-            self.out['obs'] = self.codec.unpack(self.out['obs_compact'], out=self.unpack_out)
-            if self.check_lossless and 'pack_flags' in self.out:
+            if self.check_lossless and 'pack_flags' in self.out:        # BEFORE the rows are published
                 fl = self.out['pack_flags'].view(-1).tolist()
                 if any(fl):
                     why = {1: 'per-env columns differ between the rows of an env', 2: '`connected` entry that is not 0 / 1'}
-                    raise ValueError('RolloutGather: the compact record is not lossless for this fragment -- ' + '; '.join(
+                    self.error = ('RolloutGather: the compact record is not lossless for this fragment -- ' + '; '.join(
                         f"rank {r}: " + ', '.join(m for b, m in why.items() if f & b) for r, f in enumerate(fl) if f))
+                    raise ValueError(self.error)
+            self.out['obs'] = self.codec.unpack(self.out['obs_compact'], out=self.unpack_out)
         return self.out
 
 
@@ -77,8 +83,13 @@ class RolloutGather:
     ``shard_bounds(...)[r][0] + e``.  One flat collective per tensor (large messages: on the fully connected
     xGMI mesh every GPU pushes its shard to its 7 peers concurrently)."""
 
-    def __init__(self, group=None, use_side_stream=True, reuse_buffers=0, codec=None, check_lossless=True):
-        """reuse_buffers = k > 0: the gathered tensors -- and, with a codec, the unpacked rows wait() returns, the largest tensor of a
+    def __init__(self, group=None, use_side_stream=True, reuse_buffers=0, codec=None, check_lossless=True, algo='collective'):
+        """algo: 'collective' = one all_gather_into_tensor per tensor (RCCL picks ring / direct by its own thresholds; rccl_direct_hints()
+        moves them); 'p2p' = the direct all-gather spelled out: every rank posts one send of its shard to, and one receive from, each of
+        its N - 1 peers in ONE batch (dist.batch_isend_irecv -> one RCCL group call) -- on the fully connected xGMI mesh every pair has
+        its own link, so all N - 1 transfers of a rank run concurrently and none is forwarded ("direct (one-shot, all-peers)
+        all-gather rather than ring"); the own shard is a device-local copy.  Same result tensor, same handle; gloo runs both.
+        reuse_buffers = k > 0: the gathered tensors -- and, with a codec, the unpacked rows wait() returns, the largest tensor of a
         hand-off -- come from k alternating sets of buffers instead of fresh allocations (a hand-off every few steps should not pay
         the allocator: a GB-sized hipMalloc was seen to cost 30 ms): the tensors of a handle are valid until k further calls.
         The side stream, the communicator's channels and the buffer sets come into being with the first k hand-offs, and the first use
@@ -94,6 +105,9 @@ class RolloutGather:
         # lossless compact record -- 3.2-3.7x fewer bytes -- packed here, unpacked by GatherHandle.wait()
         self.codec = codec
         self.check_lossless = bool(check_lossless)      # wait() reads the gathered pack flags (one host sync per hand-off) and raises if set
+        if algo not in ('collective', 'p2p'):
+            raise ValueError("RolloutGather: algo must be 'collective' or 'p2p'")
+        self.algo = algo
 
     def all_gather_async(self, fragment):
         out, works = {}, []
@@ -101,6 +115,8 @@ class RolloutGather:
             fragment = dict(fragment)
             fragment['obs_compact'] = self.codec.pack(fragment.pop('obs').contiguous())      # on the caller's stream, before the hand-over
             # THIS fragment's flag word travels with it (the codec's word is sticky over all of its pack() calls: snapshot, then clear)
+            # (so FragmentCodec.check() no longer sees a bad pack made through this class: the travelling word is the signal --
+            # GatherHandle.wait() raises on it, or, with check_lossless=False, the caller reads out['pack_flags'])
             fragment['pack_flags'] = self.codec.flags.clone()
             self.codec.flags.zero_()
         some = next(iter(fragment.values()))
@@ -121,7 +137,16 @@ class RolloutGather:
                         o = self._sets[key] = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
                 else:
                     o = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-                works.append(dist.all_gather_into_tensor(o.view(-1), t.view(-1), group=self.group, async_op=True))
+                if self.algo == 'p2p' and self.world > 1:
+                    o[self.rank].copy_(t, non_blocking=True)
+                    ops = []
+                    for d in range(1, self.world):      # rank r sends to r + d while it receives from r - d: every link busy in both directions
+                        to, frm = (self.rank + d) % self.world, (self.rank - d) % self.world
+                        ops.append(dist.P2POp(dist.isend, t, dist.get_global_rank(self.group, to) if self.group is not None else to, self.group))
+                        ops.append(dist.P2POp(dist.irecv, o[frm], dist.get_global_rank(self.group, frm) if self.group is not None else frm, self.group))
+                    works.extend(dist.batch_isend_irecv(ops))
+                else:
+                    works.append(dist.all_gather_into_tensor(o.view(-1), t.view(-1), group=self.group, async_op=True))
                 out[name] = o
         unpack_out = None
         if self.codec is not None and 'obs_compact' in out and self._reuse:
@@ -135,6 +160,14 @@ class RolloutGather:
 
     def all_gather(self, fragment):
         return self.all_gather_async(fragment).wait()
+
+
+def rccl_direct_hints(threshold_bytes=1 << 34):
+    """Environment hints that make RCCL take its DIRECT all-gather (each rank writes its shard straight to every peer over that pair's
+    own xGMI link) for messages up to threshold_bytes instead of the ring, and the Simple protocol for them.  Must be in the environment
+    before the communicator is created (bench.py --rccl-direct sets them before init_process_group); what the installed librccl reads:
+    `strings librccl.so` lists RCCL_DIRECT_ALLGATHER_THRESHOLD and NCCL_PROTO.  Returns the dict (the caller updates os.environ)."""
+    return {'RCCL_DIRECT_ALLGATHER_THRESHOLD': str(int(threshold_bytes)), 'NCCL_PROTO': 'Simple'}
 
 
 class _NullCtx:

@@ -133,6 +133,9 @@ int dcomp_rollout_is_fused(const dcomp_env *env);      /* 1: T steps = one launc
  * steps (>= 4, or a policy loop), and an every-step fragment of >= 2^31 rows (num_steps * num_envs * num_ue) takes the
  * one-launch-per-step path (same results).  1 / 0; -1: bad arguments. */
 int dcomp_rollout_fused_for(const dcomp_env *env, int32_t num_steps, int32_t every_step, int32_t policy_loop);
+int dcomp_needs_conn_hi(const dcomp_env *env);         /* 1: the env runs on the generic kernel (more than 32 stations, more than 256 UE slots, or
+                                                         * DCOMP_FORCE_BIG) and dcomp_state.conn_hi (stations 32-63 of every connection set) must be
+                                                         * given; 0: it is ignored.  Ask after dcomp_create_v instead of re-deriving the rule. */
 int dcomp_lanes_per_env(const dcomp_env *env);         /* lanes an env occupies in dcomp_step: next power of two >= num_ue, or
                                                          * num_ue itself when envs are packed tightly (throughput-bound batches of
                                                          * UE lists that are not a power of two long; DCOMP_TIGHT=0/1 overrides) */
@@ -173,6 +176,11 @@ int dcomp_mt_draw_tape(const dcomp_cfg *cfg, const int64_t *seeds, int32_t num_e
                        int32_t *pos0, uint16_t *triples);
 
 double dcomp_connect_threshold(void);                 /* smallest double d with snr(d) <= 2e-8 (station.py:10,222-226) */
+/* X = the smallest double q with sqrt_rn(q) >= dcomp_connect_threshold(): the reference decides can_connect as
+ * snr(sqrt(dx*dx + dy*dy)) > 2e-8 (station.py:122-127, 222-226), i.e. q < X with q = fl(fl(dx*dx) + fl(dy*dy)).  The kernels compare
+ * exactly that (round 6; X is one ulp BELOW fl(d_T * d_T) for the reference's constants).  -1: the host's libm makes snr non-monotone
+ * around d_T (dcomp_create_v then fails with DCOMP_EUNSUPPORTED). */
+double dcomp_connect_boundary_sq(void);
 const char *dcomp_last_error(void);
 const char *dcomp_version(void);
 

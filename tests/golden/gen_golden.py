@@ -14,6 +14,7 @@ fixed action tape and records inputs + outputs as ``.npz`` data files:
   G6 estack_*.npz       the E-axis stack: env e seeded 42 + 20000*e
   G9 reseed_*.npz       MobileEnv.seed() on a live env, mid-episode and before a reset      (base.py:132-143,171-173)
   G10 ue_arrival_schedules.json   the CLI's five named UE-arrival schedules, from the reference's own get_ue_arrival   (env_setup.py:205-226)
+  G11 traj_threshold_ulps_*.npz   stations within doubles of the connect-threshold circle of static and of moving UEs   (station.py:122-127,222-226)
 
 Fixtures are data only: numbers in, numbers out.  Usage:  python tests/golden/gen_golden.py
 """
@@ -120,7 +121,7 @@ def snapshot(env, kind, obs, reward=None, info=None):
 
 
 def run_trajectory(name, scn, kind, seed, num_steps, reward='avg', tape_mode='uniform', rand_episodes=False,
-                   episodes=1, eps_len=100, scripted=None, save=True, seed_at=None, seed_before_reset=None):
+                   episodes=1, eps_len=100, scripted=None, save=True, seed_at=None, seed_before_reset=None, extra=None):
     """reset() then num_steps x step(); optionally several episodes (reset in between).
     seed_at {global step index: s}: env.seed(s) (base.py:132-143) right before that step -- the streams of the RUNNING episode are
     re-seeded; seed_before_reset {episode: s}: env.seed(s) right before that episode's reset()."""
@@ -180,6 +181,8 @@ def run_trajectory(name, scn, kind, seed, num_steps, reward='avg', tape_mode='un
         out['reset_' + k] = np.stack([r[k] for r in resets])
     for k in steps[0]:
         out['step_' + k] = np.stack([s[k] for s in steps])
+    if extra:
+        out.update(extra)
     if not save:                      # fuzz_oracle_vs_reference.py: compare in memory
         return out
     path = os.path.join(HERE, name + '.npz')
@@ -599,6 +602,93 @@ def gen_many_ues():
     run_trajectory('traj_crowd300x4_central_min_s43', scn, 'central', 43, 10, reward='min', tape_mode='uniform')
 
 
+def ref_connect_threshold():
+    """d_T = the smallest double whose snr -- the body of Basestation.snr, station.py:122-127 -- is not above SNR_THRESHOLD, by bisection on the
+    reference's own methods, plus a check that the computed snr is monotone over the 2 000 doubles either side (else `d < d_T` would not be
+    the reference's decision)."""
+    import math
+    from deepcomp.env.entities.station import SNR_THRESHOLD
+    bs = Basestation('A', Point(0, 0), 'resource-fair')
+
+    def snr(d):
+        return bs.received_power(d) / bs.noise
+
+    lo, hi = 60.0, 80.0
+    while True:
+        mid = 0.5 * (lo + hi)
+        if mid == lo or mid == hi:
+            break
+        if snr(mid) > SNR_THRESHOLD:
+            lo = mid
+        else:
+            hi = mid
+    a = b = hi
+    for _ in range(2000):
+        a = math.nextafter(a, 0.0)
+        assert snr(a) > SNR_THRESHOLD and not snr(b) > SNR_THRESHOLD, 'reference snr is not monotone around d_T'
+        b = math.nextafter(b, math.inf)
+    return hi
+
+
+def gen_threshold():
+    """G11 (round 6): the connect / drop decision within doubles of the threshold circle -- `snr(sqrt(dx*dx + dy*dy)) > 2e-8` decided by the
+    reference itself.  tests/threshold_cases.py places the stations (pure arithmetic on the reference's d_T); the recorded masks are the
+    reference's.  (a) static UEs on integer points, three stations each, incl. the placement of VERDICT r5 (UE (0, 0), station
+    (55.84602421623396, 40.396300411194126): d = d_T exactly -> not connectable); (b) moving UEs: a first reference run records the
+    trajectory (movement does not depend on the stations), the stations then sit on the threshold circle of positions held AFTER a move."""
+    import math
+    from tests import threshold_cases as tc
+    from oracle import oracle as orc
+    d_t = ref_connect_threshold()
+    assert d_t == orc.connect_threshold_distance(), 'oracle and reference disagree on d_T'
+    X = tc.boundary_q(d_t)
+    rng = np.random.default_rng(20261001)
+    # ---- (a) static
+    U, B, W, H = 8, 24, 300, 260
+    ue_xy, bs_pos, tgt, info = tc.static_case(rng, U, B, W, H, d_t)
+    ue_xy[0] = (0, 0)
+    bs_pos[0] = (55.84602421623396, 40.396300411194126)
+    scn = scenarios.Scenario(W, H, scenarios._ids(B), [(float(x), float(y)) for x, y in bs_pos],
+                             [scenarios.sharing_for_bs('mixed', i) for i in range(B)], 'threshold')
+    scn.with_ues(num_static=U)
+    for i, (x, y) in enumerate(ue_xy):
+        scn.ue_specs[i]['pos_x'], scn.ue_specs[i]['pos_y'] = int(x), int(y)
+    rounds = [[(u + s * U) + 1 for u in range(U)] for s in range(B // U)]
+    script = rounds + [[0] * U] + rounds + rounds + [[0] * U]
+    # what the reference's can_connect says for every (target UE, station) placement, and where q sits relative to X
+    ref_can, q_ulps = [], []
+    for b in range(B):
+        bsobj = Basestation('t', Point(*bs_pos[b]), 'resource-fair')
+        px, py = (float(v) for v in ue_xy[tgt[b]])
+        ref_can.append(bool(bsobj.can_connect(Point(px, py))))
+        q_ulps.append((tc.q_ref(px, py, *bs_pos[b]) - X) / math.ulp(X))
+        assert ref_can[-1] == (tc.q_ref(px, py, *bs_pos[b]) < X), 'q < X is not the reference decision'
+    assert ref_can[0] is False
+    extra = {'cfg_threshold_d': np.array(d_t), 'cfg_threshold_q': np.array(X), 'placement_ue': np.asarray(tgt, dtype=np.int32),
+             'placement_can_connect': np.array(ref_can), 'placement_q_minus_X_ulps': np.array(q_ulps)}
+    run_trajectory('traj_threshold_ulps_static_multi_s42', scn, 'multi', 42, len(script), scripted=script, eps_len=len(script) + 1, extra=extra)
+    print('   static placements: connectable', int(np.sum(ref_can)), 'of', B, '| differ from fma(dy,dy,dx*dx) < fl(d_T^2):',
+          info['differs_from_round5_predicate'])
+    # ---- (b) moving
+    U, B, W, H, T = 6, 16, 240, 200, 16
+    def scn_with(bs):
+        sc = scenarios.Scenario(W, H, scenarios._ids(B), [(float(x), float(y)) for x, y in bs],
+                                [scenarios.sharing_for_bs('mixed', i) for i in range(B)], 'threshold')
+        sc.with_ues(num_slow=3, num_fast=1, num_static=2)
+        sc.ue_specs[0]['velocity'], sc.ue_specs[1]['velocity'] = 2, 2.5       # the two 'static' ones: fixed velocities
+        return sc
+    dummy = [(float(rng.uniform(0, W)), float(rng.uniform(0, H))) for _ in range(B)]
+    first = run_trajectory('-', scn_with(dummy), 'central', 43, T, scripted=[[0] * U] * T, eps_len=T + 1, save=False)
+    traj = np.concatenate([first['reset_pos'][:1], first['step_pos']])[:, None]          # [T + 1, E = 1, U, 2]
+    bs_pos, acts, n_dec = tc.moving_case(traj, rng, B, d_t)
+    extra = {'cfg_threshold_d': np.array(d_t), 'cfg_threshold_q': np.array(X)}
+    second = run_trajectory('traj_threshold_ulps_moving_central_s43', scn_with(bs_pos), 'central', 43, T, scripted=acts[:, 0].tolist(),
+                            eps_len=T + 1, extra=extra)
+    chk = np.load(os.path.join(HERE, 'traj_threshold_ulps_moving_central_s43.npz'))
+    assert np.array_equal(chk['step_pos'], first['step_pos']), 'the trajectory depends on the stations?'
+    print('   moving: scripted boundary decisions', n_dec)
+
+
 def gen_ue_arrival():
     """The five named UE-arrival schedules of the CLI (env_setup.py:205-226).  deepcomp.util.env_setup cannot be imported here (it needs a
     real ray), so the reference's OWN get_ue_arrival is lifted out of its module with `ast` -- the function's source, compiled and run
@@ -641,3 +731,4 @@ if __name__ == '__main__':
     gen_ue_arrival()
     gen_many_stations()
     gen_many_ues()
+    gen_threshold()

@@ -3,7 +3,7 @@
 Same synthetic inputs as bench.py / SURVEY.md 8d: grid BS layout, all UEs 'slow', mixed sharing, log utility, reward
 avg, uniform random actions, reset every 100 steps, rand_episodes=True.  The shim Point.distance is a plain sqrt, i.e.
 lighter than real shapely/GEOS: these figures are optimistic for the reference.
-Usage: python tests/golden/time_reference.py > profiles/r01_reference_cpu_timing.txt"""
+Usage: python tests/golden/time_reference.py > profiles/archive/r01_reference_cpu_timing.txt"""
 import os
 import platform
 import random

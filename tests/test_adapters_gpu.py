@@ -155,13 +155,16 @@ def test_protocol_adapters_build_their_views_once(torch_cuda):
     U, B = 10, 5
     vec = CentralVectorEnv(_env_config(gs[0], 8))
     fresh = CentralVectorEnv(dict(_env_config(gs[0], 8), persistent_views=False, info_level='scalar'))
-    o0, f0 = vec.vector_reset(), fresh.vector_reset()
+    r0, f0 = vec.vector_reset(), fresh.vector_reset()
     keep = [o['dr'].copy() for o in f0]
+    o0 = None
     for t in range(5):
         acts = [g['actions'][t].tolist() for g in gs]
         o1, rew, dones, infos = vec.vector_step(acts)
         f1, frew, _, finfos = fresh.vector_step(acts)
+        o0 = o1 if o0 is None else o0
         assert o1 is o0 and all(a is b for a, b in zip(o1, o0)) and o1[3]['dr'].base is not None       # the same list of the same dicts of views
+        assert o1 is not r0                                                   # (a reset's observations live in a buffer of their own; round 6)
         assert f1 is not f0 and rew == frew
         assert 'vector_metrics' in infos[0] and 'vector_metrics' not in finfos[0] and finfos[2]['scalar_metrics'] == infos[2]['scalar_metrics']
         for e in range(8):
@@ -173,16 +176,111 @@ def test_protocol_adapters_build_their_views_once(torch_cuda):
     gm = _load('estack_grid32x10_multi')
     U, B = 32, 10
     base = MultiAgentBaseEnv(_env_config(gm[0], 8))
-    obs0 = base.poll()[0]
+    reset_obs = base.poll()[0]
+    obs0 = None
     for t in range(4):
         base.send_actions({e: {str(u + 1): int(gm[e]['actions'][t][u]) for u in range(U)} for e in range(8)})
         obs, rew, dones, infos, _ = base.poll()
-        assert obs is obs0 and obs[5]['7'] is obs0[5]['7']
+        obs0 = obs if obs0 is None else obs0
+        assert obs is obs0 and obs[5]['7'] is obs0[5]['7'] and obs is not reset_obs
         assert infos[0]['1'] == {'time': t + 1} and infos[7]['32']['time'] == t + 1 and dones[4] == {'__all__': False}
         for e in (0, 3, 7):
             for u in (0, 9, 31):
                 _check_agent(obs[e][str(u + 1)], gm[e], 'step', t, u, B)
                 assert rew[e][str(u + 1)] == pytest.approx(float(gm[e]['step_reward'][t][u]), abs=ATOL_UTIL)
+
+
+def test_step_views_survive_a_reset_requested_env_by_env(torch_cuda):
+    """RLlib's sampler calls try_reset(env_id) / reset_at(i) inside its per-env loop at the horizon, BEFORE it has
+    preprocessed the other envs' last-step observations; the first such request resets the whole batch.  With persistent views the reset
+    used to refill the buffer those observations are views of.  Now resets have buffers of their own: after reset_at(0) / try_reset(0) the
+    step observations of envs 1 .. 7 that the caller still holds are what the step wrote -- dict mode and flat_obs mode."""
+    from deepcomp_amd.rllib_adapter import CentralVectorEnv, MultiAgentBaseEnv
+    gs = _load('estack_grid10x5_central')
+    for flat in (False, True):
+        vec = CentralVectorEnv(dict(_env_config(gs[0], 8), flat_obs=flat))
+        vec.vector_reset()
+        for t in range(3):
+            obs, _, _, _ = vec.vector_step([g['actions'][t].tolist() for g in gs])
+        want = [o.copy() if flat else {k: v.copy() for k, v in o.items()} for o in obs]
+        first = vec.reset_at(0)                          # resets the whole batch
+        for e in range(1, 8):                            # the step views the sampler has not consumed yet
+            if flat:
+                assert np.array_equal(obs[e], want[e])
+            else:
+                assert all(np.array_equal(obs[e][k], want[e][k]) for k in want[e])
+        r3 = vec.reset_at(3)
+        assert not np.array_equal(np.asarray(r3 if flat else r3['dr']), np.asarray(want[3] if flat else want[3]['dr']))   # a reset observation, not the step's
+        keep_first = first.copy() if flat else {k: v.copy() for k, v in first.items()}
+        vec.vector_step([g['actions'][0].tolist() for g in gs])
+        assert np.array_equal(first, keep_first) if flat else all(np.array_equal(first[k], keep_first[k]) for k in keep_first)   # ... and a step leaves the reset's alone
+    gm = _load('estack_grid32x10_multi')
+    U = 32
+    for flat in (False, True):
+        base = MultiAgentBaseEnv(dict(_env_config(gm[0], 8), flat_obs=flat))
+        base.poll()
+        for t in range(3):
+            base.send_actions({e: {str(u + 1): int(gm[e]['actions'][t][u]) for u in range(U)} for e in range(8)})
+            obs = base.poll()[0]
+        snap = lambda o: o.copy() if flat else {k: v.copy() for k, v in o.items()}      # noqa: E731
+        same = lambda a, b: np.array_equal(a, b) if flat else all(np.array_equal(a[k], b[k]) for k in b)      # noqa: E731
+        want = {e: {a: snap(o) for a, o in obs[e].items()} for e in obs}
+        base.try_reset(0)
+        for e in range(1, 8):
+            assert all(same(obs[e][a], want[e][a]) for a in want[e]), f'env {e}: the last step\'s observations changed under a reset'
+
+
+def test_flat_obs_rows_are_the_flattening_of_the_reference_dicts(torch_cuda):
+    """env_config['flat_obs'] (round 6): observation_space is the flattened Box, the protocol methods hand out rows of ONE
+    pinned array.  The rows must be what RLlib's Dict-flattening preprocessor makes of the REFERENCE's observation dicts (sorted keys:
+    connected, dr, [ues_at_bs, util_at_bs,] utility): held to the reference-run estack fixtures piece by piece, and bit-identical to
+    flatten_obs() of the dict-mode adapter stepping the same batch."""
+    from deepcomp_amd.rllib_adapter import CentralVectorEnv, MultiAgentBaseEnv, flatten_obs
+    gs = _load('estack_grid10x5_central')
+    U, B = 10, 5
+    flat = CentralVectorEnv(dict(_env_config(gs[0], 8), flat_obs=True))
+    dic = CentralVectorEnv(_env_config(gs[0], 8))
+    assert flat.observation_space.shape == (U * (2 * B + 1),) and flat.observation_space.low == -1 and flat.observation_space.high == 1
+    fo, do = flat.vector_reset(), dic.vector_reset()
+    assert fo[0].base is not None and fo[0].shape == (U * (2 * B + 1),)
+    for e in range(8):
+        assert np.array_equal(fo[e], flatten_obs(do[e])) and flat.observation_space.contains(fo[e])
+        _check_central({'connected': fo[e][:U * B], 'dr': fo[e][U * B:2 * U * B], 'utility': fo[e][2 * U * B:]}, gs[e], 'reset', 0, U, B)
+    for t in range(gs[0]['actions'].shape[0]):
+        acts = [g['actions'][t].tolist() for g in gs]
+        fo, frew, _, _ = flat.vector_step(acts)
+        do, drew, _, _ = dic.vector_step(acts)
+        assert frew == drew
+        for e in range(8):
+            assert np.array_equal(fo[e], flatten_obs(do[e])) and flat.observation_space.contains(fo[e])
+            _check_central({'connected': fo[e][:U * B], 'dr': fo[e][U * B:2 * U * B], 'utility': fo[e][2 * U * B:]}, gs[e], 'step', t, U, B)
+    assert fo[2].base is flat.vector_step([g['actions'][0].tolist() for g in gs])[0][2].base        # rows of ONE persistent array
+    gm = _load('estack_grid32x10_multi')
+    U, B = 32, 10
+    flat = MultiAgentBaseEnv(dict(_env_config(gm[0], 8), flat_obs=True))
+    dic = MultiAgentBaseEnv(_env_config(gm[0], 8))
+    assert flat.observation_space.shape == (4 * B + 1,)
+    fo, do = flat.poll()[0], dic.poll()[0]
+
+    def as_dict(row):
+        return {'connected': row[:B], 'dr': row[B:2 * B], 'ues_at_bs': row[2 * B:3 * B], 'util_at_bs': row[3 * B:4 * B], 'utility': row[4 * B:]}
+    for e in range(8):
+        for u in range(U):
+            a = str(u + 1)
+            assert np.array_equal(fo[e][a], flatten_obs(do[e][a]))
+            _check_agent(as_dict(fo[e][a]), gm[e], 'reset', 0, u, B)
+    for t in range(10):
+        acts = {e: {str(u + 1): int(gm[e]['actions'][t][u]) for u in range(U)} for e in range(8)}
+        flat.send_actions(acts); dic.send_actions(acts)
+        fo, frew = flat.poll()[:2]
+        do, drew = dic.poll()[:2]
+        assert frew == drew
+        for e in range(8):
+            assert list(fo[e]) == flat.agent_ids
+            for u in range(U):
+                a = str(u + 1)
+                assert np.array_equal(fo[e][a], flatten_obs(do[e][a])) and fo[e][a].shape == (4 * B + 1,)
+                _check_agent(as_dict(fo[e][a]), gm[e], 'step', t, u, B)
 
 
 # ------------------------------------------------------------------------------------ heuristic policy kernel (f4)

@@ -86,3 +86,29 @@ def test_tracked_traffic_goes_stale_with_the_sources_it_was_profiled_on(monkeypa
     assert nbytes is None and 'STALE' in src and 'dcomp_big.h' in src
     monkeypatch.setattr(build, 'kernel_fingerprint', lambda read=None: 'edited')
     assert bench.traffic_from_profile('65536x32x10_multi_mixed', 'step_kernel<10, 32, 2>')[0] is None
+
+
+def test_predict_prints_the_1_to_8_gpu_curve_without_a_gpu():
+    """`python bench.py --predict`: the predicted weak- / strong-scaling curve and the throughput with the rollout hand-off,
+    from the measured single-GPU figures and the stated link assumptions -- a markdown table and one JSON line, no torch, no GPU.  The table in
+    DESIGN.md section 7 is this output."""
+    import json
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--predict'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.strip().splitlines()
+    pr = json.loads(lines[-1])['predicted']
+    rows = {r['n_gpus']: r for r in pr['rows']}
+    assert sorted(rows) == [1, 2, 4, 8] and pr['steps'] == 20
+    assert rows[1]['weak_speedup'] == 1.0 and 6.0 <= rows[8]['weak_speedup'] <= 8.0          # north_star: >= 6 x at 8 GPUs
+    assert all(rows[a]['weak_ms_per_step'] <= rows[b]['weak_ms_per_step'] for a, b in ((1, 2), (2, 4), (4, 8)))
+    assert rows[8]['config5_strong_speedup'] > 8.0 > rows[8]['config4_strong_speedup'] > 6.0  # config 5's share fits the Infinity Cache
+    # the full-observation hand-off is link-bound at every N > 1: far below stepping, and the compact record moves ~3.1 x fewer bytes
+    assert rows[8]['with_rollout_handoff_rows_env_steps_per_s'] < 0.05 * rows[8]['weak_value_env_steps_per_s']
+    assert 2.9 < rows[8]['with_rollout_handoff_compact_env_steps_per_s'] / rows[8]['with_rollout_handoff_rows_env_steps_per_s'] < 3.3
+    table = [l for l in lines if l.startswith('|')]
+    assert len(table) == 6 and table[2].startswith('| 1 |') and table[5].startswith('| 8 |')
+    design = open(os.path.join(REPO, 'DESIGN.md')).read()
+    for l in table[2:]:
+        assert l in design, 'DESIGN.md section 7 does not hold the table `bench.py --predict` prints'
+    assert bench.predict(steps=1000)['rows'][3]['weak_speedup'] > rows[8]['weak_speedup']     # a longer timed region dilutes the bracket

@@ -82,6 +82,39 @@ def test_connect_threshold_matches_reference_constant(lib):
     assert lib.dcomp_connect_threshold() == pytest.approx(68.92488308058013, abs=1e-9)
 
 
+def test_connect_boundary_is_the_reference_decision_to_the_last_bit(lib):
+    """The range decision the kernels take is `fl(fl(dx*dx) + fl(dy*dy)) < X` (dcomp_connect_boundary_sq); the reference's is
+    `snr(sqrt(dx*dx + dy*dy)) > 2e-8` (station.py:122-127, 222-226).  (1) d_T and X equal what tests/golden/gen_golden.py recorded from the
+    reference's own Basestation methods, BIT for bit; (2) X is the smallest double whose correctly rounded root reaches d_T -- one ulp below
+    fl(d_T * d_T), which round 5 compared against; (3) on 20 000 placements within doubles of the circle (tests/threshold_cases.py) `q < X` equals
+    the oracle's literal can_connect(sqrt(q)); (4) the reference-run fixture's own can_connect column agrees."""
+    import math
+    from oracle import oracle as orc
+    from tests import threshold_cases as tc
+    g = np.load(os.path.join(REPO, 'tests', 'golden', 'traj_threshold_ulps_static_multi_s42.npz'))
+    d_t, X = lib.dcomp_connect_threshold(), lib.dcomp_connect_boundary_sq()
+    assert d_t == float(g['cfg_threshold_d']) == orc.connect_threshold_distance()
+    assert X == float(g['cfg_threshold_q']) == tc.boundary_q(d_t)
+    assert math.sqrt(X) >= d_t > math.sqrt(math.nextafter(X, 0.0))
+    assert X == math.nextafter(d_t * d_t, 0.0), 'fl(d_T^2) is one ulp above the boundary for the reference constants'
+    rng = np.random.default_rng(5)
+    n_edge = 0
+    for _ in range(20000):
+        px, py = float(rng.integers(0, 600)), float(rng.integers(0, 600))
+        theta = rng.uniform(0, 2 * math.pi) if rng.random() < 0.5 else rng.choice([0.0, math.pi]) + rng.uniform(2e-5, 0.03) * rng.choice([-1, 1])
+        bx, by = tc.station_at_threshold(px, py, theta, int(rng.integers(-3, 4)), d_t, X, int(rng.integers(-2, 3)))
+        q = tc.q_ref(px, py, bx, by)
+        n_edge += int(abs(q - X) <= 2 * math.ulp(X))
+        assert (q < X) == bool(orc.can_connect(math.sqrt(q))), (px, py, bx, by)
+    assert n_edge > 5000
+    bs = g['cfg_bs_pos']
+    ue = g['cfg_ue_init_xy']
+    for b, u in enumerate(g['placement_ue']):
+        q = tc.q_ref(float(ue[u][0]), float(ue[u][1]), float(bs[b][0]), float(bs[b][1]))
+        assert (q < X) == bool(g['placement_can_connect'][b])
+    assert not g['placement_can_connect'][0] and tc.q_fused(0.0, 0.0, *bs[0]) < d_t * d_t       # VERDICT r5's placement: round 5 connected it
+
+
 def _cfg(U, w, h, vlo, vhi, ix=None, iy=None):
     from deepcomp_amd import _lib
     c = _lib.DcompCfg()

@@ -44,10 +44,12 @@ def _worker(rank, world, port, total_envs, ret):
             'reward': (env_ids.view(1, count, 1) + torch.arange(T).view(T, 1, 1) * 0.5).expand(T, count, U).contiguous(),
             'action': torch.full((T, count, U), rank, dtype=torch.uint8),
         }
-        g = RolloutGather()
-        h = g.all_gather_async(frag)
-        out = h.wait()
         ok = True
+        # 'p2p': the direct all-gather spelled out (one send to / one receive from every peer in one batch) must give the same tensors
+        outs = {algo: RolloutGather(algo=algo).all_gather_async(frag).wait() for algo in ('collective', 'p2p')}
+        for k in frag:
+            ok &= torch.equal(outs['collective'][k], outs['p2p'][k])
+        out = outs['p2p']
         for r in range(world):
             s_r, c_r = shard_bounds(total_envs, world)[r]
             ids = torch.arange(s_r, s_r + c_r, dtype=torch.float32)
@@ -72,6 +74,26 @@ def test_rollout_all_gather_world2():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, 16, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def test_rollout_all_gather_world3_p2p():
+    """Three ranks: every rank has two peers, so the p2p form posts two sends and two receives per tensor in one batch."""
+    world, port = 3, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, 18, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True, 2: True}
+
+
+def test_rccl_direct_hints_name_knobs_the_installed_library_reads():
+    from deepcomp_amd.sharded import rccl_direct_hints
+    h = rccl_direct_hints()
+    assert int(h['RCCL_DIRECT_ALLGATHER_THRESHOLD']) >= 1 << 31 and h['NCCL_PROTO'] == 'Simple'
+    path = '/opt/rocm/lib/librccl.so'
+    if os.path.exists(path):
+        blob = open(path, 'rb').read()
+        for k in h:
+            assert k.encode() in blob, f'{k} is not a knob of the installed librccl'
 
 
 def test_shard_bounds_partition():

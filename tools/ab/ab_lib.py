@@ -44,9 +44,12 @@ def build(a):
         o = os.path.join(objdir, f'b{b}.o')
         procs.append((o, subprocess.Popen(['hipcc'] + flags + [f'-DDCOMP_B={b}', '-c', os.path.join(csrc, 'dcomp_inst.hip'), '-o', o],
                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    o = os.path.join(objdir, 'api.o')
-    procs.append((o, subprocess.Popen(['hipcc'] + flags + ['-c', os.path.join(csrc, 'dcomp_api.hip'), '-o', o], stdout=subprocess.PIPE,
-                                      stderr=subprocess.STDOUT, text=True)))
+    for name in ('api', 'big'):                  # the ABI + dispatch, and the generic kernel dcomp_api.hip links against (round 5 on)
+        if not os.path.exists(os.path.join(csrc, f'dcomp_{name}.hip')):
+            continue
+        o = os.path.join(objdir, f'{name}.o')
+        procs.append((o, subprocess.Popen(['hipcc'] + flags + ['-c', os.path.join(csrc, f'dcomp_{name}.hip'), '-o', o], stdout=subprocess.PIPE,
+                                          stderr=subprocess.STDOUT, text=True)))
     for o, p in procs:
         out, _ = p.communicate()
         if p.returncode:

@@ -9,6 +9,9 @@ Per (env kind, E): env-steps/s of
   persistent  the dicts of views built ONCE over the env's pinned host buffer (round 5 default)
   + flatten   the same, with the minimal consumer RLlib has: every observation dict flattened in sorted-key order (flatten_obs)
   info=none   central only: without the per-UE metric dicts of info (env_config['info_level'])
+  flat_obs    env_config['flat_obs'] = True (round 6): observation_space is the flattened Box, the protocol methods hand out rows of one pinned
+              array; the consumer is what RLlib's preprocessor for a Box does -- NoPreprocessor.transform returns its argument -- called once per
+              observation (a Python call per env / per agent: at 1 024 x 32 agents that call alone is ~1.5 ms per step)
   tensors     poll_tensors() / send_action_tensor(): device tensors, no per-env objects (upper bound; a torch.randint policy on the device)
 Actions are random, generated outside the timed loop.  Not a product path; numbers go to INTEGRATION.md section 1.
 """
@@ -32,6 +35,11 @@ def cfg(U, B, E, **kw):
     c = dict(map=m, bs_list=bs, ue_list=ues, seed=42, episode_length=100, reward='avg', rand_episodes=True, num_envs=E, rng='philox')
     c.update(kw)
     return c
+
+
+def no_preprocessor(o):
+    """RLlib's NoPreprocessor.transform (what it picks for a Box space): the observation itself."""
+    return o
 
 
 def loop(step, seconds):
@@ -62,6 +70,9 @@ def central(U, B, E, seconds, flatten=False, tensors=False, **kw):
         if flatten:
             for o in obs:
                 flatten_obs(o)
+        elif kw.get('flat_obs') and not os.environ.get('ADAPTER_RATE_NO_TOUCH'):
+            for o in obs:
+                no_preprocessor(o)
     r = loop(step, seconds)
     torch.cuda.synchronize()
     return r * E
@@ -90,6 +101,10 @@ def multi(U, B, E, seconds, flatten=False, tensors=False, **kw):
             for per_env in obs.values():
                 for o in per_env.values():
                     flatten_obs(o)
+        elif kw.get('flat_obs') and not os.environ.get('ADAPTER_RATE_NO_TOUCH'):
+            for per_env in obs.values():
+                for o in per_env.values():
+                    no_preprocessor(o)
     r = loop(step, seconds)
     torch.cuda.synchronize()
     return r * E
@@ -102,8 +117,8 @@ def main():
     a = ap.parse_args()
     lines = ['# tools/adapter_rate.py: env-steps/s through the RLlib protocol adapters (one MI355X, one host thread)',
              f'# {torch.cuda.get_device_name(0)}, torch {torch.__version__}, {a.seconds:.1f} s per cell',
-             '| env | E | before (fresh dicts per step) | persistent views | ... + flatten_obs of every dict | info_level=none | tensor path (no per-env objects) |',
-             '|---|---|---|---|---|---|---|']
+             '| env | E | before (fresh dicts per step) | persistent views | ... + flatten_obs of every dict | info_level=none | flat_obs rows + the no-op preprocessor per observation | flat_obs, rows not touched | tensor path (no per-env objects) |',
+             '|---|---|---|---|---|---|---|---|---|']
     for name, fn, U, B in (('central 10 x 5 (VectorEnv.vector_step)', central, 10, 5), ('multi 32 x 10 (BaseEnv.poll + send_actions)', multi, 32, 10)):
         for E in (1, 16, 256, 1024):
             before = fn(U, B, E, a.seconds, persistent_views=False)
@@ -111,7 +126,12 @@ def main():
             flat = fn(U, B, E, a.seconds, flatten=True)
             none = fn(U, B, E, a.seconds, info_level='none') if fn is central else None
             tens = fn(U, B, E, a.seconds, tensors=True)
-            lines.append(f'| {name} | {E} | {before:,.0f} | {pers:,.0f} ({pers / before:.2f} x) | {flat:,.0f} | {"-" if none is None else f"{none:,.0f}"} | {tens:,.0f} |')
+            kw = {'info_level': 'none'} if fn is central else {}
+            rows = fn(U, B, E, a.seconds, flat_obs=True, **kw)
+            os.environ['ADAPTER_RATE_NO_TOUCH'] = '1'
+            rows0 = fn(U, B, E, a.seconds, flat_obs=True, **kw)
+            del os.environ['ADAPTER_RATE_NO_TOUCH']
+            lines.append(f'| {name} | {E} | {before:,.0f} | {pers:,.0f} ({pers / before:.2f} x) | {flat:,.0f} | {"-" if none is None else f"{none:,.0f}"} | {rows:,.0f} | {rows0:,.0f} | {tens:,.0f} |')
             print(lines[-1], flush=True)
     txt = '\n'.join(lines) + '\n'
     if a.out:

@@ -60,6 +60,13 @@ def main():
         if line.startswith('void ') and kern in line and '{' in line:
             d = ast.literal_eval(line[line.index('{'):line.index('}') + 1])
             vals.update(d)
+    avg_ns = calls = None
+    for line in txt.splitlines():             # "== kernel stats ==" rows: {'Name': 'void dcomp::step_kernel<10, 32, 2>(...)', 'Calls': ..., 'AverageNs': ...}
+        line = line.strip()
+        if line.startswith("{'Name'") and kern in line:
+            d = ast.literal_eval(line)
+            avg_ns, calls = float(d['AverageNs']), int(d['Calls'])
+            break
     if 'FETCH_SIZE' not in vals or 'WRITE_SIZE' not in vals:
         sys.exit(f'no FETCH_SIZE / WRITE_SIZE rows for {kern!r} in profiles/{tag}_summary.txt')
     try:
@@ -75,6 +82,7 @@ def main():
                'source_fingerprint': fp.group(1) if fp else None, 'kernel_fingerprint': kfp.group(1) if kfp else None, 'commit': commit,
                'bytes_per_launch': (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0,
                'valu_insts_per_launch': vals.get('SQ_INSTS_VALU'), 'waves_per_launch': vals.get('SQ_WAVES'),
+               'avg_ns': avg_ns, 'calls': calls,             # rocprofv3 --kernel-trace --stats mean of the same kernel (bench.py roofline.frac_profile)
                'note': 'bytes = (2 x FETCH_SIZE [gfx950 wide-read correction] + WRITE_SIZE) KiB per launch'}
     if kern.startswith('big_kernel'):
         # the generic kernel's own sources (build.generic_fingerprint); a summary from before that line existed belongs to the tree whose FULL
