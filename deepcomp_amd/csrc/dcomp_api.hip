@@ -73,7 +73,7 @@ struct dcomp_env {
     int64_t episode;            // index of the current episode (-1 before the first reset)
     // 33 ... 64 stations (or DCOMP_FORCE_BIG=1): the generic kernel of dcomp_big.h instead of `kern`
     bool big = false;
-    dcomp::BigKernels bigk{nullptr, nullptr, 0, 0};
+    dcomp::BigKernels bigk{nullptr, nullptr, nullptr, 0, 0};
     dcomp::BigParams bigp{};
     double2 *d_bs = nullptr;
     int32_t *d_mode = nullptr;
@@ -127,20 +127,27 @@ extern "C" double dcomp_connect_boundary_sq(void)
     return q;
 }
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the FUNCTION on a DEVICE, shared by every env that launches it: it is raised
-// ONCE per (function, device) to the most the kernel can ever ask for (the CU's 160 KB for the generic kernel, 72 KB for the heuristic
-// kernel), never to the current caller's own figure -- a later env with a smaller footprint must not lower the limit under an earlier one.
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the FUNCTION on a DEVICE, shared by every env that launches it: it only ever
+// goes UP -- a running maximum per (function, device) -- so that a later env with a smaller footprint does not lower the limit under an
+// earlier one.  (Asking for the CU's whole 160 KB once and for all is refused by the runtime: "invalid argument".)
 static hipError_t raise_lds_limit(const void *fn, int bytes)
 {
+    struct Raised { const void *fn; int dev, bytes; };
     static std::mutex mu;
-    static std::vector<std::pair<const void *, int>> done;            // (function, device) pairs already raised
+    static std::vector<Raised> done;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lock(mu);
-    for (const auto &d : done) if (d.first == fn && d.second == dev) return hipSuccess;
+    for (auto &d : done) {
+        if (d.fn != fn || d.dev != dev) continue;
+        if (d.bytes >= bytes) return hipSuccess;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) d.bytes = bytes;
+        return e;
+    }
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess) done.emplace_back(fn, dev);
+    if (e == hipSuccess) done.push_back(Raised{fn, dev, bytes});
     return e;
 }
 
@@ -224,13 +231,13 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
     env->big = B > DCOMP_MASK32_MAX_BS || CAP > DCOMP_SPECIAL_MAX_UE || (getenv("DCOMP_FORCE_BIG") && atoi(getenv("DCOMP_FORCE_BIG")) != 0);
     env->mp_pattern = mp;
     if (env->big) {
-        if (DYN) { delete env; return fail(DCOMP_EUNSUPPORTED, "UE arrival / departure (max_ues) is not available with more than %d stations or %d UE slots per env (generic kernel)", DCOMP_MASK32_MAX_BS, DCOMP_SPECIAL_MAX_UE); }
-        if (dcomp::big_lds_bound(B, env->upad < 64 ? 64 : env->upad) > 160 * 1024) {
-            delete env;
-            return fail(DCOMP_EINVAL, "%d UEs x %d stations do not fit one workgroup's LDS (generic kernel: (num_bs + 1) * %d lanes * 4 bytes of rows + tables > 160 KB)", U, B, env->upad);
-        }
         env->bigk = dcomp::big_kernels_for_upad(env->upad);
         if (!env->bigk.step) { delete env; return fail(DCOMP_EUNSUPPORTED, "no generic kernel for %d lanes per env", env->upad); }
+        if (DYN) env->bigk.step = env->bigk.step_dyn;        // UE arrival / departure (round 6: the generic kernel has the event phase too)
+        if ((size_t)dcomp::big_carve(B, env->bigk.gpb, env->bigk.block).total > 160 * 1024) {
+            delete env;
+            return fail(DCOMP_EINVAL, "%d UE slots x %d stations do not fit one workgroup's LDS (generic kernel)", CAP, B);
+        }
         env->kern = dcomp::KernelPair{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         env->grid = (E + env->bigk.gpb - 1) / env->bigk.gpb;
     } else {
@@ -290,7 +297,7 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
         if (m < 0 || m > 3) { delete env; return fail(DCOMP_EINVAL, "bs_sharing[%d]=%d not supported", b, m); }   // station.py:22
         if (b < DCOMP_MASK32_MAX_BS) { kp.bs_x[b] = cfg->bs_x[b]; kp.bs_y[b] = cfg->bs_y[b]; kp.bs_mode[b] = m; }
         if (m == DCOMP_MAX_CAP) { kp.any_maxcap = 1; if (b < 32) kp.maxcap_mask |= 1u << b; env->bigp.maxcap_mask |= 1ull << b; }
-        if (m == DCOMP_RATE_FAIR || m == DCOMP_PROP_FAIR) kp.any_sum_mode = 1;
+        if (m == DCOMP_RATE_FAIR || m == DCOMP_PROP_FAIR) { kp.any_sum_mode = 1; env->bigp.summode_mask |= 1ull << b; }
     }
     std::vector<UeCfg> uc(U);
     kp.all_log_util = 1;
@@ -323,9 +330,9 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
         if (e == hipSuccess) e = hipMalloc((void **)&env->d_mode, sizeof(int32_t) * B);
         if (e == hipSuccess) e = hipMemcpy(env->d_bs, xy.data(), sizeof(double) * 2 * B, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(env->d_mode, md.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice);
-        env->big_lds = (size_t)dcomp::big_carve(B, env->bigk.gpb, env->bigk.block, env->bigp.maxcap_mask != 0ull).total;
-        if (e == hipSuccess) e = raise_lds_limit(reinterpret_cast<const void *>(env->bigk.step), 160 * 1024);
-        if (e == hipSuccess) e = raise_lds_limit(reinterpret_cast<const void *>(env->bigk.reset), 160 * 1024);
+        env->big_lds = (size_t)dcomp::big_carve(B, env->bigk.gpb, env->bigk.block).total;
+        if (e == hipSuccess) e = raise_lds_limit(reinterpret_cast<const void *>(env->bigk.step), (int)env->big_lds);
+        if (e == hipSuccess) e = raise_lds_limit(reinterpret_cast<const void *>(env->bigk.reset), (int)env->big_lds);
         if (e != hipSuccess) { dcomp_destroy(env); return fail(DCOMP_EHIP, "device setup failed (generic kernel, %zu bytes of LDS per workgroup): %s", env->big_lds, hipGetErrorString(e)); }
         env->bigp.bs = env->d_bs; env->bigp.mode = env->d_mode; env->bigp.B = B;
     }
@@ -370,7 +377,7 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
         env->wide_pad_lds = row_bytes >= 1.0e9 ? 24000 : row_bytes >= 4.0e8 ? 13000 : 0;
         if (const char *e = getenv("DCOMP_WIDE_PAD_LDS")) env->wide_pad_lds = atoi(e);                 // A/B
     }
-    if (DYN) {
+    if (DYN && !env->big) {
         if (!env->kern.step_dyn) { dcomp_destroy(env); return fail(DCOMP_EUNSUPPORTED, "no dynamic-UE kernel for this shape"); }
         env->kern.step = env->kern.step_dyn;
     }
@@ -577,7 +584,8 @@ extern "C" int dcomp_step_dyn(dcomp_env *env, const dcomp_state *st, const uint8
     kp.n_remove = nrem; kp.n_add = nadd;
     kp.ev_remove = ev ? ev->remove_idx : nullptr; kp.ev_add_xy = ev ? ev->add_xy : nullptr;
     kp.ev_rem_base = env->n_removed; kp.ev_add_base = env->n_arrived;
-    hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
+    if (env->big) hipLaunchKernelGGL(env->bigk.step, dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, kp, env->bigp);
+    else hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
     HIP_TRY(hipGetLastError());
     env->time += 1;
     env->cur_ue += nadd - nrem;
@@ -766,7 +774,7 @@ extern "C" int dcomp_step_kernel_name(const dcomp_env *env, char *buf, int32_t l
 {
     if (!env || !buf || len < 1) return fail(DCOMP_EINVAL, "null argument");
     const int B = env->cfg.num_bs, W = env->upad, MP = env->mp_pattern;
-    if (env->big) std::snprintf(buf, (size_t)len, "big_kernel<%d, false>", W < 4 ? 4 : W);
+    if (env->big) std::snprintf(buf, (size_t)len, "big_kernel<%d, false, %s>", W < 4 ? 4 : W, env->dyn ? "true" : "false");
     else if (env->tight_g) {
         const bool cen = env->cfg.env_kind == DCOMP_CENTRAL && env->kern.tight_central;
         std::snprintf(buf, (size_t)len, "step_kernel_tight<%d, %d, %d, %d>", B, W, MP, cen ? 0 : -1);

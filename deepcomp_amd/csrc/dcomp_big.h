@@ -1,43 +1,42 @@
-// dcomp_big.h -- the env step for 33 ... 64 base stations (round 5; the reference has no limit: station.py:16-30, base.py:79-84).
+// dcomp_big.h -- the GENERIC env step: any station count up to 64, up to 1 024 UE slots per env, UE arrival / departure included
+// (the reference limits neither: station.py:16-30, base.py:79-84, 433-443, 592-618).
 //
 // The kernels of dcomp_device.h / dcomp_wide.h unroll the station loop (one object file per B = 1 ... 32, per-station register arrays,
-// a 32-bit connection mask): the right shape for the BASELINE configurations, not for arbitrary B.  This file is the GENERIC path:
-// ONE instantiation per lane-group width serves every B up to 64 -- B is a run-time value, the per-station values of a UE live in
-// its row of LDS (stride B + 1), the connection set is two 32-bit state words per UE (`conn` = stations 0-31 as before, `conn_hi` =
-// stations 32-63: dcomp_state.conn_hi), the BS table is a device array staged in LDS per workgroup.  Same semantics, same
-// numerics (FP64 positions / decisions in the reference's operation order, FP32 log2-domain rates via the same device functions),
-// same outputs as the narrow kernels -- tests/test_bigb_gpu.py holds it to the oracle at B = 33 ... 64 and to the narrow kernels
-// at B <= 32 (DCOMP_FORCE_BIG=1).  Three workgroup-wide reduction passes per step (sharing terms before and after the move, utility
-// sums); 0.2-0.45 of the HBM peak where the specialised kernels reach 0.7-0.85.  What round 5 found it bound by (DESIGN_LOG R5.7): partial-line
-// non-temporal stores (now plain), the LDS rows' cap on resident wavefronts (the carve below), per-mode loops in the reduction passes (now one).
+// a 32-bit connection mask): the right shape for the BASELINE configurations, not for arbitrary B.  Here ONE instantiation per
+// lane-group width serves every B <= 64: B is a run-time value, the connection set is two 32-bit state words per UE (`conn` = stations
+// 0-31, `conn_hi` = 32-63: dcomp_state.conn_hi), the BS table is a device array.  Same semantics and numerics as the specialised kernels
+// (FP64 positions / decisions in the reference's form, FP32 log2-domain rates through the same device functions); tests/test_bigb_gpu.py
+// holds it to the oracle at B = 33 ... 64 and to the specialised kernels at B <= 32 (DCOMP_FORCE_BIG=1).
 //
-// Mapping: one lane = one (env, UE); an env takes UPAD = next pow2 >= U lanes; a workgroup is ONE wavefront (64 / UPAD envs) or, for
-// envs of more than 64 lanes, the env's own UPAD lanes.
-// Per-station sums over an env's UEs (station.py:152-202, 63-83): thread t of the workgroup OWNS the (env, station) pairs
-// t, t + BLK, ... and adds up the rows of that env in UE order -- deterministic, no atomics, conflict-free (consecutive threads own
-// consecutive stations).  Not supported here (dcomp_create_v says so): UE arrival / departure, the fused rollout (dcomp_rollout_ex
-// launches one step per launch), the in-step policy, the compact record.
+// Round 6 rewrite.  Round 5 kept every UE's per-station values in a row of LDS (20.5 KB per wavefront at B = 64:
+// eight wavefronts per CU) and had owner threads walk those rows: 6 190 VALU + 3 380 SALU + 880 LDS instructions per wave-step, 0.17-0.44 of
+// the HBM peak.  Now NOTHING per (UE, station) lives in LDS:
+//   * one lane = one (env, UE slot) for the state, the movement and the SPARSE work (a UE walks the bits of its own connection set: its shares,
+//     the drop, the stale-rate EWMA -- a handful of stations, each pair re-evaluated where it is needed instead of parked);
+//   * one lane = one STATION for everything that is per (env, station) or dense over the stations: the wave walks the UE rows of its envs,
+//     a row's position and connection set arrive as ONE broadcast LDS read, and lane b evaluates (row, station b) -- the in-range compare's
+//     lane mask IS the row's in-range set, a `connected` entry is one bit-field extract of the row's set, the row maximum of the relative-snr
+//     block is one wave reduction, and the row leaves as four coalesced stores (B floats each) straight from registers: no transposition buffer;
+//   * per-station counts / utility sums: lane b adds bit b of every row's mask (three to five instructions per row);
+//   * per-station sums of the rate-fair / proportional-fair terms (the only per-pair values that must cross from the UE lanes to the station
+//     lanes): a UE publishes up to four {station, term} slots, lane b picks the slots that name it -- in UE order, deterministic, no atomics;
+//     UEs with more than four such connections take further rounds;
+//   * envs wider than a wavefront combine per-wave partial sums in wave order.
+// LDS per wavefront: 4.6 KB of per-lane slots + the tables -- the kernel is bound by registers (no per-B arrays), not by LDS; 513 ... 1 024 UE
+// slots no longer limit the station count.  UE arrival / departure (DYN): slots shift inside the env's lane group exactly as in dcomp_dyn.h.
+// Not here: the fused rollout (dcomp_rollout_ex launches one step per launch), the in-step policy, the compact record (its connection
+// word is 32 bits).
 #pragma once
 #include "dcomp_device.h"
 
-// A/B switches (tools/ab/ablate_big.sh, DESIGN_LOG R5.7); the defaults are the measured best
-#ifndef DCOMP_BIG_WUNROLL
-#define DCOMP_BIG_WUNROLL 4   // rows of the observation writer in flight per wavefront (1: -4 %)
-#endif
-#ifndef DCOMP_BIG_PUNROLL
-#define DCOMP_BIG_PUNROLL 2   // stations of the post-move pair loop in flight per lane
+#ifndef DCOMP_BIG_RUNROLL
+#define DCOMP_BIG_RUNROLL 2   // UE rows of the observation loop in flight per wavefront
 #endif
 #ifndef DCOMP_BIG_NT
-#define DCOMP_BIG_NT 0        // 1: non-temporal stores like the narrow kernels (whose stores are whole 16-byte-per-lane lines); see big_store
-#endif
-#ifndef DCOMP_BIG_EARLY
-#define DCOMP_BIG_EARLY 1     // the connected | dr blocks of the observation leave right after the post-move pairs, under the rest of the step (0: +1-3 %)
-#endif
-#ifndef DCOMP_BIG_PARK
-#define DCOMP_BIG_PARK 1      // post-move pass: rates parked in the rows by the UEs' own lanes (needs DCOMP_BIG_EARLY or no observation; 0: +3-5 % in mixed sharing)
+#define DCOMP_BIG_NT 0        // 1: non-temporal row stores (partial lines: measured slower in round 5, R5.7)
 #endif
 #ifndef DCOMP_BIG_ABL
-#define DCOMP_BIG_ABL 0       // timing-only ablation (results WRONG): 1 max-cap winner, 2 utility aggregates, 4 rows, 8 pairs, 16 sharing aggregates, 32 move
+#define DCOMP_BIG_ABL 0       // timing-only ablation (results WRONG): 1 max-cap winner, 2 utility aggregates, 4 rows, 8 row pairs, 16 sharing aggregates, 32 move, 64 sparse share loops
 #endif
 
 namespace dcomp {
@@ -48,53 +47,41 @@ struct BigParams {
     const int32_t *mode;               // [B] DCOMP_*_FAIR / MAX_CAP
     int32_t B;
     unsigned long long maxcap_mask;    // bit b: station b is max-cap
+    unsigned long long summode_mask;   // bit b: station b is rate-fair or proportional-fair (its share needs a sum of per-pair terms)
 };
 
-// Workgroup size: ONE wavefront, or as many as an env needs.  The rows cost (B + 1) * 4 bytes of LDS per lane (260 at B = 64), so a CU holds
-// 7-8 wavefronts of this kernel at most; 256-lane workgroups (the first version) fit ONCE per CU at B = 64 -- 4 wavefronts, one per SIMD,
-// nothing to hide a barrier or an LDS round trip behind (8 192 x 32 x 64: 181 us, SQ_WAIT_ANY 44 % of the wave cycles).
+// Workgroup: ONE wavefront (64 / UPAD envs), or the env's own UPAD lanes above 64.
 __host__ __device__ constexpr int big_block(int upad) { return upad < 64 ? 64 : upad; }
-// LDS one workgroup carves (host and device use the same function).  Per lane: its row (B stations + one pad column that also holds the row
-// maximum), its connection set, ewma / utility (one slot: the utility is written after the last reader of the ewma) and reward_before; per
-// (env, station): three aggregate slots (count | sum of the sharing terms, later of the utilities | max-cap winner, later the minimum
-// utility).  Only where they are used: the partial sums of split pairs, the FP64 positions (max-cap stations only).
-// 64 stations, 32 UEs, no max-cap: 20 480 bytes = EIGHT wavefronts per CU (the first carve, 24 064 bytes, held six).
-struct BigCarve { int mask, row, ewma, rb, agg, mode, part, pos, total; };
-__host__ __device__ inline BigCarve big_carve(int B, int gpb, int blk, bool maxcap)
+// LDS one workgroup carves (host and device use the same function): the BS table, then per LANE 16 B position + 16 B {mask lo, mask hi,
+// ewma | utility, reward_before} + 8 B in-range set + 32 B of term slots, per (env, station) three aggregates, per (wave, station) three
+// partial sums where an env spans waves.  64 stations, 32 UEs: 7.9 KB per wavefront.
+struct BigCarve { int mode, pos, slot, inr, term, agg, part, total; };
+__host__ __device__ inline BigCarve big_carve(int B, int gpb, int blk)
 {
     BigCarve c;
     int o = B * (int)sizeof(double2);
-    c.mask = o; o += blk * 8;
-    c.row = o; o += blk * (B + 1) * 4;
-    c.ewma = o; o += blk * 4;
-    c.rb = o; o += blk * 4;
-    c.agg = o; o += 3 * gpb * B * 4;
-    c.mode = o; o += B * 4;
-    o = (o + 15) & ~15;
-    c.part = o; if (2 * gpb * B <= blk) o += blk * 16;          // aggregate() splits a pair's rows over >= 2 threads
-    c.pos = o; if (maxcap) o += blk * 16;
-    c.total = o;
+    c.mode = o; o += B * 4; o = (o + 15) & ~15;
+    c.pos = o; o += blk * 16;
+    c.slot = o; o += blk * 16;
+    c.inr = o; o += blk * 8;
+    c.term = o; o += blk * 32;
+    c.agg = o; o += 3 * gpb * B * 4; o = (o + 15) & ~15;
+    c.part = o; o += blk > 64 ? 3 * (blk / 64) * B * 4 : 0;
+    c.total = (o + 15) & ~15;
     return c;
-}
-// what dcomp_create_v checks against the 160 KB of a CU (before it knows the sharing modes; the documented bound of include/dcomp_types.h)
-__host__ __device__ inline size_t big_lds_bound(int B, int blk)
-{
-    return 64 * sizeof(double2) + (size_t)blk * sizeof(double2) + (size_t)blk * sizeof(unsigned long long) + (size_t)blk * (B + 1) * 4 + (size_t)4 * blk * 4 +
-           (size_t)5 * B * 4 + 64 * 4 + (size_t)blk * 16;
 }
 
 __device__ __forceinline__ void big_pair(double px, double py, const double2 bp, const KParams &p, bool &in_range, float &l2)
 {
     bool near;
-    pair_eval(px, py, bp.x, bp.y, p, in_range, l2, near);
+    pair_eval(px, py, bp.x, bp.y, p, in_range, l2, near);          // (incl. the reference-form re-check at the range boundary)
     if (near) {                                                    // rare, per lane: within 1.26 m of the station
         const double dx = bp.x - px, dy = bp.y - py;
         if ((float)__builtin_fma(dy, dy, dx * dx) < 1e-20f) l2 = pair_eval_tiny(px, py, bp.x, bp.y, p);
     }
 }
-// Every output store of this kernel.  PLAIN stores: the rows leave as 4-byte-per-lane pieces of B floats at a stride of 4B + 1 floats, i.e. as
-// partial cache lines, and a non-temporal partial line does not wait in the L2 for its other half (8 192 x 32 x 64, resource-fair, same box:
-// 134 us with non-temporal, 81 us with plain stores; staging 4 rows in LDS for 16-byte-per-lane whole lines was SLOWER than either, R5.7).
+// Every row store: PLAIN.  The rows leave as B floats per block at a stride of 4B + 1 floats, i.e. as partial cache lines, and a non-temporal
+// partial line does not wait in the L2 for its other half (round 5, 8 192 x 32 x 64: 134 us non-temporal, 81 us plain).
 __device__ __forceinline__ void big_store(float *ptr, float v)
 {
 #if DCOMP_BIG_NT
@@ -110,134 +97,357 @@ __device__ __forceinline__ float big_rate(float l2)                // bw * log2(
     if (big) r = rate_unshared_any(l2);
     return r;
 }
+// max over the 64 lanes of a wavefront, result uniform (an SGPR): six v_max_f32 with DPP operands + one v_readlane.  (The compiler's form of the
+// same butterfly -- group_reduce<64, OpMax> -- is a v_mov_b32_dpp + v_med3_f32 pair per stage plus a ds_swizzle and a ds_bpermute: 14
+// instructions on the critical path of every observation row.)  Needs every lane active; no NaN reaches it.
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+    int s;
+    asm volatile("s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_readlane_b32 %1, %0, 63\n"
+                 "s_nop 3\n"
+                 : "+v"(v), "=s"(s));
+    return __int_as_float(s);
+}
+// (row, station) for a lane in its STATION role: log2 snr and the in-range decision.  The two rare cases -- the fused d^2 cannot decide
+// (pair_eval_q), a UE within 1.26 m of the station -- sit behind ONE wave-uniform branch (a per-lane `if` here is if-converted: v_sqrt + a
+// second v_log in every row).  ok: the lane holds a station and the row exists.
+__device__ __forceinline__ void big_row_pair(double qx, double qy, const double2 bp, const KParams &p, bool ok, bool &in_range, float &l2)
+{
+    float qf;
+    pair_eval_q(qx, qy, bp.x, bp.y, p, in_range, l2, qf);
+    const bool special = ok && (qf == p.dt2f || qf < NEAR_D2);
+    if (__ballot(special) != 0ull || p.dsq_exact) {
+        if (ok && (qf == p.dt2f || p.dsq_exact)) in_range = in_range_exact(qx, qy, bp.x, bp.y, p.dt2);
+        if (ok && qf < NEAR_D2) {
+            const double dx = bp.x - qx, dy = bp.y - qy;
+            if ((float)__builtin_fma(dy, dy, dx * dx) < 1e-20f) l2 = pair_eval_tiny(qx, qy, bp.x, bp.y, p);
+        }
+    }
+    in_range = in_range && ok;
+    l2 = ok ? l2 : -3.0e38f;
+}
+// a UE's share of one station (station.py:152-202): n = connected UEs, s = the station's sum of sharing terms
+__device__ __forceinline__ float big_share(int mode, float dru, float n, float s, float inv_ewma, bool winner)
+{
+    if (mode == DCOMP_RES_FAIR) return dru * fast_rcp(fmaxf(n, 1.f));                        // station.py:171-173
+    if (mode == DCOMP_RATE_FAIR) return fast_rcp(s);                                         // station.py:180
+    if (mode == DCOMP_PROP_FAIR) return (dru * inv_ewma) * fast_rcp(s + EPS) * dru;          // station.py:194-195
+    return winner ? dru : 0.f;                                                               // station.py:183-187
+}
 
-template <int UPAD, bool RESET>
+template <int UPAD, bool RESET, bool DYN>
 __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, const BigParams x)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
     constexpr int BLK = big_block(UPAD), NWAVE = BLK / 64, GPB = BLK / UPAD;
-    const int B = x.B, BR = B + 1, U = p.U;
-    const bool any_maxcap = x.maxcap_mask != 0ull;
-    const BigCarve cv = big_carve(B, GPB, BLK, any_maxcap);
+    constexpr int EPW = UPAD >= 64 ? 1 : 64 / UPAD;                // env pieces a wavefront holds
+    constexpr int PL = UPAD >= 64 ? 64 : UPAD;                     // lane slots per piece
+    const int B = x.B, U = p.U;
+    const bool any_maxcap = x.maxcap_mask != 0ull, any_sum = x.summode_mask != 0ull;
+    const BigCarve cv = big_carve(B, GPB, BLK);
     double2 *const bs_s = reinterpret_cast<double2 *>(big_smem);
-    unsigned long long *const mask_s = reinterpret_cast<unsigned long long *>(big_smem + cv.mask);
-    float *const row = reinterpret_cast<float *>(big_smem + cv.row);
-    float *const ewma_s = reinterpret_cast<float *>(big_smem + cv.ewma), *const util_s = ewma_s, *const rb_s = reinterpret_cast<float *>(big_smem + cv.rb);
+    int *const mode_s = reinterpret_cast<int *>(big_smem + cv.mode);
+    double2 *const pos_s = reinterpret_cast<double2 *>(big_smem + cv.pos);
+    uint4 *const slot_s = reinterpret_cast<uint4 *>(big_smem + cv.slot);               // {mask lo, mask hi, ewma | utility, reward_before}
+    unsigned long long *const inr_s = reinterpret_cast<unsigned long long *>(big_smem + cv.inr);
+    uint4 *const term_s = reinterpret_cast<uint4 *>(big_smem + cv.term);               // two per lane: {station, term} x 4
     float *const agg_n = reinterpret_cast<float *>(big_smem + cv.agg), *const agg_s = agg_n + GPB * B, *const agg_u = agg_s;
     uint32_t *const mc_win = reinterpret_cast<uint32_t *>(agg_s + GPB * B);
     float *const agg_m = reinterpret_cast<float *>(mc_win);
-    int *const mode_s = reinterpret_cast<int *>(big_smem + cv.mode);
-    float4 *const part_s = reinterpret_cast<float4 *>(big_smem + cv.part);     // partial sums of split pairs (aggregate)
-    double2 *const pos_s = reinterpret_cast<double2 *>(big_smem + cv.pos);     // max-cap stations only
+    float *const part_s = reinterpret_cast<float *>(big_smem + cv.part);               // [3][NWAVE][B] (envs wider than a wavefront)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = NWAVE > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;     // (uniform, and the compiler must know it: every row loop below is scalar control flow)
     const int env_local = tid / UPAD, u = tid % UPAD;
-    const int env0 = blockIdx.x * GPB, env = env0 + env_local;
+    const int env0 = xcd_contiguous_block() * GPB, env = env0 + env_local;
     const bool active = env < p.E && u < U;
-    const bool alive = active && (!RESET || u < p.U0);
+    int cur = DYN ? p.cur_ue : (RESET ? p.U0 : U);                 // UEs in the list (the same in every env: the schedule is configuration)
+    bool alive = active && u < cur;
     const int idx = env * U + u;
-    float *const myrow = row + tid * BR;
     for (int i = tid; i < B; i += BLK) { bs_s[i] = x.bs[i]; mode_s[i] = x.mode[i]; }
+    // the lane's STATION role.  Up to 32 stations a wavefront takes SEVERAL rows per trip: lane = (row of the trip, station) with BP = 8 / 16 / 32 / 64
+    // lanes per row (the next power of two >= B), SUB = 64 / BP rows per trip (10 stations: four rows at once instead of 10 busy lanes of 64);
+    // per-station partial sums are then added across the SUB lane groups (ds_bpermute butterflies), always in the same order.
+    const int LBP = B > 32 ? 6 : B > 16 ? 5 : B > 8 ? 4 : 3, BP = 1 << LBP, SUB = 64 >> LBP;
+    const int sb = lane & (BP - 1), sub = lane >> LBP;
+    const bool st_ok = sb < B;
+    const double2 mybs = st_ok ? x.bs[sb] : make_double2(0.0, 0.0);
+    const bool hi_lane = sb >= 32;
+    const uint32_t sh = (uint32_t)sb & 31u;
+    auto sub_sum_i = [&](int v) { for (int off = BP; off < 64; off <<= 1) v += __shfl_xor(v, off, 64); return v; };
+    auto sub_sum_f = [&](float v) { for (int off = BP; off < 64; off <<= 1) v += __shfl_xor(v, off, 64); return v; };
+    auto sub_min_f = [&](float v) { for (int off = BP; off < 64; off <<= 1) v = fminf(v, __shfl_xor(v, off, 64)); return v; };
+    const bool st_writer = st_ok && sub == 0;                      // the lane that publishes station sb's aggregate
 
     double px = 0.0, py = 0.0;
     unsigned long long mv = 0, conn = 0;
-    uint32_t act = 0;
+    uint32_t act = 0, uidw = (uint32_t)u + 1u;
     float ewma = 0.f, dr_req = 1.f;
     bool step_util = false;
     int vrange = MV_CFG_ARRIVED;
-    if (alive) {
-        const UeCfg c = p.ue_cfg[u];
-        step_util = c.util == DCOMP_UTIL_STEP; dr_req = c.dr_req;
-        vrange = mv_cfg_pack(c.vel_lo, c.vel_hi, c.pause, c.border);
-    }
     if (RESET) {                                                   // MobileEnv.reset (base.py:169-189): user.py:98-116 + movement.py:110-122
-        if (alive) reset_ue(p, env, u, p.episode, px, py, mv);
+        if (alive) {
+            const UeCfg c = p.ue_cfg[u];
+            step_util = c.util == DCOMP_UTIL_STEP; dr_req = c.dr_req;
+            reset_ue(p, env, u, p.episode, px, py, mv);
+        }
         if (active) {
             p.pos[idx] = make_double2(px, py);
             p.mv[idx] = mv;
             p.conn[idx] = 0u;
             x.conn_hi[idx] = 0u;
             p.ewma[idx] = 0.f;
+            if (p.uid) p.uid[idx] = alive ? (uint16_t)(u + 1) : (uint16_t)0;
+            if (p.orig_consumed && alive) p.orig_consumed[(size_t)env * p.U0 + u] = 0xFFFFu;
         }
-    } else if (active) {
+    } else if (alive) {
         const double2 q = p.pos[idx];
         px = q.x; py = q.y;
         mv = p.mv[idx];
         conn = (unsigned long long)p.conn[idx] | ((unsigned long long)x.conn_hi[idx] << 32);
         ewma = p.ewma[idx];
         act = p.action[idx];
+        if (DYN) uidw = p.uid[idx];
         if (act > (uint32_t)B) { atomicOr(p.flags, DCOMP_FLAG_BAD_ACTION); act = 0; }
     }
     __syncthreads();                                               // the BS table
 
-    // (env, station) sums over the UEs of an env.  WHAT: 0 = sharing terms from the l2snr values parked in the rows (count, sum of
-    // 1 / rate resp. rate / (ewma + eps), the max-cap winner), 1 = utility sums (count, sum, min over the connected UEs).
-    // Envs of many lanes have few pairs per workgroup (512 lanes, 10 stations: 10 owners walking 512 rows each while 502 lanes wait: 4 096 x 512 x 10
-    // took 1.39 ms): there the rows of a pair are split over NSPLIT threads -- thread q * NSPLIT + k sums rows k, k + NSPLIT, ... -- and the owner
-    // adds the partial sums in the order k = 0 ... NSPLIT - 1 (still deterministic).
-    auto aggregate = [&](int what, bool parked) {
-        if ((DCOMP_BIG_ABL & 2) && what == 1) return;
-        if ((DCOMP_BIG_ABL & 16) && what == 0) return;
-        const int P = GPB * B;
-        int nsplit = P >= BLK ? 1 : BLK / P;
-        nsplit = nsplit > 32 ? 32 : nsplit;
-        // Branch-free and unrolled (a branch per row saved little -- SOME lane of the 64 is connected in most trips -- and put an LDS round trip + a
-        // rate evaluation on one dependent chain per row), and ONE loop for rate-fair and proportional-fair owners (the threads of a wavefront own
-        // stations of every mode: a loop per mode ran with a quarter of the lanes each).  Same sums: a row that is not connected adds +0.
-        // parked: the rows hold the RATES of the connected stations (pre-move pass), not log2 snr.
-        auto rows_of = [&](int el, int b, int first, int stride, float &n, float &s, float &mn) {
-            const int base = el * UPAD, mode = mode_s[b];
-            const bool sums = what == 0 && (mode == DCOMP_RATE_FAIR || mode == DCOMP_PROP_FAIR), rate_fair = mode == DCOMP_RATE_FAIR;
-            if (what == 1) {
-#pragma unroll 4
-                for (int v = first; v < U; v += stride) {
-                    const bool c = (mask_s[base + v] >> b) & 1ull;
-                    const float uv = util_s[base + v];
-                    n += c ? 1.f : 0.f; s += c ? uv : 0.f; mn = c ? fminf(mn, uv) : mn;
+    if (!RESET) {
+        // 1. toggle (base.py:247-263 -> user.py:190-222): only the station the UE acts on matters at the pre-move position
+        if (act > 0u) {
+            const unsigned long long bit = 1ull << (act - 1u);
+            if (conn & bit) conn &= ~bit;
+            else {
+                bool ir;
+                float l;
+                big_pair(px, py, bs_s[act - 1u], p, ir, l);
+                if (ir) {
+                    conn |= bit;
+                    if (x.maxcap_mask & bit) p.conn_since[(size_t)idx * B + (act - 1u)] = (uint16_t)p.time;
                 }
-            } else if (__builtin_amdgcn_ballot_w64(sums) != 0ull) {            // station.py:177-180 | station.py:150, 192-195
-#pragma unroll 4
-                for (int v = first; v < U; v += stride) {
-                    const bool c = ((mask_s[base + v] >> b) & 1ull) != 0ull, cs = c && sums;
-                    const float l = cs ? row[(base + v) * BR + b] : 0.f;          // (a row without this station holds leftovers)
-                    const float r = parked ? l : big_rate(l);
-                    const float y = fast_rcp(rate_fair ? r : ewma_s[base + v] + EPS);
-                    n += c ? 1.f : 0.f; s += cs ? (rate_fair ? y : r * y) : 0.f;
-                }
-            } else {
-#pragma unroll 4
-                for (int v = first; v < U; v += stride) n += ((mask_s[base + v] >> b) & 1ull) ? 1.f : 0.f;
             }
-        };
-        if (nsplit > 1) {
-            float n = 0.f, s = 0.f, mn = MAX_UTIL;
-            if (tid < P * nsplit) {
-                const int q = tid / nsplit, k = tid - q * nsplit, el = q / B, b = q - el * B;
-                if (env0 + el < p.E) rows_of(el, b, k, nsplit, n, s, mn);
-            }
-            part_s[tid] = make_float4(n, s, mn, 0.f);
-            __syncthreads();
         }
-        for (int q = tid; q < P; q += BLK) {
-            const int el = q / B, b = q - el * B, base = el * UPAD;
-            float n = 0.f, s = 0.f, mn = MAX_UTIL;
-            uint32_t win = 0xFFFFFFFFu;
-            if (env0 + el < p.E) {
-                const int mode = mode_s[b];
-                if (nsplit > 1) {
-                    for (int k = 0; k < nsplit; k++) { const float4 t = part_s[q * nsplit + k]; n += t.x; s += t.y; mn = fminf(mn, t.z); }
-                } else rows_of(el, b, 0, 1, n, s, mn);
-                if (!(DCOMP_BIG_ABL & 1) && what == 0 && mode == DCOMP_MAX_CAP && n > 0.f) {
-                    // station.py:183-187: the UE with the highest FP64 rate is served; equal rates -> the oldest connection, then the lowest UE
-                    // index (dcomp_device.h shared_rates has the derivation: nearest UE, contenders within 1e-7, the collapsing FP64 key)
+        // 1b. UE departure / arrival (base.py:433-443), after the actions and before the rates: dcomp_dyn.h's event phase with a 64-bit set
+        if (DYN && (p.n_remove > 0 || p.n_add > 0)) {
+            uint32_t *const xw = reinterpret_cast<uint32_t *>(big_smem + cv.pos);         // exchange words (envs wider than a wavefront): pos | slot | inr areas
+            for (int k = 0; k < p.n_remove; k++) {                 // base.py:608-618: pop(idx) + disconnect_from_all
+                int r;
+                if (p.rng_mode == DCOMP_RNG_TAPE) r = (env < p.E) ? p.ev_remove[(size_t)env * p.n_remove + k] : 0;
+                else {
+                    uint32_t d[4];
+                    philox4x32_10(p.env_base + (uint32_t)env, 0xFFFE0000u + p.ev_rem_base + (uint32_t)k, p.episode, 0u, p.seed_lo, p.seed_hi, d);
+                    r = (int)__umulhi(d[0], (uint32_t)cur);
+                }
+                if (alive && u == r && !(uidw & UID_BORN) && p.orig_consumed)             // host bookkeeping of the initial UEs' streams
+                    p.orig_consumed[(size_t)env * p.U0 + ((uidw & 0x7FFFu) - 1u)] = (uint16_t)(mv >> 48);
+                const bool take = active && u >= r && u + 1 < cur;                        // slots behind the leaver move up
+                if (any_maxcap) {                                  // the step-of-connection rows travel with their UEs (rare: an event step with max-cap stations)
+                    for (int b = 0; b < B; b++) {
+                        uint16_t t = 0;
+                        if (take) t = p.conn_since[(size_t)(idx + 1) * B + b];
+                        __syncthreads();
+                        if (take) p.conn_since[(size_t)idx * B + b] = t;
+                        __syncthreads();
+                    }
+                }
+                if constexpr (UPAD <= 64) {
+                    const double nx = __shfl_down(px, 1, UPAD), ny = __shfl_down(py, 1, UPAD);
+                    const unsigned long long nmv = __shfl_down(mv, 1, UPAD), nconn = __shfl_down(conn, 1, UPAD);
+                    const uint32_t nuid = __shfl_down(uidw, 1, UPAD);
+                    const float newma = __shfl_down(ewma, 1, UPAD);
+                    if (take) { px = nx; py = ny; mv = nmv; conn = nconn; uidw = nuid; ewma = newma; }
+                } else {
+                    const unsigned long long bx = (unsigned long long)__double_as_longlong(px), by = (unsigned long long)__double_as_longlong(py);
+                    uint32_t wd[10] = {(uint32_t)bx, (uint32_t)(bx >> 32), (uint32_t)by, (uint32_t)(by >> 32), (uint32_t)mv, (uint32_t)(mv >> 32),
+                                       (uint32_t)conn, (uint32_t)(conn >> 32), uidw, __float_as_uint(ewma)};
+                    __syncthreads();
+#pragma unroll
+                    for (int w = 0; w < 10; w++) xw[w * BLK + tid] = wd[w];
+                    __syncthreads();
+                    if (take) {
+#pragma unroll
+                        for (int w = 0; w < 10; w++) wd[w] = xw[w * BLK + tid + 1];     // (take: the next slot belongs to the same env)
+                    }
+                    __syncthreads();
+                    px = __longlong_as_double((long long)(((unsigned long long)wd[1] << 32) | wd[0]));
+                    py = __longlong_as_double((long long)(((unsigned long long)wd[3] << 32) | wd[2]));
+                    mv = ((unsigned long long)wd[5] << 32) | wd[4];
+                    conn = ((unsigned long long)wd[7] << 32) | wd[6];
+                    uidw = wd[8]; ewma = __uint_as_float(wd[9]);
+                }
+                cur -= 1;
+                if (u == cur) {
+                    conn = 0; uidw = 0; ewma = 0.f; mv = 0; px = 0.0; py = 0.0;
+                    if (any_maxcap && active) for (int b = 0; b < B; b++) p.conn_since[(size_t)idx * B + b] = 0;
+                }
+                alive = active && u < cur;
+            }
+            for (int k = 0; k < p.n_add; k++) {                    // base.py:592-606
+                uint32_t last;                                     // id of ue_list[-1]
+                if constexpr (UPAD <= 64) last = __shfl(uidw, (lane & ~(UPAD - 1)) + (cur - 1), 64);
+                else {
+                    __syncthreads();
+                    xw[tid] = uidw;
+                    __syncthreads();
+                    last = xw[cur - 1];
+                    __syncthreads();
+                }
+                if (active && u == cur) {
+                    int ax, ay;
+                    if (p.rng_mode == DCOMP_RNG_TAPE) { const size_t t = ((size_t)env * p.n_add + k) * 2; ax = p.ev_add_xy[t]; ay = p.ev_add_xy[t + 1]; }
+                    else {                                         // map.rand_border_point (map.py:52-65)
+                        uint32_t d[4];
+                        philox4x32_10(p.env_base + (uint32_t)env, 0xFFFF0000u + p.ev_add_base + (uint32_t)k, p.episode, 0u, p.seed_lo, p.seed_hi, d);
+                        const int rx = (int)__umulhi(d[0], (uint32_t)p.map_w + 1u), ry = (int)__umulhi(d[1], (uint32_t)p.map_h + 1u);
+                        const int border = (int)__umulhi(d[2], 4u);                      // left, right, top, bottom
+                        ax = border == 0 ? 0 : border == 1 ? p.map_w - 1 : rx;
+                        ay = border == 2 ? p.map_h - 1 : border == 3 ? 0 : ry;
+                    }
+                    uidw = ((last & 0x7FFFu) + 1u) | UID_BORN;
+                    px = (double)ax; py = (double)ay;
+                    uint32_t vel, wx, wy;
+                    draw_triple(p, env, uidw, 0u, p.episode, vel, wx, wy, load_mv_cfg(p, uidw));
+                    mv = mv_pack(wx, wy, vel, 0u, 0u, 1u);
+                    conn = 0; ewma = 0.f;
+                    if (any_maxcap) for (int b = 0; b < B; b++) p.conn_since[(size_t)idx * B + b] = 0;
+                }
+                cur += 1;
+            }
+            alive = active && u < cur;
+            __syncthreads();                                       // the exchange words are free again
+        }
+        if (alive) {                                               // per-UE configuration (by id where the list changes)
+            if (DYN) {
+                vrange = load_mv_cfg(p, uidw);
+                if (!(uidw & UID_BORN) && !p.all_log_util) { const UeCfg c = p.ue_cfg[(uidw & 0x7FFFu) - 1u]; step_util = c.util == DCOMP_UTIL_STEP; dr_req = c.dr_req; }
+            } else {
+                const UeCfg c = p.ue_cfg[u];
+                step_util = c.util == DCOMP_UTIL_STEP; dr_req = c.dr_req;
+                vrange = mv_cfg_pack(c.vel_lo, c.vel_hi, c.pause, c.border);
+            }
+        }
+    }
+
+    // ---- per-(env, station) aggregates of the rows this workgroup holds: connected count n, sum of the sharing terms s, max-cap winner.
+    // qx / qy: the position the rates are taken at.  Slots and positions must be published (and a barrier passed) before the call.
+    auto piece_rows = [&](int el, int &r0, int &envl, int &uu0) -> int {              // rows (lane slots) of env piece el of this wave
+        r0 = wave * 64 + el * PL;
+        envl = r0 / UPAD;
+        uu0 = UPAD > 64 ? wave * 64 : 0;
+        if (env0 + envl >= p.E) return 0;
+        const int n = U - uu0;
+        return n < 0 ? 0 : (n > PL ? PL : n);
+    };
+    auto sharing_aggregates = [&](double qx, double qy, float ewma_v) {
+        if (DCOMP_BIG_ABL & 16) return;
+        float s_acc[EPW];
+        int n_acc[EPW];
+#pragma unroll
+        for (int el = 0; el < EPW; el++) {                         // counts: lane b adds bit b of every row's connection set
+            int r0, envl, uu0;
+            const int nrows = piece_rows(el, r0, envl, uu0);
+            int n = 0;
+            for (int uu = sub; uu < nrows; uu += SUB) {
+                const uint4 sl = slot_s[r0 + uu];
+                n += (int)__builtin_amdgcn_ubfe(hi_lane ? sl.y : sl.x, sh, 1u);
+            }
+            n_acc[el] = sub_sum_i(n); s_acc[el] = 0.f;
+        }
+        if (any_sum) {
+            // station.py:177-180 | 150, 192-195: the terms 1 / rate resp. rate / (ewma + eps) of the connected UEs.  A UE evaluates its own
+            // connections (sparse), four per round, and publishes {station, term}; lane b adds the slots that name station b, rows in UE order.
+            unsigned long long todo = alive ? (conn & x.summode_mask) : 0ull;
+            const float inv_e = fast_rcp(ewma_v + EPS);
+            while (true) {
+                uint32_t tb[4];
+                float tv[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    tb[k] = 0xFFu; tv[k] = 0.f;
+                    if (todo) {
+                        const int b = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1ull;
+                        bool ir;
+                        float l;
+                        big_pair(qx, qy, bs_s[b], p, ir, l);
+                        const float r = big_rate(l);
+                        tb[k] = (uint32_t)b;
+                        tv[k] = mode_s[b] == DCOMP_RATE_FAIR ? fast_rcp(r) : r * inv_e;
+                    }
+                }
+                term_s[2 * tid] = make_uint4(tb[0], __float_as_uint(tv[0]), tb[1], __float_as_uint(tv[1]));
+                term_s[2 * tid + 1] = make_uint4(tb[2], __float_as_uint(tv[2]), tb[3], __float_as_uint(tv[3]));
+                __syncthreads();
+#pragma unroll
+                for (int el = 0; el < EPW; el++) {
+                    int r0, envl, uu0;
+                    const int nrows = piece_rows(el, r0, envl, uu0);
+                    float s = 0.f;
+                    for (int uu = sub; uu < nrows; uu += SUB) {               // (slots fill in order: the first empty one ends the row)
+                        const uint4 t0 = term_s[2 * (r0 + uu)];
+                        if (t0.x != 0xFFu) {
+                            s += t0.x == (uint32_t)sb ? __uint_as_float(t0.y) : 0.f;
+                            if (t0.z != 0xFFu) {
+                                s += t0.z == (uint32_t)sb ? __uint_as_float(t0.w) : 0.f;
+                                const uint4 t1 = term_s[2 * (r0 + uu) + 1];
+                                if (t1.x != 0xFFu) {
+                                    s += t1.x == (uint32_t)sb ? __uint_as_float(t1.y) : 0.f;
+                                    if (t1.z != 0xFFu) s += t1.z == (uint32_t)sb ? __uint_as_float(t1.w) : 0.f;
+                                }
+                            }
+                        }
+                    }
+                    s_acc[el] += sub_sum_f(s);
+                }
+                const bool more = __syncthreads_or(todo != 0ull) != 0;                   // (also: every reader is done with the slots)
+                if (!more) break;
+            }
+        }
+        if (NWAVE > 1) {                                           // one env over several waves: partial sums, combined in wave order
+            if (st_writer) { part_s[wave * B + sb] = (float)n_acc[0]; part_s[(NWAVE + wave) * B + sb] = s_acc[0]; }
+            __syncthreads();
+            if (wave == 0 && st_writer) {
+                float n = 0.f, s = 0.f;
+                for (int w = 0; w < NWAVE; w++) { n += part_s[w * B + sb]; s += part_s[(NWAVE + w) * B + sb]; }
+                agg_n[sb] = n; agg_s[sb] = s;
+            }
+        } else if (st_writer) {
+#pragma unroll
+            for (int el = 0; el < EPW; el++) {
+                const int envl = (wave * 64 + el * PL) / UPAD;
+                agg_n[envl * B + sb] = (float)n_acc[el]; agg_s[envl * B + sb] = s_acc[el];
+            }
+        }
+        if (any_maxcap && !(DCOMP_BIG_ABL & 1)) {
+            // station.py:183-187: the UE with the highest FP64 rate is served; equal rates -> the oldest connection, then the lowest UE index
+            // (dcomp_device.h shared_rates has the derivation: nearest UE, contenders within 1e-7, the collapsing FP64 key).  Owner threads.
+            __syncthreads();
+            for (int q = tid; q < GPB * B; q += BLK) {
+                const int el = q / B, b = q - el * B, base = el * UPAD;
+                uint32_t win = 0xFFFFFFFFu;
+                if (env0 + el < p.E && mode_s[b] == DCOMP_MAX_CAP && agg_n[q] > 0.f) {
                     const double2 bp = bs_s[b];
+                    auto has = [&](int v) { const uint4 sl = slot_s[base + v]; return (((b < 32 ? sl.x : sl.y) >> (b & 31)) & 1u) != 0u; };
                     double dmin = 1e300;
-                    for (int v = 0; v < U; v++) if ((mask_s[base + v] >> b) & 1ull) {
+                    for (int v = 0; v < U; v++) if (has(v)) {
                         const double dx = bp.x - pos_s[base + v].x, dy = bp.y - pos_s[base + v].y;
                         dmin = fmin(dmin, __builtin_fma(dy, dy, dx * dx));
                     }
                     int ncand = 0, only = 0;
-                    for (int v = 0; v < U; v++) if ((mask_s[base + v] >> b) & 1ull) {
+                    for (int v = 0; v < U; v++) if (has(v)) {
                         const double dx = bp.x - pos_s[base + v].x, dy = bp.y - pos_s[base + v].y;
                         if (__builtin_fma(dy, dy, dx * dx) <= dmin * (1.0 + 1e-7)) { ncand++; only = v; }
                     }
@@ -245,7 +455,7 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                     else {
                         unsigned long long best = 0ull;
                         uint32_t bestw = 0xFFFFFFFFu;
-                        for (int v = 0; v < U; v++) if ((mask_s[base + v] >> b) & 1ull) {
+                        for (int v = 0; v < U; v++) if (has(v)) {
                             const double dx = bp.x - pos_s[base + v].x, dy = bp.y - pos_s[base + v].y;
                             if (__builtin_fma(dy, dy, dx * dx) > dmin * (1.0 + 1e-7)) continue;
                             const unsigned long long key = maxcap_rate_key(p.pl_c1, p.pl_c2, pos_s[base + v].x, pos_s[base + v].y, bp.x, bp.y);
@@ -255,167 +465,224 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                         win = bestw & 0x3FFu;
                     }
                 }
+                mc_win[q] = win;
             }
-            if (what == 1) { agg_n[q] = n; agg_u[q] = s; agg_m[q] = mn; }
-            else { agg_n[q] = n; agg_s[q] = s; mc_win[q] = win; }
         }
+        __syncthreads();
     };
-    // this UE's share of every station it is connected to (station.py:152-202); keep = park it in the row (the stale rates of user.py:148-157)
-    auto shared = [&](bool keep, bool parked) -> float {
-        const float inv_ewma = fast_rcp(ewma + EPS);
-        float curr = 0.f;
-        for (unsigned long long m = conn; m; m &= m - 1ull) {
-            const int b = __ffsll((long long)m) - 1, q = env_local * B + b, mode = mode_s[b];
-            const float dru = parked ? myrow[b] : big_rate(myrow[b]);
-            float out;
-            if (mode == DCOMP_RES_FAIR) out = dru * fast_rcp(fmaxf(agg_n[q], 1.f));                         // station.py:171-173
-            else if (mode == DCOMP_RATE_FAIR) out = fast_rcp(agg_s[q]);                                     // station.py:180
-            else if (mode == DCOMP_PROP_FAIR) out = (dru * inv_ewma) * fast_rcp(agg_s[q] + EPS) * dru;      // station.py:194-195
-            else out = mc_win[q] == (uint32_t)u ? dru : 0.f;                                                // station.py:183-187
-            curr += out;
-            if (keep) myrow[b] = out;
-        }
-        return curr;
+    auto publish = [&](float third) {                              // this lane's row for the station-role loops
+        pos_s[tid] = make_double2(px, py);
+        slot_s[tid] = make_uint4(alive ? (uint32_t)conn : 0u, alive ? (uint32_t)(conn >> 32) : 0u, __float_as_uint(third), 0u);
     };
 
-    float reward_before = 0.f;
+    float reward_before = 0.f, curr = 0.f;
     if (!RESET) {
-        // 1. the pre-move position matters where the UE is connected and at the station it acts on (base.py:247-263 -> user.py:190-222)
-        const unsigned long long act_bit = act ? 1ull << (act - 1u) : 0ull;
-        unsigned long long inr_old = 0ull;
-        for (unsigned long long need = active ? (conn | act_bit) : 0ull; need; need &= need - 1ull) {
-            const int b = __ffsll((long long)need) - 1;
-            bool ir;
-            float l;
-            big_pair(px, py, bs_s[b], p, ir, l);
-            inr_old |= (unsigned long long)ir << b;
-            myrow[b] = big_rate(l);                                // parked: rates, not log2 snr (nothing after this pass needs the latter)
-        }
-        if (act_bit) {
-            if (conn & act_bit) conn &= ~act_bit;
-            else if (inr_old & act_bit) {
-                conn |= act_bit;
-                if (x.maxcap_mask & act_bit) p.conn_since[(size_t)idx * B + (act - 1u)] = (uint16_t)p.time;
-            }
-        }
-        mask_s[tid] = active ? conn : 0ull;
-        ewma_s[tid] = ewma;
-        if (any_maxcap) pos_s[tid] = make_double2(px, py);
-        __threadfence_block();
-        __syncthreads();
         // 2. rates before the move (base.py:446) -> reward_before (base.py:158-167)
-        aggregate(0, true);
+        publish(ewma);
         __syncthreads();
-        const float curr_pre = shared(true, true);
-        reward_before = clamp_med3(ue_utility(curr_pre, step_util, dr_req), MIN_UTIL, MAX_UTIL) * (1.0f / MAX_UTIL);
-        // 3. move (base.py:447 -> user.py:159-173)
-        if (active && !(DCOMP_BIG_ABL & 32)) {
-            move_ue<false>(p, env, (uint32_t)u + 1u, p.episode, px, py, mv, vrange);
+        sharing_aggregates(px, py, ewma);
+        // 3. move (base.py:447 -> user.py:159-173); the old position stays for the pre-move rates below
+        const double ox = px, oy = py;
+        if (alive && !(DCOMP_BIG_ABL & 32)) {
+            move_ue<false>(p, env, uidw, p.episode, px, py, mv, vrange);
             if (px < 0.0 || py < 0.0 || px > (double)p.map_w || py > (double)p.map_h) atomicOr(p.flags, DCOMP_FLAG_OUTSIDE_MAP);
         }
-        // 4. drop what is out of range at the new position (user.py:175-188); EWMA from the STALE rates of what stays (user.py:148-157)
-        float stale = 0.f;
-        for (unsigned long long m = conn; m; m &= m - 1ull) {
-            const int b = __ffsll((long long)m) - 1;
-            const double dx = bs_s[b].x - px, dy = bs_s[b].y - py;
-            if (dist_sq_ref(dx, dy) < p.dt2) stale += myrow[b];
-            else conn &= ~(1ull << b);
+        // 4. this UE's pre-move shares (station.py:152-202), and for each: does the connection survive at the new position (user.py:175-188)?
+        //    EWMA from the STALE rates of what stays (user.py:148-157).
+        float curr_pre = 0.f, stale = 0.f;
+        if (!(DCOMP_BIG_ABL & 64)) {
+            const float inv_ewma = fast_rcp(ewma + EPS);
+            for (unsigned long long m = conn; m; m &= m - 1ull) {
+                const int b = __ffsll((long long)m) - 1, q = env_local * B + b;
+                const double2 bp = bs_s[b];
+                bool ir;
+                float l;
+                big_pair(ox, oy, bp, p, ir, l);
+                const float out = big_share(mode_s[b], big_rate(l), agg_n[q], agg_s[q], inv_ewma, mc_win[q] == (uint32_t)u);
+                curr_pre += out;
+                const double dx = bp.x - px, dy = bp.y - py;
+                const double dsq = __builtin_fma(dy, dy, dx * dx);
+                bool stays = dsq < p.dt2;
+                if ((float)dsq == p.dt2f || p.dsq_exact) stays = in_range_exact(px, py, bp.x, bp.y, p.dt2);
+                if (stays) stale += out;
+                else conn &= ~(1ull << b);
+            }
         }
-        ewma = __builtin_fmaf(0.9f, stale, 0.1f * ewma);
-        __syncthreads();                                           // every owner thread is done with the pre-move rows / masks
+        reward_before = clamp_med3(ue_utility(curr_pre, step_util, dr_req), MIN_UTIL, MAX_UTIL) * (1.0f / MAX_UTIL);
+        ewma = __builtin_fmaf(0.9f, stale, 0.1f * ewma);           // one explicit contraction: every kernel variant rounds alike
+        __syncthreads();                                           // every reader of the pre-move slots / aggregates is done
+        // 5. rates after the move (base.py:451)
+        publish(ewma);
+        __syncthreads();
+        sharing_aggregates(px, py, ewma);
+        if (!(DCOMP_BIG_ABL & 64)) {
+            const float inv_ewma = fast_rcp(ewma + EPS);
+            for (unsigned long long m = conn; m; m &= m - 1ull) {
+                const int b = __ffsll((long long)m) - 1, q = env_local * B + b;
+                bool ir;
+                float l;
+                big_pair(px, py, bs_s[b], p, ir, l);
+                curr += big_share(mode_s[b], big_rate(l), agg_n[q], agg_s[q], inv_ewma, mc_win[q] == (uint32_t)u);
+            }
+        }
+        if (active) {                                              // state write-back: every slot (unlisted slots are cleared)
+            p.pos[idx] = alive ? make_double2(px, py) : make_double2(0.0, 0.0);
+            p.mv[idx] = alive ? mv : 0ull;
+            p.conn[idx] = alive ? (uint32_t)conn : 0u;
+            x.conn_hi[idx] = alive ? (uint32_t)(conn >> 32) : 0u;
+            p.ewma[idx] = alive ? ewma : 0.f;
+            if (DYN) p.uid[idx] = alive ? (uint16_t)uidw : (uint16_t)0;
+        }
+        __syncthreads();                                           // the sparse loops are done with the aggregates / slots
     }
-    // 5. every station at the (new) position: log2 snr into the row, the in-range mask, the row maximum
-    unsigned long long in_range = 0ull;
-    float l2max = -3.0e38f;
-#pragma unroll DCOMP_BIG_PUNROLL
-    for (int b = 0; b < B; b++) {
-        bool ir = true;
-        float l = 0.f;
-        if (!(DCOMP_BIG_ABL & 8)) big_pair(px, py, bs_s[b], p, ir, l);
-        in_range |= (unsigned long long)ir << b;
-        myrow[b] = l;
-        l2max = fmaxf(l2max, l);
-    }
-    mask_s[tid] = alive ? conn : 0ull;
-    ewma_s[tid] = ewma;
-    if (any_maxcap) pos_s[tid] = make_double2(px, py);
-    myrow[B] = l2max;                                              // the pad column
+    const float util = ue_utility(curr, step_util, dr_req);
+    // 6. publish the row as the outputs need it: the new position, the post-drop connection set, utility, reward_before
+    pos_s[tid] = make_double2(px, py);
+    slot_s[tid] = make_uint4(alive ? (uint32_t)conn : 0u, alive ? (uint32_t)(conn >> 32) : 0u, __float_as_uint(alive ? util : 0.f),
+                             __float_as_uint(alive ? reward_before : 0.f));
     __syncthreads();
-    // Observation, first half (variants.py:271-284): `connected` and the relative snr are final here -- their stores drain under the rest of the
-    // step instead of queueing behind it (a wavefront waiting on its stores holds its rows of LDS and keeps the next one out).
-    // Multi-agent rows: a wavefront per UE row, lanes along the stations (B <= 64: one trip), uniform control flow.
-    const int w0 = __builtin_amdgcn_readfirstlane(wave);
-    const int ROW = 4 * B + 1, UB = U * B, kind = p.kind;
-    auto rows_early = [&]() {
-        for (int el = 0; el < GPB && kind == DCOMP_MULTI; el++) {
-            if (env0 + el >= p.E) break;                           // (uniform)
-            float *const dst0 = p.obs + (size_t)(env0 + el) * U * ROW;
-#pragma unroll DCOMP_BIG_WUNROLL
-            for (int uu = w0; uu < U; uu += NWAVE) {
-                const int r = el * UPAD + uu;
-                const bool live = !RESET || uu < p.U0;
-                float *const dst = dst0 + (size_t)uu * ROW;
-                if (lane < B) {
-                    big_store(dst + lane, live ? (float)((mask_s[r] >> lane) & 1ull) : 0.f);
-                    big_store(dst + B + lane, live ? fast_exp2(row[r * BR + lane] - row[r * BR + B]) : 0.f);                               // variants.py:276-284
+    const int kind = p.kind, n_eff = cur;
+    const bool want_min = p.reward_agg == DCOMP_REWARD_MIN;
+    // 7. per-station utility aggregates (station.py:63-83) -- multi-agent envs only: central observations and rewards carry none
+    if (kind == DCOMP_MULTI && !(DCOMP_BIG_ABL & 2)) {
+        float nn[EPW], su[EPW], mn[EPW];
+#pragma unroll
+        for (int el = 0; el < EPW; el++) {
+            int r0, envl, uu0;
+            const int nrows = piece_rows(el, r0, envl, uu0);
+            int n = 0;
+            float s = 0.f, m_ = MAX_UTIL;
+            for (int uu = sub; uu < nrows; uu += SUB) {
+                const uint4 sl = slot_s[r0 + uu];
+                const int c = __builtin_amdgcn_sbfe((int)(hi_lane ? sl.y : sl.x), sh, 1u);         // 0 / -1
+                n -= c;
+                s += __uint_as_float(sl.z & (uint32_t)c);
+                if (want_min) m_ = c ? fminf(m_, __uint_as_float(sl.z)) : m_;
+            }
+            nn[el] = (float)sub_sum_i(n); su[el] = sub_sum_f(s); mn[el] = want_min ? sub_min_f(m_) : m_;
+        }
+        if (NWAVE > 1) {
+            if (st_writer) { part_s[wave * B + sb] = nn[0]; part_s[(NWAVE + wave) * B + sb] = su[0]; part_s[(2 * NWAVE + wave) * B + sb] = mn[0]; }
+            __syncthreads();
+            if (wave == 0 && st_writer) {
+                float n = 0.f, s = 0.f, m_ = MAX_UTIL;
+                for (int w = 0; w < NWAVE; w++) { n += part_s[w * B + sb]; s += part_s[(NWAVE + w) * B + sb]; m_ = fminf(m_, part_s[(2 * NWAVE + w) * B + sb]); }
+                agg_n[sb] = n; agg_u[sb] = s; agg_m[sb] = m_;
+            }
+        } else if (st_writer) {
+#pragma unroll
+            for (int el = 0; el < EPW; el++) {
+                const int envl = (wave * 64 + el * PL) / UPAD;
+                agg_n[envl * B + sb] = nn[el]; agg_u[envl * B + sb] = su[el]; agg_m[envl * B + sb] = mn[el];
+            }
+        }
+        __syncthreads();
+    }
+    // 8. observation rows (variants.py:271-305 / central.py:36-55), lane = station: the pair (row, station), the row's in-range set (the
+    //    compare's lane mask), the relative snr against the row maximum, `connected` from the row's set, the per-env columns -- four
+    //    coalesced stores per row, straight from registers.  Unlisted slots write zero rows (central.py:46-55).
+    const int ROW = 4 * B + 1, UB = U * B;
+    const float inv_u = 1.0f / (float)n_eff;
+    if (!(DCOMP_BIG_ABL & 4)) {
+#pragma unroll
+        for (int el = 0; el < EPW; el++) {
+            int r0, envl, uu0;
+            const int nrows = piece_rows(el, r0, envl, uu0);
+            float n_col = 0.f, u_col = 0.f;
+            if (kind == DCOMP_MULTI && st_ok && nrows > 0) {
+                const float n = agg_n[envl * B + sb];
+                n_col = n * inv_u;
+                u_col = agg_u[envl * B + sb] * fast_rcp(fmaxf(n, 1.f)) * (1.0f / MAX_UTIL);
+            }
+            float *const dst_env = p.obs ? p.obs + (size_t)(env0 + envl) * U * (kind == DCOMP_MULTI ? ROW : 2 * B + 1) : nullptr;
+            if (LBP == 6) {
+                // more than 32 stations: ONE row per trip, everything about the row uniform (position / set: broadcast reads; destination: scalar)
+                for (int uu = 0; uu < nrows; uu++) {
+                    const int r = r0 + uu, ue = uu0 + uu;
+                    const bool live = ue < cur;
+                    const double2 q = pos_s[r];
+                    const uint4 sl = slot_s[r];
+                    float l = -3.0e38f;
+                    bool ir = false;
+                    if (!(DCOMP_BIG_ABL & 8)) big_row_pair(q.x, q.y, mybs, p, st_ok, ir, l);
+                    const unsigned long long bal = __ballot(ir);
+                    if (lane == 0) inr_s[r] = bal;
+                    if (dst_env) {
+                        const float lmax = wave_max_f32(l);
+                        const float dr = live ? fast_exp2(l - lmax) : 0.f;                // variants.py:276-284
+                        const float cf = (float)__builtin_amdgcn_ubfe(hi_lane ? sl.y : sl.x, sh, 1u);
+                        if (kind == DCOMP_MULTI) {
+                            float *const dst = dst_env + (size_t)ue * ROW;
+                            if (st_ok) {
+                                big_store(dst + lane, cf);
+                                big_store(dst + B + lane, dr);
+                                big_store(dst + 2 * B + lane, live ? n_col : 0.f);
+                                big_store(dst + 3 * B + lane, live ? u_col : 0.f);
+                            }
+                            if (lane == 0) big_store(dst + 4 * B, __uint_as_float(sl.z) * (1.0f / MAX_UTIL));
+                        } else {
+                            if (st_ok) {
+                                big_store(dst_env + (size_t)ue * B + lane, cf);
+                                big_store(dst_env + UB + (size_t)ue * B + lane, dr);
+                            }
+                            if (lane == 0) big_store(dst_env + 2 * UB + ue, __uint_as_float(sl.z) * (1.0f / MAX_UTIL));
+                        }
+                    }
+                }
+            } else {
+                // up to 32 stations: SUB rows per trip, lane = (row sub, station sb)
+                const int trips = (nrows + SUB - 1) >> (6 - LBP);
+                for (int it = 0; it < trips; it++) {
+                    const int uu = it * SUB + sub;
+                    const bool rv = uu < nrows;
+                    const int r = r0 + (rv ? uu : 0), ue = uu0 + uu;
+                    const bool live = ue < cur;
+                    const double2 q = pos_s[r];
+                    const uint4 sl = slot_s[r];
+                    float l = -3.0e38f;
+                    bool ir = false;
+                    if (!(DCOMP_BIG_ABL & 8)) big_row_pair(q.x, q.y, mybs, p, st_ok && rv, ir, l);
+                    const unsigned long long bal = __ballot(ir);
+                    if (sb == 0 && rv) inr_s[r] = (bal >> (sub * BP)) & ((1ull << BP) - 1ull);
+                    if (dst_env) {
+                        const float lmax = BP == 32 ? group_reduce<32, OpMax>(l) : BP == 16 ? group_reduce<16, OpMax>(l) : group_reduce<8, OpMax>(l);
+                        const float dr = live ? fast_exp2(l - lmax) : 0.f;                // variants.py:276-284
+                        const float cf = (float)__builtin_amdgcn_ubfe(sl.x, sh, 1u);
+                        if (kind == DCOMP_MULTI) {
+                            const int off = ue * ROW + sb;
+                            if (st_ok && rv) {
+                                big_store(dst_env + off, cf);
+                                big_store(dst_env + off + B, dr);
+                                big_store(dst_env + off + 2 * B, live ? n_col : 0.f);
+                                big_store(dst_env + off + 3 * B, live ? u_col : 0.f);
+                            }
+                            if (sb == 0 && rv) big_store(dst_env + off + 4 * B, __uint_as_float(sl.z) * (1.0f / MAX_UTIL));
+                        } else {
+                            const int off = ue * B + sb;
+                            if (st_ok && rv) {
+                                big_store(dst_env + off, cf);
+                                big_store(dst_env + UB + off, dr);
+                            }
+                            if (sb == 0 && rv) big_store(dst_env + 2 * UB + ue, __uint_as_float(sl.z) * (1.0f / MAX_UTIL));
+                        }
+                    }
                 }
             }
         }
-        if (kind == DCOMP_CENTRAL && env < p.E) {
-            // central rows are short (U (2B+1) floats per ENV): the lanes of an env walk its connected / dr blocks, (UE, station) advanced
-            // incrementally (no division per element)
-            float *const dst = p.obs + (size_t)env * U * (2 * B + 1);
-            const int base = env_local * UPAD;
-            int uu = u / B, b = u - uu * B;
-            for (int c = u; c < UB; c += UPAD) {
-                const bool live = !RESET || uu < p.U0;
-                big_store(dst + c, live ? (float)((mask_s[base + uu] >> b) & 1ull) : 0.f);
-                big_store(dst + UB + c, live ? fast_exp2(row[(base + uu) * BR + b] - row[(base + uu) * BR + B]) : 0.f);
-                b += UPAD;
-                while (b >= B) { b -= B; uu++; }
-            }
-        }
-    };
-    if (DCOMP_BIG_EARLY && p.obs && !(DCOMP_BIG_ABL & 4)) rows_early();
-    // 6. rates after the move (base.py:451)
-    float curr = 0.f;
-    if (!RESET) {
-        // With the first half of the rows gone (or no observation asked for) nothing needs log2 snr any more: every lane parks the RATES of its
-        // connected stations, like the pre-move pass, and the owner threads evaluate none (mixed sharing: they walked 64 rows x 2 pairs each).
-        const bool park = DCOMP_BIG_PARK && NWAVE <= 4 && (DCOMP_BIG_EARLY || !p.obs);     // (two more barriers: 16-wave workgroups lose 3 %)
-        if (park) {
-            __syncthreads();                                       // the readers of the log2 snr rows (rows_early) are done
-            for (unsigned long long m = conn; m; m &= m - 1ull) { const int b = __ffsll((long long)m) - 1; myrow[b] = big_rate(myrow[b]); }
-            __syncthreads();
-        }
-        aggregate(0, park);
-        __syncthreads();
-        curr = shared(false, park);
     }
-    const float util = ue_utility(curr, step_util, dr_req);
-    if (!RESET && active) {
-        p.pos[idx] = make_double2(px, py);
-        p.mv[idx] = mv;
-        p.conn[idx] = (uint32_t)conn;
-        x.conn_hi[idx] = (uint32_t)(conn >> 32);
-        p.ewma[idx] = ewma;
-    }
-    util_s[tid] = alive ? util : 0.f;
-    rb_s[tid] = alive ? reward_before : 0.f;
     __syncthreads();
-    // 7. per-station utility aggregates (station.py:63-83), reward, info, observation
-    aggregate(1, false);
-    __syncthreads();
-    const int n_eff = RESET ? p.U0 : U;
+    // 9. reward, info
+    const unsigned long long in_range = inr_s[tid];
     if (kind == DCOMP_CENTRAL) {                                   // central.py:65-73: over the UEs' rewards_before
         if (active && u == 0) {
             const int base = env_local * UPAD;
-            float r = p.reward_agg == DCOMP_REWARD_MIN ? 1.f : 0.f, su = 0.f;
+            float r = want_min ? 1.f : 0.f, su = 0.f;
             for (int v = 0; v < n_eff; v++) {
-                r = p.reward_agg == DCOMP_REWARD_MIN ? fminf(r, rb_s[base + v]) : r + rb_s[base + v];
-                su += util_s[base + v];
+                const uint4 sl = slot_s[base + v];
+                r = want_min ? fminf(r, __uint_as_float(sl.w)) : r + __uint_as_float(sl.w);
+                su += __uint_as_float(sl.z);
             }
-            if (p.reward_agg == DCOMP_REWARD_AVG) r = r / (float)n_eff;
+            if (p.reward_agg == DCOMP_REWARD_AVG) r = r * fast_rcp((float)n_eff);         // (one reciprocal: the form of write_outputs)
             if (p.reward) p.reward[env] = RESET ? 0.f : r;
             if (p.sum_util) p.sum_util[env] = su;
         }
@@ -426,14 +693,15 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
             if (p.reward_agg == DCOMP_REWARD_SUM) {                // multi_agent.py:73-79
                 if (in_range != 0ull) {
                     const int base = env_local * UPAD;
+                    const uint32_t clo = (uint32_t)conn, chi = (uint32_t)(conn >> 32);
                     float s = 0.f;
-                    for (int v = 0; v < U; v++) if (mask_s[base + v] & conn) s += rb_s[base + v];
+                    for (int v = 0; v < U; v++) { const uint4 sl = slot_s[base + v]; if ((sl.x & clo) | (sl.y & chi)) s += __uint_as_float(sl.w); }
                     reward = s;
                 }
             } else if (p.reward_agg == DCOMP_REWARD_AVG) {         // multi_agent.py:60-71
                 float n = 0.f, t = 0.f;
                 for (unsigned long long m = in_range; m; m &= m - 1ull) { const int q = env_local * B + __ffsll((long long)m) - 1; n += agg_n[q]; t += agg_u[q]; }
-                if (n > 0.f) reward = conn == 0ull ? (t + util) / (n + 1.f) : t / n;
+                if (n > 0.f) reward = conn == 0ull ? (t + util) * fast_rcp(n + 1.f) : t * fast_rcp(n);
             } else {                                               // multi_agent.py:81-85, station.py:78-83
                 float m_ = util;
                 for (unsigned long long m = in_range; m; m &= m - 1ull) { const int q = env_local * B + __ffsll((long long)m) - 1; m_ = fminf(m_, agg_n[q] > 0.f ? agg_m[q] : MAX_UTIL); }
@@ -444,7 +712,7 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
         if (active && u == 0 && p.sum_util) {
             const int base = env_local * UPAD;
             float su = 0.f;
-            for (int v = 0; v < n_eff; v++) su += util_s[base + v];
+            for (int v = 0; v < n_eff; v++) su += __uint_as_float(slot_s[base + v].z);
             p.sum_util[env] = su;
         }
     }
@@ -453,41 +721,10 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
         if (p.ue_util) big_store(&p.ue_util[idx], alive ? util : 0.f);
         if (p.rb_out) big_store(&p.rb_out[idx], alive ? reward_before : 0.f);
     }
-    if (!p.obs || (DCOMP_BIG_ABL & 4)) return;
-    if (!DCOMP_BIG_EARLY) rows_early();
-    const float inv_u = 1.0f / (float)n_eff;
-    // second half (variants.py:286-305): ues_at_bs | util_at_bs (the same in every row of an env: variants.py:296, 299) + the row's utility
-    for (int el = 0; el < GPB && kind == DCOMP_MULTI; el++) {
-        if (env0 + el >= p.E) break;                               // (uniform)
-        float n_col = 0.f, u_col = 0.f;
-        if (lane < B) {
-            const int q = el * B + lane;
-            const float n = agg_n[q];
-            n_col = n * inv_u;
-            u_col = agg_u[q] * fast_rcp(fmaxf(n, 1.f)) * (1.0f / MAX_UTIL);
-        }
-        float *const dst0 = p.obs + (size_t)(env0 + el) * U * ROW;
-#pragma unroll DCOMP_BIG_WUNROLL
-        for (int uu = w0; uu < U; uu += NWAVE) {
-            const int r = el * UPAD + uu;
-            const bool live = !RESET || uu < p.U0;
-            float *const dst = dst0 + (size_t)uu * ROW;
-            if (lane < B) {
-                big_store(dst + 2 * B + lane, live ? n_col : 0.f);
-                big_store(dst + 3 * B + lane, live ? u_col : 0.f);
-            }
-            if (lane == 0) big_store(dst + 4 * B, live ? util_s[r] * (1.0f / MAX_UTIL) : 0.f);
-        }
-    }
-    if (kind == DCOMP_CENTRAL && env < p.E) {
-        float *const dst = p.obs + (size_t)env * U * (2 * B + 1);
-        const int base = env_local * UPAD;
-        for (int c = u; c < U; c += UPAD) big_store(dst + 2 * UB + c, util_s[base + c] * (1.0f / MAX_UTIL));
-    }
 }
 
 using BigKernelFn = void (*)(const KParams, const BigParams);
-struct BigKernels { BigKernelFn step, reset; int gpb, block; };
+struct BigKernels { BigKernelFn step, reset, step_dyn; int gpb, block; };
 BigKernels big_kernels_for_upad(int upad);
 
 }  // namespace dcomp

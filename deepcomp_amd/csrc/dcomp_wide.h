@@ -278,18 +278,29 @@ __device__ __forceinline__ void wide_step_one(const KParams &p, WideShared<B, UP
     auto pairs = [&](const int c0, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;       // every slot of the chunk is a station: no bounds tests
         float l2n[PC];
-        bool anytiny = false;
+        bool anytiny = false, edge = false;
 #pragma unroll
         for (int j = 0; j < PC; j++) {
             const int b = c0 + j;
             l2n[j] = -30.f;
             if (FULL || b < B) {
-                bool inr_n, t1;
-                pair_eval(px, py, p.bs_x[b], p.bs_y[b], p, inr_n, l2n[j], t1);
-                anytiny |= t1;
+                bool inr_n;
+                float q;
+                pair_eval_q(px, py, p.bs_x[b], p.bs_y[b], p, inr_n, l2n[j], q);
+                anytiny |= q < NEAR_D2;
+                edge |= q == p.dt2f;                             // the fused d^2 cannot decide this pair (dcomp_device.h, dist_sq_ref)
                 inr_new |= (uint32_t)inr_n << b;
             }
         }
+#if !DCOMP_DSQ_FUSED
+        if (__ballot(edge) != 0ull || p.dsq_exact) {            // rare (~1e-7 per pair), wave-uniform: this chunk's decisions in the reference's form
+#pragma unroll
+            for (int j = 0; j < PC; j++) {
+                const int b = c0 + j;
+                if (FULL || b < B) inr_new = (inr_new & ~(1u << b)) | ((uint32_t)in_range_exact(px, py, p.bs_x[b], p.bs_y[b], p.dt2) << b);
+            }
+        }
+#endif
         if (__ballot(anytiny) != 0ull) {                       // a lane within 1.26 m of one of these stations (new position)
 #pragma unroll
             for (int j = 0; j < PC; j++) {

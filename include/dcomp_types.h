@@ -18,8 +18,8 @@ extern "C" {
                                   * 33 ... 64 stations take the generic kernel of csrc/dcomp_big.h and need state.conn_hi */
 #define DCOMP_MAX_UE 1024        /* an env is ONE workgroup (its per-station sums meet in one LDS): 1 024 lanes at most */
 #define DCOMP_SPECIAL_MAX_UE 256 /* up to here the specialised kernels (256-lane workgroups); 257 ... 1 024 UEs per env take the generic kernel of
-                                  * csrc/dcomp_big.h, as long as its LDS fits: (4 (num_bs + 1) + 56) * next_pow2(num_ue) bytes + tables <= 160 KB
-                                  * (up to 512 UEs: every station count; 513 ... 1 024 UEs: up to 24 stations) */
+                                  * csrc/dcomp_big.h with a 512- / 1 024-lane workgroup (round 6: 88 bytes of LDS per lane + tables, whatever the
+                                  * station count -- every num_bs <= 64 goes with every num_ue <= 1 024) */
 
 enum { DCOMP_OK = 0, DCOMP_EINVAL = -1, DCOMP_EHIP = -2, DCOMP_EACTION = -3, DCOMP_ETAPE = -4, DCOMP_EPOS = -5,
        DCOMP_EUNSUPPORTED = -6 };

@@ -502,6 +502,15 @@ def gen_dynamic():
                            ue_arrival={2: 2, 9: -1, 12: 2, 20: -3}, episodes=2, rand_episodes=True)
     run_dynamic_trajectory('dyn_large_multi_2eps_fixed_s43', S.large_map('mixed').with_ues(num_slow=3), 'multi', 43, 30,
                            ue_arrival={2: 2, 9: -1, 12: 2, 20: -3}, episodes=2, rand_episodes=False, reward='min')
+    # round 6: UE arrival / departure with MORE THAN 32 stations (the generic kernel got the event phase): dense grids so that arriving UEs
+    # (border points) and the listed ones hold connections at stations of index >= 32; one of them with max-cap stations (the
+    # step-of-connection rows travel with their UEs when slots shift)
+    run_dynamic_trajectory('dyn_dense40_multi_updown_s42', S.grid_map(40, 'mixed', pitch=45, border=25).with_ues(num_static=1, num_slow=3, num_fast=1),
+                           'multi', 42, 40, ue_arrival={3: 2, 6: -1, 8: 1, 10: -2, 15: 3, 22: -2, 30: 1})
+    scn = S.grid_map(36, 'max-cap', pitch=45, border=25).with_ues(num_slow=3, num_fast=1)
+    scn.bs_sharing[33] = 'rate-fair'; scn.bs_sharing[34] = 'proportional-fair'; scn.bs_sharing[3] = 'resource-fair'
+    run_dynamic_trajectory('dyn_dense36_maxcap_central_2eps_rand_s43', scn, 'central', 43, 30,
+                           ue_arrival={2: 2, 5: -1, 9: 2, 14: -3, 20: 1}, episodes=2, rand_episodes=True, reward='sum')
 
 
 def gen_single():

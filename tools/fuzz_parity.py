@@ -96,8 +96,8 @@ def _spec_rest(**kw):
 
 def many_stations(spec, frac):
     """Round 5 (a stream of its own, keyed by the case's seed: every older spec stays what it was): with probability `frac` the case gets
-    33 ... 64 stations -- the generic kernel of csrc/dcomp_big.h.  The extra stations are drawn like the first ones; features the generic
-    kernel does not have are dropped from the case (UE arrival / departure; the compact-record twin is skipped by run_case)."""
+    33 ... 64 stations -- the generic kernel of csrc/dcomp_big.h.  The extra stations are drawn like the first ones; what the generic
+    kernel does not have is dropped from the case (the compact-record twin is skipped by run_case)."""
     r5 = np.random.default_rng(spec['seed'] ^ 0x51ED270B)
     if r5.random() >= frac:
         return spec
@@ -112,7 +112,7 @@ def many_stations(spec, frac):
     c['bs_xy'] = list(c['bs_xy']) + [[float(r5.integers(0, c['w'] + 1)), float(r5.integers(0, c['h'] + 1))] if integer_bs else
                                       [float(r5.uniform(0, c['w'])), float(r5.uniform(0, c['h']))] for _ in range(B - B0)]
     c['sh'] = list(c['sh']) + [c['sh'][b % B0] if len(set(c['sh'])) > 1 or r5.random() < 0.5 else SHARING[int(r5.integers(0, 4))] for b in range(B0, B)]
-    c['B'], c['arrival'], c['many_stations'] = B, None, True
+    c['B'], c['many_stations'] = B, True            # (round 6: the case keeps its UE arrival / departure schedule -- the generic kernel has the event phase)
     return c
 
 
@@ -126,14 +126,20 @@ def many_ues(spec, frac):
     c = dict(spec)
     U0, U = c['U'], int(r6.choice([257, 300, 400, 512, 600, 1000, 1024]))
     lanes = 512 if U <= 512 else 1024
-    Bmax = min(64, (160 * 1024 - 2048 - 60 * lanes) // (lanes * 4) - 1)          # big_lds_bound(): (4 (B + 1) + 56) bytes per lane + tables <= 160 KB
-    if c['B'] > Bmax:
-        c['B'] = int(Bmax)
-        c['bs_xy'], c['sh'] = c['bs_xy'][:c['B']], c['sh'][:c['B']]
+    # (round 5 had to shrink the station count until the UEs' LDS rows fitted; the round-6 kernel keeps nothing per (UE, station) in LDS)
     for k in ('vel', 'util', 'req', 'init', 'pause', 'border'):
         if c.get(k) is not None:
             c[k] = [c[k][i % U0] for i in range(U)]
-    c['U'], c['arrival'], c['many_ues'] = U, None, True
+    c['U'], c['many_ues'] = U, True
+    if c.get('arrival'):                             # keep the schedule inside 1 024 slots
+        cur, arr = U, {}
+        for t in sorted(c['arrival'], key=int):
+            n = min(int(c['arrival'][t]), 1024 - cur)
+            n = max(n, 1 - cur)
+            if n:
+                arr[t] = n
+                cur += n
+        c['arrival'] = arr or None
     c['E'], c['steps'] = min(c['E'], 3), min(c['steps'], 16)
     return c
 

@@ -8,7 +8,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-stream --no-also $*"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-stream --no-also --sustained-launches 0 $*"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $BENCH --steps ${PROF_STEPS:-300} --warmup 20 > $OUT/trace_bench.log 2>&1
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_WR SQ_LDS_BANK_CONFLICT" \
