@@ -17,12 +17,12 @@
 //     a row's position and connection set arrive as ONE broadcast LDS read, and lane b evaluates (row, station b) -- the in-range compare's
 //     lane mask IS the row's in-range set, a `connected` entry is one bit-field extract of the row's set, the row maximum of the relative-snr
 //     block is one wave reduction, and the row leaves as four coalesced stores (B floats each) straight from registers: no transposition buffer;
-//   * per-station counts / utility sums: lane b adds bit b of every row's mask (three to five instructions per row);
-//   * per-station sums of the rate-fair / proportional-fair terms (the only per-pair values that must cross from the UE lanes to the station
-//     lanes): a UE publishes up to four {station, term} slots, lane b picks the slots that name it -- in UE order, deterministic, no atomics;
-//     UEs with more than four such connections take further rounds;
+//   * per-station utility sums: lane b adds bit b of every row's mask (five instructions per row);
+//   * per-station connected counts and sums of the rate-fair / proportional-fair terms: the UE lanes add them into the per-env arrays in LDS
+//     themselves, each for the few stations of its own set -- `ds_add_f32` of 1.0 for the counts (exact, any order), the terms UE by UE (a
+//     uniform loop enables the lanes of UE index uu; LDS operations of a wavefront complete in program order): deterministic;
 //   * envs wider than a wavefront combine per-wave partial sums in wave order.
-// LDS per wavefront: 4.6 KB of per-lane slots + the tables -- the kernel is bound by registers (no per-B arrays), not by LDS; 513 ... 1 024 UE
+// LDS per wavefront: 2.6 KB of per-lane slots + the tables -- the kernel is bound by registers (no per-B arrays), not by LDS; 513 ... 1 024 UE
 // slots no longer limit the station count.  UE arrival / departure (DYN): slots shift inside the env's lane group exactly as in dcomp_dyn.h.
 // Not here: the fused rollout (dcomp_rollout_ex launches one step per launch), the in-step policy, the compact record (its connection
 // word is 32 bits).
@@ -53,9 +53,9 @@ struct BigParams {
 // Workgroup: ONE wavefront (64 / UPAD envs), or the env's own UPAD lanes above 64.
 __host__ __device__ constexpr int big_block(int upad) { return upad < 64 ? 64 : upad; }
 // LDS one workgroup carves (host and device use the same function): the BS table, then per LANE 16 B position + 16 B {mask lo, mask hi,
-// ewma | utility, reward_before} + 8 B in-range set + 32 B of term slots, per (env, station) three aggregates, per (wave, station) three
-// partial sums where an env spans waves.  64 stations, 32 UEs: 7.9 KB per wavefront.
-struct BigCarve { int mode, pos, slot, inr, term, agg, part, total; };
+// ewma | utility, reward_before} + 8 B in-range set, per (env, station) three aggregates, per (wave, station) three partial sums where an
+// env spans waves.  64 stations, 32 UEs: 5.4 KB per wavefront.
+struct BigCarve { int mode, pos, slot, inr, agg, part, total; };
 __host__ __device__ inline BigCarve big_carve(int B, int gpb, int blk)
 {
     BigCarve c;
@@ -64,8 +64,7 @@ __host__ __device__ inline BigCarve big_carve(int B, int gpb, int blk)
     c.pos = o; o += blk * 16;
     c.slot = o; o += blk * 16;
     c.inr = o; o += blk * 8;
-    c.term = o; o += blk * 32;
-    c.agg = o; o += 3 * gpb * B * 4; o = (o + 15) & ~15;
+    c.agg = o; o += 3 * gpb * B * 4 + 16; o = (o + 15) & ~15;      // (+ one scratch word: where the empty term slots add their 0.0)
     c.part = o; o += blk > 64 ? 3 * (blk / 64) * B * 4 : 0;
     c.total = (o + 15) & ~15;
     return c;
@@ -163,7 +162,6 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
     double2 *const pos_s = reinterpret_cast<double2 *>(big_smem + cv.pos);
     uint4 *const slot_s = reinterpret_cast<uint4 *>(big_smem + cv.slot);               // {mask lo, mask hi, ewma | utility, reward_before}
     unsigned long long *const inr_s = reinterpret_cast<unsigned long long *>(big_smem + cv.inr);
-    uint4 *const term_s = reinterpret_cast<uint4 *>(big_smem + cv.term);               // two per lane: {station, term} x 4
     float *const agg_n = reinterpret_cast<float *>(big_smem + cv.agg), *const agg_s = agg_n + GPB * B, *const agg_u = agg_s;
     uint32_t *const mc_win = reinterpret_cast<uint32_t *>(agg_s + GPB * B);
     float *const agg_m = reinterpret_cast<float *>(mc_win);
@@ -353,22 +351,22 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
     };
     auto sharing_aggregates = [&](double qx, double qy, float ewma_v) {
         if (DCOMP_BIG_ABL & 16) return;
-        float s_acc[EPW];
-        int n_acc[EPW];
-#pragma unroll
-        for (int el = 0; el < EPW; el++) {                         // counts: lane b adds bit b of every row's connection set
-            int r0, envl, uu0;
-            const int nrows = piece_rows(el, r0, envl, uu0);
-            int n = 0;
-            for (int uu = sub; uu < nrows; uu += SUB) {
-                const uint4 sl = slot_s[r0 + uu];
-                n += (int)__builtin_amdgcn_ubfe(hi_lane ? sl.y : sl.x, sh, 1u);
-            }
-            n_acc[el] = sub_sum_i(n); s_acc[el] = 0.f;
-        }
+        // Both aggregates are built by the UE lanes themselves, each walking the few bits of its OWN connection set (round 6, second pass: the
+        // station lanes used to scan every row -- 40 rows x 13 instructions per pass at 10 x 40 central, 47 of its 130 us):
+        //  * the COUNT n_b: `ds_add_f32 1.0` per connected station -- sums of ones below 2^24 are exact, so the order is irrelevant;
+        //  * the SUM of the rate-fair / proportional-fair terms (station.py:177-180 | 150, 192-195): the order matters in the last bit, so the
+        //    adds are issued UE by UE -- trip uu of a uniform loop enables the lanes whose UE index is uu (one per env of the wavefront: different
+        //    envs, different addresses), four terms per UE and round; LDS operations of a wavefront complete in program order.  Envs wider than
+        //    a wavefront add into per-wave partial sums first and combine them in wave order.  Deterministic, no compare-and-swap loops.
+        for (int i = tid; i < 2 * GPB * B; i += BLK) agg_n[i] = 0.f;              // (agg_s follows agg_n)
+        if (NWAVE > 1 && lane < B) part_s[(NWAVE + wave) * B + lane] = 0.f;
+        __syncthreads();
+        float *const cnt_row = agg_n + env_local * B;
+        for (unsigned long long m = alive ? conn : 0ull; m; m &= m - 1ull) __hip_atomic_fetch_add(cnt_row + (__ffsll((long long)m) - 1), 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (any_sum) {
-            // station.py:177-180 | 150, 192-195: the terms 1 / rate resp. rate / (ewma + eps) of the connected UEs.  A UE evaluates its own
-            // connections (sparse), four per round, and publishes {station, term}; lane b adds the slots that name station b, rows in UE order.
+            float *const sum_row = NWAVE > 1 ? part_s + (NWAVE + wave) * B : agg_s + env_local * B;
+            const int my_uu = NWAVE > 1 ? u - wave * 64 : u;            // this lane's row inside its wavefront's piece
+            const int piece_len = NWAVE > 1 ? (U - wave * 64 < 64 ? U - wave * 64 : 64) : U;
             unsigned long long todo = alive ? (conn & x.summode_mask) : 0ull;
             const float inv_e = fast_rcp(ewma_v + EPS);
             while (true) {
@@ -388,48 +386,33 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                         tv[k] = mode_s[b] == DCOMP_RATE_FAIR ? fast_rcp(r) : r * inv_e;
                     }
                 }
-                term_s[2 * tid] = make_uint4(tb[0], __float_as_uint(tv[0]), tb[1], __float_as_uint(tv[1]));
-                term_s[2 * tid + 1] = make_uint4(tb[2], __float_as_uint(tv[2]), tb[3], __float_as_uint(tv[3]));
-                __syncthreads();
+                // (empty slots add 0.0 to a scratch word, slots no lane of the wavefront uses are skipped: the loop body is one compare, the
+                //  exec switch and one ds_add_f32 per slot in use)
+                float *ta[4];
+                bool use[4];
 #pragma unroll
-                for (int el = 0; el < EPW; el++) {
-                    int r0, envl, uu0;
-                    const int nrows = piece_rows(el, r0, envl, uu0);
-                    float s = 0.f;
-                    for (int uu = sub; uu < nrows; uu += SUB) {               // (slots fill in order: the first empty one ends the row)
-                        const uint4 t0 = term_s[2 * (r0 + uu)];
-                        if (t0.x != 0xFFu) {
-                            s += t0.x == (uint32_t)sb ? __uint_as_float(t0.y) : 0.f;
-                            if (t0.z != 0xFFu) {
-                                s += t0.z == (uint32_t)sb ? __uint_as_float(t0.w) : 0.f;
-                                const uint4 t1 = term_s[2 * (r0 + uu) + 1];
-                                if (t1.x != 0xFFu) {
-                                    s += t1.x == (uint32_t)sb ? __uint_as_float(t1.y) : 0.f;
-                                    if (t1.z != 0xFFu) s += t1.z == (uint32_t)sb ? __uint_as_float(t1.w) : 0.f;
-                                }
-                            }
-                        }
-                    }
-                    s_acc[el] += sub_sum_f(s);
+                for (int k = 0; k < 4; k++) {
+                    ta[k] = tb[k] != 0xFFu ? sum_row + tb[k] : agg_n + 3 * GPB * B;
+                    use[k] = __ballot(tb[k] != 0xFFu) != 0ull;
                 }
-                const bool more = __syncthreads_or(todo != 0ull) != 0;                   // (also: every reader is done with the slots)
-                if (!more) break;
+                for (int uu = 0; uu < piece_len; uu++) {                // UE order
+                    if (my_uu == uu) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (use[k]) __hip_atomic_fetch_add(ta[k], tv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                if (!__syncthreads_or(todo != 0ull)) break;             // further rounds: UEs with more than four such connections
             }
         }
-        if (NWAVE > 1) {                                           // one env over several waves: partial sums, combined in wave order
-            if (st_writer) { part_s[wave * B + sb] = (float)n_acc[0]; part_s[(NWAVE + wave) * B + sb] = s_acc[0]; }
+        __syncthreads();
+        if (NWAVE > 1 && any_sum) {                                // one env over several waves: the partial sums, combined in wave order
+            if (wave == 0 && lane < B) {
+                float sacc = 0.f;
+                for (int w = 0; w < NWAVE; w++) sacc += part_s[(NWAVE + w) * B + lane];
+                agg_s[lane] = sacc;
+            }
             __syncthreads();
-            if (wave == 0 && st_writer) {
-                float n = 0.f, s = 0.f;
-                for (int w = 0; w < NWAVE; w++) { n += part_s[w * B + sb]; s += part_s[(NWAVE + w) * B + sb]; }
-                agg_n[sb] = n; agg_s[sb] = s;
-            }
-        } else if (st_writer) {
-#pragma unroll
-            for (int el = 0; el < EPW; el++) {
-                const int envl = (wave * 64 + el * PL) / UPAD;
-                agg_n[envl * B + sb] = (float)n_acc[el]; agg_s[envl * B + sb] = s_acc[el];
-            }
         }
         if (any_maxcap && !(DCOMP_BIG_ABL & 1)) {
             // station.py:183-187: the UE with the highest FP64 rate is served; equal rates -> the oldest connection, then the lowest UE index
@@ -606,7 +589,7 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                     bool ir = false;
                     if (!(DCOMP_BIG_ABL & 8)) big_row_pair(q.x, q.y, mybs, p, st_ok, ir, l);
                     const unsigned long long bal = __ballot(ir);
-                    if (lane == 0) inr_s[r] = bal;
+                    if (lane == 0 && kind == DCOMP_MULTI) inr_s[r] = bal;      // (only the multi-agent rewards read the in-range sets)
                     if (dst_env) {
                         const float lmax = wave_max_f32(l);
                         const float dr = live ? fast_exp2(l - lmax) : 0.f;                // variants.py:276-284
@@ -619,13 +602,11 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                                 big_store(dst + 2 * B + lane, live ? n_col : 0.f);
                                 big_store(dst + 3 * B + lane, live ? u_col : 0.f);
                             }
-                            if (lane == 0) big_store(dst + 4 * B, __uint_as_float(sl.z) * (1.0f / MAX_UTIL));
                         } else {
                             if (st_ok) {
                                 big_store(dst_env + (size_t)ue * B + lane, cf);
                                 big_store(dst_env + UB + (size_t)ue * B + lane, dr);
                             }
-                            if (lane == 0) big_store(dst_env + 2 * UB + ue, __uint_as_float(sl.z) * (1.0f / MAX_UTIL));
                         }
                     }
                 }
@@ -643,7 +624,7 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                     bool ir = false;
                     if (!(DCOMP_BIG_ABL & 8)) big_row_pair(q.x, q.y, mybs, p, st_ok && rv, ir, l);
                     const unsigned long long bal = __ballot(ir);
-                    if (sb == 0 && rv) inr_s[r] = (bal >> (sub * BP)) & ((1ull << BP) - 1ull);
+                    if (sb == 0 && rv && kind == DCOMP_MULTI) inr_s[r] = (bal >> (sub * BP)) & ((1ull << BP) - 1ull);
                     if (dst_env) {
                         const float lmax = BP == 32 ? group_reduce<32, OpMax>(l) : BP == 16 ? group_reduce<16, OpMax>(l) : group_reduce<8, OpMax>(l);
                         const float dr = live ? fast_exp2(l - lmax) : 0.f;                // variants.py:276-284
@@ -656,23 +637,27 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                                 big_store(dst_env + off + 2 * B, live ? n_col : 0.f);
                                 big_store(dst_env + off + 3 * B, live ? u_col : 0.f);
                             }
-                            if (sb == 0 && rv) big_store(dst_env + off + 4 * B, __uint_as_float(sl.z) * (1.0f / MAX_UTIL));
                         } else {
                             const int off = ue * B + sb;
                             if (st_ok && rv) {
                                 big_store(dst_env + off, cf);
                                 big_store(dst_env + UB + off, dr);
                             }
-                            if (sb == 0 && rv) big_store(dst_env + 2 * UB + ue, __uint_as_float(sl.z) * (1.0f / MAX_UTIL));
                         }
                     }
                 }
             }
         }
     }
+    // the rows' own utility entry: by the UE lanes (one store instruction per wavefront instead of a lane-0 store in every trip of the row loop)
+    if (active && p.obs && !(DCOMP_BIG_ABL & 4)) {
+        const float ut = alive ? util * (1.0f / MAX_UTIL) : 0.f;
+        if (kind == DCOMP_MULTI) big_store(p.obs + (size_t)idx * ROW + 4 * B, ut);
+        else big_store(p.obs + (size_t)env * U * (2 * B + 1) + 2 * UB + u, ut);
+    }
     __syncthreads();
     // 9. reward, info
-    const unsigned long long in_range = inr_s[tid];
+    const unsigned long long in_range = kind == DCOMP_MULTI ? inr_s[tid] : 0ull;
     if (kind == DCOMP_CENTRAL) {                                   // central.py:65-73: over the UEs' rewards_before
         if (active && u == 0) {
             const int base = env_local * UPAD;

@@ -167,6 +167,7 @@ def main():
             for k in ('vel', 'util', 'req', 'init', 'pause', 'border'):
                 if spec.get(k) is not None:
                     spec[k] = spec[k][:n]
+            spec['arrival'] = fuzz_parity._clamp_arrival(spec.get('arrival'), n, 250)     # (round 6: many-station cases keep their UE arrival / departure schedule)
         done += 1
         try:
             (run_one_dynamic if spec['arrival'] else run_one)(spec)

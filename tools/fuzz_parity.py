@@ -94,6 +94,20 @@ def _spec_rest(**kw):
     return kw
 
 
+def _clamp_arrival(arrival, U, cap):
+    """A schedule drawn for another UE count: keep at least one UE in the list and at most `cap` slots."""
+    if not arrival:
+        return None
+    cur, arr = U, {}
+    for t in sorted(arrival, key=int):
+        n = min(int(arrival[t]), cap - cur)
+        n = max(n, 1 - cur)
+        if n:
+            arr[t] = n
+            cur += n
+    return arr or None
+
+
 def many_stations(spec, frac):
     """Round 5 (a stream of its own, keyed by the case's seed: every older spec stays what it was): with probability `frac` the case gets
     33 ... 64 stations -- the generic kernel of csrc/dcomp_big.h.  The extra stations are drawn like the first ones; what the generic
@@ -112,6 +126,7 @@ def many_stations(spec, frac):
     c['bs_xy'] = list(c['bs_xy']) + [[float(r5.integers(0, c['w'] + 1)), float(r5.integers(0, c['h'] + 1))] if integer_bs else
                                       [float(r5.uniform(0, c['w'])), float(r5.uniform(0, c['h']))] for _ in range(B - B0)]
     c['sh'] = list(c['sh']) + [c['sh'][b % B0] if len(set(c['sh'])) > 1 or r5.random() < 0.5 else SHARING[int(r5.integers(0, 4))] for b in range(B0, B)]
+    c['arrival'] = _clamp_arrival(c.get('arrival'), c['U'], 250)
     c['B'], c['many_stations'] = B, True            # (round 6: the case keeps its UE arrival / departure schedule -- the generic kernel has the event phase)
     return c
 
@@ -131,15 +146,7 @@ def many_ues(spec, frac):
         if c.get(k) is not None:
             c[k] = [c[k][i % U0] for i in range(U)]
     c['U'], c['many_ues'] = U, True
-    if c.get('arrival'):                             # keep the schedule inside 1 024 slots
-        cur, arr = U, {}
-        for t in sorted(c['arrival'], key=int):
-            n = min(int(c['arrival'][t]), 1024 - cur)
-            n = max(n, 1 - cur)
-            if n:
-                arr[t] = n
-                cur += n
-        c['arrival'] = arr or None
+    c['arrival'] = _clamp_arrival(c.get('arrival'), U, 1024)
     c['E'], c['steps'] = min(c['E'], 3), min(c['steps'], 16)
     return c
 
