@@ -128,7 +128,7 @@ __device__ __forceinline__ void big_row_pair(double qx, double qy, const double2
     float qf;
     pair_eval_q(qx, qy, bp.x, bp.y, p, in_range, l2, qf);
     const bool special = ok && (qf == p.dt2f || qf < NEAR_D2);
-    if (__ballot(special) != 0ull || p.dsq_exact) {
+    if (__builtin_amdgcn_ballot_w64(special) != 0ull || p.dsq_exact) {
         if (ok && (qf == p.dt2f || p.dsq_exact)) in_range = in_range_exact(qx, qy, bp.x, bp.y, p.dt2);
         if (ok && qf < NEAR_D2) {
             const double dx = bp.x - qx, dy = bp.y - qy;
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     ta[k] = tb[k] != 0xFFu ? sum_row + tb[k] : agg_n + 3 * GPB * B;
-                    use[k] = __ballot(tb[k] != 0xFFu) != 0ull;
+                    use[k] = __builtin_amdgcn_ballot_w64(tb[k] != 0xFFu) != 0ull;
                 }
                 for (int uu = 0; uu < piece_len; uu++) {                // UE order
                     if (my_uu == uu) {
@@ -578,6 +578,7 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                 u_col = agg_u[envl * B + sb] * fast_rcp(fmaxf(n, 1.f)) * (1.0f / MAX_UTIL);
             }
             float *const dst_env = p.obs ? p.obs + (size_t)(env0 + envl) * U * (kind == DCOMP_MULTI ? ROW : 2 * B + 1) : nullptr;
+            const unsigned long long ok_mask = __builtin_amdgcn_ballot_w64(st_ok);
             if (LBP == 6) {
                 // more than 32 stations: ONE row per trip, everything about the row uniform (position / set: broadcast reads; destination: scalar)
                 for (int uu = 0; uu < nrows; uu++) {
@@ -586,27 +587,53 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                     const double2 q = pos_s[r];
                     const uint4 sl = slot_s[r];
                     float l = -3.0e38f;
-                    bool ir = false;
-                    if (!(DCOMP_BIG_ABL & 8)) big_row_pair(q.x, q.y, mybs, p, st_ok, ir, l);
-                    const unsigned long long bal = __ballot(ir);
-                    if (lane == 0 && kind == DCOMP_MULTI) inr_s[r] = bal;      // (only the multi-agent rewards read the in-range sets)
+                    unsigned long long bal = 0ull;
+                    if (!(DCOMP_BIG_ABL & 8)) {
+                        // the lane masks straight from the compares (a ballot of a derived bool costs a v_cndmask + v_cmp pair each)
+                        bool ir;
+                        float qf;
+                        pair_eval_q(q.x, q.y, mybs.x, mybs.y, p, ir, l, qf);
+                        const double dx = mybs.x - q.x, dy = mybs.y - q.y;
+                        const double dsq = __builtin_fma(dy, dy, dx * dx);             // (the same expression as inside pair_eval_q: one evaluation)
+                        bal = __builtin_amdgcn_ballot_w64(dsq < p.dt2) & ok_mask;
+                        const unsigned long long rare = (__builtin_amdgcn_ballot_w64(qf == p.dt2f) | __builtin_amdgcn_ballot_w64(qf < NEAR_D2)) & ok_mask;
+                        if (rare != 0ull || p.dsq_exact) {                               // wave-uniform: the fused d^2 cannot decide / a UE within 1.26 m of a station
+                            bool fix = st_ok && ((bal >> lane) & 1ull);
+                            if (st_ok && (qf == p.dt2f || p.dsq_exact)) fix = in_range_exact(q.x, q.y, mybs.x, mybs.y, p.dt2);
+                            if (st_ok && qf < NEAR_D2 && (float)dsq < 1e-20f) l = pair_eval_tiny(q.x, q.y, mybs.x, mybs.y, p);
+                            bal = __builtin_amdgcn_ballot_w64(fix);
+                        }
+                        l = st_ok ? l : -3.0e38f;
+                    }
+                    if (kind == DCOMP_MULTI) { if (lane == 0) inr_s[r] = bal; }      // (only the multi-agent rewards read the in-range sets)
                     if (dst_env) {
-                        const float lmax = wave_max_f32(l);
-                        const float dr = live ? fast_exp2(l - lmax) : 0.f;                // variants.py:276-284
-                        const float cf = (float)__builtin_amdgcn_ubfe(hi_lane ? sl.y : sl.x, sh, 1u);
+                        // (uniform row base + the lane's 32-bit offset: the store's scalar-base form, no 64-bit address arithmetic per store;
+                        //  an unlisted slot -- `live` is uniform -- takes the zero-row branch instead of a select per value)
+                        const uint32_t lo = (uint32_t)lane;
                         if (kind == DCOMP_MULTI) {
                             float *const dst = dst_env + (size_t)ue * ROW;
-                            if (st_ok) {
-                                big_store(dst + lane, cf);
-                                big_store(dst + B + lane, dr);
-                                big_store(dst + 2 * B + lane, live ? n_col : 0.f);
-                                big_store(dst + 3 * B + lane, live ? u_col : 0.f);
+                            if (live) {
+                                const float lmax = wave_max_f32(l);
+                                const float dr = fast_exp2(l - lmax);                        // variants.py:276-284
+                                const float cf = (float)__builtin_amdgcn_ubfe(hi_lane ? sl.y : sl.x, sh, 1u);
+                                if (st_ok) {
+                                    big_store(dst + lo, cf);
+                                    big_store(dst + (lo + (uint32_t)B), dr);
+                                    big_store(dst + (lo + (uint32_t)(2 * B)), n_col);
+                                    big_store(dst + (lo + (uint32_t)(3 * B)), u_col);
+                                }
+                            } else if (st_ok) {
+                                big_store(dst + lo, 0.f); big_store(dst + (lo + (uint32_t)B), 0.f);
+                                big_store(dst + (lo + (uint32_t)(2 * B)), 0.f); big_store(dst + (lo + (uint32_t)(3 * B)), 0.f);
                             }
                         } else {
-                            if (st_ok) {
-                                big_store(dst_env + (size_t)ue * B + lane, cf);
-                                big_store(dst_env + UB + (size_t)ue * B + lane, dr);
-                            }
+                            float *const dc = dst_env + (size_t)ue * B;
+                            if (live) {
+                                const float lmax = wave_max_f32(l);
+                                const float dr = fast_exp2(l - lmax);
+                                const float cf = (float)__builtin_amdgcn_ubfe(hi_lane ? sl.y : sl.x, sh, 1u);
+                                if (st_ok) { big_store(dc + lo, cf); big_store(dc + (lo + (uint32_t)UB), dr); }
+                            } else if (st_ok) { big_store(dc + lo, 0.f); big_store(dc + (lo + (uint32_t)UB), 0.f); }
                         }
                     }
                 }
@@ -623,7 +650,7 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                     float l = -3.0e38f;
                     bool ir = false;
                     if (!(DCOMP_BIG_ABL & 8)) big_row_pair(q.x, q.y, mybs, p, st_ok && rv, ir, l);
-                    const unsigned long long bal = __ballot(ir);
+                    const unsigned long long bal = __builtin_amdgcn_ballot_w64(ir);
                     if (sb == 0 && rv && kind == DCOMP_MULTI) inr_s[r] = (bal >> (sub * BP)) & ((1ull << BP) - 1ull);
                     if (dst_env) {
                         const float lmax = BP == 32 ? group_reduce<32, OpMax>(l) : BP == 16 ? group_reduce<16, OpMax>(l) : group_reduce<8, OpMax>(l);
