@@ -361,6 +361,14 @@ __device__ __forceinline__ float clamp_med3(float x, float lo, float hi) { retur
 // and redo the decision in the reference's literal form exactly where the two CAN differ: when (float)fused == (float)X.  The host checks
 // that every double within 4 ulp of X has that float image (dsq_exact = 1 otherwise: always the reference form).  Hit rate ~1e-7 per pair;
 // tests/test_threshold_gpu.py puts 1 000+ placements per kernel family there.
+#ifndef DCOMP_EDGE_MODE
+// How a lane notes "(float)fused d^2 == (float)X" over its stations: 0 = v_cmp_eq_f32 + s_or per pair (one vector + one scalar instruction, and a
+// VALU -> SALU hand-over), 1 = min |q - (float)X| (two vector instructions, nothing scalar), 2 = by kernel: form 0 where many waves per SIMD hide the
+// hand-over and the vector ALU is the co-limit (step_kernel: config 3 +0.1-0.3 % against +0.0-1.2 %), form 1 where one or two waves per SIMD run
+// (the fused rollout, the wide kernel beyond the Infinity Cache: config 2 +2.9 % against +4.2 %, config 5 whole +2.9 % against +4.8 %;
+// profiles/r06_ab_edge_mode*.txt, all against the round-5 predicate).
+#define DCOMP_EDGE_MODE 2
+#endif
 #ifndef DCOMP_DSQ_FUSED
 #define DCOMP_DSQ_FUSED 0          // 1: the round-5 predicate, fused value only (A/B; fails the threshold tests)
 #endif
@@ -371,7 +379,15 @@ __device__ __forceinline__ double dist_sq_ref(double dx, double dy)
     return xx + yy;
 }
 // the rare side of the decision, kept out of line: (float)fused d^2 == (float)X
-__device__ __noinline__ bool in_range_exact(double px, double py, double bx, double by, double dt2)
+#ifndef DCOMP_EXACT_INLINE
+#define DCOMP_EXACT_INLINE 0         // 1: the rare reference-form re-check inlined at every site instead of one out-of-line function (A/B)
+#endif
+#if DCOMP_EXACT_INLINE
+__device__ __forceinline__
+#else
+__device__ __noinline__
+#endif
+bool in_range_exact(double px, double py, double bx, double by, double dt2)
 {
     return dist_sq_ref(bx - px, by - py) < dt2;
 }
@@ -439,7 +455,10 @@ __device__ __forceinline__ uint32_t eval_pairs(double px, double py, const KPara
 {
     uint32_t in_range = 0;
     float qmin = 3.0e38f;
-    bool edge = false;                           // some station of this lane sits where the fused d^2 cannot decide (pair_eval_q)
+    // some station of this lane sits where the fused d^2 cannot decide (pair_eval_q): noted by compares (form 0) or as min |q - (float)X| (form 1)
+    const bool vec_form = DCOMP_EDGE_MODE == 1 || (DCOMP_EDGE_MODE == 2 && bsx != nullptr);      // (bsx: the latency-bound fused rollout)
+    bool edge = false;
+    float emin = 3.0e38f;
 #pragma unroll
     for (int b = 0; b < B; b++) {
         bool ir;
@@ -447,8 +466,10 @@ __device__ __forceinline__ uint32_t eval_pairs(double px, double py, const KPara
         pair_eval_q(px, py, bsx ? bsx[b] : DCOMP_BSX(b), bsy ? bsy[b] : DCOMP_BSY(b), p, ir, l2[b], q);
         in_range |= (uint32_t)ir << b;
         qmin = min_med3(qmin, q);
-        edge |= q == p.dt2f;
+        if (vec_form) emin = min_med3(emin, __builtin_fabsf(q - p.dt2f));
+        else edge |= q == p.dt2f;
     }
+    if (vec_form) edge = emin == 0.f;
 #if !DCOMP_DSQ_FUSED
     if (__ballot(edge) != 0ull || p.dsq_exact) {  // rare (~1e-7 per pair), wave-uniform: every station of the wave again, in the reference's form
         in_range = 0;

@@ -278,7 +278,12 @@ __device__ __forceinline__ void wide_step_one(const KParams &p, WideShared<B, UP
     auto pairs = [&](const int c0, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;       // every slot of the chunk is a station: no bounds tests
         float l2n[PC];
-        bool anytiny = false, edge = false;
+        bool anytiny = false;
+#if DCOMP_EDGE_MODE == 0
+        bool edge = false;
+#else
+        float emin = 3.0e38f;                                    // (the wide kernel runs two to four waves per SIMD: the vector-only form, dcomp_device.h DCOMP_EDGE_MODE)
+#endif
 #pragma unroll
         for (int j = 0; j < PC; j++) {
             const int b = c0 + j;
@@ -288,10 +293,17 @@ __device__ __forceinline__ void wide_step_one(const KParams &p, WideShared<B, UP
                 float q;
                 pair_eval_q(px, py, p.bs_x[b], p.bs_y[b], p, inr_n, l2n[j], q);
                 anytiny |= q < NEAR_D2;
+#if DCOMP_EDGE_MODE == 0
                 edge |= q == p.dt2f;                             // the fused d^2 cannot decide this pair (dcomp_device.h, dist_sq_ref)
+#else
+                emin = min_med3(emin, __builtin_fabsf(q - p.dt2f));
+#endif
                 inr_new |= (uint32_t)inr_n << b;
             }
         }
+#if DCOMP_EDGE_MODE != 0
+        const bool edge = emin == 0.f;
+#endif
 #if !DCOMP_DSQ_FUSED
         if (__ballot(edge) != 0ull || p.dsq_exact) {            // rare (~1e-7 per pair), wave-uniform: this chunk's decisions in the reference's form
 #pragma unroll
