@@ -73,7 +73,7 @@ struct dcomp_env {
     int64_t episode;            // index of the current episode (-1 before the first reset)
     // 33 ... 64 stations (or DCOMP_FORCE_BIG=1): the generic kernel of dcomp_big.h instead of `kern`
     bool big = false;
-    dcomp::BigKernels bigk{nullptr, nullptr, nullptr, 0, 0};
+    dcomp::BigKernels bigk{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     dcomp::BigParams bigp{};
     double2 *d_bs = nullptr;
     int32_t *d_mode = nullptr;
@@ -233,7 +233,7 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
     if (env->big) {
         env->bigk = dcomp::big_kernels_for_upad(env->upad);
         if (!env->bigk.step) { delete env; return fail(DCOMP_EUNSUPPORTED, "no generic kernel for %d lanes per env", env->upad); }
-        if (DYN) env->bigk.step = env->bigk.step_dyn;        // UE arrival / departure (round 6: the generic kernel has the event phase too)
+        if (DYN) { env->bigk.step = env->bigk.step_dyn; env->bigk.step_c = env->bigk.step_dyn_c; }      // UE arrival / departure (round 6: the generic kernel has the event phase too)
         if ((size_t)dcomp::big_carve(B, env->bigk.gpb, env->bigk.block).total > 160 * 1024) {
             delete env;
             return fail(DCOMP_EINVAL, "%d UE slots x %d stations do not fit one workgroup's LDS (generic kernel)", CAP, B);
@@ -333,6 +333,8 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
         env->big_lds = (size_t)dcomp::big_carve(B, env->bigk.gpb, env->bigk.block).total;
         if (e == hipSuccess) e = raise_lds_limit(reinterpret_cast<const void *>(env->bigk.step), (int)env->big_lds);
         if (e == hipSuccess) e = raise_lds_limit(reinterpret_cast<const void *>(env->bigk.reset), (int)env->big_lds);
+        if (e == hipSuccess) e = raise_lds_limit(reinterpret_cast<const void *>(env->bigk.step_c), (int)env->big_lds);
+        if (e == hipSuccess) e = raise_lds_limit(reinterpret_cast<const void *>(env->bigk.reset_c), (int)env->big_lds);
         if (e != hipSuccess) { dcomp_destroy(env); return fail(DCOMP_EHIP, "device setup failed (generic kernel, %zu bytes of LDS per workgroup): %s", env->big_lds, hipGetErrorString(e)); }
         env->bigp.bs = env->d_bs; env->bigp.mode = env->d_mode; env->bigp.B = B;
     }
@@ -466,7 +468,7 @@ extern "C" int dcomp_obs_dim(const dcomp_env *env, int32_t *floats_per_env, int3
 static void launch_step(dcomp_env *env, KParams &kp, void *stream)
 {
     if (env->big) {
-        hipLaunchKernelGGL(env->bigk.step, dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, kp, env->bigp);
+        hipLaunchKernelGGL(kp.obs_compact ? env->bigk.step_c : env->bigk.step, dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, kp, env->bigp);
         return;
     }
     if (env->tight_g) {
@@ -501,7 +503,6 @@ static int fill_params(dcomp_env *env, const dcomp_state *st, const dcomp_out *o
     if (env->kp.any_maxcap && !st->conn_since) return fail(DCOMP_EINVAL, "a max-cap BS needs state.conn_since (see dcomp_state_sizes)");
     if (env->big) {
         if (!st->conn_hi) return fail(DCOMP_EINVAL, "more than %d stations: state.conn_hi (stations 32-63 of the connection set, sized like conn) is required", DCOMP_MASK32_MAX_BS);
-        if (out->obs_compact) return fail(DCOMP_EUNSUPPORTED, "out->obs_compact: the compact record holds one 32-bit connection mask per UE (num_bs <= %d)", DCOMP_MASK32_MAX_BS);
         if (env->kp.next_act) return fail(DCOMP_EUNSUPPORTED, "dcomp_set_policy is not available on the generic kernel (num_bs > %d)", DCOMP_MASK32_MAX_BS);
         env->bigp.conn_hi = st->conn_hi;
     }
@@ -538,7 +539,7 @@ extern "C" int dcomp_reset(dcomp_env *env, const dcomp_state *st, const dcomp_ta
     env->cur_ue = env->cfg.num_ue; env->n_removed = env->n_arrived = 0;      // base.py:177-182
     kp.cur_ue = env->cur_ue;
     kp.episode = (uint32_t)env->episode;
-    if (env->big) hipLaunchKernelGGL(env->bigk.reset, dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, kp, env->bigp);
+    if (env->big) hipLaunchKernelGGL(kp.obs_compact ? env->bigk.reset_c : env->bigk.reset, dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, kp, env->bigp);
     else hipLaunchKernelGGL(env->kern.reset, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
     HIP_TRY(hipGetLastError());
     return DCOMP_OK;
@@ -584,7 +585,7 @@ extern "C" int dcomp_step_dyn(dcomp_env *env, const dcomp_state *st, const uint8
     kp.n_remove = nrem; kp.n_add = nadd;
     kp.ev_remove = ev ? ev->remove_idx : nullptr; kp.ev_add_xy = ev ? ev->add_xy : nullptr;
     kp.ev_rem_base = env->n_removed; kp.ev_add_base = env->n_arrived;
-    if (env->big) hipLaunchKernelGGL(env->bigk.step, dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, kp, env->bigp);
+    if (env->big) hipLaunchKernelGGL(kp.obs_compact ? env->bigk.step_c : env->bigk.step, dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, kp, env->bigp);
     else hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
     HIP_TRY(hipGetLastError());
     env->time += 1;
@@ -642,7 +643,7 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
         k.cur_ue = env->cur_ue;
         k.episode = (uint32_t)env->episode;
         k.time = 0u;
-        if (env->big) hipLaunchKernelGGL(env->bigk.reset, dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, k, env->bigp);
+        if (env->big) hipLaunchKernelGGL(k.obs_compact ? env->bigk.reset_c : env->bigk.reset, dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, k, env->bigp);
         else hipLaunchKernelGGL(env->kern.reset, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, k);
     };
     if (env->dyn) {
@@ -774,7 +775,7 @@ extern "C" int dcomp_step_kernel_name(const dcomp_env *env, char *buf, int32_t l
 {
     if (!env || !buf || len < 1) return fail(DCOMP_EINVAL, "null argument");
     const int B = env->cfg.num_bs, W = env->upad, MP = env->mp_pattern;
-    if (env->big) std::snprintf(buf, (size_t)len, "big_kernel<%d, false, %s>", W < 4 ? 4 : W, env->dyn ? "true" : "false");
+    if (env->big) std::snprintf(buf, (size_t)len, "big_kernel<%d, false, %s, false>", W < 4 ? 4 : W, env->dyn ? "true" : "false");
     else if (env->tight_g) {
         const bool cen = env->cfg.env_kind == DCOMP_CENTRAL && env->kern.tight_central;
         std::snprintf(buf, (size_t)len, "step_kernel_tight<%d, %d, %d, %d>", B, W, MP, cen ? 0 : -1);
@@ -1154,14 +1155,14 @@ extern "C" int dcomp_selftest(int op, int width, const double *x, const double *
 // ---- compact rollout fragments for the learner hand-off (dcomp_fragment.h) ----
 extern "C" int dcomp_fragment_words(int32_t num_ue, int32_t num_bs)
 {
-    if (num_ue < 1 || num_ue > DCOMP_SPECIAL_MAX_UE || num_bs < 1 || num_bs > DCOMP_MASK32_MAX_BS) return -1;    // one 32-bit connection mask per UE; envs of the specialised kernels
+    if (num_ue < 1 || num_ue > DCOMP_MAX_UE || num_bs < 1 || num_bs > DCOMP_MAX_BS) return -1;    // (round 6: two mask words per UE with more than 32 stations)
     return dcomp_frag::env_words(num_ue, num_bs);
 }
 
 static int fragment_params(dcomp_frag::FragParams &p, int64_t n, int U, int B, int &grid, size_t &lds_pack, size_t &lds_unpack)
 {
-    if (n < 1 || U < 1 || U > DCOMP_SPECIAL_MAX_UE || B < 1 || B > DCOMP_MASK32_MAX_BS)
-        return fail(DCOMP_EINVAL, "fragment: need num_env_steps >= 1, 1 <= num_ue <= %d, 1 <= num_bs <= %d", DCOMP_SPECIAL_MAX_UE, DCOMP_MASK32_MAX_BS);
+    if (n < 1 || U < 1 || U > DCOMP_MAX_UE || B < 1 || B > DCOMP_MAX_BS)
+        return fail(DCOMP_EINVAL, "fragment: need num_env_steps >= 1, 1 <= num_ue <= %d, 1 <= num_bs <= %d", DCOMP_MAX_UE, DCOMP_MAX_BS);
     if (dcomp_frag::fill(p, n, U, B, grid, lds_pack, lds_unpack)) return fail(DCOMP_EINVAL, "fragment too long for one launch: split it (num_env_steps * chunks >= 2^31)");
     return DCOMP_OK;
 }

@@ -24,8 +24,8 @@
 //   * envs wider than a wavefront combine per-wave partial sums in wave order.
 // LDS per wavefront: 2.6 KB of per-lane slots + the tables -- the kernel is bound by registers (no per-B arrays), not by LDS; 513 ... 1 024 UE
 // slots no longer limit the station count.  UE arrival / departure (DYN): slots shift inside the env's lane group exactly as in dcomp_dyn.h.
-// Not here: the fused rollout (dcomp_rollout_ex launches one step per launch), the in-step policy, the compact record (its connection
-// word is 32 bits).
+// The compact record (dcomp_out.obs_compact; two set words per UE above 32 stations) is written here too.  Not here: the fused rollout
+// (dcomp_rollout_ex launches one step per launch) and the in-step policy.
 #pragma once
 #include "dcomp_device.h"
 
@@ -147,7 +147,7 @@ __device__ __forceinline__ float big_share(int mode, float dru, float n, float s
     return winner ? dru : 0.f;                                                               // station.py:183-187
 }
 
-template <int UPAD, bool RESET, bool DYN>
+template <int UPAD, bool RESET, bool DYN, bool COMPACT>
 __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, const BigParams x)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
@@ -565,6 +565,8 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
     //    compare's lane mask), the relative snr against the row maximum, `connected` from the row's set, the per-env columns -- four
     //    coalesced stores per row, straight from registers.  Unlisted slots write zero rows (central.py:46-55).
     const int ROW = 4 * B + 1, UB = U * B;
+    constexpr bool compact = COMPACT;                              // (its own instantiation: the branch in the row loop cost the row format 3-8 %; multi-agent envs only: the host checks)
+    const int CWC = B + 1 + (B > 32 ? 2 : 1), REC = U * CWC + 2 * B;     // words per UE / per env-step of the compact record (dcomp_frag::ue_words / env_words)
     const float inv_u = 1.0f / (float)n_eff;
     if (!(DCOMP_BIG_ABL & 4)) {
 #pragma unroll
@@ -577,7 +579,14 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                 n_col = n * inv_u;
                 u_col = agg_u[envl * B + sb] * fast_rcp(fmaxf(n, 1.f)) * (1.0f / MAX_UTIL);
             }
-            float *const dst_env = p.obs ? p.obs + (size_t)(env0 + envl) * U * (kind == DCOMP_MULTI ? ROW : 2 * B + 1) : nullptr;
+            // where this env's rows go: the row format, or (multi-agent envs, dcomp_out.obs_compact) the compact record of dcomp_fragment.h --
+            // U x {dr[B], utility, connection word(s)} + ues_at_bs[B] | util_at_bs[B]: the station lanes store the dr blocks and, once per env,
+            // the two per-env columns; utility and the set words are the UE lanes' (below)
+            float *const dst_env = !p.obs ? nullptr : compact ? p.obs + (size_t)(env0 + envl) * REC : p.obs + (size_t)(env0 + envl) * U * (kind == DCOMP_MULTI ? ROW : 2 * B + 1);
+            if (compact && dst_env && st_writer && nrows > 0 && uu0 == 0) {
+                big_store(dst_env + U * CWC + sb, n_col);
+                big_store(dst_env + U * CWC + B + sb, u_col);
+            }
             const unsigned long long ok_mask = __builtin_amdgcn_ballot_w64(st_ok);
             if (LBP == 6) {
                 // more than 32 stations: ONE row per trip, everything about the row uniform (position / set: broadcast reads; destination: scalar)
@@ -610,7 +619,11 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                         // (uniform row base + the lane's 32-bit offset: the store's scalar-base form, no 64-bit address arithmetic per store;
                         //  an unlisted slot -- `live` is uniform -- takes the zero-row branch instead of a select per value)
                         const uint32_t lo = (uint32_t)lane;
-                        if (kind == DCOMP_MULTI) {
+                        if (compact) {
+                            float *const dst = dst_env + (size_t)ue * CWC;
+                            const float lmax = wave_max_f32(l);
+                            if (st_ok) big_store(dst + lo, live ? fast_exp2(l - lmax) : 0.f);
+                        } else if (kind == DCOMP_MULTI) {
                             float *const dst = dst_env + (size_t)ue * ROW;
                             if (live) {
                                 const float lmax = wave_max_f32(l);
@@ -656,7 +669,9 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                         const float lmax = BP == 32 ? group_reduce<32, OpMax>(l) : BP == 16 ? group_reduce<16, OpMax>(l) : group_reduce<8, OpMax>(l);
                         const float dr = live ? fast_exp2(l - lmax) : 0.f;                // variants.py:276-284
                         const float cf = (float)__builtin_amdgcn_ubfe(sl.x, sh, 1u);
-                        if (kind == DCOMP_MULTI) {
+                        if (compact) {
+                            if (st_ok && rv) big_store(dst_env + ue * CWC + sb, dr);
+                        } else if (kind == DCOMP_MULTI) {
                             const int off = ue * ROW + sb;
                             if (st_ok && rv) {
                                 big_store(dst_env + off, cf);
@@ -679,7 +694,12 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
     // the rows' own utility entry: by the UE lanes (one store instruction per wavefront instead of a lane-0 store in every trip of the row loop)
     if (active && p.obs && !(DCOMP_BIG_ABL & 4)) {
         const float ut = alive ? util * (1.0f / MAX_UTIL) : 0.f;
-        if (kind == DCOMP_MULTI) big_store(p.obs + (size_t)idx * ROW + 4 * B, ut);
+        if (compact) {
+            float *const rec = p.obs + (size_t)env * REC + (size_t)u * CWC;
+            big_store(rec + B, ut);
+            big_store(rec + B + 1, __uint_as_float(alive ? (uint32_t)conn : 0u));
+            if (B > 32) big_store(rec + B + 2, __uint_as_float(alive ? (uint32_t)(conn >> 32) : 0u));
+        } else if (kind == DCOMP_MULTI) big_store(p.obs + (size_t)idx * ROW + 4 * B, ut);
         else big_store(p.obs + (size_t)env * U * (2 * B + 1) + 2 * UB + u, ut);
     }
     __syncthreads();
@@ -736,7 +756,7 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
 }
 
 using BigKernelFn = void (*)(const KParams, const BigParams);
-struct BigKernels { BigKernelFn step, reset, step_dyn; int gpb, block; };
+struct BigKernels { BigKernelFn step, reset, step_dyn, step_c, reset_c, step_dyn_c; int gpb, block; };     // _c: the instantiations that write the compact record
 BigKernels big_kernels_for_upad(int upad);
 
 }  // namespace dcomp

@@ -1,10 +1,14 @@
 // dcomp_big.hip -- instantiates the generic kernel of dcomp_big.h (any station count up to 64) for every lane-group width: one object,
-// 27 kernels (step, reset, step with UE arrival / departure), whatever the station count.
+// 54 kernels (step, reset, step with UE arrival / departure; each also as the instantiation that writes the compact record), whatever the station count.
 #include "dcomp_big.h"
 
 namespace dcomp {
 template <int UPAD>
-static BigKernels big_make() { return BigKernels{big_kernel<UPAD, false, false>, big_kernel<UPAD, true, false>, big_kernel<UPAD, false, true>, big_block(UPAD) / UPAD, big_block(UPAD)}; }
+static BigKernels big_make()
+{
+    return BigKernels{big_kernel<UPAD, false, false, false>, big_kernel<UPAD, true, false, false>, big_kernel<UPAD, false, true, false>,
+                      big_kernel<UPAD, false, false, true>, big_kernel<UPAD, true, false, true>, big_kernel<UPAD, false, true, true>, big_block(UPAD) / UPAD, big_block(UPAD)};
+}
 
 BigKernels big_kernels_for_upad(int upad)
 {
@@ -18,7 +22,7 @@ BigKernels big_kernels_for_upad(int upad)
     case 256: return big_make<256>();
     case 512: return big_make<512>();
     case 1024: return big_make<1024>();
-    default: return BigKernels{nullptr, nullptr, nullptr, 0, 0};
+    default: return BigKernels{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     }
 }
 }  // namespace dcomp

@@ -7,6 +7,7 @@
 // bs.avg_utility / MAX_UTILITY) replicated into every UE's row, and `connected` is B bits (variants.py:273).  The compact
 // record of one env-step therefore is
 //     U x { dr[B] f32 | utility f32 | connected bit mask u32 }   +   ues_at_bs[B] f32 | util_at_bs[B] f32
+// (round 6: with more than 32 stations the mask is TWO words -- U (B + 3) + 2B; the generic kernel of dcomp_big.h writes that record too)
 // = U (B + 2) + 2B words instead of U (4B + 1): 1 616 B instead of 5 248 B at 32 x 10 (3.25x fewer bytes on the links), 17 664 B
 // instead of 66 048 B at 128 x 32 (3.7x).  unpack(pack(rows)) is BIT-IDENTICAL to the rows: floats are copied, never
 // recomputed; `connected` entries are exactly 0.0f / 1.0f; rows of dead UE slots (UE arrival / departure: all zeros,
@@ -48,7 +49,9 @@ struct FragParams {
 };
 
 // words of one env-step record
-__host__ __device__ inline int env_words(int U, int B) { return U * (B + 2) + 2 * B; }
+__host__ __device__ inline int mask_words(int B) { return B > 32 ? 2 : 1; }                 // connection-set words per UE
+__host__ __device__ inline int ue_words(int B) { return B + 1 + mask_words(B); }             // dr[B] | utility | mask word(s)
+__host__ __device__ inline int env_words(int U, int B) { return U * ue_words(B) + 2 * B; }
 
 // Workgroup b runs on XCD b mod 8: with this map every XCD streams ONE contiguous eighth of the fragment (see xcd_contiguous_block
 // in dcomp_device.h: worth up to 19 % of the sustained write rate beyond the Infinity Cache).
@@ -72,7 +75,7 @@ __device__ __forceinline__ void wave_fence()
 __global__ __launch_bounds__(BLOCK) void pack_kernel(const FragParams p)
 {
     extern __shared__ float4 lds4[];
-    const int B = p.B, U = p.U, ROW = 4 * B + 1, CW = B + 2;
+    const int B = p.B, U = p.U, ROW = 4 * B + 1, CW = ue_words(B);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *rows = reinterpret_cast<float *>(lds4) + (size_t)wave * p.lw_pack, *t0 = rows + p.rows_words;
     const int64_t unit = (int64_t)xcd_block() * (BLOCK / 64) + wave;             // every XCD a contiguous eighth of the units
@@ -93,6 +96,7 @@ __global__ __launch_bounds__(BLOCK) void pack_kernel(const FragParams p)
     }
     const float tail = lane < (nf & 3) ? src[(nf & ~3) + lane] : 0.f;
     const float t0v = lane < 2 * B ? p.obs_in[(size_t)env * U * ROW + 2 * B + lane] : 0.f;     // row 0 of the env: the per-env columns
+    const float t0w = lane + 64 < 2 * B ? p.obs_in[(size_t)env * U * ROW + 2 * B + lane + 64] : 0.f;       // (more than 32 stations: 2B > 64)
 #pragma unroll
     for (int k = 0; k < NQ; k++) {
         const int i = lane * 4 + k * 256;
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(BLOCK) void pack_kernel(const FragParams p)
     }
     if (lane < (nf & 3)) rows[(nf & ~3) + lane] = tail;
     if (lane < 2 * B) t0[lane] = t0v;
+    if (lane + 64 < 2 * B) t0[lane + 64] = t0w;
     wave_fence();
     // lane r < 32: row r's `connected` block -> bit mask (and: every entry is 0 or 1), then its ues_at_bs replicas against row 0's;
     // lane 32 + r: row r's dr block -> "listed" (some entry is non-zero), then its util_at_bs replicas.  Row stride 4B + 1 is odd:
@@ -107,15 +112,15 @@ __global__ __launch_bounds__(BLOCK) void pack_kernel(const FragParams p)
     const int r = lane & 31, hi = lane >> 5;
     const bool mine = r < nr;
     const float *blk = rows + (mine ? r : 0) * ROW + hi * B;
-    uint32_t mask = 0;
+    unsigned long long mask = 0;
     int bad = 0;
     for (int b = 0; b < B; b++) {
         const float c = blk[b];
-        mask |= (c != 0.f ? 1u : 0u) << b;
+        mask |= (c != 0.f ? 1ull : 0ull) << b;
         bad |= (!hi && c != 0.f && c != 1.f) ? 2 : 0;
     }
-    const uint32_t dmask = (uint32_t)__shfl((int)mask, r + 32, 64);                          // the dr mask of my row (held by lane 32 + r)
-    const bool listed = dmask != 0u;
+    const unsigned long long dmask = __shfl(mask, r + 32, 64);                               // the dr mask of my row (held by lane 32 + r)
+    const bool listed = dmask != 0ull;
     {
         const float *rep = blk + 2 * B, *want = t0 + hi * B;                                   // ues_at_bs (lanes < 32) | util_at_bs (lanes >= 32)
         for (int b = 0; b < B; b++) bad |= (__float_as_uint(rep[b]) != (listed ? __float_as_uint(want[b]) : 0u)) ? 1 : 0;
@@ -124,13 +129,16 @@ __global__ __launch_bounds__(BLOCK) void pack_kernel(const FragParams p)
     // the connection words go where the per-row utility float sits in the compact record's neighbour: write them into the rows
     // buffer's `connected[0]` cell (dead from here on), so that word() below reads everything from one place
     wave_fence();
-    if (mine && !hi) rows[r * ROW] = __uint_as_float(mask);
+    if (mine && !hi) {
+        rows[r * ROW] = __uint_as_float((uint32_t)mask);
+        if (B > 32) rows[r * ROW + 1] = __uint_as_float((uint32_t)(mask >> 32));          // (`connected[1]`: dead from here on, too)
+    }
     wave_fence();
     uint32_t *dst = p.packed_out + (size_t)env * env_words(U, B) + (size_t)r0 * CW;
     const int nw = nr * CW;
     auto word = [&](int w) -> uint32_t {                          // (generic form: the tail words)
         const int rr = (int)__umulhi((uint32_t)w, p.magic_cw), k = w - rr * CW;
-        const int at = k < B ? B + k : k == B ? 4 * B : 0;                                    // dr[k] | utility | connection mask
+        const int at = k < B ? B + k : k == B ? 4 * B : k - B - 1;                            // dr[k] | utility | connection mask word(s)
         return __float_as_uint(rows[rr * ROW + at]);
     };
     {
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(BLOCK) void pack_kernel(const FragParams p)
             int r2 = rr, k2 = k;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int at = k2 < B ? B + k2 : k2 == B ? 4 * B : 0;
+                const int at = k2 < B ? B + k2 : k2 == B ? 4 * B : k2 - B - 1;
                 o[j] = __float_as_uint(rows[__umul24(r2, ROW) + at]);
                 k2++;
                 if (k2 == CW) { k2 = 0; r2++; }
@@ -155,14 +163,14 @@ __global__ __launch_bounds__(BLOCK) void pack_kernel(const FragParams p)
         }
     }
     if (lane < (nw & 3)) dst[(nw & ~3) + lane] = word((nw & ~3) + lane);
-    if (chunk == 0 && lane < 2 * B) p.packed_out[(size_t)env * env_words(U, B) + (size_t)U * CW + lane] = __float_as_uint(t0[lane]);
+    if (chunk == 0) for (int i = lane; i < 2 * B; i += 64) p.packed_out[(size_t)env * env_words(U, B) + (size_t)U * CW + i] = __float_as_uint(t0[i]);
 }
 
 // Per-wave LDS: the chunk's compact words (R (B + 2), 16-byte aligned) | per-env columns (2B) | listed[R]
 __global__ __launch_bounds__(BLOCK) void unpack_kernel(const FragParams p)
 {
     extern __shared__ float4 lds4[];
-    const int B = p.B, U = p.U, ROW = 4 * B + 1, CW = B + 2;
+    const int B = p.B, U = p.U, ROW = 4 * B + 1, CW = ue_words(B);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t unit = (int64_t)xcd_block() * (BLOCK / 64) + wave;             // every XCD a contiguous eighth of the units
     if (unit >= p.units) return;
@@ -183,6 +191,7 @@ __global__ __launch_bounds__(BLOCK) void unpack_kernel(const FragParams p)
     }
     const uint32_t tail = lane < (nw & 3) ? src[(nw & ~3) + lane] : 0u;
     const uint32_t t0v = lane < 2 * B ? p.packed_in[(size_t)env * env_words(U, B) + (size_t)U * CW + lane] : 0u;
+    const uint32_t t0w = lane + 64 < 2 * B ? p.packed_in[(size_t)env * env_words(U, B) + (size_t)U * CW + lane + 64] : 0u;
 #pragma unroll
     for (int k = 0; k < NQ; k++) {
         const int i = lane * 4 + k * 256;
@@ -190,6 +199,7 @@ __global__ __launch_bounds__(BLOCK) void unpack_kernel(const FragParams p)
     }
     if (lane < (nw & 3)) cw[(nw & ~3) + lane] = tail;
     if (lane < 2 * B) t0[lane] = t0v;
+    if (lane + 64 < 2 * B) t0[lane + 64] = t0w;
     wave_fence();
     if (lane < nr) {                                                                          // listed <=> some dr entry is non-zero
         uint32_t any = 0;
@@ -202,7 +212,7 @@ __global__ __launch_bounds__(BLOCK) void unpack_kernel(const FragParams p)
     auto val = [&](int f) -> float {
         const int r = (int)__umulhi((uint32_t)f, p.magic_row), c = f - r * ROW;
         const uint32_t *q = cw + r * CW;
-        if (c < B) return (float)((q[B + 1] >> c) & 1u);                            // connected          variants.py:273
+        if (c < B) return (float)((q[B + 1 + (c >> 5)] >> (c & 31)) & 1u);           // connected          variants.py:273
         if (c < 2 * B) return __uint_as_float(q[c - B]);                            // dr                 variants.py:279-284
         if (c < 4 * B) return listed[r] ? __uint_as_float(t0[c - 2 * B]) : 0.f;     // ues_at_bs | util_at_bs   variants.py:296-299
         return __uint_as_float(q[B]);                                               // utility            variants.py:287
@@ -216,11 +226,11 @@ __global__ __launch_bounds__(BLOCK) void unpack_kernel(const FragParams p)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t *q = cw + __umul24(r2, CW);
-                const uint32_t w = q[c2 < B ? B + 1 : c2 < 2 * B ? c2 - B : B];               // connection mask | dr[c - B] | utility
+                const uint32_t w = q[c2 < B ? B + 1 + (c2 >> 5) : c2 < 2 * B ? c2 - B : B];   // connection mask word | dr[c - B] | utility
                 const int e = c2 - 2 * B;
                 const uint32_t env = t0[e >= 0 && e < 2 * B ? e : 0];                         // ues_at_bs | util_at_bs of the env
                 const bool isenv = e >= 0 && e < 2 * B;
-                const uint32_t bits = c2 < B ? __float_as_uint((float)((w >> c2) & 1u)) : w;
+                const uint32_t bits = c2 < B ? __float_as_uint((float)((w >> (c2 & 31)) & 1u)) : w;
                 o[j] = __uint_as_float(isenv ? (listed[r2] ? env : 0u) : bits);
                 c2++;
                 if (c2 == ROW) { c2 = 0; r2++; }
@@ -248,7 +258,8 @@ static int rows_per_chunk(int U, int B)
 
 static int fill(FragParams &p, int64_t n, int U, int B, int &grid, size_t &lds_pack, size_t &lds_unpack)
 {
-    if (n < 1 || U < 1 || U > DCOMP_SPECIAL_MAX_UE || B < 1 || B > DCOMP_MASK32_MAX_BS) return DCOMP_EINVAL;
+    if (n < 1 || U < 1 || U > DCOMP_MAX_UE || B < 1 || B > DCOMP_MAX_BS) return DCOMP_EINVAL;
+    const int CW = ue_words(B);
     p.U = U; p.B = B;
     p.R = rows_per_chunk(U, B);
     p.chunks = (U + p.R - 1) / p.R;
@@ -257,12 +268,12 @@ static int fill(FragParams &p, int64_t n, int U, int B, int &grid, size_t &lds_p
     if (blocks > 0x7FFFFFFFll) return DCOMP_EINVAL;
     grid = (int)blocks;
     p.magic_row = (uint32_t)(0x100000000ull / (uint32_t)(4 * B + 1)) + 1u;
-    p.magic_cw = (uint32_t)(0x100000000ull / (uint32_t)(B + 2)) + 1u;
-    p.step_r_cw = 256 / (B + 2); p.step_k_cw = 256 % (B + 2);
+    p.magic_cw = (uint32_t)(0x100000000ull / (uint32_t)CW) + 1u;
+    p.step_r_cw = 256 / CW; p.step_k_cw = 256 % CW;
     p.step_r_row = 256 / (4 * B + 1); p.step_c_row = 256 % (4 * B + 1);
     p.rows_words = (p.R * (4 * B + 1) + 3) & ~3;
     p.lw_pack = (p.rows_words + 2 * B + 3) & ~3;
-    p.cw_words = (p.R * (B + 2) + 3) & ~3;
+    p.cw_words = (p.R * CW + 3) & ~3;
     p.lw_unpack = (p.cw_words + 2 * B + p.R + 3) & ~3;
     lds_pack = (size_t)p.lw_pack * 4 * (BLOCK / 64);
     lds_unpack = (size_t)p.lw_unpack * 4 * (BLOCK / 64);

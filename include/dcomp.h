@@ -22,7 +22,7 @@
  *   mv    uint64[E*U]      waypoint x:16 | y:16 | velocity:8 | pausing:1 (bit 47) + curr_pause:7 (bits 40-46) | draw cursor:16
  *   conn  uint32[E*U]      bit b set <=> UE connected to BS b                  (user.py:34 bs_dr keys)
  *   conn_hi uint32[E*U]    the same for stations 32 ... 63; required for envs of the generic kernel (csrc/dcomp_big.h): more than 32 stations
- *                          or more than 256 UE slots (dcomp_needs_conn_hi) -- no fused rollout, no in-step policy, no compact record there
+ *                          or more than 256 UE slots (dcomp_needs_conn_hi) -- no fused rollout and no in-step policy there
  *   ewma  float [E*U]      exponentially weighted average rate                 (user.py:148-157)
  *   flags uint32[4]        sticky device-side error bits, read by dcomp_check()
  *   With UE arrival / departure (cfg.max_ues >= cfg.num_ue; 0 = fixed list) every per-UE array has max_ues slots per env; slot =

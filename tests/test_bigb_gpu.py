@@ -208,10 +208,7 @@ def test_many_stations_what_works_and_what_says_no(torch_cuda):
         a.check()
     # what the generic kernel does not have (the stand-alone policy kernel DOES serve 64 stations: test_heuristic_policies_with_many_stations)
     assert a.set_policy('3gpp') is False
-    with pytest.raises((ValueError, NotImplementedError)):
-        fragment.fragment_words(U, B)
-    with pytest.raises((ValueError, NotImplementedError)):
-        a.step_compact(acts[0], torch.empty((E, 4), dtype=torch.int32, device='cuda'), a.reward)
+    assert fragment.fragment_words(U, B) == U * (B + 3) + 2 * B                    # (round 6: the compact record with two set words per UE)
     assert BatchedMobileEnv(m, bs, ues, 'multi', ue_arrival={3: 1}, **kw).step_kernel_name.startswith('big_kernel<')      # (round 6: UE arrival / departure too)
     with pytest.raises(ValueError):
         BatchedMobileEnv(*build_from_scenario(_scenario(4, 65, 'mixed')), 'multi', num_envs=2, rng='philox')
@@ -305,7 +302,7 @@ def test_generic_kernel_with_ue_arrival_and_departure(torch_cuda, shape):
     scn = _scenario(U0, B, sharing)
     m, bs, ues = build_from_scenario(scn)
     core = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=5, episode_length=L, reward=reward, rng='philox', rand_episodes=True, ue_arrival=arrival)
-    assert core.step_kernel_name.startswith('big_kernel<') and core.step_kernel_name.endswith('true>') and core.conn_hi is not None
+    assert core.step_kernel_name.startswith('big_kernel<') and core.step_kernel_name.endswith('true, false>') and core.conn_hi is not None
     M = core.U
     sched = orc.arrival_schedule(L, arrival)
     oenvs = []
@@ -354,3 +351,50 @@ def test_generic_kernel_on_the_reference_run_ue_arrival_fixtures(torch_cuda, nam
     monkeypatch.setenv('DCOMP_FORCE_BIG', '1')
     tp.test_golden_dynamic_ue_trajectory(torch_cuda, name, False)
     tp.test_golden_dynamic_ue_trajectory(torch_cuda, name, True)
+
+
+@pytest.mark.parametrize('U,B,E,arrival', [(32, 64, 40, None), (12, 40, 64, None), (7, 33, 50, {2: 3, 5: -2, 9: 2}), (130, 48, 3, None), (300, 36, 2, None)])
+def test_generic_kernel_writes_the_compact_record(torch_cuda, U, B, E, arrival):
+    """dcomp_out.obs_compact on the generic kernel (round 6: with more than 32 stations the record carries TWO connection words per UE:
+    U (B + 3) + 2B words): reset / step / rollout write the record themselves, `unpack` of it is BIT-identical to the rows a twin env writes --
+    with UE arrival / departure (unlisted slots are zero records), envs wider than a wavefront, and through dcomp_pack_fragment of the twin's rows."""
+    torch = torch_cuda
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    from deepcomp_amd.fragment import FragmentCodec
+    scn = _scenario(U, B, 'mixed')
+    m, bs, ues = build_from_scenario(scn)
+    kw = dict(num_envs=E, seed=21, rng='philox', rand_episodes=True, episode_length=30, ue_arrival=arrival)
+    rows_env = BatchedMobileEnv(m, bs, ues, 'multi', **kw)
+    comp_env = BatchedMobileEnv(m, bs, ues, 'multi', **kw)
+    M = rows_env.U
+    codec = FragmentCodec(M, B)
+    assert comp_env.compact_words == codec.words == M * (B + 3) + 2 * B and comp_env.step_kernel_name.startswith('big_kernel<')
+    packed = torch.empty((E, codec.words), dtype=torch.int32, device='cuda')
+    rows_env.reset()
+    comp_env.reset_compact(packed)
+    assert torch.equal(codec.unpack(packed).view(torch.int32), rows_env.obs.view(torch.int32)), 'reset'
+    rng = np.random.default_rng(5)
+    high = 0
+    for t in range(14):
+        a = torch.from_numpy(_near_actions(rng, rows_env, B)).cuda()
+        rows_env.step(a)
+        comp_env.step_compact(a, packed, comp_env.reward)
+        got = codec.unpack(packed)
+        assert torch.equal(got.view(torch.int32), rows_env.obs.view(torch.int32)), f'step {t}: unpack(compact record) != rows'
+        assert torch.equal(comp_env.reward, rows_env.reward) and torch.equal(comp_env.conn_hi, rows_env.conn_hi) and torch.equal(comp_env.pos, rows_env.pos)
+        assert torch.equal(codec.pack(rows_env.obs), packed), f'step {t}: the step\'s record != dcomp_pack_fragment of the rows'
+        high += int((rows_env.conn_hi != 0).sum())
+    codec.check(); rows_env.check(); comp_env.check()
+    assert high > 0
+    # a whole fragment through rollout(out={'obs_compact': ...})
+    T = 6
+    acts = torch.from_numpy(np.stack([_near_actions(rng, rows_env, B) for _ in range(T)])).cuda()
+    frag = {'obs_compact': torch.empty((T, E, codec.words), dtype=torch.int32, device='cuda'), 'reward': torch.empty((T, E, M), device='cuda')}
+    want = torch.empty((T, E, M, 4 * B + 1), device='cuda')
+    if arrival is None:
+        comp_env.rollout(acts, out=frag)
+        for t in range(T):
+            rows_env.step(acts[t])
+            want[t] = rows_env.obs
+        assert torch.equal(codec.unpack(frag['obs_compact']).view(torch.int32), want.view(torch.int32))

@@ -46,23 +46,23 @@ def test_round_trip_on_rows_the_reference_produced(torch_cuda, pattern):
         rows = _rows_from_fixture(np.load(f))
         T, U, row = rows.shape
         B = (row - 1) // 4
-        if B > 32:                          # (dyn_dense40_*: the compact record's connection word is 32 bits -- INTEGRATION section 3)
-            continue
         x = torch.from_numpy(rows).cuda()
         codec = FragmentCodec(U, B)
         packed = codec.pack(x)
-        assert packed.shape == (T, U * (B + 2) + 2 * B) and packed.dtype == torch.int32
+        CW = B + 2 + (B > 32)               # dr[B] | utility | connection word(s): two above 32 stations (dyn_dense40_*; round 6)
+        assert packed.shape == (T, U * CW + 2 * B) and packed.dtype == torch.int32
         y = codec.unpack(packed)
         codec.check()
         assert torch.equal(_bits(x), _bits(y)), os.path.basename(f)
         # the record holds what it says: dr and utility copied, connection bits, the per-env columns once
         p = packed.cpu().numpy().view(np.uint32).reshape(T, -1)
-        per_ue = p[:, :U * (B + 2)].reshape(T, U, B + 2)
+        per_ue = p[:, :U * CW].reshape(T, U, CW)
         assert np.array_equal(per_ue[..., :B].view(np.float32), rows[..., B:2 * B])
         assert np.array_equal(per_ue[..., B].view(np.float32), rows[..., 4 * B])
-        want_bits = (rows[..., :B] != 0).astype(np.uint64) @ (1 << np.arange(B, dtype=np.uint64))
-        assert np.array_equal(per_ue[..., B + 1].astype(np.uint64), want_bits)
-        assert np.array_equal(p[:, U * (B + 2):].view(np.float32), rows[:, 0, 2 * B:4 * B])
+        want_bits = (rows[..., :B] != 0).astype(np.uint64) @ (np.uint64(1) << np.arange(B, dtype=np.uint64))
+        got_bits = per_ue[..., B + 1].astype(np.uint64) | ((per_ue[..., B + 2].astype(np.uint64) << np.uint64(32)) if B > 32 else np.uint64(0))
+        assert np.array_equal(got_bits, want_bits)
+        assert np.array_equal(p[:, U * CW:].view(np.float32), rows[:, 0, 2 * B:4 * B])
 
 
 @pytest.mark.parametrize('E,U,B,T', [(65536, 32, 10, 1), (4096, 128, 32, 1), (1024, 32, 10, 8), (333, 7, 3, 5), (77, 130, 6, 2), (50, 5, 32, 3),

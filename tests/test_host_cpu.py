@@ -65,14 +65,15 @@ def test_fragment_entry_points_on_the_host(lib):
     assert lib.dcomp_fragment_words(32, 10) == 32 * 12 + 20                     # U (B + 2) + 2B words: 1 616 B instead of 5 248 B
     assert lib.dcomp_fragment_words(128, 32) * 4 == 17664
     assert lib.dcomp_fragment_words(1, 1) == 5 and lib.dcomp_fragment_words(256, 32) == 256 * 34 + 64
-    for bad in ((0, 10), (257, 10), (32, 0), (32, 33)):
+    assert lib.dcomp_fragment_words(32, 40) == 32 * 43 + 80 and lib.dcomp_fragment_words(1024, 64) == 1024 * 67 + 128    # round 6: two set words per UE above 32 stations
+    for bad in ((0, 10), (1025, 10), (32, 0), (32, 65)):
         assert lib.dcomp_fragment_words(*bad) == -1
     fake = ctypes.c_void_p(4096)                       # never dereferenced: every case below fails validation first
     assert lib.dcomp_pack_fragment(None, 4, 32, 10, fake, fake, None) == EINVAL
     assert lib.dcomp_pack_fragment(fake, 4, 32, 10, fake, None, None) == EINVAL       # the flag word is not optional
     assert lib.dcomp_pack_fragment(fake, 0, 32, 10, fake, fake, None) == EINVAL
-    assert lib.dcomp_pack_fragment(fake, 4, 32, 40, fake, fake, None) == EINVAL
-    assert lib.dcomp_unpack_fragment(fake, 4, 300, 10, fake, None) == EINVAL
+    assert lib.dcomp_pack_fragment(fake, 4, 32, 65, fake, fake, None) == EINVAL
+    assert lib.dcomp_unpack_fragment(fake, 4, 1025, 10, fake, None) == EINVAL
     assert lib.dcomp_unpack_fragment(None, 4, 32, 10, fake, None) == EINVAL
     assert lib.dcomp_last_error()
 

@@ -62,7 +62,7 @@ def build(a):
     print(so, os.path.getsize(so) >> 20, 'MiB')
 
 
-WORKLOADS = ['c3', 'c2roll', 'c5', 'c5mid', 'c5big', 'c4share', 'c4big', 'central10x5', 'central10x5roll', 'central10x5f', 'central32x10', 'c2policy', 'c3rf', 'c3roll']
+WORKLOADS = ['big64', 'big40c', 'c3', 'c2roll', 'c5', 'c5mid', 'c5big', 'c4share', 'c4big', 'central10x5', 'central10x5roll', 'central10x5f', 'central32x10', 'c2policy', 'c3rf', 'c3roll']
 
 
 def measure(a):
@@ -77,7 +77,11 @@ def measure(a):
     only = a.only.split(',') if a.only else WORKLOADS
     out = {}
     for w in only:
-        if w == 'c3':
+        if w == 'big64':                               # the generic kernel (dcomp_big.h): 8 192 x 32 x 64 multi / 65 536 x 10 x 40 central
+            out[w] = bench.measure_steps(*mk, 8192, 32, 64, 'multi')['kernel_ms']
+        elif w == 'big40c':
+            out[w] = bench.measure_steps(*mk, 65536, 10, 40, 'central')['kernel_ms']
+        elif w == 'c3':
             out[w] = bench.measure_steps(*mk, 65536, 32, 10, 'multi')['kernel_ms']
         elif w == 'c3rf':
             out[w] = bench.measure_steps(*mk, 65536, 32, 10, 'multi', sharing='resource-fair')['kernel_ms']
