@@ -62,6 +62,7 @@ struct dcomp_env {
     bool dyn;                  // UE list changes during an episode (cfg.max_ues > 0)
     int mp_pattern;            // sharing-pattern specialisation the kernels were looked up with (dcomp::MP_*)
     bool fused;                // kern.step is step_kernel: T steps in one launch (the wide / dynamic kernels step once per launch)
+    bool fused_big = false;    // the generic kernel's fused rollout (fixed UE list): T steps = one launch per stretch of an episode
     bool fused_long;           // ... for rollouts of >= 4 steps at ANY batch size (small central rows: see dcomp_create)
     int upad, grid;
     int wide_pad_lds = 0;      // step_kernel_wide: extra dynamic LDS per workgroup = fewer resident workgroups per CU (see dcomp_create)
@@ -73,7 +74,8 @@ struct dcomp_env {
     int64_t episode;            // index of the current episode (-1 before the first reset)
     // 33 ... 64 stations (or DCOMP_FORCE_BIG=1): the generic kernel of dcomp_big.h instead of `kern`
     bool big = false;
-    dcomp::BigKernels bigk{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    dcomp::BigKernels bigk{};
+    int big_step = 0;                                      // BigKernels::fn's `which` of a step: 0, or 2 with UE arrival / departure
     dcomp::BigParams bigp{};
     double2 *d_bs = nullptr;
     int32_t *d_mode = nullptr;
@@ -232,8 +234,9 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
     env->mp_pattern = mp;
     if (env->big) {
         env->bigk = dcomp::big_kernels_for_upad(env->upad);
-        if (!env->bigk.step) { delete env; return fail(DCOMP_EUNSUPPORTED, "no generic kernel for %d lanes per env", env->upad); }
-        if (DYN) { env->bigk.step = env->bigk.step_dyn; env->bigk.step_c = env->bigk.step_dyn_c; }      // UE arrival / departure (round 6: the generic kernel has the event phase too)
+        if (!env->bigk.fn[0][0][0]) { delete env; return fail(DCOMP_EUNSUPPORTED, "no generic kernel for %d lanes per env", env->upad); }
+        env->big_step = DYN ? 2 : 0;
+        env->fused_big = !DYN && !getenv("DCOMP_NO_FUSED_BIG");                               // UE arrival / departure (round 6: the generic kernel has the event phase too)
         if ((size_t)dcomp::big_carve(B, env->bigk.gpb, env->bigk.block).total > 160 * 1024) {
             delete env;
             return fail(DCOMP_EINVAL, "%d UE slots x %d stations do not fit one workgroup's LDS (generic kernel)", CAP, B);
@@ -331,10 +334,10 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
         if (e == hipSuccess) e = hipMemcpy(env->d_bs, xy.data(), sizeof(double) * 2 * B, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(env->d_mode, md.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice);
         env->big_lds = (size_t)dcomp::big_carve(B, env->bigk.gpb, env->bigk.block).total;
-        if (e == hipSuccess) e = raise_lds_limit(reinterpret_cast<const void *>(env->bigk.step), (int)env->big_lds);
-        if (e == hipSuccess) e = raise_lds_limit(reinterpret_cast<const void *>(env->bigk.reset), (int)env->big_lds);
-        if (e == hipSuccess) e = raise_lds_limit(reinterpret_cast<const void *>(env->bigk.step_c), (int)env->big_lds);
-        if (e == hipSuccess) e = raise_lds_limit(reinterpret_cast<const void *>(env->bigk.reset_c), (int)env->big_lds);
+        for (int pol = 0; pol < 2; pol++)
+            for (int c = 0; c < 2; c++)
+                for (int w = 0; w < 3; w++)                        // the step this env launches (plain or with events), the reset, the fused rollout
+                    if (e == hipSuccess) e = raise_lds_limit(reinterpret_cast<const void *>(env->bigk.fn[pol][c][w == 0 ? env->big_step : w == 1 ? 1 : 3]), (int)env->big_lds);
         if (e != hipSuccess) { dcomp_destroy(env); return fail(DCOMP_EHIP, "device setup failed (generic kernel, %zu bytes of LDS per workgroup): %s", env->big_lds, hipGetErrorString(e)); }
         env->bigp.bs = env->d_bs; env->bigp.mode = env->d_mode; env->bigp.B = B;
     }
@@ -464,11 +467,17 @@ extern "C" int dcomp_obs_dim(const dcomp_env *env, int32_t *floats_per_env, int3
     return DCOMP_OK;
 }
 
+// The generic kernel's instantiation for this launch: with / without the in-step policy, row format / compact record.
+static dcomp::BigKernelFn big_fn(const dcomp_env *env, const KParams &kp, int which)
+{
+    return env->bigk.fn[kp.next_act ? 1 : 0][kp.obs_compact ? 1 : 0][which];
+}
+
 // One launch of the step kernel (plain step; also the per-step launches of a rollout that is not fused).
 static void launch_step(dcomp_env *env, KParams &kp, void *stream)
 {
     if (env->big) {
-        hipLaunchKernelGGL(kp.obs_compact ? env->bigk.step_c : env->bigk.step, dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, kp, env->bigp);
+        hipLaunchKernelGGL(big_fn(env, kp, env->big_step), dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, kp, env->bigp);
         return;
     }
     if (env->tight_g) {
@@ -503,7 +512,6 @@ static int fill_params(dcomp_env *env, const dcomp_state *st, const dcomp_out *o
     if (env->kp.any_maxcap && !st->conn_since) return fail(DCOMP_EINVAL, "a max-cap BS needs state.conn_since (see dcomp_state_sizes)");
     if (env->big) {
         if (!st->conn_hi) return fail(DCOMP_EINVAL, "more than %d stations: state.conn_hi (stations 32-63 of the connection set, sized like conn) is required", DCOMP_MASK32_MAX_BS);
-        if (env->kp.next_act) return fail(DCOMP_EUNSUPPORTED, "dcomp_set_policy is not available on the generic kernel (num_bs > %d)", DCOMP_MASK32_MAX_BS);
         env->bigp.conn_hi = st->conn_hi;
     }
     if (env->dyn && !st->uid) return fail(DCOMP_EINVAL, "UE arrival/departure needs state.uid");
@@ -539,7 +547,7 @@ extern "C" int dcomp_reset(dcomp_env *env, const dcomp_state *st, const dcomp_ta
     env->cur_ue = env->cfg.num_ue; env->n_removed = env->n_arrived = 0;      // base.py:177-182
     kp.cur_ue = env->cur_ue;
     kp.episode = (uint32_t)env->episode;
-    if (env->big) hipLaunchKernelGGL(kp.obs_compact ? env->bigk.reset_c : env->bigk.reset, dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, kp, env->bigp);
+    if (env->big) hipLaunchKernelGGL(big_fn(env, kp, 1), dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, kp, env->bigp);
     else hipLaunchKernelGGL(env->kern.reset, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
     HIP_TRY(hipGetLastError());
     return DCOMP_OK;
@@ -585,7 +593,7 @@ extern "C" int dcomp_step_dyn(dcomp_env *env, const dcomp_state *st, const uint8
     kp.n_remove = nrem; kp.n_add = nadd;
     kp.ev_remove = ev ? ev->remove_idx : nullptr; kp.ev_add_xy = ev ? ev->add_xy : nullptr;
     kp.ev_rem_base = env->n_removed; kp.ev_add_base = env->n_arrived;
-    if (env->big) hipLaunchKernelGGL(kp.obs_compact ? env->bigk.step_c : env->bigk.step, dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, kp, env->bigp);
+    if (env->big) hipLaunchKernelGGL(big_fn(env, kp, env->big_step), dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, kp, env->bigp);
     else hipLaunchKernelGGL(env->kern.step, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, kp);
     HIP_TRY(hipGetLastError());
     env->time += 1;
@@ -619,10 +627,9 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
     } else if ((rc = check_horizon(env, T))) return rc;
     if (!env->dyn && (ev_rem || ev_add)) return fail(DCOMP_EINVAL, "handle was created without max_ues (fixed UE list): no arrival / departure events");
     const bool loop = opts && opts->policy_loop != 0;
-    if (loop) {
-        if (!env->kp.next_act) return fail(DCOMP_EINVAL, "policy_loop needs a policy (dcomp_set_policy)");
-        if (!env->fused && !env->fused_long) return fail(DCOMP_EUNSUPPORTED, "policy_loop needs the fused rollout kernel (dcomp_rollout_is_fused)");
-    }
+    // (round 6: the closed loop runs on every kernel -- where rollouts are not fused, one launch per step, each reading the actions the
+    //  previous one wrote)
+    if (loop && !env->kp.next_act) return fail(DCOMP_EINVAL, "policy_loop needs a policy (dcomp_set_policy)");
     const size_t EU = (size_t)env->cfg.num_envs * env->cap, E = (size_t)env->cfg.num_envs;
     const bool multi = env->cfg.env_kind == DCOMP_MULTI;
     const size_t obs_step = EU * (size_t)(multi ? 4 * env->cfg.num_bs + 1 : 2 * env->cfg.num_bs + 1);
@@ -643,7 +650,7 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
         k.cur_ue = env->cur_ue;
         k.episode = (uint32_t)env->episode;
         k.time = 0u;
-        if (env->big) hipLaunchKernelGGL(k.obs_compact ? env->bigk.reset_c : env->bigk.reset, dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, k, env->bigp);
+        if (env->big) hipLaunchKernelGGL(big_fn(env, k, 1), dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, k, env->bigp);
         else hipLaunchKernelGGL(env->kern.reset, dim3(env->grid), dim3(DCOMP_BLOCK), 0, (hipStream_t)stream, k);
     };
     if (env->dyn) {
@@ -664,9 +671,8 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
         }
     }
     // the fused kernel addresses step t's outputs as (idx + t * E * U) on the caller's base pointers with 32-bit row indices: a
-    // fragment beyond that takes the one-launch-per-step path below (same results), except the closed loop, which has no other path
+    // fragment beyond that takes the one-launch-per-step path below (same results)
     const bool fits32 = !(every && (uint64_t)T * EU >= fused_row_limit());
-    if (loop && !fits32) return fail(DCOMP_EINVAL, "policy_loop fragment too long: num_steps * num_envs * num_ue must stay below 2^31 (split the rollout)");
     if (fits32 && (env->fused || (env->fused_long && (T >= 4 || loop)))) {
         // with a registered policy: the variant that carries the rules; tape-driven central envs: the central-only instantiation
         dcomp::KernelFn kern = kp.next_act ? env->kern.rollout_pol : (!multi && env->kern.rollout_central) ? env->kern.rollout_central : env->kern.rollout;
@@ -716,12 +722,37 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
         return DCOMP_OK;
     }
     // one launch per step: wide envs, envs whose UE list changes (event feed), batches too large for the latency-optimised kernel
+    if (env->fused_big) {
+        // The generic kernel's fused rollout (big_kernel<..., ROLL>): one launch per stretch of an episode, the UE state in registers from step to
+        // step, step t's outputs in slice t of the caller's buffers; at the horizon the reset kernel (which, with a policy, also decides the first
+        // action of the new episode).  64-bit offsets throughout: no row limit.
+        const uint8_t *act_src = actions;
+        for (int t = 0; t < T;) {
+            out_slice(kp, t);
+            if (L > 0 && env->time == L) { launch_reset(kp); if (loop) act_src = kp.next_act; }
+            const int n = (L > 0 && L - env->time < T - t) ? L - env->time : T - t;
+            kp.action = loop ? act_src : actions + EU * t;
+            kp.num_steps = n; kp.out_every_step = every; kp.policy_loop = loop; kp.horizon = 0; kp.episode_inc = 0;
+            kp.time = (uint32_t)env->time; kp.episode = (uint32_t)env->episode;
+            hipLaunchKernelGGL(big_fn(env, kp, 3), dim3(env->grid), dim3(env->bigk.block), env->big_lds, (hipStream_t)stream, kp, env->bigp);
+            env->time += n;
+            t += n;
+            if (loop) act_src = kp.next_act;
+        }
+        HIP_TRY(hipGetLastError());
+        return DCOMP_OK;
+    }
+    // The closed loop here: step 0 acts on actions[0] (the next_action the previous launch wrote), every later step -- and the first step of a
+    // new episode -- on what the launch before it decided.  next_action is ONE buffer read and written in place: a lane reads the action of
+    // its own slot when the kernel starts and writes the decision for that same slot at its end (with UE arrival / departure the UEs move
+    // between slots through LDS, not through this buffer).
     size_t rem_off = 0, add_off = 0;
+    const uint8_t *act_src = actions;
     for (int t = 0; t < T; t++) {
         out_slice(kp, t);
-        if (L > 0 && env->time == L) launch_reset(kp);
+        if (L > 0 && env->time == L) { launch_reset(kp); if (loop) act_src = kp.next_act; }
         kp.episode = (uint32_t)env->episode;
-        kp.action = actions + EU * t;
+        kp.action = loop ? act_src : actions + EU * t;
         kp.time = (uint32_t)env->time;
         kp.n_remove = kp.n_add = 0;
         if (env->dyn) {                                            // base.py:433-443: this step's departures / arrivals
@@ -737,6 +768,7 @@ static int rollout_impl(dcomp_env *env, const dcomp_state *st, const uint8_t *ac
         }
         launch_step(env, kp, stream);
         env->time += 1;
+        if (loop) act_src = kp.next_act;
     }
     HIP_TRY(hipGetLastError());
     return DCOMP_OK;
@@ -754,13 +786,14 @@ extern "C" int dcomp_rollout_ex(dcomp_env *env, const dcomp_state *st, const uin
     return rollout_impl(env, st, actions, num_steps, out, opts, stream);
 }
 
-extern "C" int dcomp_rollout_is_fused(const dcomp_env *env) { return env ? ((env->fused || env->fused_long) ? 1 : 0) : -1; }
+extern "C" int dcomp_rollout_is_fused(const dcomp_env *env) { return env ? ((env->fused || env->fused_long || env->fused_big) ? 1 : 0) : -1; }
 // Whether THIS rollout is one launch: fusion of the short-row shapes (fused_long) depends on the number of steps -- a rollout of
 // fewer than 4 tape-driven steps goes out as one launch per step, as does an every-step fragment of >= 2^31 rows.
 extern "C" int dcomp_rollout_fused_for(const dcomp_env *env, int32_t num_steps, int32_t every_step, int32_t policy_loop)
 {
     if (!env || num_steps < 1) return -1;
     const uint64_t EU = (uint64_t)env->cfg.num_envs * env->cap;
+    if (env->fused_big) return 1;                                  // (one launch per stretch of an episode; 64-bit offsets: no row limit)
     if (every_step && (uint64_t)num_steps * EU >= fused_row_limit()) return 0;
     return (env->fused || (env->fused_long && (num_steps >= 4 || policy_loop))) ? 1 : 0;
 }
@@ -775,7 +808,7 @@ extern "C" int dcomp_step_kernel_name(const dcomp_env *env, char *buf, int32_t l
 {
     if (!env || !buf || len < 1) return fail(DCOMP_EINVAL, "null argument");
     const int B = env->cfg.num_bs, W = env->upad, MP = env->mp_pattern;
-    if (env->big) std::snprintf(buf, (size_t)len, "big_kernel<%d, false, %s, false>", W < 4 ? 4 : W, env->dyn ? "true" : "false");
+    if (env->big) std::snprintf(buf, (size_t)len, "big_kernel<%d, false, %s, false, %s, false>", W < 4 ? 4 : W, env->dyn ? "true" : "false", env->kp.next_act ? "true" : "false");
     else if (env->tight_g) {
         const bool cen = env->cfg.env_kind == DCOMP_CENTRAL && env->kern.tight_central;
         std::snprintf(buf, (size_t)len, "step_kernel_tight<%d, %d, %d, %d>", B, W, MP, cen ? 0 : -1);
@@ -1058,7 +1091,6 @@ extern "C" int dcomp_set_policy(dcomp_env *env, const dcomp_policy *p, uint8_t *
 {
     if (!env) return fail(DCOMP_EINVAL, "null argument");
     if (!p || !next_action) { env->kp.next_act = nullptr; return DCOMP_OK; }
-    if (env->big) return fail(DCOMP_EUNSUPPORTED, "the in-step policy is not available on the generic kernel (num_bs > %d); use dcomp_heuristic_actions on the observation tensor", DCOMP_MASK32_MAX_BS);
     if (p->policy < DCOMP_POLICY_3GPP || p->policy > DCOMP_POLICY_CLUSTER) return fail(DCOMP_EINVAL, "unknown policy %d", p->policy);
     if ((p->num_envs && p->num_envs != env->cfg.num_envs) || (p->num_ue && p->num_ue != env->kp.U) || (p->num_bs && p->num_bs != env->cfg.num_bs))
         return fail(DCOMP_EINVAL, "policy shape (%d, %d, %d) is not the env's (%d, %d, %d)", p->num_envs, p->num_ue, p->num_bs,

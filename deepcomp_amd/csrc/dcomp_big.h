@@ -147,14 +147,78 @@ __device__ __forceinline__ float big_share(int mode, float dru, float n, float s
     return winner ? dru : 0.f;                                                               // station.py:183-187
 }
 
-template <int UPAD, bool RESET, bool DYN, bool COMPACT>
+// The in-step heuristic policy (dcomp_set_policy; agent/heuristics.py:13-187) on one observation row held by the lanes in their STATION role --
+// the rules, first-maximum ties and index order of heuristic_kernel (dcomp_api.hip) / policy_action (dcomp_device.h), on the dr values the row
+// loop is about to store.  A row over the whole wavefront (more than 32 stations): argmax, sets and candidates are lane masks of compares.
+// d: the lane's dr entry; ok: the lane holds a station (ok_mask: those lanes); conn: the row's connection set (uniform).  Every lane must be here.
+__device__ __forceinline__ int big_policy_wave(const KParams &p, unsigned long long conn, float d, bool ok, unsigned long long ok_mask, int lane, int B)
+{
+    d = ok ? d : -3.0e38f;
+    const float mx = wave_max_f32(d);
+    const int best = __ffsll((long long)(__builtin_amdgcn_ballot_w64(d == mx) & ok_mask)) - 1;      // np.argmax: the first maximum (heuristics.py:27)
+    if (p.policy == DCOMP_POLICY_3GPP)                                                           // heuristics.py:30-38
+        return ((conn >> best) & 1ull) ? 0 : conn ? __ffsll((long long)conn) : best + 1;
+    unsigned long long sel = ok_mask;                                                            // FullCoMP: every cell
+    if (p.policy == DCOMP_POLICY_DYNAMIC) sel = __builtin_amdgcn_ballot_w64(d >= mx * p.policy_eps) & ok_mask;      // heuristics.py:87-90
+    else if (p.policy == DCOMP_POLICY_CLUSTER)                                                   // :172-176; two words (lo, hi) per station beyond 32 stations
+        sel = B <= 32 ? (unsigned long long)p.policy_cluster[best] : ((unsigned long long)p.policy_cluster[2 * best] | ((unsigned long long)p.policy_cluster[2 * best + 1] << 32));
+    const unsigned long long drop = conn & ~sel;
+    const unsigned long long cand = sel & ~conn & ok_mask;
+    const bool c = (cand >> lane) & 1ull;
+    const float m2 = wave_max_f32(c ? d : -3.0e38f);                                             // strongest candidate, first of equals (:57-63, :101-106)
+    const int a = __ffsll((long long)__builtin_amdgcn_ballot_w64(c && d == m2));
+    return drop ? __ffsll((long long)drop) : cand ? a : 0;                                       // cells outside the set first, index order (:96-99, :178-181)
+}
+// The same for the rows of a trip that holds SEVERAL rows (up to 32 stations): lane = (row `sub` of the trip, station sb), BP lanes per row.
+template <int BP>
+__device__ __forceinline__ int big_policy_group(const KParams &p, uint32_t conn, float d, bool ok, int sub, int sb, int B)
+{
+    const uint32_t all = B == 32 ? ~0u : (1u << (B & 31)) - 1u;
+    auto mine = [&](unsigned long long bal) { return (uint32_t)(bal >> (sub * BP)) & all; };      // this row's lanes of a wave-wide mask
+    d = ok ? d : -3.0e38f;
+    const float mx = group_reduce<BP, OpMax>(d);
+    const uint32_t ism = mine(__builtin_amdgcn_ballot_w64(d == mx));
+    const int best = ism ? __builtin_ffs((int)ism) - 1 : 0;
+    uint32_t sel = all;
+    if (p.policy == DCOMP_POLICY_DYNAMIC) sel = mine(__builtin_amdgcn_ballot_w64(d >= mx * p.policy_eps));
+    else if (p.policy == DCOMP_POLICY_CLUSTER) sel = p.policy_cluster[best];
+    const uint32_t drop = conn & ~sel, cand = sel & ~conn & all;
+    const bool c = ok && ((cand >> sb) & 1u);
+    const float m2 = group_reduce<BP, OpMax>(c ? d : -3.0e38f);
+    const int a = __builtin_ffs((int)mine(__builtin_amdgcn_ballot_w64(c && d == m2)));
+    if (p.policy == DCOMP_POLICY_3GPP) return ((conn >> best) & 1u) ? 0 : conn ? __builtin_ffs((int)conn) : best + 1;
+    return drop ? __builtin_ffs((int)drop) : cand ? a : 0;
+}
+
+template <int UPAD, bool RESET, bool DYN, bool COMPACT, bool POL, bool ROLL = false>
 __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, const BigParams x)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
     constexpr int BLK = big_block(UPAD), NWAVE = BLK / 64, GPB = BLK / UPAD;
     constexpr int EPW = UPAD >= 64 ? 1 : 64 / UPAD;                // env pieces a wavefront holds
     constexpr int PL = UPAD >= 64 ? 64 : UPAD;                     // lane slots per piece
-    const int B = x.B, U = p.U;
+    {                                                              // the BS table, once per launch
+        const int B = x.B;
+        const BigCarve cv = big_carve(B, GPB, BLK);
+        double2 *const bs_s = reinterpret_cast<double2 *>(big_smem);
+        int *const mode_s = reinterpret_cast<int *>(big_smem + cv.mode);
+        for (int i = threadIdx.x; i < B; i += BLK) { bs_s[i] = x.bs[i]; mode_s[i] = x.mode[i]; }
+    }
+    // ROLL: the fused rollout (dcomp_rollout on the generic kernel, round 6) -- p.num_steps consecutive steps in ONE launch: the UE state stays in
+    // these registers from step to step (it is still written back every step: 36 bytes per UE against a row of 4B + 1 floats), step t's outputs go
+    // to slice t of the caller's [T][...] buffers (out_every_step) or only the last step's are written, the actions come from the tape -- or, in
+    // the closed loop (policy_loop), from the next_action buffer the step before wrote.  Resets at the horizon are the host's (one launch per
+    // stretch of an episode, the reset kernel in between).
+    static_assert(!ROLL || (!RESET && !DYN), "the fused rollout steps a fixed UE list");
+    double px = 0.0, py = 0.0;
+    unsigned long long mv = 0, conn = 0;
+    float ewma = 0.f;
+    const int nsteps = ROLL ? p.num_steps : 1;
+    const bool ploop = ROLL && POL && p.policy_loop != 0;
+    // (one step as a lambda, called once or from the step loop: a `for` around the body -- even one of a single trip -- cost the plain step 11 VGPRs and a wave of occupancy)
+    auto one_step = [&](const int t) __attribute__((always_inline)) {
+    int B = x.B, U = p.U;
+    if (ROLL) asm volatile("" : "+s"(B), "+s"(U));               // (fused rollout: opaque per step, like tid below -- or every derived offset is carried across the loop in spilled SGPRs)
     const bool any_maxcap = x.maxcap_mask != 0ull, any_sum = x.summode_mask != 0ull;
     const BigCarve cv = big_carve(B, GPB, BLK);
     double2 *const bs_s = reinterpret_cast<double2 *>(big_smem);
@@ -167,7 +231,10 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
     float *const agg_m = reinterpret_cast<float *>(mc_win);
     float *const part_s = reinterpret_cast<float *>(big_smem + cv.part);               // [3][NWAVE][B] (envs wider than a wavefront)
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid = threadIdx.x;
+    if (ROLL) asm volatile("" : "+v"(tid));                        // (fused rollout: opaque per step, or the compiler carries every per-lane address and
+                                                                   //  role value across the step loop -- 172 VGPRs, two waves per SIMD)
+    const int lane = tid & 63;
     const int wave = NWAVE > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;     // (uniform, and the compiler must know it: every row loop below is scalar control flow)
     const int env_local = tid / UPAD, u = tid % UPAD;
     const int env0 = xcd_contiguous_block() * GPB, env = env0 + env_local;
@@ -175,7 +242,6 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
     int cur = DYN ? p.cur_ue : (RESET ? p.U0 : U);                 // UEs in the list (the same in every env: the schedule is configuration)
     bool alive = active && u < cur;
     const int idx = env * U + u;
-    for (int i = tid; i < B; i += BLK) { bs_s[i] = x.bs[i]; mode_s[i] = x.mode[i]; }
     // the lane's STATION role.  Up to 32 stations a wavefront takes SEVERAL rows per trip: lane = (row of the trip, station) with BP = 8 / 16 / 32 / 64
     // lanes per row (the next power of two >= B), SUB = 64 / BP rows per trip (10 stations: four rows at once instead of 10 busy lanes of 64);
     // per-station partial sums are then added across the SUB lane groups (ds_bpermute butterflies), always in the same order.
@@ -190,10 +256,20 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
     auto sub_min_f = [&](float v) { for (int off = BP; off < 64; off <<= 1) v = fminf(v, __shfl_xor(v, off, 64)); return v; };
     const bool st_writer = st_ok && sub == 0;                      // the lane that publishes station sb's aggregate
 
-    double px = 0.0, py = 0.0;
-    unsigned long long mv = 0, conn = 0;
+    const size_t obs_stride = (size_t)p.E * (COMPACT ? (size_t)(U * (B + 1 + (B > 32 ? 2 : 1)) + 2 * B) : (size_t)U * (p.kind == DCOMP_MULTI ? 4 * B + 1 : 2 * B + 1));
+    const bool emit = !ROLL || p.out_every_step || t == nsteps - 1;        // (uniform) whether this step's outputs are written
+    const size_t ts = (ROLL && p.out_every_step) ? (size_t)t : 0;
+    const size_t EUs = (size_t)p.E * U;
+    float *const o_obs = (emit && p.obs) ? p.obs + ts * obs_stride : nullptr;
+    float *const o_reward = (emit && p.reward) ? p.reward + ts * (p.kind == DCOMP_MULTI ? EUs : (size_t)p.E) : nullptr;
+    float *const o_sum_util = (emit && p.sum_util) ? p.sum_util + ts * p.E : nullptr;
+    float *const o_ue_dr = (emit && p.ue_dr) ? p.ue_dr + ts * EUs : nullptr;
+    float *const o_ue_util = (emit && p.ue_util) ? p.ue_util + ts * EUs : nullptr;
+    float *const o_rb = (emit && p.rb_out) ? p.rb_out + ts * EUs : nullptr;
+    const uint8_t *const action = !ROLL ? p.action : ploop ? (t ? p.next_act : p.action) : p.action + (size_t)t * EUs;
+    const uint32_t time = p.time + (uint32_t)t;
     uint32_t act = 0, uidw = (uint32_t)u + 1u;
-    float ewma = 0.f, dr_req = 1.f;
+    float dr_req = 1.f;
     bool step_util = false;
     int vrange = MV_CFG_ARRIVED;
     if (RESET) {                                                   // MobileEnv.reset (base.py:169-189): user.py:98-116 + movement.py:110-122
@@ -212,12 +288,14 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
             if (p.orig_consumed && alive) p.orig_consumed[(size_t)env * p.U0 + u] = 0xFFFFu;
         }
     } else if (alive) {
-        const double2 q = p.pos[idx];
-        px = q.x; py = q.y;
-        mv = p.mv[idx];
-        conn = (unsigned long long)p.conn[idx] | ((unsigned long long)x.conn_hi[idx] << 32);
-        ewma = p.ewma[idx];
-        act = p.action[idx];
+        if (!ROLL || t == 0) {
+            const double2 q = p.pos[idx];
+            px = q.x; py = q.y;
+            mv = p.mv[idx];
+            conn = (unsigned long long)p.conn[idx] | ((unsigned long long)x.conn_hi[idx] << 32);
+            ewma = p.ewma[idx];
+        }
+        act = action[idx];
         if (DYN) uidw = p.uid[idx];
         if (act > (uint32_t)B) { atomicOr(p.flags, DCOMP_FLAG_BAD_ACTION); act = 0; }
     }
@@ -234,7 +312,7 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                 big_pair(px, py, bs_s[act - 1u], p, ir, l);
                 if (ir) {
                     conn |= bit;
-                    if (x.maxcap_mask & bit) p.conn_since[(size_t)idx * B + (act - 1u)] = (uint16_t)p.time;
+                    if (x.maxcap_mask & bit) p.conn_since[(size_t)idx * B + (act - 1u)] = (uint16_t)time;
                 }
             }
         }
@@ -582,7 +660,7 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
             // where this env's rows go: the row format, or (multi-agent envs, dcomp_out.obs_compact) the compact record of dcomp_fragment.h --
             // U x {dr[B], utility, connection word(s)} + ues_at_bs[B] | util_at_bs[B]: the station lanes store the dr blocks and, once per env,
             // the two per-env columns; utility and the set words are the UE lanes' (below)
-            float *const dst_env = !p.obs ? nullptr : compact ? p.obs + (size_t)(env0 + envl) * REC : p.obs + (size_t)(env0 + envl) * U * (kind == DCOMP_MULTI ? ROW : 2 * B + 1);
+            float *const dst_env = !o_obs ? nullptr : compact ? o_obs + (size_t)(env0 + envl) * REC : o_obs + (size_t)(env0 + envl) * U * (kind == DCOMP_MULTI ? ROW : 2 * B + 1);
             if (compact && dst_env && st_writer && nrows > 0 && uu0 == 0) {
                 big_store(dst_env + U * CWC + sb, n_col);
                 big_store(dst_env + U * CWC + B + sb, u_col);
@@ -615,18 +693,26 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                         l = st_ok ? l : -3.0e38f;
                     }
                     if (kind == DCOMP_MULTI) { if (lane == 0) inr_s[r] = bal; }      // (only the multi-agent rewards read the in-range sets)
+                    float lmax_p = 0.f;
+                    if (POL) {                                                       // dcomp_set_policy: the rules on the row's dr entries (the instantiation of its own)
+                        lmax_p = wave_max_f32(l);
+                        if (p.next_act) {
+                            const int a = big_policy_wave(p, (unsigned long long)sl.x | ((unsigned long long)sl.y << 32), live ? fast_exp2(l - lmax_p) : 0.f, st_ok, ok_mask, lane, B);
+                            if (lane == 0) p.next_act[(size_t)(env0 + envl) * U + ue] = (uint8_t)(live ? a : 0);
+                        }
+                    }
                     if (dst_env) {
                         // (uniform row base + the lane's 32-bit offset: the store's scalar-base form, no 64-bit address arithmetic per store;
                         //  an unlisted slot -- `live` is uniform -- takes the zero-row branch instead of a select per value)
                         const uint32_t lo = (uint32_t)lane;
                         if (compact) {
                             float *const dst = dst_env + (size_t)ue * CWC;
-                            const float lmax = wave_max_f32(l);
+                            const float lmax = POL ? lmax_p : wave_max_f32(l);
                             if (st_ok) big_store(dst + lo, live ? fast_exp2(l - lmax) : 0.f);
                         } else if (kind == DCOMP_MULTI) {
                             float *const dst = dst_env + (size_t)ue * ROW;
                             if (live) {
-                                const float lmax = wave_max_f32(l);
+                                const float lmax = POL ? lmax_p : wave_max_f32(l);
                                 const float dr = fast_exp2(l - lmax);                        // variants.py:276-284
                                 const float cf = (float)__builtin_amdgcn_ubfe(hi_lane ? sl.y : sl.x, sh, 1u);
                                 if (st_ok) {
@@ -642,7 +728,7 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                         } else {
                             float *const dc = dst_env + (size_t)ue * B;
                             if (live) {
-                                const float lmax = wave_max_f32(l);
+                                const float lmax = POL ? lmax_p : wave_max_f32(l);
                                 const float dr = fast_exp2(l - lmax);
                                 const float cf = (float)__builtin_amdgcn_ubfe(hi_lane ? sl.y : sl.x, sh, 1u);
                                 if (st_ok) { big_store(dc + lo, cf); big_store(dc + (lo + (uint32_t)UB), dr); }
@@ -665,9 +751,16 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                     if (!(DCOMP_BIG_ABL & 8)) big_row_pair(q.x, q.y, mybs, p, st_ok && rv, ir, l);
                     const unsigned long long bal = __builtin_amdgcn_ballot_w64(ir);
                     if (sb == 0 && rv && kind == DCOMP_MULTI) inr_s[r] = (bal >> (sub * BP)) & ((1ull << BP) - 1ull);
-                    if (dst_env) {
+                    if (dst_env || (POL && p.next_act)) {
                         const float lmax = BP == 32 ? group_reduce<32, OpMax>(l) : BP == 16 ? group_reduce<16, OpMax>(l) : group_reduce<8, OpMax>(l);
                         const float dr = live ? fast_exp2(l - lmax) : 0.f;                // variants.py:276-284
+                        if (POL && p.next_act) {                                          // dcomp_set_policy: the rules on the rows of this trip
+                            const bool ok = st_ok && rv;
+                            const int a = BP == 32 ? big_policy_group<32>(p, sl.x, dr, ok, sub, sb, B) : BP == 16 ? big_policy_group<16>(p, sl.x, dr, ok, sub, sb, B)
+                                                                                                              : big_policy_group<8>(p, sl.x, dr, ok, sub, sb, B);
+                            if (sb == 0 && rv) p.next_act[(size_t)(env0 + envl) * U + ue] = (uint8_t)(live ? a : 0);
+                        }
+                        if (!dst_env) continue;
                         const float cf = (float)__builtin_amdgcn_ubfe(sl.x, sh, 1u);
                         if (compact) {
                             if (st_ok && rv) big_store(dst_env + ue * CWC + sb, dr);
@@ -692,15 +785,15 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
         }
     }
     // the rows' own utility entry: by the UE lanes (one store instruction per wavefront instead of a lane-0 store in every trip of the row loop)
-    if (active && p.obs && !(DCOMP_BIG_ABL & 4)) {
+    if (active && o_obs && !(DCOMP_BIG_ABL & 4)) {
         const float ut = alive ? util * (1.0f / MAX_UTIL) : 0.f;
         if (compact) {
-            float *const rec = p.obs + (size_t)env * REC + (size_t)u * CWC;
+            float *const rec = o_obs + (size_t)env * REC + (size_t)u * CWC;
             big_store(rec + B, ut);
             big_store(rec + B + 1, __uint_as_float(alive ? (uint32_t)conn : 0u));
             if (B > 32) big_store(rec + B + 2, __uint_as_float(alive ? (uint32_t)(conn >> 32) : 0u));
-        } else if (kind == DCOMP_MULTI) big_store(p.obs + (size_t)idx * ROW + 4 * B, ut);
-        else big_store(p.obs + (size_t)env * U * (2 * B + 1) + 2 * UB + u, ut);
+        } else if (kind == DCOMP_MULTI) big_store(o_obs + (size_t)idx * ROW + 4 * B, ut);
+        else big_store(o_obs + (size_t)env * U * (2 * B + 1) + 2 * UB + u, ut);
     }
     __syncthreads();
     // 9. reward, info
@@ -715,8 +808,8 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                 su += __uint_as_float(sl.z);
             }
             if (p.reward_agg == DCOMP_REWARD_AVG) r = r * fast_rcp((float)n_eff);         // (one reciprocal: the form of write_outputs)
-            if (p.reward) p.reward[env] = RESET ? 0.f : r;
-            if (p.sum_util) p.sum_util[env] = su;
+            if (o_reward) o_reward[env] = RESET ? 0.f : r;
+            if (o_sum_util) o_sum_util[env] = su;
         }
     } else {
         float reward = 0.f;
@@ -740,23 +833,32 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                 reward = in_range != 0ull ? m_ : util;
             }
         }
-        if (active && p.reward) big_store(&p.reward[idx], alive ? reward : 0.f);
-        if (active && u == 0 && p.sum_util) {
+        if (active && o_reward) big_store(&o_reward[idx], alive ? reward : 0.f);
+        if (active && u == 0 && o_sum_util) {
             const int base = env_local * UPAD;
             float su = 0.f;
             for (int v = 0; v < n_eff; v++) su += __uint_as_float(slot_s[base + v].z);
-            p.sum_util[env] = su;
+            o_sum_util[env] = su;
         }
     }
     if (active) {                                                  // base.py:383-411
-        if (p.ue_dr) big_store(&p.ue_dr[idx], alive ? curr : 0.f);
-        if (p.ue_util) big_store(&p.ue_util[idx], alive ? util : 0.f);
-        if (p.rb_out) big_store(&p.rb_out[idx], alive ? reward_before : 0.f);
+        if (o_ue_dr) big_store(&o_ue_dr[idx], alive ? curr : 0.f);
+        if (o_ue_util) big_store(&o_ue_util[idx], alive ? util : 0.f);
+        if (o_rb) big_store(&o_rb[idx], alive ? reward_before : 0.f);
     }
+    };
+    if constexpr (ROLL) {
+        for (int t = 0; t < nsteps; t++) {
+            one_step(t);
+            __syncthreads();                                       // the next step republishes the slots / aggregates this one's rewards have just read
+        }
+    } else one_step(0);
 }
 
 using BigKernelFn = void (*)(const KParams, const BigParams);
-struct BigKernels { BigKernelFn step, reset, step_dyn, step_c, reset_c, step_dyn_c; int gpb, block; };     // _c: the instantiations that write the compact record
+// fn[pol][compact][which]: which = 0 step, 1 reset, 2 step with UE arrival / departure, 3 fused rollout (fixed UE list); compact = 1: the instantiations that write the compact record;
+// pol = 1: the ones that carry the in-step heuristic policy (dcomp_set_policy)
+struct BigKernels { BigKernelFn fn[2][2][4]; int gpb, block; };
 BigKernels big_kernels_for_upad(int upad);
 
 }  // namespace dcomp

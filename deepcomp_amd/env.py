@@ -626,9 +626,10 @@ class BatchedMobileEnv:
 
     def rollout_policy(self, num_steps, out=None, horizon=None):
         """num_steps steps of the closed loop `act = policy(obs); step(act)` with the policy registered through set_policy().
-        On the fused kernel (dcomp_rollout_ex, policy_loop) this is ONE call: one launch per stretch of an episode -- the
+        ONE call (dcomp_rollout_ex, policy_loop).  On the fused kernel: one launch per stretch of an episode -- the
         decisions never leave the registers -- and at the horizon a reset launch that also decides the first action of the new
-        episode; no host work in between.  Falls back to one step launch per step where rollouts are not fused.  Needs a
+        episode; no host work in between.  Where rollouts are not fused (wide / generic kernels, UE arrival / departure): one
+        launch per step, enqueued by the library, every step writing straight into its slice of `out`.  Needs a
         current next_action: call it after reset() / step() with the policy set.  out: as in rollout(), [num_steps, ...]
         buffers of every step."""
         if self._policy_key is None or not self._next_action_fresh:
@@ -638,26 +639,15 @@ class BatchedMobileEnv:
         keys = ('obs', 'obs_compact', 'reward', 'sum_utility', 'ue_dr', 'ue_utility', 'reward_before')
         if out is not None and out.get('obs_compact') is not None:
             self._require_compact(out['obs_compact'], T)
-        host_resets = L and self.rng_mode == _lib.RNG_TAPE and (self.rand_episodes or self._live is not None)   # a fresh host-drawn tape per episode
-        if self.fused_rollout and not self.dynamic and not host_resets:
+        host_resets = L and self.rng_mode == _lib.RNG_TAPE and (self.rand_episodes or self.dynamic or self._live is not None)   # a fresh host-drawn tape per episode
+        if not host_resets:
             return self.rollout(self.next_action.view(1, self.E, self.U), out=out, horizon=L, _policy_steps=T)
         while t0 < T:
-            if L and self.time >= L:
+            if self.time >= L:
                 self.reset()
-            n = min(T - t0, L - self.time) if L else T - t0
+            n = min(T - t0, L - self.time)
             frag = None if out is None else {k: out[k][t0:t0 + n] for k in keys if out.get(k) is not None}
-            if self.fused_rollout and not self.dynamic:
-                self.rollout(self.next_action.view(1, self.E, self.U), out=frag, _policy_steps=n)
-            else:
-                for i in range(n):
-                    if frag is not None and 'obs_compact' in frag:       # the step writes this step's record straight into the fragment
-                        self.step_compact(self.next_action, frag['obs_compact'][i], frag['reward'][i])
-                    else:
-                        self.step(self.next_action)
-                    if frag is not None:
-                        for k in frag:
-                            if k != 'obs_compact' and not (k == 'reward' and 'obs_compact' in frag):
-                                frag[k][i].copy_(getattr(self, k))
+            self.rollout(self.next_action.view(1, self.E, self.U), out=frag, _policy_steps=n)
             t0 += n
         return (self.obs, self.reward) if out is None else (_fragment_obs(out), out['reward'])
 

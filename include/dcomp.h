@@ -22,7 +22,7 @@
  *   mv    uint64[E*U]      waypoint x:16 | y:16 | velocity:8 | pausing:1 (bit 47) + curr_pause:7 (bits 40-46) | draw cursor:16
  *   conn  uint32[E*U]      bit b set <=> UE connected to BS b                  (user.py:34 bs_dr keys)
  *   conn_hi uint32[E*U]    the same for stations 32 ... 63; required for envs of the generic kernel (csrc/dcomp_big.h): more than 32 stations
- *                          or more than 256 UE slots (dcomp_needs_conn_hi) -- no fused rollout and no in-step policy there
+ *                          or more than 256 UE slots (dcomp_needs_conn_hi) -- rollouts there are one launch per step (no fused rollout kernel)
  *   ewma  float [E*U]      exponentially weighted average rate                 (user.py:148-157)
  *   flags uint32[4]        sticky device-side error bits, read by dcomp_check()
  *   With UE arrival / departure (cfg.max_ues >= cfg.num_ue; 0 = fixed list) every per-UE array has max_ues slots per env; slot =
@@ -103,11 +103,12 @@ int dcomp_rollout(dcomp_env *env, const dcomp_state *st, const uint8_t *actions,
  *   policy_loop         1: closed loop with the policy registered through dcomp_set_policy -- step 0 takes actions[0][E][U]
  *                       (the next_action the previous launch wrote), every later step the policy's decision on the
  *                       observation of the step before, taken from registers: a heuristic agent's whole evaluation run
- *                       (simulation.py:512-541) in one call; `actions` holds ONE step.  Needs the fused kernel
- *                       (dcomp_rollout_is_fused; DCOMP_EUNSUPPORTED otherwise).  With a horizon the run may cross episode
+ *                       (simulation.py:512-541) in one call; `actions` holds ONE step.  With a horizon the run may cross episode
  *                       boundaries: at each one the library launches the reset kernel -- which writes the first observation of
  *                       the new episode AND the policy's action on it -- and continues the loop from that action: one launch
- *                       per stretch of an episode plus one reset launch per episode, no host work in between.
+ *                       per stretch of an episode plus one reset launch per episode, no host work in between.  Where rollouts
+ *                       are not fused (dcomp_rollout_fused_for: wide and generic kernels, UE arrival / departure) the same loop is
+ *                       one launch per step, each step reading the next_action buffer the launch before it wrote (round 6).
  *   ev_n_remove/ev_n_add  UE departures / arrivals of an env with a changing UE list (cfg.max_ues > 0), per step of THIS
  *                       rollout: host arrays [num_steps]; entry t = the UEs that leave / arrive in step t (base.py:433-443; the
  *                       schedule is configuration, identical in every env).  NULL: no events.  Such envs are launched once
@@ -218,7 +219,8 @@ int dcomp_heuristic_actions(const dcomp_policy *p, const float *obs, uint8_t *ac
  * the step reads its actions from: a lane reads its slot before it writes it -- except with UE arrival / departure, where
  * slots shift: use two buffers there).  p: policy / epsilon / cluster_mask are read (cluster_mask must stay valid), the
  * shape fields must be 0 or match the env; p == NULL or next_action == NULL switches it off.
- * Every step kernel has it (narrow, tight, wide, dynamic); DCOMP_EUNSUPPORTED is reserved for kernels that might not. */
+ * Every step kernel has it (narrow, tight, wide, dynamic, and since round 6 the generic kernel of more than 32 stations / 256 UE slots: the rules
+ * on the row's station lanes, argmax / sets / candidates as lane masks); DCOMP_EUNSUPPORTED is reserved for kernels that might not. */
 int dcomp_set_policy(dcomp_env *env, const dcomp_policy *p, uint8_t *next_action);
 
 /* Compact rollout fragments for the learner hand-off (the RCCL all-gather of rollouts; in the reference the sample

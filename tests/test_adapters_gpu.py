@@ -414,7 +414,13 @@ def test_policy_kernel_with_ue_arrival_and_departure(kind):
                                            ('central', 33, 16, 21, {}), ('multi', 5, 6, 33000, {}),       # 33 000 x 5: tight packing
                                            ('central', 5, 32, 9, {}), ('multi', 100, 12, 9, {}),
                                            ('multi', 128, 32, 5, {}), ('central', 70, 24, 7, {}), ('multi', 200, 21, 3, {}),   # wide kernel
-                                           ('multi', 4, 5, 37, dict(ue_arrival={2: 2, 4: -1, 6: 3, 9: -2}, max_ues=9))])
+                                           ('multi', 4, 5, 37, dict(ue_arrival={2: 2, 4: -1, 6: 3, 9: -2}, max_ues=9)),
+                                           # the generic kernel (round 6: it carries the rules too): a row over the whole wavefront (> 32 stations),
+                                           # several rows per trip (<= 32 stations, > 256 UE slots), envs wider than a wavefront, UE arrival / departure
+                                           ('multi', 32, 64, 40, {}), ('central', 10, 40, 30, {}), ('multi', 70, 33, 4, {}), ('central', 12, 50, 9, {}),
+                                           ('multi', 300, 12, 3, {}), ('central', 260, 7, 2, {}), ('multi', 600, 20, 2, {}), ('multi', 257, 32, 2, {}),
+                                           ('multi', 6, 40, 17, dict(ue_arrival={2: 3, 4: -2, 6: 3, 9: -4}, max_ues=12)),
+                                           ('central', 5, 36, 11, dict(ue_arrival={1: 2, 5: -1, 8: 2}, max_ues=9))])
 def test_in_step_policy_equals_the_policy_kernel(kind, U, B, E, kw):
     """dcomp_set_policy: the step / reset / rollout launches write next_action = dcomp_heuristic_actions(obs they wrote),
     for every policy, over a closed loop driven by those very actions (incl. resets, a fused rollout fragment, UE arrival)."""
@@ -448,9 +454,49 @@ def test_in_step_policy_equals_the_policy_kernel(kind, U, B, E, kw):
     assert env.next_action is None
 
 
+@pytest.mark.parametrize('kind,U0,B,E,rng', [('multi', 4, 5, 37, 'philox'), ('central', 6, 12, 300, 'philox'), ('multi', 5, 40, 21, 'philox'),
+                                             ('central', 4, 6, 5, 'reference')])
+def test_closed_loop_rollout_with_ue_arrival_and_departure(kind, U0, B, E, rng):
+    """rollout_policy() on envs whose UE list changes (one launch per step inside ONE dcomp_rollout_ex call, the event feed and the
+    actions of the launch before read in place; rng='reference': cut at the episode boundaries, where the host draws the next tape)
+    against `act = heuristic_actions(obs); step(act)` with reset() at the horizon: every step's observation and reward, the final
+    state and the next decision bit-identical.  Narrow dynamic kernel and the generic one (40 stations)."""
+    import torch
+    from deepcomp_amd import scenarios
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    L, T = 11, 27
+    arrival = {1: 2, 3: -1, 4: 3, 7: -3, 9: 1}
+    scn = scenarios.grid_map(B, 'mixed').with_ues(num_static=1, num_slow=U0 - 2, num_fast=1)
+    m, bs, ues = build_from_scenario(scn)
+    mk = lambda: BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=13, rng=rng, rand_episodes=True, episode_length=L, ue_arrival=arrival, max_ues=U0 + 5)
+    for name, eps in (('3gpp', 0.0), ('dynamic', 0.5), ('fullcomp', 0.0)):
+        ref, env = mk(), mk()
+        ref.reset()
+        want_obs, want_rew, want_n = [], [], []
+        for t in range(T):
+            if ref.time == L:
+                ref.reset()
+            ref.step(ref.heuristic_actions(name, eps))
+            want_obs.append(ref.obs.clone()); want_rew.append(ref.reward.clone()); want_n.append(ref.num_ue)
+        ref.check()
+        assert len(set(want_n)) >= 3
+        assert env.set_policy(name, eps)
+        env.reset()
+        out = {'obs': torch.full((T,) + tuple(env.obs.shape), float('nan'), device='cuda'), 'reward': torch.empty((T,) + tuple(env.reward.shape), device='cuda')}
+        env.rollout_policy(T, out=out, horizon=L)
+        env.check()
+        assert torch.equal(out['obs'], torch.stack(want_obs)) and torch.equal(out['reward'], torch.stack(want_rew)), name
+        assert env.time == ref.time and env.num_ue == ref.num_ue
+        for k in ('pos', 'mv', 'conn', 'ewma', 'uid') + (('conn_hi',) if env.conn_hi is not None else ()):
+            assert torch.equal(getattr(env, k), getattr(ref, k)), (name, k)
+        assert torch.equal(env.next_action, ref.heuristic_actions(name, eps))
+
+
 @pytest.mark.parametrize('kind,U,B,E,rng', [('central', 10, 5, 4096, 'philox'), ('multi', 32, 10, 200, 'philox'), ('multi', 7, 3, 50, 'philox'),
                                             ('central', 12, 16, 40, 'philox'), ('multi', 5, 4, 9, 'reference'),
-                                            ('multi', 128, 32, 3, 'philox')])
+                                            ('multi', 128, 32, 3, 'philox'),
+                                            ('multi', 24, 48, 6, 'philox'), ('central', 300, 9, 2, 'philox')])      # generic kernel: one launch per step
 def test_closed_loop_rollout_equals_step_by_step(kind, U, B, E, rng):
     """rollout_policy(T) -- the policy's decisions taken inside the fused rollout kernel, reset() at the horizon -- against the
     same loop issued as `act = heuristic_actions(obs); step(act)`: every step's observation / reward and the final state
@@ -486,7 +532,7 @@ def test_closed_loop_rollout_equals_step_by_step(kind, U, B, E, rng):
         env.check()
         assert torch.equal(out['obs'], torch.stack(want_obs)) and torch.equal(out['reward'], torch.stack(want_rew)), name
         assert env.time == ref.time and env.episode == ref.episode
-        for k in ('pos', 'mv', 'conn', 'ewma'):
+        for k in ('pos', 'mv', 'conn', 'ewma') + (('conn_hi',) if env.conn_hi is not None else ()):
             assert torch.equal(getattr(env, k), getattr(ref, k)), (name, k)
         assert torch.equal(env.next_action, ref.heuristic_actions(name, eps, cm))
         env2 = mk()                                       # last-step outputs only (out=None), then on with single steps

@@ -75,14 +75,14 @@ def test_tracked_traffic_goes_stale_with_the_sources_it_was_profiled_on(monkeypa
     """roofline.traffic is a tracked PMC figure, valid only for the kernel sources it was taken from: the specialised kernels' entries
     hang on build.kernel_fingerprint, a `big_kernel` entry also on csrc/dcomp_big.h (build.generic_fingerprint)."""
     from deepcomp_amd import build
-    for key, kern in (('65536x32x10_multi_mixed', 'step_kernel<10, 32, 2>'), ('8192x32x64_multi_mixed', 'big_kernel<32, false, false, false>')):
+    for key, kern in (('65536x32x10_multi_mixed', 'step_kernel<10, 32, 2>'), ('8192x32x64_multi_mixed', 'big_kernel<32, false, false, false, false, false>')):
         nbytes, src = bench.traffic_from_profile(key, kern)
         assert nbytes and nbytes > 1e8, (key, src)                     # the committed entries belong to the committed sources
         assert bench.traffic_from_profile(key, kern + ' ')[0] is None   # another instantiation is dispatched
     monkeypatch.setattr(build, 'generic_fingerprint', lambda read=None: 'edited')
     monkeypatch.setattr(build, 'source_fingerprint', lambda: 'edited')
     assert bench.traffic_from_profile('65536x32x10_multi_mixed', 'step_kernel<10, 32, 2>')[0]        # untouched by an edit of dcomp_big.h
-    nbytes, src = bench.traffic_from_profile('8192x32x64_multi_mixed', 'big_kernel<32, false, false, false>')
+    nbytes, src = bench.traffic_from_profile('8192x32x64_multi_mixed', 'big_kernel<32, false, false, false, false, false>')
     assert nbytes is None and 'STALE' in src and 'dcomp_big.h' in src
     monkeypatch.setattr(build, 'kernel_fingerprint', lambda read=None: 'edited')
     assert bench.traffic_from_profile('65536x32x10_multi_mixed', 'step_kernel<10, 32, 2>')[0] is None

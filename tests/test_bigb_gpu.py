@@ -167,8 +167,83 @@ def test_generic_kernel_equals_the_specialised_kernels(torch_cuda, kind, U, B, E
     ref.check(); big.check()
 
 
+@pytest.mark.parametrize('kind,U,B,E,sharing,reward,rng', [('multi', 32, 64, 24, 'mixed', 'avg', 'philox'), ('central', 10, 40, 50, 'mixed', 'sum', 'philox'),
+                                                          ('multi', 12, 33, 9, 'max-cap', 'min', 'philox'), ('multi', 300, 12, 3, 'mixed', 'sum', 'philox'),
+                                                          ('central', 600, 7, 2, 'proportional-fair', 'avg', 'philox'), ('multi', 70, 50, 3, 'rate-fair', 'avg', 'philox'),
+                                                          ('multi', 6, 36, 5, 'mixed', 'avg', 'reference'), ('central', 5, 64, 4, 'resource-fair', 'min', 'reference')])
+def test_generic_kernel_fused_rollout_equals_single_steps(torch_cuda, kind, U, B, E, sharing, reward, rng, monkeypatch):
+    """big_kernel<..., ROLL>: T steps in one launch per stretch of an episode (UE state in registers in between, step t's outputs in slice t)
+    against the same steps issued one by one with reset() at the horizon: every step's outputs, the last-step-only form, the compact record, the
+    closed policy loop and the final state, bit for bit; DCOMP_NO_FUSED_BIG=1 (one launch per step inside the same call) gives the same again."""
+    torch = torch_cuda
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    from deepcomp_amd.fragment import FragmentCodec
+    L, T = 9, 22
+    scn = _scenario(U, B, sharing)
+    m, bs, ues = build_from_scenario(scn)
+    mk = lambda: BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=21, rng=rng, rand_episodes=(rng == 'philox'), episode_length=L, reward=reward)
+    ref, env, last, comp = mk(), mk(), mk(), mk()
+    assert env.step_kernel_name.startswith('big_kernel<') and env.fused_rollout and env.rollout_is_fused(T)
+    nprng = np.random.default_rng(5)
+    for e_ in (ref, env, last, comp):
+        e_.reset()
+    acts = torch.from_numpy(np.stack([_near_actions(nprng, ref, B) for _ in range(T)])).cuda()
+    keys = ('obs', 'reward', 'sum_utility', 'ue_dr', 'ue_utility')
+    want = {k: torch.empty((T,) + tuple(getattr(ref, k).shape), device='cuda') for k in keys}
+    for t in range(T):
+        if ref.time == L:
+            ref.reset()
+        ref.step(acts[t])
+        for k in keys:
+            want[k][t].copy_(getattr(ref, k))
+    got = {k: torch.full_like(v, float('nan')) for k, v in want.items()}
+    env.rollout(acts, out=got, horizon=L)
+    for k in keys:
+        assert torch.equal(got[k], want[k]), k
+    state = ('pos', 'mv', 'conn', 'conn_hi', 'ewma')
+    for k in state:
+        assert torch.equal(getattr(env, k), getattr(ref, k)), k
+    assert env.time == ref.time and env.episode == ref.episode
+    last.rollout(acts, horizon=L)                                  # outputs of the last step only
+    assert torch.equal(last.obs, want['obs'][-1]) and torch.equal(last.reward, want['reward'][-1]) and torch.equal(last.pos, ref.pos)
+    if kind == 'multi':                                            # every step's compact record straight from the fused kernel
+        codec = FragmentCodec(U, B)
+        packed = {'obs_compact': torch.empty((T, E, codec.words), dtype=torch.int32, device='cuda'), 'reward': torch.empty_like(want['reward'])}
+        comp.rollout(acts, out=packed, horizon=L)
+        assert torch.equal(codec.unpack(packed['obs_compact']).view(torch.int32), want['obs'].view(torch.int32)) and torch.equal(packed['reward'], want['reward'])
+    monkeypatch.setenv('DCOMP_NO_FUSED_BIG', '1')
+    steps = mk()
+    assert not steps.rollout_is_fused(T)
+    steps.reset()
+    got2 = {k: torch.full_like(v, float('nan')) for k, v in want.items()}
+    steps.rollout(acts, out=got2, horizon=L)
+    for k in keys:
+        assert torch.equal(got2[k], want[k]), k
+    monkeypatch.delenv('DCOMP_NO_FUSED_BIG')
+    # the closed loop: fused (decisions read back from next_action inside the launch) against heuristic_actions + step
+    a, b = mk(), mk()
+    a.reset()
+    assert b.set_policy('dynamic', 0.4)
+    b.reset()
+    w_obs, w_rew = [], []
+    for t in range(T):
+        if a.time == L:
+            a.reset()
+        a.step(a.heuristic_actions('dynamic', 0.4))
+        w_obs.append(a.obs.clone()); w_rew.append(a.reward.clone())
+    out = {'obs': torch.full((T,) + tuple(b.obs.shape), float('nan'), device='cuda'), 'reward': torch.empty((T,) + tuple(b.reward.shape), device='cuda')}
+    b.rollout_policy(T, out=out, horizon=L)
+    assert torch.equal(out['obs'], torch.stack(w_obs)) and torch.equal(out['reward'], torch.stack(w_rew))
+    for k in state:
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert torch.equal(b.next_action, a.heuristic_actions('dynamic', 0.4))
+    for e_ in (ref, env, last, comp, steps, a, b):
+        e_.check()
+
+
 def test_many_stations_what_works_and_what_says_no(torch_cuda):
-    """48 stations: rollout() (one launch per step) == step(), checkpoints carry conn_hi, bad actions are flagged; the features that
+    """48 stations: rollout() (fused: one launch per stretch of an episode) == step(), checkpoints carry conn_hi, bad actions are flagged; the features that
     live in the specialised kernels only say so (UE arrival / departure, in-step policy, compact record, the fragment codec)."""
     torch = torch_cuda
     from deepcomp_amd import fragment
@@ -183,7 +258,7 @@ def test_many_stations_what_works_and_what_says_no(torch_cuda):
     a.reset(); b.reset()
     T = 30                                                        # across the horizon of 20
     acts = torch.from_numpy(np.stack([_near_actions(rng, a, B) for _ in range(T)])).cuda()
-    assert not a.rollout_is_fused(T)
+    assert a.rollout_is_fused(T) and a.fused_rollout            # (round 6: the generic kernel's fused rollout, one launch per stretch of an episode)
     want = {'obs': torch.empty((T,) + tuple(a.obs.shape), device='cuda'), 'reward': torch.empty((T,) + tuple(a.reward.shape), device='cuda')}
     got = {k: torch.empty_like(v) for k, v in want.items()}
     for t in range(T):
@@ -206,8 +281,9 @@ def test_many_stations_what_works_and_what_says_no(torch_cuda):
     a.step(bad)
     with pytest.raises(AssertionError):
         a.check()
-    # what the generic kernel does not have (the stand-alone policy kernel DOES serve 64 stations: test_heuristic_policies_with_many_stations)
-    assert a.set_policy('3gpp') is False
+    # (round 6: the generic kernel carries the in-step policy too -- tests/test_adapters_gpu.py::test_in_step_policy_equals_the_policy_kernel)
+    assert a.set_policy('3gpp') is True and a.step_kernel_name.endswith('false, true, false>')
+    a.set_policy(None)
     assert fragment.fragment_words(U, B) == U * (B + 3) + 2 * B                    # (round 6: the compact record with two set words per UE)
     assert BatchedMobileEnv(m, bs, ues, 'multi', ue_arrival={3: 1}, **kw).step_kernel_name.startswith('big_kernel<')      # (round 6: UE arrival / departure too)
     with pytest.raises(ValueError):
@@ -218,8 +294,7 @@ def test_many_stations_what_works_and_what_says_no(torch_cuda):
 def test_heuristic_policies_with_many_stations(torch_cuda, kind, U, B, E):
     """The reference's heuristic baselines (agent/heuristics.py:13-187) on observations of 33 ... 64 stations: dcomp_heuristic_actions
     (64-bit sets, two cluster-mask words per station) against the tensor-expression form of the rules, on live and on tie-ridden
-    synthetic observations; a 3GPP-driven closed loop (`agent.act(env)`: the in-step policy is refused, the stand-alone kernel takes
-    over) stays bit-exact with the oracle fed the same actions."""
+    synthetic observations; a heuristic-driven closed loop (`agent.act(env)`) stays bit-exact with the oracle fed the same actions."""
     torch = torch_cuda
     from deepcomp_amd import agents
     from deepcomp_amd.entities import build_from_scenario
@@ -302,7 +377,7 @@ def test_generic_kernel_with_ue_arrival_and_departure(torch_cuda, shape):
     scn = _scenario(U0, B, sharing)
     m, bs, ues = build_from_scenario(scn)
     core = BatchedMobileEnv(m, bs, ues, kind, num_envs=E, seed=5, episode_length=L, reward=reward, rng='philox', rand_episodes=True, ue_arrival=arrival)
-    assert core.step_kernel_name.startswith('big_kernel<') and core.step_kernel_name.endswith('true, false>') and core.conn_hi is not None
+    assert core.step_kernel_name.startswith('big_kernel<') and core.step_kernel_name.endswith('true, false, false, false>') and core.conn_hi is not None
     M = core.U
     sched = orc.arrival_schedule(L, arrival)
     oenvs = []

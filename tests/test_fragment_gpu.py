@@ -345,7 +345,8 @@ def test_compact_record_is_refused_where_it_is_not_defined(torch_cuda):
     assert rc == _lib.EINVAL
 
 
-@pytest.mark.parametrize('E,U,B,policy', [(64, 32, 10, '3gpp'), (4096, 10, 5, 'dynamic'), (16, 128, 32, 'fullcomp'), (24, 70, 24, '3gpp'), (2000, 32, 10, 'cluster')])
+@pytest.mark.parametrize('E,U,B,policy', [(64, 32, 10, '3gpp'), (4096, 10, 5, 'dynamic'), (16, 128, 32, 'fullcomp'), (24, 70, 24, '3gpp'), (2000, 32, 10, 'cluster'),
+                                          (40, 32, 40, 'dynamic'), (3, 300, 12, '3gpp'), (9, 20, 64, 'fullcomp')])      # the generic kernel (round 6)
 def test_closed_policy_loop_with_compact_records(torch_cuda, E, U, B, policy):
     """dcomp_set_policy decides on the registers the observation is written from, so a heuristic-driven loop needs no rows: twin
     envs, one stepping rows, one the compact record, take the same decisions and produce the same observations -- step by step and

@@ -149,6 +149,35 @@ def test_bench_self_spawn_single_rank_rccl():
     assert j['n_gpus'] == 1 and j['handoff']['rccl_ranks'] == 1 and j['handoff']['backend'] == 'rccl'
 
 
+@pytest.mark.parametrize('mode', ['obs', 'summary'])
+def test_bench_direct_all_gather_spelled_out_two_gloo_ranks(mode):
+    """`--gather-algo p2p`: every rank posts one send to, and one receive from, each peer in one batch (RolloutGather(algo='p2p'),
+    SURVEY.md 8e "direct (one-shot, all-peers) all-gather rather than ring") -- same fragments, same byte counts, same handle as the
+    collective form; the record names the algorithm."""
+    rc, out, j = _run([sys.executable, 'bench.py', '--gpus', '2', '--backend', 'gloo', '--same-device', '--gather', mode, '--gather-algo', 'p2p',
+                       '--fragment', '5'] + COMMON)
+    assert rc == 0 and j is not None, out[-3000:]
+    h = j['handoff']
+    assert h['algo'] == 'p2p' and h['rccl_ranks'] == 2 and h['mode'] == mode and j['value'] > 0 and h['collectives_in_timed_region'] > 0
+    assert h['bytes_in_timed_region']['received_per_rank'] == 2 * h['bytes_in_timed_region']['sent_per_rank'] > 0
+    if mode == 'obs':
+        assert h['fragments'] == 4 and h['bytes_sent_per_rank_per_fragment'] == 5 * 2048 * 32 * (41 + 1) * 4
+        assert h['bytes_received_per_rank_per_fragment'] == 2 * h['bytes_sent_per_rank_per_fragment']
+
+
+def test_bench_rccl_direct_hints_are_set_before_the_communicator_exists():
+    """`--rccl-direct`: the hints of sharded.rccl_direct_hints() are in the rank's environment when init_process_group runs, and the
+    record carries what was set (a real RCCL communicator of size 1: the box has one GPU)."""
+    env_clean = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+                                                                     'RCCL_DIRECT_ALLGATHER_THRESHOLD', 'NCCL_PROTO')}
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '1', '--spawn', '--rccl-direct', '--gather', 'obs', '--fragment', '5'] + COMMON, cwd=REPO,
+                       env=env_clean, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    j = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert j['handoff']['backend'] == 'rccl' and j['handoff']['algo'] == 'collective'
+    assert j['handoff']['rccl_hints'] == {'RCCL_DIRECT_ALLGATHER_THRESHOLD': str(1 << 34), 'NCCL_PROTO': 'Simple'}
+
+
 @pytest.mark.parametrize('via_pack', [False, True])
 def test_bench_compact_observation_handoff_single_rank_rccl(via_pack):
     """`--gather obs --compact`: the fragment crosses the collective as the lossless compact record, U (B + 2) + 2B words per env-step

@@ -431,7 +431,7 @@ def test_fragments_beyond_the_fused_kernels_row_limit_fall_back_to_one_launch_pe
     """an every-step fragment of >= 2^31 rows (num_steps x num_envs x num_ue) leaves the fused rollout kernel (32-bit row
     indices) for one launch per step with 64-bit offsets on the host -- a branch no test reached (it would take a 2^31-row
     fragment).  DCOMP_FUSED_ROW_LIMIT_LOG2 lowers the limit: the same rollout, fragment and final state, bit for bit; the
-    closed loop, which has no other path, is refused."""
+    closed loop included."""
     torch = torch_cuda
     T = 16
     g = torch.Generator(device='cuda').manual_seed(3)
@@ -453,7 +453,16 @@ def test_fragments_beyond_the_fused_kernels_row_limit_fall_back_to_one_launch_pe
     for k in keys:
         assert torch.equal(got[k], want[k]), k
     assert _same_state(_state(env), _state(fused)) and env.time == T
-    assert env.set_policy('fullcomp')
+    # the closed loop takes the same way out (round 6: one launch per step, each reading the actions the launch before wrote) -- against
+    # the fused closed loop of the twin env, run with the limit back in place
+    assert env.set_policy('fullcomp') and fused.set_policy('fullcomp')
     env.reset()
-    with pytest.raises(ValueError, match='policy_loop fragment too long'):
-        env.rollout_policy(T, out={k: torch.empty_like(v) for k, v in want.items()})
+    got = {k: torch.full_like(v, float('nan')) for k, v in want.items()}
+    env.rollout_policy(T, out=got, horizon=7)
+    monkeypatch.delenv('DCOMP_FUSED_ROW_LIMIT_LOG2')
+    fused.reset()
+    fused.rollout_policy(T, out=want, horizon=7)
+    for k in keys:
+        assert torch.equal(got[k], want[k]), k
+    assert _same_state(_state(env), _state(fused)) and env.time == fused.time == T - 14 and torch.equal(env.next_action, fused.next_action)
+    env.check(); fused.check()

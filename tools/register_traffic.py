@@ -57,7 +57,8 @@ def main():
     vals = {}
     for line in txt.splitlines():
         line = line.strip()
-        if line.startswith('void ') and kern in line and '{' in line:
+        # (tools/summarize_prof.py cuts the names of the counter rows: a cut name is a prefix of the kernel's)
+        if line.startswith('void ') and '{' in line and (kern in line or (len(line[5:line.index('{')].strip()) >= 40 and ('dcomp::' + kern).startswith(line[5:line.index('{')].strip()))):
             d = ast.literal_eval(line[line.index('{'):line.index('}') + 1])
             vals.update(d)
     avg_ns = calls = None

@@ -34,7 +34,7 @@ for f in find('pmc_*/**/*counter_collection.csv'):
     agg = defaultdict(lambda: defaultdict(list))
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            agg[row['Kernel_Name'][:60]][row['Counter_Name']].append(float(row['Counter_Value']))
+            agg[row['Kernel_Name'][:96]][row['Counter_Name']].append(float(row['Counter_Value']))
     print(os.path.relpath(f, out))
     for k, cs in agg.items():
         if 'step_kernel' not in k and 'reset_kernel' not in k and 'rollout_kernel' not in k and 'big_kernel' not in k:
