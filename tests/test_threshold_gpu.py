@@ -42,6 +42,10 @@ FAMILIES = [
     ('big_32x40', 'multi', 32, 40, 2, {}, 'step', 'big_kernel'),
     ('big_16x64', 'central', 16, 64, 2, {}, 'step', 'big_kernel'),
     ('big_forced_32x10', 'multi', 32, 10, 2, {'DCOMP_FORCE_BIG': '1'}, 'step', 'big_kernel'),
+    # the generic kernel's other instantiations compile the same decision again: the fused rollout (ROLL) and the event phase (DYN)
+    ('big_rollout_12x40', 'multi', 12, 40, 2, {}, 'rollout', 'big_kernel'),
+    ('big_rollout_forced_10x5', 'central', 10, 5, 3, {'DCOMP_FORCE_BIG': '1'}, 'rollout', 'big_kernel'),
+    ('big_dyn_6x40', 'multi', 6, 40, 3, {}, 'dyn', 'big_kernel'),
 ]
 ARRIVAL = {1: 2, 3: -1, 5: 1, 8: -2}            # UE arrival / departure while the threshold decisions are taken (base.py:433-443)
 

@@ -111,7 +111,7 @@ def _clamp_arrival(arrival, U, cap):
 def many_stations(spec, frac):
     """Round 5 (a stream of its own, keyed by the case's seed: every older spec stays what it was): with probability `frac` the case gets
     33 ... 64 stations -- the generic kernel of csrc/dcomp_big.h.  The extra stations are drawn like the first ones; what the generic
-    kernel does not have is dropped from the case (the compact-record twin is skipped by run_case)."""
+    kernel did not have then was dropped from the case; since round 6 nothing is: compact-record twin, rollout fragments (its fused rollout) and arrival schedules stay)."""
     r5 = np.random.default_rng(spec['seed'] ^ 0x51ED270B)
     if r5.random() >= frac:
         return spec
@@ -244,7 +244,7 @@ def run_case(c, torch):
     # round 4: multi-agent envs also run a TWIN whose steps write the compact record themselves
     # (dcomp_out.obs_compact): unpack of it must be the core env's rows bit for bit, pack of the rows the record word for word
     twin = codec = packed = trew = None
-    if kind == 'multi' and B <= 32 and c['U'] <= 256:   # (the compact record: one 32-bit connection mask per UE, envs of the specialised kernels)
+    if kind == 'multi':                                 # (round 6: the generic kernel writes the record too -- two connection words per UE above 32 stations)
         from deepcomp_amd.fragment import FragmentCodec
         os.environ['DCOMP_TIGHT'] = '1' if c.get('tight') else '0'
         try:
