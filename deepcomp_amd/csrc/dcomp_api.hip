@@ -340,6 +340,10 @@ extern "C" int dcomp_create_v(int32_t abi_version, size_t cfg_size, size_t state
                     if (e == hipSuccess) e = raise_lds_limit(reinterpret_cast<const void *>(env->bigk.fn[pol][c][w == 0 ? env->big_step : w == 1 ? 1 : 3]), (int)env->big_lds);
         if (e != hipSuccess) { dcomp_destroy(env); return fail(DCOMP_EHIP, "device setup failed (generic kernel, %zu bytes of LDS per workgroup): %s", env->big_lds, hipGetErrorString(e)); }
         env->bigp.bs = env->d_bs; env->bigp.mode = env->d_mode; env->bigp.B = B;
+        // multi-agent rows of more than 32 stations: one 16-byte store per lane and row (dcomp_big.h, row loop) once a step's rows no longer sit in
+        // the Infinity Cache (measured at 32 x 64: 2 048 envs = 67 MB 41.4 -> 43.1 us, 8 192 = 270 MB 63.9 -> 62.5, 16 384 = 539 MB 196 -> 145,
+        // 65 536 = 2.2 GB 693 -> 495); DCOMP_BIG_ROW_X4=0 / 1 forces the four-block form / the 16-byte form
+        env->bigp.row_x4 = getenv("DCOMP_BIG_ROW_X4") ? atoi(getenv("DCOMP_BIG_ROW_X4")) : ((size_t)E * CAP * (4 * B + 1) * 4 >= ((size_t)128 << 20) ? 1 : 0);
     }
     if (cfg->ue_velocity) {
         // movement.py:116-117 / 142-156 with a velocity that is no integer in 0..255: the device takes {v, qmax(v)} from a table,

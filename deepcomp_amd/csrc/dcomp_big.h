@@ -48,6 +48,7 @@ struct BigParams {
     int32_t B;
     unsigned long long maxcap_mask;    // bit b: station b is max-cap
     unsigned long long summode_mask;   // bit b: station b is rate-fair or proportional-fair (its share needs a sum of per-pair terms)
+    int32_t row_x4;                    // multi-agent rows of more than 32 stations leave as ONE 16-byte store per lane and row (see the row loop)
 };
 
 // Workgroup: ONE wavefront (64 / UPAD envs), or the env's own UPAD lanes above 64.
@@ -55,7 +56,7 @@ __host__ __device__ constexpr int big_block(int upad) { return upad < 64 ? 64 : 
 // LDS one workgroup carves (host and device use the same function): the BS table, then per LANE 16 B position + 16 B {mask lo, mask hi,
 // ewma | utility, reward_before} + 8 B in-range set, per (env, station) three aggregates, per (wave, station) three partial sums where an
 // env spans waves.  64 stations, 32 UEs: 5.4 KB per wavefront.
-struct BigCarve { int mode, pos, slot, inr, agg, part, total; };
+struct BigCarve { int mode, pos, slot, inr, agg, part, stage, total; };
 __host__ __device__ inline BigCarve big_carve(int B, int gpb, int blk)
 {
     BigCarve c;
@@ -65,7 +66,8 @@ __host__ __device__ inline BigCarve big_carve(int B, int gpb, int blk)
     c.slot = o; o += blk * 16;
     c.inr = o; o += blk * 8;
     c.agg = o; o += 3 * gpb * B * 4 + 16; o = (o + 15) & ~15;      // (+ one scratch word: where the empty term slots add their 0.0)
-    c.part = o; o += blk > 64 ? 3 * (blk / 64) * B * 4 : 0;
+    c.part = o; o += blk > 64 ? 3 * (blk / 64) * B * 4 : 0; o = (o + 15) & ~15;
+    c.stage = o; o += B > 32 ? (blk / 64) * 4 * B * 4 : 0;           // one row (4B words) per wavefront: the 16-byte form of the multi-agent rows (row_x4)
     c.total = (o + 15) & ~15;
     return c;
 }
@@ -88,6 +90,20 @@ __device__ __forceinline__ void big_store(float *ptr, float v)
 #else
     *ptr = v;
 #endif
+}
+// The observation rows leave through BUFFER stores: resource = the env's rows (uniform, four SGPRs), scalar offset = the row / the block of the row,
+// vector offset = the lane's station (loop-invariant).  As plain global stores every row cost ten 64-bit vector adds on per-lane pointers (one
+// v_lshl_add_u64 per store + one per pointer to step to the next row): a quarter of the row loop's vector instructions.
+using BigRsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ BigRsrc big_rsrc(float *base) { return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000); }
+__device__ __forceinline__ void big_bstore(BigRsrc r, uint32_t lane_bytes, uint32_t row_bytes, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)lane_bytes, (int)row_bytes, 0);
+}
+__device__ __forceinline__ void big_bstore4(BigRsrc r, uint32_t lane_bytes, uint32_t row_bytes, const float (&v)[4])
+{
+    using u4 = unsigned int __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(u4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, r, (int)lane_bytes, (int)row_bytes, 0);
 }
 __device__ __forceinline__ float big_rate(float l2)                // bw * log2(1 + snr), station.py:129-138
 {
@@ -666,8 +682,22 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                 big_store(dst_env + U * CWC + B + sb, u_col);
             }
             const unsigned long long ok_mask = __builtin_amdgcn_ballot_w64(st_ok);
+            const BigRsrc rs = big_rsrc(dst_env);
+            // Rows as 16-byte stores (BigParams::row_x4; multi-agent rows, more than 32 stations): the row's 4B words as they lie in memory, four per
+            // lane.  The lane-per-station values are transposed through ONE row of LDS per wavefront (two ds_write_b32 + one ds_read_b128 per lane and
+            // row; the two per-env blocks are written once per env; LDS operations of a wavefront complete in order: no barrier).  One store
+            // instruction then writes 1 KiB of consecutive bytes instead of four writing 256 B each at a stride of B floats: beyond the Infinity
+            // Cache the four-block form reached 3.1 TB/s of writes (65 536 x 32 x 64: rows alone 566 of 692 us).
+            const bool x4 = !COMPACT && LBP == 6 && x.row_x4 != 0 && kind == DCOMP_MULTI && dst_env != nullptr;
+            float *const stage = reinterpret_cast<float *>(big_smem + cv.stage) + wave * 4 * B;
+            if (x4 && st_ok) { stage[2 * B + lane] = n_col; stage[3 * B + lane] = u_col; }      // the two per-env blocks: once per env
             if (LBP == 6) {
-                // more than 32 stations: ONE row per trip, everything about the row uniform (position / set: broadcast reads; destination: scalar)
+                // more than 32 stations: ONE row per trip, everything about the row uniform (position / set: broadcast reads; destination: scalar).
+                // The loop exists once per output form (OUT: 0 nothing, 1 compact record, 2 rows as 16-byte stores, 3 rows in four blocks, 4 central):
+                // the form is picked per env piece, not per row (the chain of uniform branches in front of the central stores cost 65 536 x 10 x 40
+                // central 9 % when the 16-byte form was added to it).
+                auto rows6 = [&](auto out_tag) __attribute__((always_inline)) {
+                constexpr int OUT = decltype(out_tag)::value;
                 for (int uu = 0; uu < nrows; uu++) {
                     const int r = r0 + uu, ue = uu0 + uu;
                     const bool live = ue < cur;
@@ -701,41 +731,66 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                             if (lane == 0) p.next_act[(size_t)(env0 + envl) * U + ue] = (uint8_t)(live ? a : 0);
                         }
                     }
-                    if (dst_env) {
-                        // (uniform row base + the lane's 32-bit offset: the store's scalar-base form, no 64-bit address arithmetic per store;
+                    if (OUT != 0) {
+                        // (buffer stores: the row's offset is a scalar, the lane's a loop-invariant register -- no address arithmetic per store;
                         //  an unlisted slot -- `live` is uniform -- takes the zero-row branch instead of a select per value)
-                        const uint32_t lo = (uint32_t)lane;
-                        if (compact) {
-                            float *const dst = dst_env + (size_t)ue * CWC;
+                        const uint32_t lo = (uint32_t)lane * 4u, B4 = (uint32_t)B * 4u;
+                        if (OUT == 1) {
                             const float lmax = POL ? lmax_p : wave_max_f32(l);
-                            if (st_ok) big_store(dst + lo, live ? fast_exp2(l - lmax) : 0.f);
-                        } else if (kind == DCOMP_MULTI) {
-                            float *const dst = dst_env + (size_t)ue * ROW;
+                            if (st_ok) big_bstore(rs, lo, (uint32_t)(ue * CWC) * 4u, live ? fast_exp2(l - lmax) : 0.f);
+                        } else if (OUT == 2) {
+                            const uint32_t ro = (uint32_t)(ue * ROW) * 4u;
+                            float cf = 0.f, dr = 0.f, ut = 0.f;
+                            if (live) {
+                                const float lmax = POL ? lmax_p : wave_max_f32(l);
+                                dr = fast_exp2(l - lmax);                                    // variants.py:276-284
+                                cf = (float)__builtin_amdgcn_ubfe(hi_lane ? sl.y : sl.x, sh, 1u);
+                                ut = __uint_as_float(sl.z) * (1.0f / MAX_UTIL);
+                            }
+                            float v[4] = {0.f, 0.f, 0.f, 0.f};                                // (an unlisted slot: a zero row, the per-env blocks too)
+                            if (live) {
+                                if (st_ok) { stage[lane] = cf; stage[B + lane] = dr; }
+                                if (lane < B) {                                              // (4B words = B lanes of four; B <= 64)
+                                    const float4 q4 = *reinterpret_cast<const float4 *>(stage + 4 * lane);
+                                    v[0] = q4.x; v[1] = q4.y; v[2] = q4.z; v[3] = q4.w;
+                                }
+                            }
+                            if (lane < B) big_bstore4(rs, lo * 4u, ro, v);
+                            if (lane == 0) big_bstore(rs, 0u, ro + 4u * B4, ut);              // the row's own utility entry, right behind it
+                        } else if (OUT == 3) {
+                            const uint32_t ro = (uint32_t)(ue * ROW) * 4u;
                             if (live) {
                                 const float lmax = POL ? lmax_p : wave_max_f32(l);
                                 const float dr = fast_exp2(l - lmax);                        // variants.py:276-284
                                 const float cf = (float)__builtin_amdgcn_ubfe(hi_lane ? sl.y : sl.x, sh, 1u);
                                 if (st_ok) {
-                                    big_store(dst + lo, cf);
-                                    big_store(dst + (lo + (uint32_t)B), dr);
-                                    big_store(dst + (lo + (uint32_t)(2 * B)), n_col);
-                                    big_store(dst + (lo + (uint32_t)(3 * B)), u_col);
+                                    big_bstore(rs, lo, ro, cf);
+                                    big_bstore(rs, lo, ro + B4, dr);
+                                    big_bstore(rs, lo, ro + 2u * B4, n_col);
+                                    big_bstore(rs, lo, ro + 3u * B4, u_col);
                                 }
                             } else if (st_ok) {
-                                big_store(dst + lo, 0.f); big_store(dst + (lo + (uint32_t)B), 0.f);
-                                big_store(dst + (lo + (uint32_t)(2 * B)), 0.f); big_store(dst + (lo + (uint32_t)(3 * B)), 0.f);
+                                big_bstore(rs, lo, ro, 0.f); big_bstore(rs, lo, ro + B4, 0.f);
+                                big_bstore(rs, lo, ro + 2u * B4, 0.f); big_bstore(rs, lo, ro + 3u * B4, 0.f);
                             }
                         } else {
-                            float *const dc = dst_env + (size_t)ue * B;
+                            const uint32_t ro = (uint32_t)(ue * B) * 4u, UB4 = (uint32_t)UB * 4u;
                             if (live) {
                                 const float lmax = POL ? lmax_p : wave_max_f32(l);
                                 const float dr = fast_exp2(l - lmax);
                                 const float cf = (float)__builtin_amdgcn_ubfe(hi_lane ? sl.y : sl.x, sh, 1u);
-                                if (st_ok) { big_store(dc + lo, cf); big_store(dc + (lo + (uint32_t)UB), dr); }
-                            } else if (st_ok) { big_store(dc + lo, 0.f); big_store(dc + (lo + (uint32_t)UB), 0.f); }
+                                if (st_ok) { big_bstore(rs, lo, ro, cf); big_bstore(rs, lo, ro + UB4, dr); }
+                            } else if (st_ok) { big_bstore(rs, lo, ro, 0.f); big_bstore(rs, lo, ro + UB4, 0.f); }
                         }
                     }
                 }
+                };
+                using std::integral_constant;
+                if (!dst_env) rows6(integral_constant<int, 0>{});
+                else if (compact) rows6(integral_constant<int, 1>{});
+                else if (x4) rows6(integral_constant<int, 2>{});
+                else if (kind == DCOMP_MULTI) rows6(integral_constant<int, 3>{});
+                else rows6(integral_constant<int, 4>{});
             } else {
                 // up to 32 stations: SUB rows per trip, lane = (row sub, station sb)
                 const int trips = (nrows + SUB - 1) >> (6 - LBP);
@@ -762,21 +817,22 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
                         }
                         if (!dst_env) continue;
                         const float cf = (float)__builtin_amdgcn_ubfe(sl.x, sh, 1u);
+                        const uint32_t B4 = (uint32_t)B * 4u;                              // (buffer stores: one 32-bit offset per lane, the blocks of the row as scalar offsets)
                         if (compact) {
-                            if (st_ok && rv) big_store(dst_env + ue * CWC + sb, dr);
+                            if (st_ok && rv) big_bstore(rs, (uint32_t)(ue * CWC + sb) * 4u, 0u, dr);
                         } else if (kind == DCOMP_MULTI) {
-                            const int off = ue * ROW + sb;
+                            const uint32_t off = (uint32_t)(ue * ROW + sb) * 4u;
                             if (st_ok && rv) {
-                                big_store(dst_env + off, cf);
-                                big_store(dst_env + off + B, dr);
-                                big_store(dst_env + off + 2 * B, live ? n_col : 0.f);
-                                big_store(dst_env + off + 3 * B, live ? u_col : 0.f);
+                                big_bstore(rs, off, 0u, cf);
+                                big_bstore(rs, off, B4, dr);
+                                big_bstore(rs, off, 2u * B4, live ? n_col : 0.f);
+                                big_bstore(rs, off, 3u * B4, live ? u_col : 0.f);
                             }
                         } else {
-                            const int off = ue * B + sb;
+                            const uint32_t off = (uint32_t)(ue * B + sb) * 4u;
                             if (st_ok && rv) {
-                                big_store(dst_env + off, cf);
-                                big_store(dst_env + UB + off, dr);
+                                big_bstore(rs, off, 0u, cf);
+                                big_bstore(rs, off, (uint32_t)UB * 4u, dr);
                             }
                         }
                     }
@@ -792,7 +848,7 @@ __global__ __launch_bounds__(big_block(UPAD)) void big_kernel(const KParams p, c
             big_store(rec + B, ut);
             big_store(rec + B + 1, __uint_as_float(alive ? (uint32_t)conn : 0u));
             if (B > 32) big_store(rec + B + 2, __uint_as_float(alive ? (uint32_t)(conn >> 32) : 0u));
-        } else if (kind == DCOMP_MULTI) big_store(o_obs + (size_t)idx * ROW + 4 * B, ut);
+        } else if (kind == DCOMP_MULTI) { if (!(B > 32 && x.row_x4)) big_store(o_obs + (size_t)idx * ROW + 4 * B, ut); }      // (row_x4: the row loop has written it)
         else big_store(o_obs + (size_t)env * U * (2 * B + 1) + 2 * UB + u, ut);
     }
     __syncthreads();

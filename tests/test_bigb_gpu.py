@@ -242,6 +242,46 @@ def test_generic_kernel_fused_rollout_equals_single_steps(torch_cuda, kind, U, B
         e_.check()
 
 
+@pytest.mark.parametrize('U,B,E,arrival', [(32, 64, 9, None), (13, 33, 21, None), (10, 47, 7, None), (70, 40, 3, None), (300, 36, 2, None), (7, 50, 11, {1: 3, 3: -2, 5: 4, 8: -5})])
+def test_generic_kernel_rows_as_16_byte_stores_equal_the_four_block_form(torch_cuda, U, B, E, arrival, monkeypatch):
+    """BigParams::row_x4 (multi-agent rows of more than 32 stations transposed through one LDS row per wavefront and written as one 16-byte
+    store per lane -- what dcomp_create picks once a step's rows exceed the Infinity Cache) against the four-block form on twin envs: reset,
+    steps, a fused rollout fragment, the in-step policy and UE arrival / departure (zero rows of unlisted slots), every output bit for bit.
+    Station counts that are not multiples of 4 and UE counts that leave rows at 4-byte alignment included."""
+    torch = torch_cuda
+    from deepcomp_amd.entities import build_from_scenario
+    from deepcomp_amd.env import BatchedMobileEnv
+    scn = _scenario(U, B, 'mixed')
+    m, bs, ues = build_from_scenario(scn)
+    kw = dict(num_envs=E, seed=17, rng='philox', rand_episodes=True, episode_length=12)
+    if arrival:
+        kw.update(ue_arrival=arrival, max_ues=U + 6)
+    envs = []
+    for flag in ('0', '1'):
+        monkeypatch.setenv('DCOMP_BIG_ROW_X4', flag)
+        envs.append(BatchedMobileEnv(m, bs, ues, 'multi', **kw))
+    a, b = envs
+    assert a.step_kernel_name.startswith('big_kernel<')
+    keys = ('obs', 'reward', 'sum_utility', 'ue_dr', 'ue_utility')
+    same = lambda tag: [None for k in keys if not torch.equal(getattr(a, k).view(torch.int32), getattr(b, k).view(torch.int32)) and pytest.fail(f'{tag}: {k}')]
+    a.reset(); b.reset()
+    same('reset')
+    rng = np.random.default_rng(3)
+    for t in range(10):
+        act = torch.from_numpy(rng.integers(0, B + 1, size=(E, a.U)).astype(np.uint8)).cuda()
+        a.step(act); b.step(act)
+        same(f'step {t}')
+    a.reset(); b.reset()
+    assert a.set_policy('dynamic', 0.3) and b.set_policy('dynamic', 0.3)
+    a.reset(); b.reset()
+    T = 9
+    outs = [{'obs': torch.full((T,) + tuple(e_.obs.shape), float('nan'), device='cuda'), 'reward': torch.empty((T,) + tuple(e_.reward.shape), device='cuda')} for e_ in envs]
+    a.rollout_policy(T, out=outs[0]); b.rollout_policy(T, out=outs[1])
+    assert torch.equal(outs[0]['obs'].view(torch.int32), outs[1]['obs'].view(torch.int32)) and torch.equal(outs[0]['reward'], outs[1]['reward'])
+    assert torch.equal(a.next_action, b.next_action) and torch.equal(a.pos, b.pos) and torch.equal(a.conn_hi, b.conn_hi)
+    a.check(); b.check()
+
+
 def test_many_stations_what_works_and_what_says_no(torch_cuda):
     """48 stations: rollout() (fused: one launch per stretch of an episode) == step(), checkpoints carry conn_hi, bad actions are flagged; the features that
     live in the specialised kernels only say so (UE arrival / departure, in-step policy, compact record, the fragment codec)."""
