@@ -1,4 +1,6 @@
-"""Debug: re-run ONE case of a fuzz_parity run (seed, index) and dump the UEs whose rates differ."""
+"""Re-run ONE case of a tools/fuzz_parity.py run and, where the per-UE rates differ, dump the connected UEs of the env (positions, squared distances,
+step of connection, both rates).  `python tools/fuzz_case.py <seed> <case index> <--many-stations fraction> <--many-ues fraction>` (GPU box);
+e.g. `tools/fuzz_case.py 990002 92 0.6 0.0`: the max-cap tie of DESIGN.md section 6 / profiles/r06_maxcap_log10_ulp.txt."""
 import os, sys
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
