@@ -28,7 +28,7 @@ BASE = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fa
 
 def build(a):
     os.makedirs(VAR, exist_ok=True)
-    src = REPO
+    src = a.src or REPO
     tmp = None
     if a.ref:
         tmp = tempfile.mkdtemp(prefix='dcomp_ref_')
@@ -177,7 +177,7 @@ def run(a):
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     sub = ap.add_subparsers(dest='cmd', required=True)
-    b = sub.add_parser('build'); b.add_argument('tag'); b.add_argument('--ref', default=''); b.add_argument('--b', default='5,10,32'); b.add_argument('--flags', default='')
+    b = sub.add_parser('build'); b.add_argument('tag'); b.add_argument('--ref', default=''); b.add_argument('--b', default='5,10,32'); b.add_argument('--flags', default=''); b.add_argument('--src', default='', help='a copy of the tree (with deepcomp_amd/csrc and include) to build instead of the working tree: experiments that leave the product sources alone')
     r = sub.add_parser('run'); r.add_argument('tags', nargs='+'); r.add_argument('--rounds', type=int, default=2); r.add_argument('--only', default='')
     m = sub.add_parser('measure'); m.add_argument('--only', default='')
     a = ap.parse_args()
