@@ -19,6 +19,43 @@ RTOL_RATE, ATOL_UTIL, ATOL_OBS = parity.RTOL_RATE, parity.ATOL_UTIL, parity.ATOL
 SHARING = ['resource-fair', 'rate-fair', 'max-cap', 'proportional-fair']
 
 
+class AmbiguousTie(Exception):
+    """A max-cap station served a different UE than the oracle's, and the two UEs' FP64 rates are within an ulp of log10 of each other: the
+    reference itself decides that case in the last bit of the host's np.log10 (AVX-512 SVML or libm) -- DESIGN.md section 6."""
+
+
+def maxcap_libm_tie(core, ob, c, st):
+    """The per-UE rates differ from the oracle's: is every difference a swapped max-cap winner between two UEs whose squared distances to the
+    station agree to 1e-11 relative?  Returns a description, or None (a real mismatch)."""
+    r = ob.rates(want_dr_rel=False)
+    want = r['curr_dr']
+    E, U = want.shape
+    got = core.ue_dr.cpu().numpy().reshape(E, U).astype(np.float64)
+    bad = np.argwhere(np.abs(got - want) > parity.RTOL_RATE * np.abs(want) + 1e-30)
+    if len(bad) == 0 or len(bad) % 2:
+        return None
+    mc = [b for b, m in enumerate(c['sh']) if m == 'max-cap']
+    notes = []
+    for e in sorted(set(int(b[0]) for b in bad)):
+        us = [int(b[1]) for b in bad if int(b[0]) == e]
+        if len(us) != 2:
+            return None
+        u1, u2 = us
+        pos, conn = st['pos'][e], st['conn'][e]
+        hit = None
+        for b in mc:
+            if (int(conn[u1]) >> b) & 1 and (int(conn[u2]) >> b) & 1:
+                bx, by = c['bs_xy'][b]
+                d1 = (pos[u1][0] - bx) ** 2 + (pos[u1][1] - by) ** 2
+                d2 = (pos[u2][0] - bx) ** 2 + (pos[u2][1] - by) ** 2
+                if abs(d1 - d2) <= 1e-11 * max(d1, d2):
+                    hit = (b, d1, d2)
+        if hit is None:
+            return None
+        notes.append(f'env {e}: UEs {u1} / {u2} at max-cap station {hit[0]}, d^2 {hit[1]!r} / {hit[2]!r}')
+    return 'max-cap winner within an ulp of log10 (DESIGN.md section 6) -- ' + '; '.join(notes)
+
+
 def random_spec(rng):
     """A random configuration as plain data (JSON-able); build_case() turns it into entity objects."""
     U = int(rng.choice([1, 2, 3, 5, 8, 10, 17, 32, 33, 64, 70, 128, 130]))
@@ -235,7 +272,13 @@ def run_case(c, torch):
                 assert core.num_ue == envs[0].num_ue(), f'{tag}: number of UEs'
                 assert np.array_equal(st['uid'], np.stack([o.uids() for o in envs])), f'{tag}: UE ids differ'
         # per-UE data rate, EWMA and the relative-SNR block 1e-5 RELATIVE against the oracle's FP64 values (tests/parity.py)
-        r = parity.assert_rates(core, ob, tag)
+        try:
+            r = parity.assert_rates(core, ob, tag)
+        except AssertionError:
+            why = maxcap_libm_tie(core, ob, c, st)
+            if why:
+                raise AmbiguousTie(f'{tag}: {why}')
+            raise
         parity.assert_obs(core.obs.cpu().numpy(), obs_o, kind, U, B, dr_rel=r['dr_rel'], msg=tag)
         if rew_o is not None:
             tol = (ATOL_UTIL if kind == 'multi' else ATOL_OBS) * (U if reward == 'sum' else 1)
@@ -340,17 +383,20 @@ def main():
     a = ap.parse_args()
     import torch
     rng = np.random.default_rng(a.seed)
-    bad = 0
+    bad = tie = 0
     for i in range(a.cases):
         c = build_case(many_ues(many_stations(random_spec(rng), a.many_stations), a.many_ues))
         try:
             run_case(c, torch)
+        except AmbiguousTie as ex:                     # the reference decides it in the last bit of the host's log10: neither side is wrong
+            tie += 1
+            print(f'case {i} AMBIGUOUS: {describe(c)}\n   {str(ex)[:600]}', flush=True)
         except (AssertionError, Exception) as ex:      # noqa: BLE001
             bad += 1
             print(f'case {i} FAILED: {describe(c)}\n   {str(ex)[:600]}', flush=True)
         if (i + 1) % 250 == 0:
             print(f'... {i + 1 - bad} / {i + 1} agree so far', flush=True)
-    print(f'{a.cases - bad} / {a.cases} random configurations agree with the oracle')
+    print(f'{a.cases - bad - tie} / {a.cases} random configurations agree with the oracle' + (f'; {tie} stopped at a max-cap tie the reference decides in the last bit of log10 (DESIGN.md section 6)' if tie else ''))
     sys.exit(1 if bad else 0)
 
 
